@@ -1,0 +1,134 @@
+/* plonky_hip.h -- C ABI of the MI355X-native NTT + MSM hot path of Plonky.
+ *
+ * The reference (0xPolygonZero/plonky, Rust) has no FFI layer; its hot path is reached through
+ * five generic functions re-exported at the crate root (src/lib.rs:14-38).  Each entry point
+ * below names the reference function it replaces (file:line into the reference tree).  The Rust
+ * side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns PLK_OK (0) or a negative PLK_ERR_* code; nothing aborts
+ *    (the reference panics on contract violations: src/curve/curve_msm.rs:67,106,
+ *    src/util.rs:17, src/field/field.rs:430 -- the shim turns a negative code into a panic);
+ *  - all buffers are caller-owned; field elements are the reference's in-memory limbs:
+ *    little-endian u64 limbs, MONTGOMERY form, fully reduced (src/field/tweedledee_base.rs:14-18),
+ *    4 limbs for TweedledeeBase / TweedledumBase / Bls12377Scalar, 6 for Bls12377Base;
+ *  - affine points cross the boundary as x limbs followed by y limbs (2*L u64) plus one
+ *    "zero" byte per point (AffinePoint.zero, src/curve/curve.rs:74-78); the structs are not
+ *    repr(C), so the shim copies fields explicitly;
+ *  - MSM results are returned as the unique affine point (ProjectivePoint::to_affine,
+ *    src/curve/curve.rs:206-214): x, y in Montgomery limbs + zero flag;
+ *  - functions with the _dev suffix take DEVICE pointers (HBM-resident data) and a hipStream_t
+ *    passed as void*; the others take HOST pointers and copy through PCIe;
+ *  - the library is thread safe: calls may come from many host threads (the reference calls
+ *    these paths from Rayon workers, src/plonk_util.rs:173-189).
+ */
+#ifndef PLONKY_HIP_H
+#define PLONKY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLK_OK 0
+#define PLK_ERR_INVALID_ARG (-1)   /* bad id, null pointer, size out of range            */
+#define PLK_ERR_SIZE_MISMATCH (-2) /* scalars.len() != generators.len() (curve_msm.rs:67) */
+#define PLK_ERR_NOT_POW2 (-3)      /* log2_strict would panic (util.rs:12-19)             */
+#define PLK_ERR_TWO_ADICITY (-4)   /* n_power > TWO_ADICITY (field.rs:430)                */
+#define PLK_ERR_HIP (-5)           /* a HIP runtime call failed; see plk_last_error()     */
+#define PLK_ERR_NO_DEVICE (-6)     /* no gfx950 device visible                            */
+#define PLK_ERR_OOM (-7)
+
+/* field ids (reference: src/field/) */
+#define PLK_FIELD_TWEEDLEDEE_BASE 0
+#define PLK_FIELD_TWEEDLEDUM_BASE 1
+#define PLK_FIELD_BLS12_377_SCALAR 2
+#define PLK_FIELD_BLS12_377_BASE 3 /* curve coordinates only; no NTT entry point needs it */
+/* curve ids (reference: src/curve/) */
+#define PLK_CURVE_TWEEDLEDEE 0
+#define PLK_CURVE_TWEEDLEDUM 1
+#define PLK_CURVE_BLS12_377 2
+
+/* ---- library ---------------------------------------------------------------------------- */
+/* Select the device this process uses (one process per GPU).  Idempotent. */
+int plk_init(int device);
+void plk_shutdown(void);
+/* Text of the last error on the calling thread (never NULL). */
+const char* plk_last_error(void);
+/* u64 limbs per element of a field / per coordinate of a curve; negative on bad id. */
+int plk_field_limbs(int field);
+int plk_curve_limbs(int curve);
+int plk_curve_scalar_field(int curve);
+
+/* ---- NTT  (src/fft.rs) -------------------------------------------------------------------- */
+/* fft_precompute (fft.rs:47-59): builds and caches the device twiddle tables for transforms of
+ * 2^log_n points over `field` (the reference's FftPrecomputation is plain host data; here the
+ * cache is keyed by (device, field, log_n) inside the library, so nothing has to be stored in
+ * the Rust struct).  Optional: plk_ntt* build the tables on first use. */
+int plk_ntt_precompute(int field, unsigned log_n);
+/* Drop every cached table (tests / memory pressure). */
+int plk_ntt_clear_cache(void);
+
+/* fft_with_precomputation_power_of_2 (fft.rs:103-156) when inverse == 0,
+ * ifft_with_precomputation_power_of_2 (fft.rs:82-101) when inverse != 0.
+ * in/out: 2^log_n elements, natural order in, natural order out; in == out allowed. */
+int plk_ntt(int field, unsigned log_n, int inverse, const uint64_t* in, uint64_t* out);
+/* `batch` independent transforms (the 9 wire polynomials, src/plonk_util.rs:169-190). */
+int plk_ntt_batch(int field, unsigned log_n, int inverse, unsigned batch, const uint64_t* const* in, uint64_t* const* out);
+/* Same on device-resident data: `batch` transforms stored back to back (batch * 2^log_n elements).
+ * d_in == d_out allowed.  Asynchronous on `stream`. */
+int plk_ntt_dev(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, void* stream);
+/* fft_with_precomputation (fft.rs:61-80): zero-pad n_in <= 2^log_n coefficients, then transform. */
+int plk_ntt_padded(int field, unsigned log_n, const uint64_t* in, size_t n_in, uint64_t* out);
+
+/* ---- MSM  (src/curve/curve_msm.rs) -------------------------------------------------------- */
+typedef struct plk_msm_ctx plk_msm_ctx;
+
+/* msm_precompute (curve_msm.rs:27-52): uploads the n generators and builds the device-side
+ * window tables [2^(c*j)] G_i.  `window_bits` = 0 lets the library choose c from n (the result
+ * of an MSM does not depend on the window; the reference's w only shapes its own tables).
+ * bases_xy: n * 2L limbs (x then y, Montgomery); base_zero: n bytes or NULL (no identity inputs). */
+int plk_msm_precompute(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, unsigned window_bits,
+                       plk_msm_ctx** out_ctx);
+/* Same with device-resident bases (n * 2L limbs) and flags (n bytes or NULL). */
+int plk_msm_precompute_dev(int curve, size_t n, const void* d_bases_xy, const void* d_base_zero, unsigned window_bits, void* stream,
+                           plk_msm_ctx** out_ctx);
+int plk_msm_free(plk_msm_ctx* ctx);
+size_t plk_msm_ctx_len(const plk_msm_ctx* ctx);       /* number of generators n          */
+unsigned plk_msm_ctx_window(const plk_msm_ctx* ctx);  /* window size c actually in use   */
+
+/* msm_execute / msm_execute_parallel (curve_msm.rs:63-157): sum_i scalars[i] * G_i.
+ * scalars: n_scalars * 4 limbs, Montgomery form IN THE CURVE'S SCALAR FIELD (to_digits converts,
+ * curve_msm.rs:164).  n_scalars must equal the context length (PLK_ERR_SIZE_MISMATCH otherwise).
+ * out_xy: 2L limbs, out_zero: 1 byte. */
+int plk_msm_execute(plk_msm_ctx* ctx, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xy, uint8_t* out_zero);
+/* `batch` scalar vectors against the same generators (commit_polynomials, src/plonk_util.rs:215-231).
+ * scalars[b]: n limbs*4 each; out_xy: batch * 2L limbs; out_zero: batch bytes. */
+int plk_msm_execute_batch(plk_msm_ctx* ctx, unsigned batch, const uint64_t* const* scalars, size_t n_scalars, uint64_t* out_xy,
+                          uint8_t* out_zero);
+/* Device-resident: d_scalars = batch * n * 4 limbs back to back; d_out_xy = batch * 2L limbs;
+ * d_out_zero = batch bytes.  Asynchronous on `stream`. */
+int plk_msm_execute_dev(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero,
+                        void* stream);
+/* msm_parallel (curve_msm.rs:54-61): precompute + execute + free in one call. */
+int plk_msm(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, const uint64_t* scalars, uint64_t* out_xy,
+            uint8_t* out_zero);
+
+/* Sum of k affine points -> affine (combining per-GPU partial MSM results after the all-gather;
+ * point addition is not an RCCL reduction op).  Host pointers. */
+int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint8_t* pts_zero, uint64_t* out_xy, uint8_t* out_zero);
+
+/* ---- utilities used by the harness and the parity tests (device kernels, not CPU code) ------ */
+/* Element-wise field ops on host arrays of `count` elements: op 0 add, 1 sub, 2 mul, 3 neg(a),
+ * 4 square(a), 5 inverse(a) (0 -> 0), 6 to_canonical(a), 7 from_canonical(a).  b ignored for unary. */
+int plk_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count);
+/* Synthetic generators B_i = G0 + (first + i) * D, i < n, affine, written to DEVICE memory
+ * (n * 2L limbs).  g0_xy / d_xy are host pointers (2L limbs each). */
+int plk_curve_gen_bases_dev(int curve, size_t n, uint64_t first, const uint64_t* g0_xy, const uint64_t* d_xy, void* d_out_xy, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLONKY_HIP_H */

@@ -87,7 +87,7 @@ template <size_t N> static inline bool is_zero_l(const Limbs<N>& x) {
 }
 template <size_t N> static inline bool is_one_l(const Limbs<N>& x) {
     u64 o = x[0] ^ 1;
-    for (int i = 1; i < N; ++i) o |= x[i];
+    for (size_t i = 1; i < N; ++i) o |= x[i];
     return o == 0;
 }
 

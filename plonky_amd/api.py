@@ -1,0 +1,242 @@
+"""Host-side mirror of the reference's hot-path interface, same names and argument meaning.
+
+  reference (Rust, generic over F / C)                        here
+  ------------------------------------------------------------------------------------------
+  fft_precompute::<F>(degree)              fft.rs:47      fft_precompute(field, degree)
+  fft_with_precomputation(c, &pre)         fft.rs:61      fft_with_precomputation(c, pre)
+  fft_with_precomputation_power_of_2       fft.rs:103     fft_with_precomputation_power_of_2(c, pre)
+  ifft_with_precomputation_power_of_2      fft.rs:82      ifft_with_precomputation_power_of_2(p, pre)
+  fft(c)                                   fft.rs:42      fft(field, c)
+  msm_precompute::<C>(generators, w)       curve_msm.rs:27   msm_precompute(curve, generators, w)
+  msm_execute(&pre, scalars)               curve_msm.rs:63   msm_execute(pre, scalars)
+  msm_execute_parallel(&pre, scalars)      curve_msm.rs:102  msm_execute_parallel(pre, scalars)
+  msm_parallel(scalars, generators, w)     curve_msm.rs:54   msm_parallel(curve, scalars, generators, w)
+
+The generic type parameter becomes an explicit field / curve id.  Field elements are numpy
+uint64 arrays of shape (n, 4) -- exactly the reference's `limbs` arrays (Montgomery form);
+generators are (n, 2, L) arrays (x, y) plus an optional zero-flag vector.  MSM results are the
+affine point `(xy, zero)` = ProjectivePoint::to_affine() of the reference's return value.
+
+Error behaviour follows the reference: contract violations raise (the reference panics):
+length mismatch (curve_msm.rs:67,106) -> AssertionError; non power of two (util.rs:17) ->
+AssertionError; beyond the 2-adicity (field.rs:430) -> AssertionError.
+
+Every function calls the HIP library through the C ABI; there is no CPU implementation here.
+"""
+import ctypes
+
+import numpy as np
+
+from . import lib as _lib
+
+TWEEDLEDEE_BASE, TWEEDLEDUM_BASE, BLS12_377_SCALAR, BLS12_377_BASE = 0, 1, 2, 3
+TWEEDLEDEE, TWEEDLEDUM, BLS12_377 = 0, 1, 2
+
+_FIELD_LIMBS = {0: 4, 1: 4, 2: 4, 3: 6}
+_CURVE_LIMBS = {0: 4, 1: 4, 2: 6}
+_TWO_ADICITY = {0: 34, 1: 33, 2: 47, 3: 46}
+CURVE_SCALAR_FIELD = {0: 1, 1: 0, 2: 2}
+CURVE_BASE_FIELD = {0: 0, 1: 1, 2: 3}
+
+
+def log2_ceil(n):  # util.rs:2-9
+    r = 0
+    while (1 << r) < n:
+        r += 1
+    return r
+
+
+def log2_strict(n):  # util.rs:12-19 (panics when n is not a power of two)
+    r = log2_ceil(n)
+    assert n == 1 << r, "Not a power of two"
+    return r
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _elems(field, a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    L = _FIELD_LIMBS[field]
+    return a.reshape(-1, L)
+
+
+class FftPrecomputation:
+    """fft.rs:28-40.  The reference stores host tables (subgroups_rev); the device tables live
+    in the library's cache keyed by (device, field, log n), so this object only records the
+    size -- it stays plain data, as the reference's serde-able struct is."""
+
+    def __init__(self, field, degree_pow):
+        self.field = field
+        self.degree_pow = degree_pow
+
+    def size(self):
+        return 1 << self.degree_pow
+
+
+def fft_precompute(field, degree):
+    degree_pow = log2_ceil(degree)
+    assert degree_pow <= _TWO_ADICITY[field], "n_power <= TWO_ADICITY"  # field.rs:430
+    _lib.check(_lib.load().plk_ntt_precompute(field, degree_pow))
+    return FftPrecomputation(field, degree_pow)
+
+
+def _ntt(field, log_n, inverse, x):
+    out = np.empty_like(x)
+    _lib.check(_lib.load().plk_ntt(field, log_n, 1 if inverse else 0, _ptr(x), _ptr(out)))
+    return out
+
+
+def fft_with_precomputation_power_of_2(coefficients, precomputation):
+    x = _elems(precomputation.field, coefficients)
+    degree_pow = log2_strict(x.shape[0])
+    # fft.rs:107-111 debug_assert_eq!: release builds accept any table at least as large (Appendix A.7)
+    assert degree_pow <= _TWO_ADICITY[precomputation.field]
+    return _ntt(precomputation.field, degree_pow, False, x)
+
+
+def ifft_with_precomputation_power_of_2(points, precomputation):
+    x = _elems(precomputation.field, points)
+    degree_pow = log2_strict(x.shape[0])
+    assert degree_pow <= _TWO_ADICITY[precomputation.field]
+    return _ntt(precomputation.field, degree_pow, True, x)
+
+
+def fft_with_precomputation(coefficients, precomputation):
+    x = _elems(precomputation.field, coefficients)
+    degree = x.shape[0]
+    log_n = log2_ceil(degree)
+    if degree == 1 << log_n:
+        return fft_with_precomputation_power_of_2(x, precomputation)
+    out = np.empty((1 << log_n, x.shape[1]), dtype=np.uint64)
+    _lib.check(_lib.load().plk_ntt_padded(precomputation.field, log_n, _ptr(x), degree, _ptr(out)))
+    return out
+
+
+def fft(field, coefficients):
+    x = _elems(field, coefficients)
+    return fft_with_precomputation(x, fft_precompute(field, x.shape[0]))
+
+
+def fft_batch(field, polys, inverse=False):
+    """`batch` independent power-of-two transforms in one call (the par_iter over the 9 wire
+    polynomials, plonk_util.rs:169-190).  polys: (batch, n, 4)."""
+    polys = np.ascontiguousarray(polys, dtype=np.uint64)
+    batch, n = polys.shape[0], polys.shape[1]
+    log_n = log2_strict(n)
+    out = np.empty_like(polys)
+    ins = (ctypes.c_void_p * batch)(*[polys[b].ctypes.data for b in range(batch)])
+    outs = (ctypes.c_void_p * batch)(*[out[b].ctypes.data for b in range(batch)])
+    _lib.check(_lib.load().plk_ntt_batch(field, log_n, 1 if inverse else 0, batch, ins, outs))
+    return out
+
+
+class MsmPrecomputation:
+    """curve_msm.rs:16-25.  Owns a device context holding the generators and the window tables
+    [2^(c j)] G_i.  `w` is kept because it is part of the reference struct; the device window c
+    is a tuning choice (the result does not depend on it)."""
+
+    def __init__(self, curve, ctx, n, w):
+        self.curve = curve
+        self._ctx = ctx
+        self.n = n
+        self.w = w
+
+    @property
+    def window(self):
+        return int(_lib.load().plk_msm_ctx_window(self._ctx))
+
+    def __len__(self):
+        return self.n
+
+    def free(self):
+        if self._ctx:
+            _lib.load().plk_msm_free(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _points(curve, generators):
+    L = _CURVE_LIMBS[curve]
+    g = np.ascontiguousarray(generators, dtype=np.uint64).reshape(-1, 2, L)
+    return g
+
+
+def msm_precompute(curve, generators, w, zero=None, device_window=0):
+    """generators: (n, 2, L) affine x,y Montgomery limbs; zero: optional n flags (AffinePoint.zero).
+    The reference takes ProjectivePoints and only ever passes normalised generators
+    (circuit_builder.rs:1127-1133); the shim in INTEGRATION.md reads powers_per_generator[i][0]."""
+    g = _points(curve, generators)
+    n = g.shape[0]
+    z = None
+    if zero is not None:
+        z = np.ascontiguousarray(zero, dtype=np.uint8)
+        assert z.shape[0] == n
+    ctx = ctypes.c_void_p()
+    _lib.check(_lib.load().plk_msm_precompute(curve, n, _ptr(g), _ptr(z) if z is not None else None, device_window, ctypes.byref(ctx)))
+    return MsmPrecomputation(curve, ctx, n, w)
+
+
+def msm_execute_parallel(precomputation, scalars):
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    # assert_eq!(precomputation.powers_per_generator.len(), scalars.len())  curve_msm.rs:106
+    assert s.shape[0] == precomputation.n, "powers_per_generator.len() != scalars.len()"
+    L = _CURVE_LIMBS[precomputation.curve]
+    out = np.zeros((2, L), dtype=np.uint64)
+    oz = np.zeros(1, dtype=np.uint8)
+    _lib.check(_lib.load().plk_msm_execute(precomputation._ctx, _ptr(s), s.shape[0], _ptr(out), _ptr(oz)))
+    return out, int(oz[0])
+
+
+# msm_execute (serial, curve_msm.rs:63) computes the same group element as msm_execute_parallel.
+msm_execute = msm_execute_parallel
+
+
+def msm_execute_batch(precomputation, scalar_vectors):
+    """commit_polynomials (plonk_util.rs:215-231): several scalar vectors, same generators."""
+    sv = np.ascontiguousarray(scalar_vectors, dtype=np.uint64)
+    batch = sv.shape[0]
+    sv = sv.reshape(batch, -1, 4)
+    assert sv.shape[1] == precomputation.n, "powers_per_generator.len() != scalars.len()"
+    L = _CURVE_LIMBS[precomputation.curve]
+    out = np.zeros((batch, 2, L), dtype=np.uint64)
+    oz = np.zeros(batch, dtype=np.uint8)
+    ptrs = (ctypes.c_void_p * batch)(*[sv[b].ctypes.data for b in range(batch)])
+    _lib.check(_lib.load().plk_msm_execute_batch(precomputation._ctx, batch, ptrs, sv.shape[1], _ptr(out), _ptr(oz)))
+    return out, oz
+
+
+def msm_parallel(curve, scalars, generators, w, zero=None):
+    pre = msm_precompute(curve, generators, w, zero=zero)
+    try:
+        return msm_execute_parallel(pre, scalars)
+    finally:
+        pre.free()
+
+
+def curve_sum_affine(curve, points, zero=None):
+    """Adds k affine points (per-GPU partial MSM results after the all-gather)."""
+    p = _points(curve, points)
+    k = p.shape[0]
+    z = None if zero is None else np.ascontiguousarray(zero, dtype=np.uint8)
+    L = _CURVE_LIMBS[curve]
+    out = np.zeros((2, L), dtype=np.uint64)
+    oz = np.zeros(1, dtype=np.uint8)
+    _lib.check(_lib.load().plk_curve_sum_affine(curve, k, _ptr(p), _ptr(z) if z is not None else None, _ptr(out), _ptr(oz)))
+    return out, int(oz[0])
+
+
+def field_op(field, op, a, b=None):
+    """Element-wise device field arithmetic (parity tests of the HIP field code)."""
+    ops = {"add": 0, "sub": 1, "mul": 2, "neg": 3, "square": 4, "inverse": 5, "to_canonical": 6, "from_canonical": 7}
+    a = _elems(field, a)
+    out = np.empty_like(a)
+    bb = _elems(field, b) if b is not None else a
+    _lib.check(_lib.load().plk_field_op(field, ops[op], _ptr(a), _ptr(bb), _ptr(out), a.shape[0]))
+    return out

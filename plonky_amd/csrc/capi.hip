@@ -1,0 +1,271 @@
+// capi.hip -- the extern "C" surface declared in include/plonky_hip.h.
+// Thin: argument validation, host<->device staging for the host-pointer variants, dispatch.
+#include <atomic>
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+struct plk_msm_ctx;
+
+namespace plk {
+
+int field_op_impl(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count);
+int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, hipStream_t stream, plk_msm_ctx** out_ctx);
+int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream);
+int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void* d_zero, void* d_out_xy, void* d_out_zero, hipStream_t stream);
+int curve_gen_bases_dev_impl(int curve, size_t n, uint64_t first, const void* d_g0d, void* d_out, hipStream_t stream);
+size_t msm_ctx_len(const plk_msm_ctx* ctx);
+unsigned msm_ctx_window(const plk_msm_ctx* ctx);
+int msm_ctx_curve(const plk_msm_ctx* ctx);
+void msm_ctx_delete(plk_msm_ctx* ctx);
+
+std::string& last_error_ref() {
+    static thread_local std::string s;
+    return s;
+}
+int set_error(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error_ref() = buf;
+    return code;
+}
+
+static std::atomic<int> g_device{-1};
+
+int ensure_device() {
+    int dev = g_device.load();
+    if (dev < 0) {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count <= 0)
+            return set_error(PLK_ERR_NO_DEVICE, "no HIP device visible (%s); the HIP path has no CPU fallback", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+        g_device.store(cur);
+        dev = cur;
+    }
+    PLK_HIP_TRY(hipSetDevice(dev));
+    return PLK_OK;
+}
+
+int field_limbs(int field) {
+    switch (field) {
+        case PLK_FIELD_TWEEDLEDEE_BASE:
+        case PLK_FIELD_TWEEDLEDUM_BASE:
+        case PLK_FIELD_BLS12_377_SCALAR: return 4;
+        case PLK_FIELD_BLS12_377_BASE: return 6;
+    }
+    return PLK_ERR_INVALID_ARG;
+}
+int curve_limbs(int curve) {
+    switch (curve) {
+        case PLK_CURVE_TWEEDLEDEE:
+        case PLK_CURVE_TWEEDLEDUM: return 4;
+        case PLK_CURVE_BLS12_377: return 6;
+    }
+    return PLK_ERR_INVALID_ARG;
+}
+int curve_scalar_field(int curve) {
+    switch (curve) {
+        case PLK_CURVE_TWEEDLEDEE: return PLK_FIELD_TWEEDLEDUM_BASE;
+        case PLK_CURVE_TWEEDLEDUM: return PLK_FIELD_TWEEDLEDEE_BASE;
+        case PLK_CURVE_BLS12_377: return PLK_FIELD_BLS12_377_SCALAR;
+    }
+    return PLK_ERR_INVALID_ARG;
+}
+
+}  // namespace plk
+
+using namespace plk;
+
+extern "C" {
+
+int plk_init(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return set_error(PLK_ERR_NO_DEVICE, "no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return set_error(PLK_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, count);
+    PLK_HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PLK_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(PLK_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    g_device.store(device);
+    return PLK_OK;
+}
+
+void plk_shutdown(void) {
+    (void)ntt_clear_cache_impl();
+    g_device.store(-1);
+}
+
+const char* plk_last_error(void) { return last_error_ref().c_str(); }
+int plk_field_limbs(int field) { return field_limbs(field); }
+int plk_curve_limbs(int curve) { return curve_limbs(curve); }
+int plk_curve_scalar_field(int curve) { return curve_scalar_field(curve); }
+
+// ---- NTT ----
+int plk_ntt_precompute(int field, unsigned log_n) { return ntt_precompute_impl(field, log_n); }
+int plk_ntt_clear_cache(void) { return ntt_clear_cache_impl(); }
+
+int plk_ntt_dev(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, void* stream) {
+    return ntt_dev_impl(field, log_n, inverse, batch, d_in, d_out, as_stream(stream));
+}
+
+int plk_ntt_batch(int field, unsigned log_n, int inverse, unsigned batch, const uint64_t* const* in, uint64_t* const* out) {
+    if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
+    if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
+    if (batch == 0) return PLK_OK;
+    if (!in || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    const size_t bytes = ((size_t)1 << log_n) * 32;
+    DevBuf buf;
+    PLK_TRY(buf.alloc(bytes * batch));
+    for (unsigned b = 0; b < batch; ++b) {
+        if (!in[b] || !out[b]) return set_error(PLK_ERR_INVALID_ARG, "null pointer in batch slot %u", b);
+        PLK_HIP_TRY(hipMemcpy((uint8_t*)buf.p + b * bytes, in[b], bytes, hipMemcpyHostToDevice));
+    }
+    PLK_TRY(ntt_dev_impl(field, log_n, inverse, batch, buf.p, buf.p, nullptr));
+    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
+    for (unsigned b = 0; b < batch; ++b) PLK_HIP_TRY(hipMemcpy(out[b], (uint8_t*)buf.p + b * bytes, bytes, hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+
+int plk_ntt(int field, unsigned log_n, int inverse, const uint64_t* in, uint64_t* out) {
+    return plk_ntt_batch(field, log_n, inverse, 1, &in, &out);
+}
+
+int plk_ntt_padded(int field, unsigned log_n, const uint64_t* in, size_t n_in, uint64_t* out) {
+    if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
+    if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
+    const size_t n = (size_t)1 << log_n;
+    if (n_in > n) return set_error(PLK_ERR_INVALID_ARG, "n_in %zu exceeds 2^%u", n_in, log_n);
+    if ((n_in && !in) || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    DevBuf buf;
+    PLK_TRY(buf.alloc(n * 32));
+    PLK_HIP_TRY(hipMemset(buf.p, 0, n * 32));  // F::ZERO is all-zero limbs in Montgomery form too
+    if (n_in) PLK_HIP_TRY(hipMemcpy(buf.p, in, n_in * 32, hipMemcpyHostToDevice));
+    PLK_TRY(ntt_dev_impl(field, log_n, 0, 1, buf.p, buf.p, nullptr));
+    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
+    PLK_HIP_TRY(hipMemcpy(out, buf.p, n * 32, hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+
+// ---- MSM ----
+int plk_msm_precompute_dev(int curve, size_t n, const void* d_bases_xy, const void* d_base_zero, unsigned window_bits, void* stream,
+                           plk_msm_ctx** out_ctx) {
+    return msm_precompute_dev_impl(curve, n, d_bases_xy, d_base_zero, window_bits, as_stream(stream), out_ctx);
+}
+
+int plk_msm_precompute(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, unsigned window_bits, plk_msm_ctx** out_ctx) {
+    const int L = curve_limbs(curve);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (n && !bases_xy) return set_error(PLK_ERR_INVALID_ARG, "null bases");
+    PLK_TRY(ensure_device());
+    DevBuf db, dz;
+    PLK_TRY(db.alloc(n * 2 * L * 8));
+    if (n) PLK_HIP_TRY(hipMemcpy(db.p, bases_xy, n * 2 * L * 8, hipMemcpyHostToDevice));
+    if (base_zero) {
+        PLK_TRY(dz.alloc(n));
+        if (n) PLK_HIP_TRY(hipMemcpy(dz.p, base_zero, n, hipMemcpyHostToDevice));
+    }
+    return msm_precompute_dev_impl(curve, n, db.p, base_zero ? dz.p : nullptr, window_bits, nullptr, out_ctx);
+}
+
+int plk_msm_free(plk_msm_ctx* ctx) {
+    if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
+    msm_ctx_delete(ctx);
+    return PLK_OK;
+}
+size_t plk_msm_ctx_len(const plk_msm_ctx* ctx) { return ctx ? msm_ctx_len(ctx) : 0; }
+unsigned plk_msm_ctx_window(const plk_msm_ctx* ctx) { return ctx ? msm_ctx_window(ctx) : 0; }
+
+int plk_msm_execute_dev(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, void* stream) {
+    return msm_execute_dev_impl(ctx, batch, d_scalars, n_scalars, d_out_xy, d_out_zero, as_stream(stream));
+}
+
+int plk_msm_execute_batch(plk_msm_ctx* ctx, unsigned batch, const uint64_t* const* scalars, size_t n_scalars, uint64_t* out_xy, uint8_t* out_zero) {
+    if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
+    if (n_scalars != msm_ctx_len(ctx))
+        return set_error(PLK_ERR_SIZE_MISMATCH, "scalars.len() = %zu but the precomputation holds %zu generators (curve_msm.rs:67)", n_scalars,
+                         msm_ctx_len(ctx));
+    if (batch == 0) return PLK_OK;
+    if (!scalars || !out_xy || !out_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    const size_t L = (size_t)curve_limbs(msm_ctx_curve(ctx));
+    const size_t sb = n_scalars * 32;
+    DevBuf ds, dxy, dz;
+    PLK_TRY(ds.alloc(sb * batch));
+    PLK_TRY(dxy.alloc((size_t)batch * 2 * L * 8));
+    PLK_TRY(dz.alloc(batch));
+    for (unsigned b = 0; b < batch; ++b) {
+        if (n_scalars && !scalars[b]) return set_error(PLK_ERR_INVALID_ARG, "null scalars in batch slot %u", b);
+        if (n_scalars) PLK_HIP_TRY(hipMemcpy((uint8_t*)ds.p + b * sb, scalars[b], sb, hipMemcpyHostToDevice));
+    }
+    PLK_TRY(msm_execute_dev_impl(ctx, batch, ds.p, n_scalars, dxy.p, dz.p, nullptr));
+    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
+    PLK_HIP_TRY(hipMemcpy(out_xy, dxy.p, (size_t)batch * 2 * L * 8, hipMemcpyDeviceToHost));
+    PLK_HIP_TRY(hipMemcpy(out_zero, dz.p, batch, hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+
+int plk_msm_execute(plk_msm_ctx* ctx, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xy, uint8_t* out_zero) {
+    return plk_msm_execute_batch(ctx, 1, &scalars, n_scalars, out_xy, out_zero);
+}
+
+int plk_msm(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, const uint64_t* scalars, uint64_t* out_xy, uint8_t* out_zero) {
+    plk_msm_ctx* ctx = nullptr;
+    PLK_TRY(plk_msm_precompute(curve, n, bases_xy, base_zero, 0, &ctx));
+    int rc = plk_msm_execute(ctx, scalars, n, out_xy, out_zero);
+    msm_ctx_delete(ctx);
+    return rc;
+}
+
+int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint8_t* pts_zero, uint64_t* out_xy, uint8_t* out_zero) {
+    const int L = curve_limbs(curve);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if ((k && !pts_xy) || !out_xy || !out_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    DevBuf dp, dz, dxy, doz;
+    PLK_TRY(dp.alloc(k * 2 * L * 8));
+    PLK_TRY(dxy.alloc(2 * L * 8));
+    PLK_TRY(doz.alloc(1));
+    if (k) PLK_HIP_TRY(hipMemcpy(dp.p, pts_xy, k * 2 * L * 8, hipMemcpyHostToDevice));
+    if (pts_zero) {
+        PLK_TRY(dz.alloc(k));
+        if (k) PLK_HIP_TRY(hipMemcpy(dz.p, pts_zero, k, hipMemcpyHostToDevice));
+    }
+    PLK_TRY(curve_sum_affine_dev_impl(curve, k, dp.p, pts_zero ? dz.p : nullptr, dxy.p, doz.p, nullptr));
+    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
+    PLK_HIP_TRY(hipMemcpy(out_xy, dxy.p, 2 * L * 8, hipMemcpyDeviceToHost));
+    PLK_HIP_TRY(hipMemcpy(out_zero, doz.p, 1, hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+
+// ---- utilities ----
+int plk_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count) {
+    return field_op_impl(field, op, a, b, out, count);
+}
+
+int plk_curve_gen_bases_dev(int curve, size_t n, uint64_t first, const uint64_t* g0_xy, const uint64_t* d_xy, void* d_out_xy, void* stream) {
+    const int L = curve_limbs(curve);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (!g0_xy || !d_xy || (n && !d_out_xy)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    DevBuf dg;
+    PLK_TRY(dg.alloc(4 * L * 8));
+    PLK_HIP_TRY(hipMemcpy(dg.p, g0_xy, 2 * L * 8, hipMemcpyHostToDevice));
+    PLK_HIP_TRY(hipMemcpy((uint8_t*)dg.p + 2 * L * 8, d_xy, 2 * L * 8, hipMemcpyHostToDevice));
+    PLK_TRY(curve_gen_bases_dev_impl(curve, n, first, dg.p, d_out_xy, as_stream(stream)));
+    PLK_HIP_TRY(hipStreamSynchronize(as_stream(stream)));  // dg is freed on return
+    return PLK_OK;
+}
+
+}  // extern "C"

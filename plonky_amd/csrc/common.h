@@ -1,0 +1,66 @@
+// common.h -- host-side plumbing shared by the translation units of libplonky_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/plonky_hip.h"
+
+namespace plk {
+
+// thread-local error text behind plk_last_error()
+std::string& last_error_ref();
+int set_error(int code, const char* fmt, ...);
+
+#define PLK_HIP_TRY(expr)                                                                              \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return ::plk::set_error(_e == hipErrorOutOfMemory ? PLK_ERR_OOM : PLK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                                    hipGetErrorString(_e), __FILE__, __LINE__);                        \
+    } while (0)
+
+#define PLK_TRY(expr)              \
+    do {                           \
+        int _rc = (expr);          \
+        if (_rc != PLK_OK) return _rc; \
+    } while (0)
+
+// Makes sure a device is selected for the calling thread (plk_init may have been called on
+// another thread: hipSetDevice is per thread).
+int ensure_device();
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        if (bytes == 0) bytes = 16;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return set_error(e == hipErrorOutOfMemory ? PLK_ERR_OOM : PLK_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        }
+        return PLK_OK;
+    }
+};
+
+// ---- entry points implemented in ntt.hip / msm.hip / fieldops.hip, wrapped by capi.hip ----
+int ntt_precompute_impl(int field, unsigned log_n);
+int ntt_clear_cache_impl();
+int ntt_dev_impl(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, hipStream_t stream);
+
+int field_limbs(int field);
+int curve_limbs(int curve);
+int curve_scalar_field(int curve);
+
+}  // namespace plk

@@ -1,0 +1,535 @@
+// msm.hip -- multi-scalar multiplication sum_i s_i * G_i on gfx950 (bucket method on window tables).
+//
+// Replaces the reference's src/curve/curve_msm.rs (+ curve_summations.rs, curve_adds.rs):
+//   msm_precompute / precompute_single_generator  curve_msm.rs:27-52  -> k_msm_table (device tables)
+//   to_digits                                     curve_msm.rs:159-180 -> k_msm_digits (signed, carry based)
+//   digit_occurrences scatter (serial in the ref) curve_msm.rs:117-126 -> histogram + scan + scatter
+//   per-digit affine multi-summation              curve_msm.rs:131-145 -> k_msm_accumulate (XYZZ mixed adds)
+//   serial Yao tail  u += acc[d]; y += u          curve_msm.rs:149-154 -> k_msm_chunks + k_msm_planes + k_msm_final
+//   msm_execute / msm_execute_parallel            curve_msm.rs:63-157  -> msm_execute_dev_impl
+// Same mathematical structure as the reference (Yao's method over per-generator power tables
+// [2^(c j)] G_i, one bucket per digit value, result = sum_d d * bucket_d) with two MI355X-first
+// changes: (1) digits are signed (carry-based integer recoding, never s -> r - s, so it is valid
+// on BLS12-377 G1 whose cofactor is even): half the buckets for the same window; (2) the serial
+// running sum is replaced by 16-bucket chunk running sums followed by bit-plane tree sums, so
+// the tail is O(log) deep instead of 2 * 2^w sequential additions.  The result is returned as
+// the unique affine point (to_affine, curve.rs:206-214), on which parity is defined.
+//
+// Work decomposition: every (scalar i, window j) with a non-zero digit is one *entry* that adds
+// +-table[j*n + i] into bucket |d|-1.  Entries are counting-sorted by bucket; every bucket is
+// cut into slices of <= SLICE entries and one lane accumulates one slice, so the load per lane
+// is bounded whatever the digit distribution (a skewed witness cannot serialise the kernel).
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "ec.cuh"
+
+namespace plk {
+
+constexpr int MSM_SLICE = 32;        // entries per accumulation slice
+constexpr int MSM_CHUNK_LOG = 4;     // buckets per running-sum chunk (16)
+constexpr int MSM_MAX_WINDOW = 22;
+constexpr uint32_t CODE_INVALID = 0xFFFFFFFFu;
+
+// ---------------------------------------------------------------------------------------------
+// table construction: tab[j*n + i] = [2^(c j)] G_i, affine  (curve_msm.rs:40-52)
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(128) k_msm_table(const uint4* __restrict__ bases, const uint8_t* __restrict__ base_zero, uint4* __restrict__ tab,
+                                                   size_t n, int c, int windows) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<FP> x = fe_load<FP>(bases + i * 2 * W), y = fe_load<FP>(bases + i * 2 * W + W);
+    bool ident = base_zero ? base_zero[i] != 0 : false;
+    affine_store<FP>(tab + i * 2 * W, x, y, ident);
+    for (int j = 1; j < windows; ++j) {
+        if (!ident) {
+            Xyzz<FP> p = xyzz_mdbl<FP>(x, y);
+            for (int k = 1; k < c; ++k) p = xyzz_dbl<FP>(p);
+            ident = xyzz_to_affine<FP>(p, x, y);
+        }
+        affine_store<FP>(tab + ((size_t)j * n + i) * 2 * W, x, y, ident);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scalars -> signed window digits + bucket histogram  (curve_msm.rs:159-180, :121-126)
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(256) k_msm_digits(const uint4* __restrict__ scalars, uint32_t* __restrict__ codes, uint32_t* __restrict__ hist,
+                                                    size_t n, int c, int windows) {
+    using SP = typename C::SP;
+    static_assert(SP::NL == 8, "scalar fields are 256-bit");
+    // Scalars are staged through LDS: the block reads its 256 * 32 B with fully coalesced 16-byte
+    // loads, each lane then picks up its own scalar, converts it and parks the canonical limbs
+    // back in LDS so the window loop can index them dynamically.
+    __shared__ uint4 s_sc[512];
+    const size_t base = (size_t)blockIdx.x * 256;
+    for (int k = threadIdx.x; k < 512; k += 256) {
+        size_t g = base * 2 + k;
+        s_sc[k] = g < n * 2 ? scalars[g] : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    const size_t i = base + threadIdx.x;
+    Fe<SP> s;
+    {
+        uint4 lo = s_sc[2 * threadIdx.x], hi = s_sc[2 * threadIdx.x + 1];
+        s.v[0] = lo.x; s.v[1] = lo.y; s.v[2] = lo.z; s.v[3] = lo.w;
+        s.v[4] = hi.x; s.v[5] = hi.y; s.v[6] = hi.z; s.v[7] = hi.w;
+    }
+    // Montgomery -> canonical in the SCALAR field (to_canonical_u64_vec, curve_msm.rs:164)
+    s = fe_to_canonical<SP>(s);
+    uint32_t* lim = reinterpret_cast<uint32_t*>(s_sc) + threadIdx.x * 8;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lim[k] = s.v[k];
+    if (i >= n) return;
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (int j = 0; j < windows; ++j) {
+        const int bp = j * c, li = bp >> 5, sh = bp & 31;
+        uint64_t two = li < 8 ? lim[li] : 0u;
+        if (li + 1 < 8) two |= (uint64_t)lim[li + 1] << 32;
+        uint32_t v = ((uint32_t)(two >> sh) & mask) + carry;
+        // signed recoding: v in [0, 2^c]; v > 2^(c-1) becomes v - 2^c with a carry into the next window
+        uint32_t neg = v > half ? 1u : 0u;
+        uint32_t mag = neg ? (1u << c) - v : v;
+        carry = neg;
+        uint32_t code = CODE_INVALID;
+        if (mag != 0) {
+            code = ((mag - 1u) << 1) | neg;
+            atomicAdd(&hist[mag - 1u], 1u);
+        }
+        codes[(size_t)j * n + i] = code;
+    }
+}
+
+// single block: exclusive scans of the bucket sizes and of the per-bucket slice counts
+__global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ off, uint32_t* __restrict__ slice_off,
+                                                   uint32_t buckets) {
+    __shared__ uint32_t s_a[1024], s_b[1024];
+    const uint32_t per = (buckets + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per, hi = min(buckets, lo + per);
+    uint32_t sa = 0, sb = 0;
+    for (uint32_t b = lo; b < hi; ++b) {
+        uint32_t h = hist[b];
+        sa += h;
+        sb += (h + MSM_SLICE - 1) / MSM_SLICE;
+    }
+    s_a[threadIdx.x] = sa;
+    s_b[threadIdx.x] = sb;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        uint32_t va = 0, vb = 0;
+        if ((int)threadIdx.x >= d) {
+            va = s_a[threadIdx.x - d];
+            vb = s_b[threadIdx.x - d];
+        }
+        __syncthreads();
+        s_a[threadIdx.x] += va;
+        s_b[threadIdx.x] += vb;
+        __syncthreads();
+    }
+    uint32_t ra = s_a[threadIdx.x] - sa, rb = s_b[threadIdx.x] - sb;  // exclusive prefix of this lane's range
+    for (uint32_t b = lo; b < hi; ++b) {
+        uint32_t h = hist[b];
+        off[b] = ra;
+        slice_off[b] = rb;
+        ra += h;
+        rb += (h + MSM_SLICE - 1) / MSM_SLICE;
+    }
+    if (threadIdx.x == 1023) {
+        off[buckets] = s_a[1023];
+        slice_off[buckets] = s_b[1023];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_msm_scatter(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor,
+                                                     uint32_t* __restrict__ sorted, size_t entries) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= entries) return;
+    uint32_t code = codes[e];
+    if (code == CODE_INVALID) return;
+    uint32_t b = code >> 1;
+    uint32_t pos = off[b] + atomicAdd(&cursor[b], 1u);
+    sorted[pos] = ((uint32_t)e << 1) | (code & 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bucket accumulation: one lane per slice of <= MSM_SLICE sorted entries
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(128) k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
+                                                        const uint32_t* __restrict__ off, const uint32_t* __restrict__ slice_off,
+                                                        uint4* __restrict__ partial, uint32_t buckets) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = slice_off[buckets];
+    if (s >= total) return;
+    // bucket of slice s: largest b with slice_off[b] <= s
+    uint32_t lo = 0, hi = buckets;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (slice_off[mid] <= s) lo = mid; else hi = mid;
+    }
+    const uint32_t b = lo;
+    const uint32_t begin = off[b] + (s - slice_off[b]) * MSM_SLICE;
+    const uint32_t end = min(off[b + 1], begin + MSM_SLICE);
+    Xyzz<FP> acc = xyzz_identity<FP>();
+    for (uint32_t k = begin; k < end; ++k) {
+        const uint32_t ent = sorted[k];
+        Fe<FP> x, y;
+        const bool ident = affine_load<FP>(tab + (size_t)(ent >> 1) * 2 * W, x, y);
+        if (ident) continue;
+        if (ent & 1u) y = fe_neg<FP>(y);
+        xyzz_madd<FP>(acc, x, y);
+    }
+    xyzz_store<FP>(partial + (size_t)s * 4 * W, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// reduction  sum_d d * bucket_d
+// ---------------------------------------------------------------------------------------------
+// level 0: chunk t of L = 2^chunk_log buckets:  S_t = sum_l B,  R_t = sum_l (l+1) B  (running sums)
+template <class C>
+__global__ void __launch_bounds__(64) k_msm_chunks(const uint4* __restrict__ partial, const uint32_t* __restrict__ slice_off, uint4* __restrict__ chunk_s,
+                                                   uint4* __restrict__ chunk_r, uint32_t n_chunks, int chunk_log) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_chunks) return;
+    Xyzz<FP> run = xyzz_identity<FP>(), acc = xyzz_identity<FP>();
+    const int L = 1 << chunk_log;
+    for (int l = L - 1; l >= 0; --l) {
+        const uint32_t b = (t << chunk_log) + l;
+        const uint32_t s0 = slice_off[b], s1 = slice_off[b + 1];
+        for (uint32_t s = s0; s < s1; ++s) run = xyzz_add<FP>(run, xyzz_load<FP>(partial + (size_t)s * 4 * W));
+        acc = xyzz_add<FP>(acc, run);
+    }
+    xyzz_store<FP>(chunk_s + (size_t)t * 4 * W, run);
+    xyzz_store<FP>(chunk_r + (size_t)t * 4 * W, acc);
+}
+
+template <class FP> PLK_DI Xyzz<FP> block_sum(Xyzz<FP> v, uint4* s_pts) {
+    constexpr int W = FP::NL / 4;
+    const int tid = threadIdx.x;
+    xyzz_store<FP>(s_pts + tid * 4 * W, v);
+    __syncthreads();
+    for (int d = blockDim.x >> 1; d >= 1; d >>= 1) {
+        if (tid < d) {
+            v = xyzz_add<FP>(v, xyzz_load<FP>(s_pts + (tid + d) * 4 * W));
+            xyzz_store<FP>(s_pts + tid * 4 * W, v);
+        }
+        __syncthreads();
+    }
+    return v;
+}
+
+// total = sum_t R_t + L * sum_t t * S_t ;  sum_t t*S_t = sum_b 2^b * (sum over t with bit b set of S_t).
+// plane p < n_bits: tree-sum of {S_t : bit p of t}; plane n_bits: tree-sum of all R_t.
+template <class C>
+__global__ void __launch_bounds__(128) k_msm_planes(const uint4* __restrict__ chunk_s, const uint4* __restrict__ chunk_r, uint4* __restrict__ plane_part,
+                                                    uint32_t n_chunks, int n_bits) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    extern __shared__ __attribute__((aligned(16))) uint4 s_pts[];
+    const int plane = blockIdx.y;
+    const uint4* src = plane == n_bits ? chunk_r : chunk_s;
+    Xyzz<FP> acc = xyzz_identity<FP>();
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_chunks; t += gridDim.x * blockDim.x) {
+        if (plane == n_bits || ((t >> plane) & 1u)) acc = xyzz_add<FP>(acc, xyzz_load<FP>(src + (size_t)t * 4 * W));
+    }
+    acc = block_sum<FP>(acc, s_pts);
+    if (threadIdx.x == 0) xyzz_store<FP>(plane_part + ((size_t)plane * gridDim.x + blockIdx.x) * 4 * W, acc);
+}
+
+// one block: per plane sum the block partials, scale by 2^(plane + chunk_log), add everything, to affine.
+template <class C>
+__global__ void __launch_bounds__(64) k_msm_final(const uint4* __restrict__ plane_part, int parts_per_plane, int n_bits, int chunk_log, uint4* __restrict__ out_xy,
+                                                  uint8_t* __restrict__ out_zero) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    extern __shared__ __attribute__((aligned(16))) uint4 s_pts[];
+    const int plane = threadIdx.x;
+    Xyzz<FP> acc = xyzz_identity<FP>();
+    if (plane <= n_bits) {
+        for (int k = 0; k < parts_per_plane; ++k) acc = xyzz_add<FP>(acc, xyzz_load<FP>(plane_part + ((size_t)plane * parts_per_plane + k) * 4 * W));
+        if (plane < n_bits)
+            for (int k = 0; k < plane + chunk_log; ++k) acc = xyzz_dbl<FP>(acc);
+    }
+    acc = block_sum<FP>(acc, s_pts);
+    if (threadIdx.x == 0) {
+        Fe<FP> x, y;
+        bool ident = xyzz_to_affine<FP>(acc, x, y);
+        fe_store<FP>(out_xy, x);
+        fe_store<FP>(out_xy + W, y);
+        *out_zero = ident ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small utilities: sum of k affine points; synthetic generators G0 + (first + i) D
+// ---------------------------------------------------------------------------------------------
+template <class C>
+__global__ void __launch_bounds__(64) k_sum_affine(const uint4* __restrict__ pts, const uint8_t* __restrict__ zero, size_t k, uint4* __restrict__ out_xy,
+                                                   uint8_t* __restrict__ out_zero) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    extern __shared__ __attribute__((aligned(16))) uint4 s_pts[];
+    Xyzz<FP> acc = xyzz_identity<FP>();
+    for (size_t i = threadIdx.x; i < k; i += blockDim.x) {
+        if (zero && zero[i]) continue;
+        Fe<FP> x = fe_load<FP>(pts + i * 2 * W), y = fe_load<FP>(pts + i * 2 * W + W);
+        xyzz_madd<FP>(acc, x, y);
+    }
+    acc = block_sum<FP>(acc, s_pts);
+    if (threadIdx.x == 0) {
+        Fe<FP> x, y;
+        bool ident = xyzz_to_affine<FP>(acc, x, y);
+        fe_store<FP>(out_xy, x);
+        fe_store<FP>(out_xy + W, y);
+        *out_zero = ident ? 1 : 0;
+    }
+}
+
+template <class C>
+__global__ void __launch_bounds__(128) k_gen_bases(const uint4* __restrict__ g0d, uint4* __restrict__ out, size_t n, uint64_t first) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fe<FP> gx = fe_load<FP>(g0d), gy = fe_load<FP>(g0d + W), dx = fe_load<FP>(g0d + 2 * W), dy = fe_load<FP>(g0d + 3 * W);
+    // (first + i) * D by double-and-add from the top bit, then + G0
+    uint64_t m = first + i;
+    Xyzz<FP> acc = xyzz_identity<FP>();
+    for (int b = 63; b >= 0; --b) {
+        acc = xyzz_dbl<FP>(acc);
+        if ((m >> b) & 1) xyzz_madd<FP>(acc, dx, dy);
+    }
+    xyzz_madd<FP>(acc, gx, gy);
+    Fe<FP> x, y;
+    bool ident = xyzz_to_affine<FP>(acc, x, y);
+    (void)ident;  // G0 + m D is the identity only for one m in the whole group; callers use small m
+    fe_store<FP>(out + i * 2 * W, x);
+    fe_store<FP>(out + i * 2 * W + W, y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+}  // namespace plk
+
+struct plk_msm_ctx {
+    int curve = 0;
+    int device = 0;
+    size_t n = 0;
+    int c = 0;          // window bits
+    int windows = 0;    // ceil((BITS + 1) / c)
+    uint32_t buckets = 0;  // 2^(c-1)
+    int chunk_log = 0;
+    uint32_t n_chunks = 0;
+    int n_bits = 0;     // log2(n_chunks)
+    int plane_blocks = 1;
+    size_t max_slices = 0;
+    // device memory
+    void* tab = nullptr;
+    void* codes = nullptr;
+    void* sorted = nullptr;
+    void* hist = nullptr;      // hist[buckets] followed by cursor[buckets]
+    void* off = nullptr;       // off[buckets+1] followed by slice_off[buckets+1]
+    void* partial = nullptr;
+    void* chunk_s = nullptr;
+    void* chunk_r = nullptr;
+    void* plane_part = nullptr;
+    std::mutex mu;             // one execution at a time per context (workspace is shared)
+    ~plk_msm_ctx() {
+        for (void* p : {tab, codes, sorted, hist, off, partial, chunk_s, chunk_r, plane_part})
+            if (p) (void)hipFree(p);
+    }
+};
+
+namespace plk {
+
+static int scalar_bits(int curve) { return curve == PLK_CURVE_BLS12_377 ? 253 : 255; }
+
+static int choose_window(size_t n) {
+    int lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) ++lg;
+    int c = lg - 3;
+    if (const char* e = getenv("PLK_MSM_WINDOW")) c = atoi(e);
+    if (c < 3) c = 3;
+    if (c > 18) c = 18;
+    return c;
+}
+
+template <class C>
+static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d_zero, hipStream_t stream) {
+    using FP = typename C::FP;
+    const size_t n = ctx->n;
+    const size_t pt_bytes = (size_t)2 * FP::NL * 4, xyzz_bytes = (size_t)4 * FP::NL * 4;
+    const size_t entries = n * ctx->windows;
+    PLK_HIP_TRY(hipMalloc(&ctx->tab, entries * pt_bytes + 16));
+    PLK_HIP_TRY(hipMalloc(&ctx->codes, entries * 4 + 16));
+    PLK_HIP_TRY(hipMalloc(&ctx->sorted, entries * 4 + 16));
+    PLK_HIP_TRY(hipMalloc(&ctx->hist, (size_t)ctx->buckets * 8));
+    PLK_HIP_TRY(hipMalloc(&ctx->off, ((size_t)ctx->buckets + 1) * 8));
+    ctx->max_slices = entries / MSM_SLICE + ctx->buckets + 1;
+    PLK_HIP_TRY(hipMalloc(&ctx->partial, ctx->max_slices * xyzz_bytes));
+    PLK_HIP_TRY(hipMalloc(&ctx->chunk_s, (size_t)ctx->n_chunks * xyzz_bytes));
+    PLK_HIP_TRY(hipMalloc(&ctx->chunk_r, (size_t)ctx->n_chunks * xyzz_bytes));
+    PLK_HIP_TRY(hipMalloc(&ctx->plane_part, (size_t)(ctx->n_bits + 1) * ctx->plane_blocks * xyzz_bytes));
+    if (n) {
+        k_msm_table<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)ctx->tab, n, ctx->c,
+                                                                       ctx->windows);
+        PLK_HIP_TRY(hipGetLastError());
+    }
+    PLK_HIP_TRY(hipStreamSynchronize(stream));
+    return PLK_OK;
+}
+
+int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, hipStream_t stream,
+                            plk_msm_ctx** out_ctx) {
+    if (!out_ctx) return set_error(PLK_ERR_INVALID_ARG, "null out_ctx");
+    *out_ctx = nullptr;
+    if (curve < 0 || curve > 2) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (n && !d_bases) return set_error(PLK_ERR_INVALID_ARG, "null bases");
+    PLK_TRY(ensure_device());
+    int c = window_bits ? (int)window_bits : choose_window(n ? n : 1);
+    if (c < 2 || c > MSM_MAX_WINDOW) return set_error(PLK_ERR_INVALID_ARG, "window_bits %d outside [2, %d]", c, MSM_MAX_WINDOW);
+    auto* ctx = new plk_msm_ctx();
+    PLK_HIP_TRY(hipGetDevice(&ctx->device));
+    ctx->curve = curve;
+    ctx->n = n;
+    ctx->c = c;
+    ctx->windows = (scalar_bits(curve) + 1 + c - 1) / c;
+    ctx->buckets = 1u << (c - 1);
+    ctx->chunk_log = (c - 1) < MSM_CHUNK_LOG ? (c - 1) : MSM_CHUNK_LOG;
+    ctx->n_chunks = ctx->buckets >> ctx->chunk_log;
+    ctx->n_bits = 0;
+    while ((1u << ctx->n_bits) < ctx->n_chunks) ++ctx->n_bits;
+    ctx->plane_blocks = (int)(ctx->n_chunks / 512);
+    if (ctx->plane_blocks < 1) ctx->plane_blocks = 1;
+    if (ctx->plane_blocks > 32) ctx->plane_blocks = 32;
+    if (n * (size_t)ctx->windows >= ((size_t)1 << 31)) {
+        delete ctx;
+        return set_error(PLK_ERR_INVALID_ARG, "n * windows = %zu entries exceeds 2^31", n * (size_t)ctx->windows);
+    }
+    int rc;
+    switch (curve) {
+        case PLK_CURVE_TWEEDLEDEE: rc = msm_precompute_t<TweedledeeCurve>(ctx, d_bases, d_zero, stream); break;
+        case PLK_CURVE_TWEEDLEDUM: rc = msm_precompute_t<TweedledumCurve>(ctx, d_bases, d_zero, stream); break;
+        default: rc = msm_precompute_t<Bls12377Curve>(ctx, d_bases, d_zero, stream); break;
+    }
+    if (rc != PLK_OK) {
+        delete ctx;
+        return rc;
+    }
+    *out_ctx = ctx;
+    return PLK_OK;
+}
+
+template <class C>
+static int msm_execute_t(plk_msm_ctx* ctx, const void* d_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream) {
+    using FP = typename C::FP;
+    const size_t n = ctx->n;
+    const size_t entries = n * ctx->windows;
+    const uint32_t buckets = ctx->buckets;
+    const size_t xyzz_bytes = (size_t)4 * FP::NL * 4;
+    uint32_t* hist = (uint32_t*)ctx->hist;
+    uint32_t* cursor = hist + buckets;
+    uint32_t* off = (uint32_t*)ctx->off;
+    uint32_t* slice_off = off + buckets + 1;
+    PLK_HIP_TRY(hipMemsetAsync(ctx->hist, 0, (size_t)buckets * 8, stream));
+    if (n) {
+        k_msm_digits<C><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const uint4*)d_scalars, (uint32_t*)ctx->codes, hist, n, ctx->c, ctx->windows);
+        PLK_HIP_TRY(hipGetLastError());
+    }
+    k_msm_scan<<<1, 1024, 0, stream>>>(hist, off, slice_off, buckets);
+    PLK_HIP_TRY(hipGetLastError());
+    if (entries) {
+        k_msm_scatter<<<(unsigned)((entries + 255) / 256), 256, 0, stream>>>((const uint32_t*)ctx->codes, off, cursor, (uint32_t*)ctx->sorted, entries);
+        PLK_HIP_TRY(hipGetLastError());
+    }
+    // the slice count is only known on the device: launch for the upper bound, lanes past it exit
+    k_msm_accumulate<C><<<(unsigned)((ctx->max_slices + 127) / 128), 128, 0, stream>>>((const uint4*)ctx->tab, (const uint32_t*)ctx->sorted, off, slice_off,
+                                                                                       (uint4*)ctx->partial, buckets);
+    PLK_HIP_TRY(hipGetLastError());
+    k_msm_chunks<C><<<(ctx->n_chunks + 63) / 64, 64, 0, stream>>>((const uint4*)ctx->partial, slice_off, (uint4*)ctx->chunk_s, (uint4*)ctx->chunk_r,
+                                                                  ctx->n_chunks, ctx->chunk_log);
+    PLK_HIP_TRY(hipGetLastError());
+    dim3 pg(ctx->plane_blocks, ctx->n_bits + 1);
+    k_msm_planes<C><<<pg, 128, 128 * xyzz_bytes, stream>>>((const uint4*)ctx->chunk_s, (const uint4*)ctx->chunk_r, (uint4*)ctx->plane_part, ctx->n_chunks,
+                                                           ctx->n_bits);
+    PLK_HIP_TRY(hipGetLastError());
+    k_msm_final<C><<<1, 64, 64 * xyzz_bytes, stream>>>((const uint4*)ctx->plane_part, ctx->plane_blocks, ctx->n_bits, ctx->chunk_log, (uint4*)d_out_xy,
+                                                       (uint8_t*)d_out_zero);
+    PLK_HIP_TRY(hipGetLastError());
+    return PLK_OK;
+}
+
+int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream) {
+    if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
+    if (n_scalars != ctx->n)
+        return set_error(PLK_ERR_SIZE_MISMATCH, "scalars.len() = %zu but the precomputation holds %zu generators (curve_msm.rs:67)", n_scalars, ctx->n);
+    if (batch == 0) return PLK_OK;
+    if ((ctx->n && !d_scalars) || !d_out_xy || !d_out_zero) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
+    PLK_TRY(ensure_device());
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const size_t L = (size_t)curve_limbs(ctx->curve);
+    for (unsigned b = 0; b < batch; ++b) {
+        const uint8_t* sc = (const uint8_t*)d_scalars + (size_t)b * ctx->n * 32;
+        uint8_t* oxy = (uint8_t*)d_out_xy + (size_t)b * 2 * L * 8;
+        uint8_t* oz = (uint8_t*)d_out_zero + b;
+        int rc;
+        switch (ctx->curve) {
+            case PLK_CURVE_TWEEDLEDEE: rc = msm_execute_t<TweedledeeCurve>(ctx, sc, oxy, oz, stream); break;
+            case PLK_CURVE_TWEEDLEDUM: rc = msm_execute_t<TweedledumCurve>(ctx, sc, oxy, oz, stream); break;
+            default: rc = msm_execute_t<Bls12377Curve>(ctx, sc, oxy, oz, stream); break;
+        }
+        if (rc != PLK_OK) return rc;
+    }
+    return PLK_OK;
+}
+
+size_t msm_ctx_len(const plk_msm_ctx* ctx) { return ctx->n; }
+unsigned msm_ctx_window(const plk_msm_ctx* ctx) { return (unsigned)ctx->c; }
+int msm_ctx_curve(const plk_msm_ctx* ctx) { return ctx->curve; }
+void msm_ctx_delete(plk_msm_ctx* ctx) { delete ctx; }
+
+int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void* d_zero, void* d_out_xy, void* d_out_zero, hipStream_t stream) {
+    switch (curve) {
+#define CASE(ID, C)                                                                                                                     \
+    case ID:                                                                                                                            \
+        k_sum_affine<C><<<1, 64, 64 * 4 * C::FP::NL * 4, stream>>>((const uint4*)d_pts, (const uint8_t*)d_zero, k, (uint4*)d_out_xy,     \
+                                                                    (uint8_t*)d_out_zero);                                              \
+        break;
+        CASE(PLK_CURVE_TWEEDLEDEE, TweedledeeCurve)
+        CASE(PLK_CURVE_TWEEDLEDUM, TweedledumCurve)
+        CASE(PLK_CURVE_BLS12_377, Bls12377Curve)
+#undef CASE
+        default: return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    }
+    PLK_HIP_TRY(hipGetLastError());
+    return PLK_OK;
+}
+
+int curve_gen_bases_dev_impl(int curve, size_t n, uint64_t first, const void* d_g0d, void* d_out, hipStream_t stream) {
+    if (n == 0) return PLK_OK;
+    switch (curve) {
+#define CASE(ID, C)                                                                                                          \
+    case ID: k_gen_bases<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_g0d, (uint4*)d_out, n, first); break;
+        CASE(PLK_CURVE_TWEEDLEDEE, TweedledeeCurve)
+        CASE(PLK_CURVE_TWEEDLEDUM, TweedledumCurve)
+        CASE(PLK_CURVE_BLS12_377, Bls12377Curve)
+#undef CASE
+        default: return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    }
+    PLK_HIP_TRY(hipGetLastError());
+    return PLK_OK;
+}
+
+}  // namespace plk

@@ -1,0 +1,411 @@
+// ntt.hip -- natural-order in / natural-order out NTT over the 256-bit fields, gfx950.
+//
+// Replaces the reference's src/fft.rs:
+//   fft_precompute                         fft.rs:47-59    -> NttPlan (device twiddle tables)
+//   fft_with_precomputation_power_of_2     fft.rs:103-156  -> ntt_dev_impl(inverse = 0)
+//   ifft_with_precomputation_power_of_2    fft.rs:82-101   -> ntt_dev_impl(inverse = 1)
+//   reverse_index_bits (both of them)      fft.rs:8-26,120,155 -> absorbed into the tile indexing
+// The reference runs log n radix-2 layers with a barrier and two full array copies per layer.
+// Here the transform is a multi-pass decomposition n = A_1 * A_2 * ... * A_m (A_t <= 2^7 for
+// strided passes): pass t performs, for every contiguous block of N_t = A_t * S_t elements and
+// every residual index r < S_t, an A_t-point NTT over the stride-S_t column, multiplies by the
+// inter-pass twiddle w_{N_t}^(r k) and stores in place; the last pass works on contiguous
+// blocks and scatters to the digit-reversed final position.  Each workgroup owns a
+// [A_t x Q] tile (1024 elements, 32 KiB of LDS) so that every global access is a run of
+// Q * 32 B (>= 256 B) contiguous bytes; the A_t-point NTTs run as radix-2 DIF stages inside
+// LDS with the stage twiddles staged in LDS, output un-bit-reversed by the store indexing.
+// out[j] = sum_k in[k] w^(jk), w = primitive_root_of_unity(log n) (field.rs:429-435): the same
+// function the reference computes, and field elements have a unique representation, so the
+// limbs are bit-identical.  iNTT = the same passes with w^-1 tables and n^-1 folded into the
+// first inter-pass twiddle table (instead of the index-reversal trick of fft.rs:90-99).
+#include <map>
+#include <memory>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "common.h"
+#include "fp.cuh"
+
+namespace plk {
+
+constexpr int TILE_LOG = 10;             // elements per workgroup tile
+constexpr int TILE = 1 << TILE_LOG;
+constexpr int NTT_THREADS = 256;
+constexpr int MAX_PASSES = 6;
+constexpr int INNER_LOG = 10;            // inner twiddle table: w_1024^e, e < 512
+
+struct NttPassArgs {
+    int log_n;        // whole transform
+    int log_a;        // this pass: NTT length A = 2^log_a
+    int log_q;        // columns per tile, Q = 2^log_q
+    int log_nt;       // N_t: size of the contiguous sub-problem blocks of this pass
+    int log_s;        // S_t = N_t / A_t
+    int last;         // 1: last pass (contiguous blocks in, digit-reversed scatter out)
+    int n_prev;       // number of earlier passes (last pass only)
+    int prev_log[MAX_PASSES];  // their log sizes a_1..a_{m-1}
+    int scale;        // 1: multiply outputs by *scale_ptr (single-pass inverse)
+};
+
+// ---------------------------------------------------------------------------------------------
+// table generation
+// ---------------------------------------------------------------------------------------------
+// pw[b]      = w^(2^b),   b < log_t, w = primitive 2^log_t-th root (ROOT_2ADIC^(2^(adicity-log_t)))
+// pw[32+b]   = w^-(2^b)
+// pw[64]     = 2^-log_n in Montgomery form (n^-1)
+template <class P> __global__ void k_ntt_pow2(uint4* pw, int log_t, int log_n) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Fe<P> w;
+#pragma unroll
+    for (int i = 0; i < P::NL; ++i) w.v[i] = P::ROOT_2ADIC[i];
+    for (int i = 0; i < P::TWO_ADICITY - log_t; ++i) w = fe_sqr<P>(w);
+    Fe<P> cur = w, winv = fe_one<P>();
+    for (int b = 0; b < log_t; ++b) {
+        fe_store<P>(pw + b * 2, cur);
+        winv = fe_mul<P>(winv, cur);  // w^(2^log_t - 1) = w^-1
+        cur = fe_sqr<P>(cur);
+    }
+    cur = winv;
+    for (int b = 0; b < log_t; ++b) {
+        fe_store<P>(pw + (32 + b) * 2, cur);
+        cur = fe_sqr<P>(cur);
+    }
+    Fe<P> ninv = fe_one<P>();
+    for (int i = 0; i < log_n; ++i) ninv = fe_half<P>(ninv);
+    fe_store<P>(pw + 64 * 2, ninv);
+}
+
+template <class P> PLK_DI Fe<P> pow_from_table(const uint4* pw, int base_off, uint64_t e, int log_t) {
+    Fe<P> r = fe_one<P>();
+    for (int b = 0; b < log_t; ++b)
+        if ((e >> b) & 1) r = fe_mul<P>(r, fe_load<P>(pw + (base_off + b) * 2));
+    return r;
+}
+
+// inner table: tw[e] = w_1024^(+-e), e < 512, expressed through the 2^log_t-th root
+template <class P> __global__ void k_ntt_fill_inner(uint4* tw, const uint4* pw, int log_t, int inverse) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (1 << (INNER_LOG - 1))) return;
+    uint64_t ex = (uint64_t)e << (log_t - INNER_LOG);
+    fe_store<P>(tw + e * 2, pow_from_table<P>(pw, inverse ? 32 : 0, ex, log_t));
+}
+// outer table of a pass: W[k * S + r] = w_{N_t}^(+- r k) (* n^-1 when scale != 0)
+template <class P> __global__ void k_ntt_fill_outer(uint4* tw, const uint4* pw, int log_t, int log_nt, int log_s, int inverse, int scale) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ((size_t)1 << log_nt)) return;
+    uint64_t r = idx & (((uint64_t)1 << log_s) - 1);
+    uint64_t k = idx >> log_s;
+    uint64_t ex = (r * k) & (((uint64_t)1 << log_nt) - 1);
+    ex <<= (log_t - log_nt);
+    Fe<P> v = pow_from_table<P>(pw, inverse ? 32 : 0, ex, log_t);
+    if (scale) v = fe_mul<P>(v, fe_load<P>(pw + 64 * 2));
+    fe_store<P>(tw + idx * 2, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the pass kernel
+// ---------------------------------------------------------------------------------------------
+PLK_DI uint32_t bitrev(uint32_t x, int bits) { return bits == 0 ? 0u : (__brev(x) >> (32 - bits)); }
+
+template <class P>
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restrict__ in, uint4* __restrict__ out,
+                                                          const uint4* __restrict__ inner_tw, const uint4* __restrict__ outer_tw,
+                                                          const uint4* __restrict__ scale_ptr, NttPassArgs a) {
+    static_assert(P::NL == 8, "NTT kernels are written for the 256-bit fields");
+    // element e of the tile lives in lo[e] (limbs 0-3) and hi[e] (limbs 4-7): consecutive lanes
+    // touch consecutive 16-byte slots -> conflict-free ds_read_b128 / ds_write_b128
+    __shared__ uint4 s_lo[TILE];
+    __shared__ uint4 s_hi[TILE];
+    __shared__ uint4 s_tw[TILE];  // A/2 stage twiddles (lo at [2e], hi at [2e+1])
+
+    const int tid = threadIdx.x;
+    const int log_a = a.log_a, log_q = a.log_q;
+    const int A = 1 << log_a, Q = 1 << log_q;
+    const int tile_elems = A << log_q;
+    const size_t n = (size_t)1 << a.log_n;
+
+    // ---- which tile ----
+    // tiles per transform = n / tile_elems; blockIdx.x enumerates (batch, tile)
+    const size_t tiles_per = n >> (log_a + log_q);
+    const size_t b = blockIdx.x / tiles_per;
+    const size_t tile = blockIdx.x % tiles_per;
+    const uint4* inb = in + b * n * 2;
+    uint4* outb = out + b * n * 2;
+
+    size_t blk_base = 0, r0 = 0, ol0 = 0;
+    if (!a.last) {
+        // tile -> (kprev, rtile): rtile fastest
+        const size_t rtiles = ((size_t)1 << a.log_s) >> log_q;
+        const size_t kprev = tile / rtiles;
+        r0 = (tile % rtiles) << log_q;
+        blk_base = kprev << a.log_nt;
+    } else {
+        ol0 = tile << log_q;
+    }
+
+    // stage twiddles: w_A^e = inner[e * (1024 / A)], e < A/2
+    for (int e = tid; e < (A >> 1); e += NTT_THREADS) {
+        const uint4* src = inner_tw + ((size_t)e << (INNER_LOG - log_a)) * 2;
+        s_tw[2 * e] = src[0];
+        s_tw[2 * e + 1] = src[1];
+    }
+
+    // ---- load ----
+    for (int e = tid; e < tile_elems; e += NTT_THREADS) {
+        const int q = e & (Q - 1), p = e >> log_q;
+        size_t g;
+        if (!a.last) {
+            g = blk_base + ((size_t)p << a.log_s) + r0 + q;
+        } else {
+            // column q of the tile is the block whose output-low index is ol0 + q; blocks are stored
+            // with k_1 most significant (kprev), the output wants k_1 least significant
+            size_t ol = ol0 + q, kprev = 0;
+            for (int t = 0; t < a.n_prev; ++t) {
+                kprev = (kprev << a.prev_log[t]) | (ol & (((size_t)1 << a.prev_log[t]) - 1));
+                ol >>= a.prev_log[t];
+            }
+            g = (kprev << log_a) + p;
+        }
+        s_lo[e] = inb[g * 2];
+        s_hi[e] = inb[g * 2 + 1];
+    }
+    __syncthreads();
+
+    // ---- A-point radix-2 DIF NTT on each of the Q columns ----
+    for (int log_h = log_a - 1; log_h >= 0; --log_h) {
+        const int h = 1 << log_h;
+        for (int bf = tid; bf < (tile_elems >> 1); bf += NTT_THREADS) {
+            const int q = bf & (Q - 1), pb = bf >> log_q;
+            const int j = pb & (h - 1), blk = pb >> log_h;
+            const int p0 = (blk << (log_h + 1)) + j;
+            const int i0 = (p0 << log_q) + q, i1 = i0 + (h << log_q);
+            Fe<P> x, y;
+            {
+                uint4 l0 = s_lo[i0], h0 = s_hi[i0], l1 = s_lo[i1], h1 = s_hi[i1];
+                x.v[0] = l0.x; x.v[1] = l0.y; x.v[2] = l0.z; x.v[3] = l0.w;
+                x.v[4] = h0.x; x.v[5] = h0.y; x.v[6] = h0.z; x.v[7] = h0.w;
+                y.v[0] = l1.x; y.v[1] = l1.y; y.v[2] = l1.z; y.v[3] = l1.w;
+                y.v[4] = h1.x; y.v[5] = h1.y; y.v[6] = h1.z; y.v[7] = h1.w;
+            }
+            Fe<P> s = fe_add<P>(x, y);
+            Fe<P> d = fe_sub<P>(x, y);
+            if (log_h > 0) {
+                const int te = j << (log_a - 1 - log_h);  // w_{2h}^j = w_A^(j * A / 2h)
+                uint4 tl = s_tw[2 * te], th = s_tw[2 * te + 1];
+                Fe<P> w;
+                w.v[0] = tl.x; w.v[1] = tl.y; w.v[2] = tl.z; w.v[3] = tl.w;
+                w.v[4] = th.x; w.v[5] = th.y; w.v[6] = th.z; w.v[7] = th.w;
+                d = fe_mul<P>(d, w);
+            }
+            s_lo[i0] = make_uint4(s.v[0], s.v[1], s.v[2], s.v[3]);
+            s_hi[i0] = make_uint4(s.v[4], s.v[5], s.v[6], s.v[7]);
+            s_lo[i1] = make_uint4(d.v[0], d.v[1], d.v[2], d.v[3]);
+            s_hi[i1] = make_uint4(d.v[4], d.v[5], d.v[6], d.v[7]);
+        }
+        __syncthreads();
+    }
+
+    // ---- store: position p holds output index k = bitrev(p) ----
+    for (int e = tid; e < tile_elems; e += NTT_THREADS) {
+        const int q = e & (Q - 1), p = e >> log_q;
+        const uint32_t k = bitrev((uint32_t)p, log_a);
+        uint4 l = s_lo[e], hh = s_hi[e];
+        size_t g;
+        if (!a.last) {
+            const size_t r = r0 + q;
+            g = blk_base + ((size_t)k << a.log_s) + r;
+            Fe<P> v, w;
+            v.v[0] = l.x; v.v[1] = l.y; v.v[2] = l.z; v.v[3] = l.w;
+            v.v[4] = hh.x; v.v[5] = hh.y; v.v[6] = hh.z; v.v[7] = hh.w;
+            w = fe_load<P>(outer_tw + (((size_t)k << a.log_s) + r) * 2);
+            v = fe_mul<P>(v, w);
+            l = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+            hh = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+        } else {
+            g = (ol0 + q) + ((size_t)k << (a.log_n - log_a));
+            if (a.scale) {
+                Fe<P> v, w;
+                v.v[0] = l.x; v.v[1] = l.y; v.v[2] = l.z; v.v[3] = l.w;
+                v.v[4] = hh.x; v.v[5] = hh.y; v.v[6] = hh.z; v.v[7] = hh.w;
+                w = fe_load<P>(scale_ptr);
+                v = fe_mul<P>(v, w);
+                l = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+                hh = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+            }
+        }
+        outb[g * 2] = l;
+        outb[g * 2 + 1] = hh;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// plans + cache
+// ---------------------------------------------------------------------------------------------
+struct NttPlan {
+    int field = 0, log_n = 0, device = 0;
+    std::vector<int> pass_log;            // a_1 .. a_m
+    void* pw = nullptr;                   // 65 elements (see k_ntt_pow2)
+    void* inner[2] = {nullptr, nullptr};  // forward / inverse stage twiddles
+    std::vector<void*> outer[2];          // per non-last pass
+    ~NttPlan() {
+        if (pw) (void)hipFree(pw);
+        for (int d = 0; d < 2; ++d) {
+            if (inner[d]) (void)hipFree(inner[d]);
+            for (void* p : outer[d])
+                if (p) (void)hipFree(p);
+        }
+    }
+};
+
+static std::vector<int> plan_passes(int log_n) {
+    std::vector<int> v;
+    if (log_n <= TILE_LOG) {
+        v.push_back(log_n);
+        return v;
+    }
+    const int MAX_A = 7;  // strided passes: Q = 1024 / A >= 8 columns = 256-byte runs
+    int m = (log_n + MAX_A - 1) / MAX_A;
+    int base = log_n / m, extra = log_n % m;
+    for (int t = 0; t < m; ++t) v.push_back(base + (t < extra ? 1 : 0));
+    return v;
+}
+
+static std::mutex g_plan_mu;
+static std::map<std::tuple<int, int, int>, std::shared_ptr<NttPlan>> g_plans;
+
+template <class P> static int build_plan_t(NttPlan& pl) {
+    const int log_n = pl.log_n;
+    const int log_t = log_n > INNER_LOG ? log_n : INNER_LOG;
+    if (log_t > P::TWO_ADICITY) return set_error(PLK_ERR_TWO_ADICITY, "log_n %d exceeds the field's 2-adicity %d", log_n, P::TWO_ADICITY);
+    PLK_HIP_TRY(hipMalloc(&pl.pw, 65 * 32));
+    k_ntt_pow2<P><<<1, 64>>>((uint4*)pl.pw, log_t, log_n);
+    PLK_HIP_TRY(hipGetLastError());
+    const int m = (int)pl.pass_log.size();
+    for (int dir = 0; dir < 2; ++dir) {
+        PLK_HIP_TRY(hipMalloc(&pl.inner[dir], (size_t)(1 << (INNER_LOG - 1)) * 32));
+        k_ntt_fill_inner<P><<<2, 256>>>((uint4*)pl.inner[dir], (const uint4*)pl.pw, log_t, dir);
+        PLK_HIP_TRY(hipGetLastError());
+        int log_nt = log_n;
+        for (int t = 0; t + 1 < m; ++t) {
+            const int log_s = log_nt - pl.pass_log[t];
+            void* tab = nullptr;
+            PLK_HIP_TRY(hipMalloc(&tab, ((size_t)1 << log_nt) * 32));
+            pl.outer[dir].push_back(tab);
+            const size_t cnt = (size_t)1 << log_nt;
+            k_ntt_fill_outer<P><<<(unsigned)((cnt + 255) / 256), 256>>>((uint4*)tab, (const uint4*)pl.pw, log_t, log_nt, log_s, dir,
+                                                                        (dir == 1 && t == 0) ? 1 : 0);
+            PLK_HIP_TRY(hipGetLastError());
+            log_nt = log_s;
+        }
+    }
+    PLK_HIP_TRY(hipDeviceSynchronize());
+    return PLK_OK;
+}
+
+static int get_plan(int field, unsigned log_n, std::shared_ptr<NttPlan>& out) {
+    PLK_TRY(ensure_device());
+    int dev = 0;
+    PLK_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto key = std::make_tuple(dev, field, (int)log_n);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) {
+        out = it->second;
+        return PLK_OK;
+    }
+    auto pl = std::make_shared<NttPlan>();
+    pl->field = field;
+    pl->log_n = (int)log_n;
+    pl->device = dev;
+    pl->pass_log = plan_passes((int)log_n);
+    int rc;
+    switch (field) {
+        case PLK_FIELD_TWEEDLEDEE_BASE: rc = build_plan_t<TweedledeeBaseParams>(*pl); break;
+        case PLK_FIELD_TWEEDLEDUM_BASE: rc = build_plan_t<TweedledumBaseParams>(*pl); break;
+        case PLK_FIELD_BLS12_377_SCALAR: rc = build_plan_t<Bls12377ScalarParams>(*pl); break;
+        default: return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
+    }
+    if (rc != PLK_OK) return rc;
+    g_plans[key] = pl;
+    out = pl;
+    return PLK_OK;
+}
+
+int ntt_precompute_impl(int field, unsigned log_n) {
+    if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
+    std::shared_ptr<NttPlan> pl;
+    return get_plan(field, log_n, pl);
+}
+
+int ntt_clear_cache_impl() {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    g_plans.clear();
+    return PLK_OK;
+}
+
+template <class P>
+static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void* d_in, void* d_out, hipStream_t stream) {
+    const int log_n = pl.log_n;
+    const int m = (int)pl.pass_log.size();
+    const int dir = inverse ? 1 : 0;
+    if (log_n == 0) {
+        if (d_in != d_out) PLK_HIP_TRY(hipMemcpyAsync(d_out, d_in, (size_t)batch * 32, hipMemcpyDeviceToDevice, stream));
+        return PLK_OK;
+    }
+    // The last pass is a transposition (reads contiguous blocks, writes digit-reversed), so with
+    // m >= 2 passes it cannot run in place: passes 1..m-1 work in a stream-ordered scratch
+    // buffer and the last pass writes the caller's output.
+    void* scratch = nullptr;
+    if (m >= 2) PLK_HIP_TRY(hipMallocAsync(&scratch, ((size_t)batch << log_n) * 32, stream));
+    int log_nt = log_n;
+    const void* src = d_in;
+    int rc = PLK_OK;
+    for (int t = 0; t < m; ++t) {
+        NttPassArgs a{};
+        a.log_n = log_n;
+        a.log_a = pl.pass_log[t];
+        a.log_nt = log_nt;
+        a.log_s = log_nt - a.log_a;
+        a.last = (t == m - 1) ? 1 : 0;
+        a.log_q = TILE_LOG - a.log_a;
+        if (a.last) {
+            const int log_blocks = log_n - a.log_a;  // number of contiguous blocks
+            if (a.log_q > log_blocks) a.log_q = log_blocks;
+            a.n_prev = m - 1;
+            for (int s = 0; s < m - 1; ++s) a.prev_log[s] = pl.pass_log[s];
+        } else if (a.log_q > a.log_s) {
+            a.log_q = a.log_s;
+        }
+        a.scale = (inverse && m == 1) ? 1 : 0;
+        const size_t tiles = (((size_t)1 << log_n) >> (a.log_a + a.log_q)) * batch;
+        const void* outer = a.last ? nullptr : pl.outer[dir][t];
+        void* dst = a.last ? d_out : scratch;
+        k_ntt_pass<P><<<(unsigned)tiles, NTT_THREADS, 0, stream>>>((const uint4*)src, (uint4*)dst, (const uint4*)pl.inner[dir],
+                                                                 (const uint4*)outer, (const uint4*)pl.pw + 64 * 2, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            rc = set_error(PLK_ERR_HIP, "ntt pass launch failed: %s", hipGetErrorString(e));
+            break;
+        }
+        src = dst;
+        log_nt = a.log_s;
+    }
+    if (scratch) PLK_HIP_TRY(hipFreeAsync(scratch, stream));
+    return rc;
+}
+
+int ntt_dev_impl(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, hipStream_t stream) {
+    if (!d_in || !d_out) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
+    if (batch == 0) return PLK_OK;
+    if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
+    std::shared_ptr<NttPlan> pl;
+    PLK_TRY(get_plan(field, log_n, pl));
+    switch (field) {
+        case PLK_FIELD_TWEEDLEDEE_BASE: return run_plan_t<TweedledeeBaseParams>(*pl, inverse, batch, d_in, d_out, stream);
+        case PLK_FIELD_TWEEDLEDUM_BASE: return run_plan_t<TweedledumBaseParams>(*pl, inverse, batch, d_in, d_out, stream);
+        case PLK_FIELD_BLS12_377_SCALAR: return run_plan_t<Bls12377ScalarParams>(*pl, inverse, batch, d_in, d_out, stream);
+    }
+    return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
+}
+
+}  // namespace plk

@@ -1,0 +1,84 @@
+"""Device-resident entry points (torch tensors as HBM buffers, raw pointers into the C ABI).
+
+PyTorch is plumbing here: it owns device memory and streams; every computation is a call into
+libplonky_hip.so.  Tensors are int64 views of the reference's u64 limbs, shape (..., L).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .api import _CURVE_LIMBS, _FIELD_LIMBS, MsmPrecomputation, log2_strict
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def init(device_index=None):
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    torch.cuda.set_device(device_index)
+    _lib.check(_lib.load().plk_init(int(device_index)))
+    return device_index
+
+
+def to_device(arr, device="cuda"):
+    a = np.ascontiguousarray(arr, dtype=np.uint64)
+    return torch.from_numpy(a.view(np.int64)).to(device)
+
+
+def to_host(t):
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+def ntt_dev(field, x, inverse=False, out=None):
+    """x: (batch, n, 4) or (n, 4) int64 CUDA tensor; returns the transforms (natural order)."""
+    assert x.is_cuda and x.dtype == torch.int64 and x.is_contiguous()
+    assert x.shape[-1] == _FIELD_LIMBS[field] == 4
+    n = x.shape[-2]
+    batch = x.numel() // (n * 4)
+    log_n = log2_strict(n)
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.load().plk_ntt_dev(field, log_n, 1 if inverse else 0, batch, ctypes.c_void_p(x.data_ptr()),
+                                       ctypes.c_void_p(out.data_ptr()), _stream()))
+    return out
+
+
+def gen_bases_dev(curve, n, g0_xy, d_xy, first=0, device="cuda"):
+    """B_i = G0 + (first + i) D on the device: (n, 2, L) int64 tensor."""
+    L = _CURVE_LIMBS[curve]
+    out = torch.empty((n, 2, L), dtype=torch.int64, device=device)
+    g0 = np.ascontiguousarray(g0_xy, dtype=np.uint64)
+    d = np.ascontiguousarray(d_xy, dtype=np.uint64)
+    _lib.check(_lib.load().plk_curve_gen_bases_dev(curve, n, first, g0.ctypes.data_as(ctypes.c_void_p), d.ctypes.data_as(ctypes.c_void_p),
+                                                   ctypes.c_void_p(out.data_ptr()), _stream()))
+    return out
+
+
+def msm_precompute_dev(curve, bases, w=11, zero=None, device_window=0):
+    """bases: (n, 2, L) int64 CUDA tensor."""
+    assert bases.is_cuda and bases.dtype == torch.int64 and bases.is_contiguous()
+    n = bases.shape[0]
+    ctx = ctypes.c_void_p()
+    zp = ctypes.c_void_p(zero.data_ptr()) if zero is not None else None
+    _lib.check(_lib.load().plk_msm_precompute_dev(curve, n, ctypes.c_void_p(bases.data_ptr()), zp, device_window, _stream(), ctypes.byref(ctx)))
+    return MsmPrecomputation(curve, ctx, n, w)
+
+
+def msm_execute_dev(pre, scalars, out_xy=None, out_zero=None):
+    """scalars: (batch, n, 4) or (n, 4) int64 CUDA tensor.  Returns (out_xy (batch, 2, L), out_zero (batch,)) on device."""
+    assert scalars.is_cuda and scalars.dtype == torch.int64 and scalars.is_contiguous()
+    n = scalars.shape[-2]
+    assert n == pre.n, "powers_per_generator.len() != scalars.len()"
+    batch = scalars.numel() // (n * 4) if n else 1
+    L = _CURVE_LIMBS[pre.curve]
+    if out_xy is None:
+        out_xy = torch.empty((batch, 2, L), dtype=torch.int64, device=scalars.device)
+    if out_zero is None:
+        out_zero = torch.empty((batch,), dtype=torch.uint8, device=scalars.device)
+    _lib.check(_lib.load().plk_msm_execute_dev(pre._ctx, batch, ctypes.c_void_p(scalars.data_ptr()), n, ctypes.c_void_p(out_xy.data_ptr()),
+                                               ctypes.c_void_p(out_zero.data_ptr()), _stream()))
+    return out_xy, out_zero

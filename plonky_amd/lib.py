@@ -1,0 +1,89 @@
+"""ctypes loader for libplonky_hip.so -- the C ABI of include/plonky_hip.h.
+
+There is deliberately NO fallback: if the shared library is missing or a call fails the
+caller gets an exception.  Nothing here imports the oracle.
+"""
+import ctypes
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+SO_PATH = os.path.join(_CSRC, "libplonky_hip.so")
+
+PLK_OK = 0
+PLK_ERR_INVALID_ARG = -1
+PLK_ERR_SIZE_MISMATCH = -2
+PLK_ERR_NOT_POW2 = -3
+PLK_ERR_TWO_ADICITY = -4
+PLK_ERR_HIP = -5
+PLK_ERR_NO_DEVICE = -6
+PLK_ERR_OOM = -7
+
+# every symbol declared in include/plonky_hip.h: (name, restype, argtypes)
+_vp, _i, _u, _sz, _u64, _cp = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_char_p
+SYMBOLS = [
+    ("plk_init", _i, [_i]),
+    ("plk_shutdown", None, []),
+    ("plk_last_error", _cp, []),
+    ("plk_field_limbs", _i, [_i]),
+    ("plk_curve_limbs", _i, [_i]),
+    ("plk_curve_scalar_field", _i, [_i]),
+    ("plk_ntt_precompute", _i, [_i, _u]),
+    ("plk_ntt_clear_cache", _i, []),
+    ("plk_ntt", _i, [_i, _u, _i, _vp, _vp]),
+    ("plk_ntt_batch", _i, [_i, _u, _i, _u, _vp, _vp]),
+    ("plk_ntt_dev", _i, [_i, _u, _i, _u, _vp, _vp, _vp]),
+    ("plk_ntt_padded", _i, [_i, _u, _vp, _sz, _vp]),
+    ("plk_msm_precompute", _i, [_i, _sz, _vp, _vp, _u, _vp]),
+    ("plk_msm_precompute_dev", _i, [_i, _sz, _vp, _vp, _u, _vp, _vp]),
+    ("plk_msm_free", _i, [_vp]),
+    ("plk_msm_ctx_len", _sz, [_vp]),
+    ("plk_msm_ctx_window", _u, [_vp]),
+    ("plk_msm_execute", _i, [_vp, _vp, _sz, _vp, _vp]),
+    ("plk_msm_execute_batch", _i, [_vp, _u, _vp, _sz, _vp, _vp]),
+    ("plk_msm_execute_dev", _i, [_vp, _u, _vp, _sz, _vp, _vp, _vp]),
+    ("plk_msm", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
+    ("plk_curve_sum_affine", _i, [_i, _sz, _vp, _vp, _vp, _vp]),
+    ("plk_field_op", _i, [_i, _i, _vp, _vp, _vp, _sz]),
+    ("plk_curve_gen_bases_dev", _i, [_i, _sz, _u64, _vp, _vp, _vp, _vp]),
+]
+
+
+class PlonkyHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libplonky_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(force=False):
+    """Compile libplonky_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", _CSRC, "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return SO_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(the HIP path has no CPU fallback)" % SO_PATH)
+        L = ctypes.CDLL(SO_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != PLK_OK:
+        raise PlonkyHipError(rc, load().plk_last_error().decode("utf-8", "replace"))
+    return rc

@@ -1,0 +1,308 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/plonky_hip.h) against the oracle.
+
+Bit-exact on integer limbs everywhere.  The tests read like the reference's own unit tests
+(src/fft.rs:164-232, src/curve/curve_msm.rs:186-241, src/curve/curve_summations.rs:164-184,
+src/field/field.rs:618-780) with the reference call replaced by the plonky_amd mirror.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import plonky_amd as pa
+from plonky_amd import api, synth
+from oracle import bigint_ref as br
+from oracle import oracle_lib as ol
+from tests.test_oracle_kats import (MSM_KAT_X_MONT, MSM_KAT_Y_MONT, _bls_test_msm_inputs, from_mont_arr, mont_arr,
+                                    reference_test_inputs)
+from tests.util import ints_to_array, limbs_to_int
+
+FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.BLS12_377_BASE]
+NTT_FIELDS = FIELDS[:3]
+CURVES = [br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377]
+
+
+# ---------------- field arithmetic: the reference's test_arithmetic! sweep on the device ----------------
+@pytest.mark.parametrize("f", FIELDS, ids=lambda f: f.name)
+def test_device_field_arithmetic_sweep(f):
+    inputs = reference_test_inputs(f.p)
+    m = len(inputs)
+    x = mont_arr(f, inputs)
+    for op in ("neg", "square", "to_canonical", "from_canonical"):
+        assert np.array_equal(api.field_op(f.field_id, op, x), ol.field_unop(f.field_id, op, x)), op
+    a = x[np.repeat(np.arange(m), m)]
+    b = x[np.tile(np.arange(m), m)]
+    for op in ("add", "sub", "mul"):
+        assert np.array_equal(api.field_op(f.field_id, op, a, b), ol.field_binop(f.field_id, op, a, b)), op
+
+
+@pytest.mark.parametrize("f", FIELDS, ids=lambda f: f.name)
+def test_device_field_inverse_and_random(f):
+    x = synth.rand_field(f.field_id, 0x1234, 4096)
+    y = synth.rand_field(f.field_id, 0x5678, 4096)
+    for op in ("add", "sub", "mul"):
+        assert np.array_equal(api.field_op(f.field_id, op, x, y), ol.field_binop(f.field_id, op, x, y))
+    small = mont_arr(f, list(range(0, 25)))
+    assert np.array_equal(api.field_op(f.field_id, "inverse", small), ol.field_unop(f.field_id, "inverse", small))
+    assert np.array_equal(api.field_op(f.field_id, "inverse", x[:256]), ol.field_unop(f.field_id, "inverse", x[:256]))
+
+
+# ---------------- NTT ----------------
+def test_fft_and_ifft():
+    """fft.rs:164-185 verbatim: degree 200, coeffs i*1337 % 100 in Bls12377Scalar."""
+    f = br.BLS12_377_SCALAR
+    degree = 200
+    degree_padded = 1 << pa.log2_ceil(degree)
+    coefficients = mont_arr(f, [(i * 1337) % 100 for i in range(degree)])
+    precomputation = pa.fft_precompute(pa.BLS12_377_SCALAR, degree)
+    assert precomputation.size() == 256
+    points = pa.fft_with_precomputation(coefficients, precomputation)
+    expected = br.ntt_naive(f, [(i * 1337) % 100 for i in range(degree)] + [0] * (degree_padded - degree))
+    assert from_mont_arr(f, points) == expected
+    interpolated = pa.ifft_with_precomputation_power_of_2(points, precomputation)
+    assert np.array_equal(interpolated[:degree], coefficients)
+    assert not interpolated[degree:].any()
+    # and limb-for-limb the oracle's (= the reference algorithm's) output
+    opre = ol.FftPrecomputation(2, degree)
+    assert np.array_equal(points, opre.fft_with_precomputation(coefficients))
+    assert np.array_equal(interpolated, opre.ifft_with_precomputation_power_of_2(points))
+
+
+@pytest.mark.parametrize("f", NTT_FIELDS, ids=lambda f: f.name)
+@pytest.mark.parametrize("log_n", list(range(0, 15)) + [16])
+def test_ntt_matches_oracle(f, log_n):
+    n = 1 << log_n
+    x = synth.rand_field(f.field_id, 0xF70000 + log_n, n)
+    pre = pa.fft_precompute(f.field_id, n)
+    opre = ol.FftPrecomputation(f.field_id, n)
+    fwd = pa.fft_with_precomputation_power_of_2(x, pre)
+    assert np.array_equal(fwd, opre.fft_with_precomputation_power_of_2(x, threads=4))
+    inv = pa.ifft_with_precomputation_power_of_2(x, pre)
+    assert np.array_equal(inv, opre.ifft_with_precomputation_power_of_2(x, threads=4))
+    assert np.array_equal(pa.ifft_with_precomputation_power_of_2(fwd, pre), x)
+
+
+def test_ntt_config1_2p14_golden():
+    """BASELINE config 1 shape (benches/fft.rs: TweedledeeBase, 2^14), seed 0xF70014."""
+    x = synth.rand_field(0, 0xF70014, 1 << 14)
+    pre = pa.fft_precompute(0, 1 << 14)
+    out = pa.fft_with_precomputation_power_of_2(x, pre)
+    assert np.array_equal(out, ol.FftPrecomputation(0, 1 << 14).fft_with_precomputation_power_of_2(x, threads=4))
+
+
+def test_ntt_2p20_full_size():
+    """BASELINE config 2: 2^20 TweedledeeBase, forward + inverse, bit-exact vs the oracle."""
+    n = 1 << 20
+    x = synth.rand_field(0, 0xF70020, n)
+    pre = pa.fft_precompute(0, n)
+    opre = ol.FftPrecomputation(0, n)
+    fwd = pa.fft_with_precomputation_power_of_2(x, pre)
+    assert np.array_equal(fwd, opre.fft_with_precomputation_power_of_2(x, threads=8))
+    inv = pa.ifft_with_precomputation_power_of_2(fwd, pre)
+    assert np.array_equal(inv, x)
+
+
+def test_ntt_linearity_and_batch_2p18():
+    """size-independent properties: NTT(a + b) = NTT(a) + NTT(b); batched == one by one."""
+    f = br.TWEEDLEDUM_BASE
+    n = 1 << 18
+    a = synth.rand_field(1, 11, n)
+    b = synth.rand_field(1, 12, n)
+    s = api.field_op(1, "add", a, b)
+    out = api.fft_batch(1, np.stack([a, b, s]))
+    assert np.array_equal(api.field_op(1, "add", out[0], out[1]), out[2])
+    pre = pa.fft_precompute(1, n)
+    assert np.array_equal(out[0], pa.fft_with_precomputation_power_of_2(a, pre))
+    back = api.fft_batch(1, out, inverse=True)
+    assert np.array_equal(back[0], a) and np.array_equal(back[1], b)
+
+
+def test_ntt_padding_and_errors():
+    f = br.TWEEDLEDEE_BASE
+    x = synth.rand_field(0, 5, 37)
+    pre = pa.fft_precompute(0, 37)
+    out = pa.fft_with_precomputation(x, pre)
+    padded = np.zeros((64, 4), dtype=np.uint64)
+    padded[:37] = x
+    assert np.array_equal(out, pa.fft_with_precomputation_power_of_2(padded, pre))
+    with pytest.raises(AssertionError):  # log2_strict panics (util.rs:17)
+        pa.fft_with_precomputation_power_of_2(x, pre)
+    with pytest.raises(AssertionError):  # field.rs:430
+        pa.fft_precompute(1, 1 << 34)
+    # the raw C ABI reports codes instead of aborting
+    from plonky_amd import lib
+    L = lib.load()
+    assert L.plk_ntt(3, 4, 0, x.ctypes.data, x.ctypes.data) == lib.PLK_ERR_INVALID_ARG
+    assert L.plk_ntt(0, 4, 0, None, None) == lib.PLK_ERR_INVALID_ARG
+    assert L.plk_ntt(0, 31, 0, x.ctypes.data, x.ctypes.data) == lib.PLK_ERR_TWO_ADICITY
+    assert len(L.plk_last_error()) > 0
+
+
+# ---------------- MSM ----------------
+def _bases(c, pts):
+    return np.array([[c.base.mont_limbs(P[0]), c.base.mont_limbs(P[1])] for P in pts], dtype=np.uint64).reshape(-1, 2, c.base.n_limbs)
+
+
+def test_msm():
+    """curve_msm.rs:218-241: BLS12-377, generators G, 2G, 3G, the three fixed scalars, w = 5."""
+    c, pts, scal = _bls_test_msm_inputs()
+    generators = _bases(c, pts)
+    scalars = mont_arr(c.scalar, scal)
+    precomputation = pa.msm_precompute(pa.BLS12_377, generators, 5)
+    result_msm, zero = pa.msm_execute(precomputation, scalars)
+    assert zero == 0
+    assert list(result_msm[0]) == MSM_KAT_X_MONT and list(result_msm[1]) == MSM_KAT_Y_MONT
+    # result_naive: sum of naive scalar multiplications (oracle's mul_naive)
+    exp = br.msm(c, scal, pts)
+    assert tuple(from_mont_arr(c.base, result_msm)) == exp
+    for win in (2, 3, 5, 8, 13):
+        pre = pa.msm_precompute(pa.BLS12_377, generators, 5, device_window=win)
+        r, z = pa.msm_execute_parallel(pre, scalars)
+        assert z == 0 and np.array_equal(r, result_msm), win
+
+
+def test_msm_tweedledee_mini_kat():
+    c = br.TWEEDLEDEE
+    G = (c.gx, c.gy)
+    pts = [G, br.ec_mul(c, 2, G), br.ec_mul(c, 3, G)]
+    pre = pa.msm_precompute(pa.TWEEDLEDEE, _bases(c, pts), 11)
+    out, zero = pa.msm_execute(pre, mont_arr(c.scalar, [1, 2, 3]))
+    assert zero == 0 and tuple(from_mont_arr(c.base, out)) == br.ec_mul(c, 14, G)
+    assert list(synth.to_limbs(br.ec_mul(c, 14, G)[0], 4)) == [14704193998986281273, 16806378273837548806, 1462211411981937090, 3084878336663070809]
+
+
+def test_msm_length_mismatch():
+    c, pts, scal = _bls_test_msm_inputs()
+    pre = pa.msm_precompute(pa.BLS12_377, _bases(c, pts), 5)
+    with pytest.raises(AssertionError):  # assert_eq! curve_msm.rs:67,106
+        pa.msm_execute(pre, mont_arr(c.scalar, scal[:2]))
+    from plonky_amd import lib
+    s = mont_arr(c.scalar, scal[:2])
+    out = np.zeros((2, 6), dtype=np.uint64)
+    oz = np.zeros(1, dtype=np.uint8)
+    assert lib.load().plk_msm_execute(pre._ctx, s.ctypes.data, 2, out.ctypes.data, oz.ctypes.data) == lib.PLK_ERR_SIZE_MISMATCH
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_msm_summation_edge_cases(c):
+    """curve_summations.rs:164-184 shapes through the MSM: {G,G}, {G,2G}, {G,G,G}, {}, G + (-G), identity operands."""
+    G = (c.gx, c.gy)
+    G2, G3 = br.ec_mul(c, 2, G), br.ec_mul(c, 3, G)
+    one = mont_arr(c.scalar, [1])[0]
+
+    def run(pts, scal=None, zero=None):
+        s = np.array([one] * len(pts), dtype=np.uint64).reshape(-1, 4) if scal is None else mont_arr(c.scalar, scal)
+        return pa.msm_parallel(c.curve_id, s, _bases(c, pts) if pts else np.zeros((0, 2, c.base.n_limbs), dtype=np.uint64), 4, zero=zero)
+
+    out, z = run([G, G])
+    assert z == 0 and tuple(from_mont_arr(c.base, out)) == G2
+    out, z = run([G, G2])
+    assert z == 0 and tuple(from_mont_arr(c.base, out)) == G3
+    out, z = run([G, G, G])
+    assert z == 0 and tuple(from_mont_arr(c.base, out)) == G3
+    out, z = run([])
+    assert z == 1
+    out, z = run([G, br.ec_neg(c, G)])
+    assert z == 1 and not out.any()
+    out, z = run([G, G2, G3], zero=[0, 1, 0])
+    assert z == 0 and tuple(from_mont_arr(c.base, out)) == br.ec_mul(c, 4, G)
+    out, z = run([G, G2], scal=[0, 0])
+    assert z == 1
+    r = c.scalar.p
+    out, z = run([G, G2, G3], scal=[r - 1, 1, 0])  # -G + 2G
+    assert z == 0 and tuple(from_mont_arr(c.base, out)) == G
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n,win", [(1, 0), (10, 0), (24, 3), (24, 7), (300, 0), (1000, 6), (4096, 0), (4096, 11)])
+def test_msm_matches_oracle(c, n, win):
+    """msm_execute_parallel on seeded inputs vs the oracle's restatement of the reference (w = 8 tables)."""
+    G = (c.gx, c.gy)
+    d = limbs_to_int(ol.rand_field(c.scalar.field_id, 7, 1)[0]) % c.scalar.p
+    D = br.ec_mul(c, d, G)
+    bases = ol.gen_bases(c.curve_id, n, _bases(c, [G])[0], _bases(c, [D])[0])
+    scalars = synth.rand_field(c.scalar.field_id, 0x350020 + n, n)
+    if n >= 10:  # edge scalars 0, 1, r-1 and a duplicated base (doubling branch)
+        scalars[0] = mont_arr(c.scalar, [0])[0]
+        scalars[1] = mont_arr(c.scalar, [1])[0]
+        scalars[2] = mont_arr(c.scalar, [c.scalar.p - 1])[0]
+        bases[5] = bases[4]
+        scalars[5] = scalars[4]
+    expected, ez = ol.MsmPrecomputation(c.curve_id, bases, 8, threads=8).execute(scalars, parallel=True, threads=8)
+    pre = pa.msm_precompute(c.curve_id, bases, 8, device_window=win)
+    got, gz = pa.msm_execute_parallel(pre, scalars)
+    assert gz == ez and np.array_equal(got, expected)
+
+
+def test_msm_skewed_digits():
+    """A witness-like scalar vector (mostly 0 / 1 / small values): a handful of huge buckets."""
+    c = br.TWEEDLEDEE
+    n = 1 << 13
+    G = (c.gx, c.gy)
+    D = br.ec_mul(c, 12345, G)
+    bases = ol.gen_bases(0, n, _bases(c, [G])[0], _bases(c, [D])[0])
+    vals = [(i % 3) for i in range(n)]
+    vals[17] = c.scalar.p - 1
+    scalars = mont_arr(c.scalar, vals)
+    expected, ez = ol.MsmPrecomputation(0, bases, 8, threads=8).execute(scalars, parallel=True, threads=8)
+    got, gz = pa.msm_execute_parallel(pa.msm_precompute(0, bases, 11), scalars)
+    assert gz == ez and np.array_equal(got, expected)
+
+
+def test_msm_batch_and_sum_affine():
+    """9-wire commit shape (plonk_util.rs:215-231) at small n + combining per-shard partial results."""
+    c = br.TWEEDLEDEE
+    n = 2048
+    G = (c.gx, c.gy)
+    D = br.ec_mul(c, 99, G)
+    bases = ol.gen_bases(0, n, _bases(c, [G])[0], _bases(c, [D])[0])
+    sv = np.stack([synth.rand_field(1, 0x350920 + k, n) for k in range(9)])
+    pre = pa.msm_precompute(0, bases, 11)
+    outs, zs = api.msm_execute_batch(pre, sv)
+    opre = ol.MsmPrecomputation(0, bases, 8, threads=8)
+    for k in range(9):
+        e, ez = opre.execute(sv[k], parallel=True, threads=8)
+        assert zs[k] == ez and np.array_equal(outs[k], e)
+    # base-range sharding: 4 shards, partial sums added by plk_curve_sum_affine
+    parts, pz = [], []
+    for s in range(4):
+        lo, hi = s * n // 4, (s + 1) * n // 4
+        o, z = pa.msm_parallel(0, sv[0][lo:hi], bases[lo:hi], 11)
+        parts.append(o)
+        pz.append(z)
+    tot, tz = api.curve_sum_affine(0, np.stack(parts), pz)
+    assert tz == 0 and np.array_equal(tot, outs[0])
+
+
+def test_gen_bases_dev_matches_oracle():
+    torch = pytest.importorskip("torch")
+    from plonky_amd import device as dev
+    dev.init(0)
+    for c in CURVES:
+        G = (c.gx, c.gy)
+        D = br.ec_mul(c, 0xABCDEF, G)
+        g0, dd = _bases(c, [G])[0], _bases(c, [D])[0]
+        got = dev.to_host(dev.gen_bases_dev(c.curve_id, 500, g0, dd)).reshape(500, 2, -1)
+        assert np.array_equal(got, ol.gen_bases(c.curve_id, 500, g0, dd))
+
+
+def test_msm_2p20_closed_form():
+    """BASELINE config 3 at full size: bases G0 + i D admit the closed form
+    sum s_i (G0 + i D) = [sum s_i] G0 + [sum i s_i] D   -- no CPU MSM needed."""
+    torch = pytest.importorskip("torch")
+    from plonky_amd import device as dev
+    from plonky_amd.selfcheck import closed_form_msm
+    dev.init(0)
+    c = br.TWEEDLEDEE
+    n = 1 << 20
+    G = (c.gx, c.gy)
+    d = limbs_to_int(synth.rand_field(1, 0x350020, 1)[0]) % c.scalar.p
+    D = br.ec_mul(c, d, G)
+    bases = dev.gen_bases_dev(0, n, _bases(c, [G])[0], _bases(c, [D])[0])
+    scal = synth.rand_field(1, 0x350020, n)
+    pre = dev.msm_precompute_dev(0, bases)
+    oxy, oz = dev.msm_execute_dev(pre, dev.to_device(scal))
+    torch.cuda.synchronize()
+    got = dev.to_host(oxy).reshape(2, 4)
+    exp = closed_form_msm(0, scal, G, D)
+    assert int(oz.cpu()[0]) == 0 and tuple(from_mont_arr(c.base, got)) == exp
