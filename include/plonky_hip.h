@@ -120,6 +120,17 @@ int plk_msm(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_z
  * point addition is not an RCCL reduction op).  Host pointers. */
 int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint8_t* pts_zero, uint64_t* out_xy, uint8_t* out_zero);
 
+/* ---- measurement hooks (bench.py's roofline: per-kernel durations from HIP events recorded on the
+ *      launch stream around each kernel; no effect on results) ------------------------------- */
+/* NTT pass kernel: enable, run transforms, then read the summed duration and the number of launches
+ * recorded since the previous read (the call waits for the recorded events). */
+int plk_ntt_set_profiling(int enable);
+int plk_ntt_get_timings(double* sum_ms, unsigned* launches);
+/* MSM pipeline: sum_ms[7] = scalar digits, scan, scatter, bucket accumulation, chunk sums, plane sums,
+ * final -- summed over `calls` executions since the previous read. */
+int plk_msm_set_profiling(plk_msm_ctx* ctx, int enable);
+int plk_msm_get_timings(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls);
+
 /* ---- utilities used by the harness and the parity tests (device kernels, not CPU code) ------ */
 /* Element-wise field ops on host arrays of `count` elements: op 0 add, 1 sub, 2 mul, 3 neg(a),
  * 4 square(a), 5 inverse(a) (0 -> 0), 6 to_canonical(a), 7 from_canonical(a).  b ignored for unary. */

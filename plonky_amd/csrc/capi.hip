@@ -16,6 +16,10 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void* d_zero, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_gen_bases_dev_impl(int curve, size_t n, uint64_t first, const void* d_g0d, void* d_out, hipStream_t stream);
+int msm_set_profiling_impl(plk_msm_ctx* ctx, int enable);
+int msm_get_timings_impl(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls);
+int ntt_set_profiling_impl(int enable);
+int ntt_get_timings_impl(double* sum_ms, unsigned* launches);
 size_t msm_ctx_len(const plk_msm_ctx* ctx);
 unsigned msm_ctx_window(const plk_msm_ctx* ctx);
 int msm_ctx_curve(const plk_msm_ctx* ctx);
@@ -248,6 +252,12 @@ int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint
     PLK_HIP_TRY(hipMemcpy(out_zero, doz.p, 1, hipMemcpyDeviceToHost));
     return PLK_OK;
 }
+
+// ---- measurement hooks ----
+int plk_ntt_set_profiling(int enable) { return ntt_set_profiling_impl(enable); }
+int plk_ntt_get_timings(double* sum_ms, unsigned* launches) { return ntt_get_timings_impl(sum_ms, launches); }
+int plk_msm_set_profiling(plk_msm_ctx* ctx, int enable) { return msm_set_profiling_impl(ctx, enable); }
+int plk_msm_get_timings(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls) { return msm_get_timings_impl(ctx, sum_ms, calls); }
 
 // ---- utilities ----
 int plk_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count) {

@@ -346,9 +346,17 @@ struct plk_msm_ctx {
     void* chunk_r = nullptr;
     void* plane_part = nullptr;
     std::mutex mu;             // one execution at a time per context (workspace is shared)
+    // optional per-kernel timing (HIP events on the launch stream) for bench.py's roofline
+    bool profiling = false;
+    static constexpr int N_STAGES = 7;  // digits, scan, scatter, accumulate, chunks, planes, final
+    std::vector<std::vector<hipEvent_t>> prof_sets;  // each N_STAGES + 1 events, recorded
+    std::vector<std::vector<hipEvent_t>> prof_free;
     ~plk_msm_ctx() {
         for (void* p : {tab, codes, sorted, hist, off, partial, chunk_s, chunk_r, plane_part})
             if (p) (void)hipFree(p);
+        for (auto* v : {&prof_sets, &prof_free})
+            for (auto& set : *v)
+                for (hipEvent_t e : set) (void)hipEventDestroy(e);
     }
 };
 
@@ -443,31 +451,55 @@ static int msm_execute_t(plk_msm_ctx* ctx, const void* d_scalars, void* d_out_xy
     uint32_t* cursor = hist + buckets;
     uint32_t* off = (uint32_t*)ctx->off;
     uint32_t* slice_off = off + buckets + 1;
+    std::vector<hipEvent_t> ev;
+    if (ctx->profiling) {
+        if (!ctx->prof_free.empty()) {
+            ev = ctx->prof_free.back();
+            ctx->prof_free.pop_back();
+        } else {
+            ev.resize(plk_msm_ctx::N_STAGES + 1);
+            for (auto& e : ev) PLK_HIP_TRY(hipEventCreate(&e));
+        }
+    }
+    int stage = 0;
+    auto mark = [&]() {
+        if (!ev.empty()) (void)hipEventRecord(ev[stage], stream);
+        ++stage;
+    };
     PLK_HIP_TRY(hipMemsetAsync(ctx->hist, 0, (size_t)buckets * 8, stream));
+    mark();
     if (n) {
         k_msm_digits<C><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const uint4*)d_scalars, (uint32_t*)ctx->codes, hist, n, ctx->c, ctx->windows);
         PLK_HIP_TRY(hipGetLastError());
     }
+    mark();
     k_msm_scan<<<1, 1024, 0, stream>>>(hist, off, slice_off, buckets);
     PLK_HIP_TRY(hipGetLastError());
+    mark();
     if (entries) {
         k_msm_scatter<<<(unsigned)((entries + 255) / 256), 256, 0, stream>>>((const uint32_t*)ctx->codes, off, cursor, (uint32_t*)ctx->sorted, entries);
         PLK_HIP_TRY(hipGetLastError());
     }
+    mark();
     // the slice count is only known on the device: launch for the upper bound, lanes past it exit
     k_msm_accumulate<C><<<(unsigned)((ctx->max_slices + 127) / 128), 128, 0, stream>>>((const uint4*)ctx->tab, (const uint32_t*)ctx->sorted, off, slice_off,
                                                                                        (uint4*)ctx->partial, buckets);
     PLK_HIP_TRY(hipGetLastError());
+    mark();
     k_msm_chunks<C><<<(ctx->n_chunks + 63) / 64, 64, 0, stream>>>((const uint4*)ctx->partial, slice_off, (uint4*)ctx->chunk_s, (uint4*)ctx->chunk_r,
                                                                   ctx->n_chunks, ctx->chunk_log);
     PLK_HIP_TRY(hipGetLastError());
+    mark();
     dim3 pg(ctx->plane_blocks, ctx->n_bits + 1);
     k_msm_planes<C><<<pg, 128, 128 * xyzz_bytes, stream>>>((const uint4*)ctx->chunk_s, (const uint4*)ctx->chunk_r, (uint4*)ctx->plane_part, ctx->n_chunks,
                                                            ctx->n_bits);
     PLK_HIP_TRY(hipGetLastError());
+    mark();
     k_msm_final<C><<<1, 64, 64 * xyzz_bytes, stream>>>((const uint4*)ctx->plane_part, ctx->plane_blocks, ctx->n_bits, ctx->chunk_log, (uint4*)d_out_xy,
                                                        (uint8_t*)d_out_zero);
     PLK_HIP_TRY(hipGetLastError());
+    mark();
+    if (!ev.empty()) ctx->prof_sets.push_back(ev);
     return PLK_OK;
 }
 
@@ -492,6 +524,33 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
         }
         if (rc != PLK_OK) return rc;
     }
+    return PLK_OK;
+}
+
+int msm_set_profiling_impl(plk_msm_ctx* ctx, int enable) {
+    if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->profiling = enable != 0;
+    return PLK_OK;
+}
+// sum_ms[7]: digits, scan, scatter, accumulate, chunks, planes, final -- summed over `calls` executions since the last read
+int msm_get_timings_impl(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls) {
+    if (!ctx || !sum_ms) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (int k = 0; k < plk_msm_ctx::N_STAGES; ++k) sum_ms[k] = 0;
+    unsigned cnt = 0;
+    for (auto& set : ctx->prof_sets) {
+        if (hipEventSynchronize(set.back()) != hipSuccess) continue;
+        for (int k = 0; k < plk_msm_ctx::N_STAGES; ++k) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, set[k], set[k + 1]);
+            sum_ms[k] += ms;
+        }
+        ++cnt;
+        ctx->prof_free.push_back(set);
+    }
+    ctx->prof_sets.clear();
+    if (calls) *calls = cnt;
     return PLK_OK;
 }
 

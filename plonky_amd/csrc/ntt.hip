@@ -270,6 +270,53 @@ static std::vector<int> plan_passes(int log_n) {
     return v;
 }
 
+// optional per-launch timing of the pass kernel (HIP events on the launch stream), for bench.py's roofline
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;  // recorded, not yet read
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_free;
+
+static bool prof_begin(hipStream_t stream, std::pair<hipEvent_t, hipEvent_t>& ev) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_on) return false;
+    if (!g_prof_free.empty()) {
+        ev = g_prof_free.back();
+        g_prof_free.pop_back();
+    } else {
+        if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) return false;
+    }
+    (void)hipEventRecord(ev.first, stream);
+    return true;
+}
+static void prof_end(hipStream_t stream, const std::pair<hipEvent_t, hipEvent_t>& ev) {
+    (void)hipEventRecord(ev.second, stream);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_events.push_back(ev);
+}
+
+int ntt_set_profiling_impl(int enable) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = enable != 0;
+    return PLK_OK;
+}
+int ntt_get_timings_impl(double* sum_ms, unsigned* launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double tot = 0;
+    unsigned cnt = 0;
+    for (auto& ev : g_prof_events) {
+        float ms = 0;
+        if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+            tot += ms;
+            ++cnt;
+        }
+        g_prof_free.push_back(ev);
+    }
+    g_prof_events.clear();
+    if (sum_ms) *sum_ms = tot;
+    if (launches) *launches = cnt;
+    return PLK_OK;
+}
+
 static std::mutex g_plan_mu;
 static std::map<std::tuple<int, int, int>, std::shared_ptr<NttPlan>> g_plans;
 
@@ -380,8 +427,11 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
         const size_t tiles = (((size_t)1 << log_n) >> (a.log_a + a.log_q)) * batch;
         const void* outer = a.last ? nullptr : pl.outer[dir][t];
         void* dst = a.last ? d_out : scratch;
+        std::pair<hipEvent_t, hipEvent_t> pev;
+        const bool prof = prof_begin(stream, pev);
         k_ntt_pass<P><<<(unsigned)tiles, NTT_THREADS, 0, stream>>>((const uint4*)src, (uint4*)dst, (const uint4*)pl.inner[dir],
                                                                  (const uint4*)outer, (const uint4*)pl.pw + 64 * 2, a);
+        if (prof) prof_end(stream, pev);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             rc = set_error(PLK_ERR_HIP, "ntt pass launch failed: %s", hipGetErrorString(e));

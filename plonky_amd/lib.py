@@ -44,6 +44,10 @@ SYMBOLS = [
     ("plk_msm_execute_dev", _i, [_vp, _u, _vp, _sz, _vp, _vp, _vp]),
     ("plk_msm", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("plk_curve_sum_affine", _i, [_i, _sz, _vp, _vp, _vp, _vp]),
+    ("plk_ntt_set_profiling", _i, [_i]),
+    ("plk_ntt_get_timings", _i, [_vp, _vp]),
+    ("plk_msm_set_profiling", _i, [_vp, _i]),
+    ("plk_msm_get_timings", _i, [_vp, _vp, _vp]),
     ("plk_field_op", _i, [_i, _i, _vp, _vp, _vp, _sz]),
     ("plk_curve_gen_bases_dev", _i, [_i, _sz, _u64, _vp, _vp, _vp, _vp]),
 ]
