@@ -3,6 +3,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -37,6 +38,80 @@ int set_error(int code, const char* fmt, ...) {
     va_end(ap);
     last_error_ref() = buf;
     return code;
+}
+
+// ---- scratch pool ----
+struct ScratchEntry {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    bool in_call = false;   // between acquire and release on some host thread
+    bool used = false;      // ev has been recorded at least once
+};
+static std::mutex g_scratch_mu;
+static std::vector<ScratchEntry> g_scratch;
+
+void* scratch_acquire(size_t bytes, hipStream_t stream) {
+    if (bytes == 0) bytes = 16;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    ScratchEntry* best = nullptr;
+    for (auto& e : g_scratch) {
+        if (e.in_call || e.device != dev || e.bytes < bytes) continue;
+        const bool ordered = !e.used || e.stream == stream || hipEventQuery(e.ev) == hipSuccess;
+        if (!ordered) continue;
+        if (!best || e.bytes < best->bytes) best = &e;
+    }
+    if (best) {
+        best->in_call = true;
+        return best->p;
+    }
+    ScratchEntry e;
+    e.bytes = bytes;
+    e.device = dev;
+    hipError_t err = hipMalloc(&e.p, bytes);
+    if (err != hipSuccess) {
+        set_error(err == hipErrorOutOfMemory ? PLK_ERR_OOM : PLK_ERR_HIP, "hipMalloc(%zu) for scratch failed: %s", bytes, hipGetErrorString(err));
+        return nullptr;
+    }
+    if (hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(e.p);
+        set_error(PLK_ERR_HIP, "hipEventCreate failed");
+        return nullptr;
+    }
+    e.in_call = true;
+    g_scratch.push_back(e);
+    return e.p;
+}
+
+void scratch_release(void* p, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    for (auto& e : g_scratch)
+        if (e.p == p) {
+            (void)hipEventRecord(e.ev, stream);
+            e.stream = stream;
+            e.used = true;
+            e.in_call = false;
+            return;
+        }
+}
+
+void scratch_clear() {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    (void)hipDeviceSynchronize();
+    for (auto& e : g_scratch) {
+        if (e.in_call) continue;
+        (void)hipFree(e.p);
+        (void)hipEventDestroy(e.ev);
+        e.p = nullptr;
+    }
+    std::vector<ScratchEntry> keep;
+    for (auto& e : g_scratch)
+        if (e.p) keep.push_back(e);
+    g_scratch.swap(keep);
 }
 
 static std::atomic<int> g_device{-1};
@@ -106,6 +181,7 @@ int plk_init(int device) {
 
 void plk_shutdown(void) {
     (void)ntt_clear_cache_impl();
+    scratch_clear();
     g_device.store(-1);
 }
 

@@ -54,6 +54,13 @@ struct DevBuf {
     }
 };
 
+// Stream-aware scratch buffers owned by the library (no hipMallocAsync: the stream-ordered pool
+// of the runtime is left to the host framework).  A buffer is handed out again only to work that
+// is ordered after its previous use: same stream, or its last-use event has completed.
+void* scratch_acquire(size_t bytes, hipStream_t stream);  // nullptr on allocation failure (error text set)
+void scratch_release(void* p, hipStream_t stream);       // call after the last kernel using p is enqueued
+void scratch_clear();
+
 // ---- entry points implemented in ntt.hip / msm.hip / fieldops.hip, wrapped by capi.hip ----
 int ntt_precompute_impl(int field, unsigned log_n);
 int ntt_clear_cache_impl();

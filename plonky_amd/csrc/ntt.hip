@@ -18,6 +18,7 @@
 // function the reference computes, and field elements have a unique representation, so the
 // limbs are bit-identical.  iNTT = the same passes with w^-1 tables and n^-1 folded into the
 // first inter-pass twiddle table (instead of the index-reversal trick of fft.rs:90-99).
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -259,6 +260,20 @@ struct NttPlan {
 
 static std::vector<int> plan_passes(int log_n) {
     std::vector<int> v;
+    // debugging / tuning override: PLK_NTT_PLAN="7,7,6" (must sum to log_n, else ignored)
+    if (const char* e = getenv("PLK_NTT_PLAN")) {
+        int sum = 0;
+        for (const char* p = e; *p;) {
+            int x = atoi(p);
+            if (x <= 0 || x > TILE_LOG) { v.clear(); sum = -1; break; }
+            v.push_back(x);
+            sum += x;
+            while (*p && *p != ',') ++p;
+            if (*p == ',') ++p;
+        }
+        if (sum == log_n && (int)v.size() <= MAX_PASSES) return v;
+        v.clear();
+    }
     if (log_n <= TILE_LOG) {
         v.push_back(log_n);
         return v;
@@ -400,10 +415,13 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
         return PLK_OK;
     }
     // The last pass is a transposition (reads contiguous blocks, writes digit-reversed), so with
-    // m >= 2 passes it cannot run in place: passes 1..m-1 work in a stream-ordered scratch
+    // m >= 2 passes it cannot run in place: passes 1..m-1 work in a library-owned scratch
     // buffer and the last pass writes the caller's output.
     void* scratch = nullptr;
-    if (m >= 2) PLK_HIP_TRY(hipMallocAsync(&scratch, ((size_t)batch << log_n) * 32, stream));
+    if (m >= 2) {
+        scratch = scratch_acquire(((size_t)batch << log_n) * 32, stream);
+        if (!scratch) return PLK_ERR_OOM;
+    }
     int log_nt = log_n;
     const void* src = d_in;
     int rc = PLK_OK;
@@ -440,7 +458,7 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
         src = dst;
         log_nt = a.log_s;
     }
-    if (scratch) PLK_HIP_TRY(hipFreeAsync(scratch, stream));
+    if (scratch) scratch_release(scratch, stream);
     return rc;
 }
 

@@ -78,6 +78,13 @@ def load():
         if not os.path.exists(SO_PATH):
             raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(the HIP path has no CPU fallback)" % SO_PATH)
+        # One HIP runtime per process: torch bundles its own libamdhip64.so.7 and hands us its
+        # streams and device pointers, so it must be loaded first; libplonky_hip.so then binds to
+        # the already-loaded runtime (same SONAME) instead of pulling in a second copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(SO_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
