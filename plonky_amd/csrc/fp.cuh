@@ -17,14 +17,24 @@
 // limbs, which the fully unrolled, constexpr-modulus loops fold away (24 instead of 64
 // reduction multiplies).  No MFMA: there is no dense contraction in this arithmetic.
 #pragma once
-#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "field_params.cuh"
 
-namespace plk {
-
+// The arithmetic below is plain C++ so that tests/test_fp_host.py can compile it with g++ and
+// sweep it against Python integers without a GPU; under hipcc it is device code.
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
 #define PLK_DI __device__ __forceinline__
+#define PLK_DNI __device__ __noinline__
+#else
+#define PLK_DI inline
+#define PLK_DNI inline
+#endif
+
+#include "fp29.cuh"
+
+namespace plk {
 
 template <class P> struct Fe {
     uint32_t v[P::NL];
@@ -115,7 +125,7 @@ template <class P> PLK_DI Fe<P> fe_dbl(const Fe<P>& a) { return fe_add<P>(a, a);
 
 // Montgomery product a*b*R^-1 mod p, fully reduced.  monty.rs:67-107 / bls12_377_base.rs:58-98,
 // restated on 32-bit limbs (same radix R, so the same value).
-template <class P> PLK_DI Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+template <class P> PLK_DI Fe<P> fe_mul_cios(const Fe<P>& a, const Fe<P>& b) {
     constexpr int N = P::NL;
     static_assert(P::MOD[0] == 1u, "q = -t0 shortcut needs p = 1 (mod 2^32)");
     static_assert(P::MOD[N - 1] < 0x80000000u, "t < 2p must fit the limbs");
@@ -154,6 +164,17 @@ template <class P> PLK_DI Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
     for (int i = 0; i < N; ++i) r.v[i] = u[i];
     return r;
 }
+// 256-bit fields: product scanning on 29-bit limbs (fp29.cuh) -- same value, ~2.3x fewer instructions.
+template <class P> PLK_DI Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+    if constexpr (P::NL == 8) {
+        Fe<P> r;
+        fe_mul29_core<P>(a.v, b.v, r.v);
+        fe_cond_sub_p<P>(r.v);
+        return r;
+    } else {
+        return fe_mul_cios<P>(a, b);
+    }
+}
 template <class P> PLK_DI Fe<P> fe_sqr(const Fe<P>& a) { return fe_mul<P>(a, a); }
 
 // Montgomery -> canonical: multiply by the integer 1 (monty.rs:174-177 "to_monty")
@@ -173,7 +194,7 @@ template <class P> PLK_DI Fe<P> fe_from_canonical(const Fe<P>& a) {
 // a^(p-2).  The reference inverts with a binary extended Euclid (bigint_inverse.rs:6-55); the
 // inverse of a non-zero element is unique, so Fermat gives the identical limbs without the
 // data-dependent loop.  fe_inv(0) = 0.
-template <class P> __device__ __noinline__ Fe<P> fe_inv(const Fe<P>& a) {
+template <class P> PLK_DNI Fe<P> fe_inv(const Fe<P>& a) {
     Fe<P> r = fe_one<P>();
     for (int i = P::BITS - 1; i >= 0; --i) {
         r = fe_sqr<P>(r);
@@ -201,6 +222,7 @@ template <class P> PLK_DI Fe<P> fe_half(const Fe<P>& a) {
     return r;
 }
 
+#ifdef __HIPCC__
 // ---- global / LDS movement: an element is NL/4 16-byte words (AoS, as the reference stores it) ----
 template <class P> PLK_DI Fe<P> fe_load(const uint4* p) {
     Fe<P> r;
@@ -218,5 +240,7 @@ template <class P> PLK_DI void fe_store(uint4* p, const Fe<P>& a) {
 #pragma unroll
     for (int k = 0; k < P::NL / 4; ++k) p[k] = make_uint4(a.v[4 * k], a.v[4 * k + 1], a.v[4 * k + 2], a.v[4 * k + 3]);
 }
+
+#endif  // __HIPCC__
 
 }  // namespace plk
