@@ -75,6 +75,13 @@ template <class P> PLK_DI void fe_mul29_core(const uint32_t (&a)[8], const uint3
             acc >>= 29;
         } else if (k == 8) {
             q[8] = (0u - (uint32_t)acc) & M24;
+#ifdef __HIPCC__
+            // ROCm 7.2 / clang 22 miscompile: the AMDGPU mul24 combine (q8 * small p_j becomes
+            // v_mul_u32_u24) strips this mask from q8 for ALL its users, including the 32-bit
+            // v_mad_u64_u32 ones (seen for Bls12377Scalar; caught by the parity sweep and
+            // reproduced by emulating the emitted ISA).  Make the masked value opaque.
+            asm volatile("" : "+v"(q[8]));
+#endif
             acc += q[8];          // low 24 bits become zero
             L[0] = (uint32_t)acc & M29;
             acc >>= 29;
