@@ -203,6 +203,88 @@ template <class P> PLK_DNI Fe<P> fe_inv(const Fe<P>& a) {
     return r;
 }
 
+// The reference's own inversion: binary extended Euclid (bigint_inverse.rs:6-55, "Algorithm 16")
+// followed by a Montgomery multiplication by R^3 (monty.rs:162-166).  Data-dependent control
+// flow: meant for single-lane use (the final normalisation of an MSM), where it is ~5x shorter
+// than the Fermat chain above.  fe_inv_eea(0) = 0.
+template <class P> PLK_DNI Fe<P> fe_inv_eea(const Fe<P>& a) {
+    constexpr int N = P::NL;
+    if (fe_is_zero<P>(a)) return a;
+    uint32_t u[N], v[N], b[N], c[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        u[i] = a.v[i];
+        v[i] = P::MOD[i];
+        b[i] = 0;
+        c[i] = 0;
+    }
+    b[0] = 1;
+    auto is_one = [](const uint32_t (&x)[N]) {
+        uint32_t o = x[0] ^ 1u;
+#pragma unroll
+        for (int i = 1; i < N; ++i) o |= x[i];
+        return o == 0;
+    };
+    auto shr1 = [](uint32_t (&x)[N]) {
+#pragma unroll
+        for (int i = 0; i < N - 1; ++i) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+        x[N - 1] >>= 1;
+    };
+    auto add_p = [](uint32_t (&x)[N]) {  // x += p (x < p, p has a spare top bit)
+        uint64_t cy = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            uint64_t t = (uint64_t)x[i] + P::MOD[i] + cy;
+            x[i] = (uint32_t)t;
+            cy = t >> 32;
+        }
+    };
+    auto less = [](const uint32_t (&x)[N], const uint32_t (&y)[N]) {
+        for (int i = N - 1; i >= 0; --i) {
+            if (x[i] != y[i]) return x[i] < y[i];
+        }
+        return false;
+    };
+    auto sub = [](uint32_t (&x)[N], const uint32_t (&y)[N]) {  // x -= y (x >= y)
+        uint64_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            uint64_t t = (uint64_t)x[i] - y[i] - bw;
+            x[i] = (uint32_t)t;
+            bw = (t >> 32) & 1;
+        }
+    };
+    while (!is_one(u) && !is_one(v)) {
+        while ((u[0] & 1u) == 0) {
+            shr1(u);
+            if (b[0] & 1u) add_p(b);
+            shr1(b);
+        }
+        while ((v[0] & 1u) == 0) {
+            shr1(v);
+            if (c[0] & 1u) add_p(c);
+            shr1(c);
+        }
+        if (less(u, v)) {
+            sub(v, u);
+            if (less(c, b)) add_p(c);
+            sub(c, b);
+        } else {
+            sub(u, v);
+            if (less(b, c)) add_p(b);
+            sub(b, c);
+        }
+    }
+    Fe<P> r, r3;
+    const bool use_b = is_one(u);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        r.v[i] = use_b ? b[i] : c[i];
+        r3.v[i] = P::R3[i];
+    }
+    return fe_mul<P>(r, r3);
+}
+
 // x/2 mod p for Montgomery or canonical x alike (used to build n^-1 = 2^-log n)
 template <class P> PLK_DI Fe<P> fe_half(const Fe<P>& a) {
     constexpr int N = P::NL;

@@ -5,13 +5,13 @@
 //   to_digits                                     curve_msm.rs:159-180 -> k_msm_digits (signed, carry based)
 //   digit_occurrences scatter (serial in the ref) curve_msm.rs:117-126 -> histogram + scan + scatter
 //   per-digit affine multi-summation              curve_msm.rs:131-145 -> k_msm_accumulate (XYZZ mixed adds)
-//   serial Yao tail  u += acc[d]; y += u          curve_msm.rs:149-154 -> k_msm_chunks + k_msm_planes + k_msm_final
+//   serial Yao tail  u += acc[d]; y += u          curve_msm.rs:149-154 -> k_msm_bucket_sum + k_msm_planes + k_msm_final
 //   msm_execute / msm_execute_parallel            curve_msm.rs:63-157  -> msm_execute_dev_impl
 // Same mathematical structure as the reference (Yao's method over per-generator power tables
 // [2^(c j)] G_i, one bucket per digit value, result = sum_d d * bucket_d) with two MI355X-first
 // changes: (1) digits are signed (carry-based integer recoding, never s -> r - s, so it is valid
 // on BLS12-377 G1 whose cofactor is even): half the buckets for the same window; (2) the serial
-// running sum is replaced by 16-bucket chunk running sums followed by bit-plane tree sums, so
+// running sum is replaced by bit-plane tree sums (sum_d d B_d = sum_p 2^p sum_{d: bit p} B_d), so
 // the tail is O(log) deep instead of 2 * 2^w sequential additions.  The result is returned as
 // the unique affine point (to_affine, curve.rs:206-214), on which parity is defined.
 //
@@ -27,8 +27,8 @@
 
 namespace plk {
 
-constexpr int MSM_SLICE = 32;        // entries per accumulation slice
-constexpr int MSM_CHUNK_LOG = 4;     // buckets per running-sum chunk (16)
+constexpr int MSM_SLICE_DEFAULT = 32;  // entries per accumulation slice (PLK_MSM_SLICE overrides)
+constexpr int MSM_MAX_PLANE_PARTS = 8;  // blocks per bit-plane in the reduction
 constexpr int MSM_MAX_WINDOW = 22;
 constexpr uint32_t CODE_INVALID = 0xFFFFFFFFu;
 
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint4* __restrict__ sc
 
 // single block: exclusive scans of the bucket sizes and of the per-bucket slice counts
 __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ off, uint32_t* __restrict__ slice_off,
-                                                   uint32_t buckets) {
+                                                   uint32_t buckets, uint32_t slice) {
     __shared__ uint32_t s_a[1024], s_b[1024];
     const uint32_t per = (buckets + 1023) / 1024;
     const uint32_t lo = threadIdx.x * per, hi = min(buckets, lo + per);
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ 
     for (uint32_t b = lo; b < hi; ++b) {
         uint32_t h = hist[b];
         sa += h;
-        sb += (h + MSM_SLICE - 1) / MSM_SLICE;
+        sb += (h + slice - 1) / slice;
     }
     s_a[threadIdx.x] = sa;
     s_b[threadIdx.x] = sb;
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ 
         off[b] = ra;
         slice_off[b] = rb;
         ra += h;
-        rb += (h + MSM_SLICE - 1) / MSM_SLICE;
+        rb += (h + slice - 1) / slice;
     }
     if (threadIdx.x == 1023) {
         off[buckets] = s_a[1023];
@@ -159,12 +159,12 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const uint32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// bucket accumulation: one lane per slice of <= MSM_SLICE sorted entries
+// bucket accumulation: one lane per slice of <= `slice` sorted entries
 // ---------------------------------------------------------------------------------------------
 template <class C>
-__global__ void __launch_bounds__(128) k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
-                                                        const uint32_t* __restrict__ off, const uint32_t* __restrict__ slice_off,
-                                                        uint4* __restrict__ partial, uint32_t buckets) {
+__global__ void __launch_bounds__(128, 4) k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
+                                                           const uint32_t* __restrict__ off, const uint32_t* __restrict__ slice_off,
+                                                           uint4* __restrict__ partial, uint32_t buckets, uint32_t slice) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -177,8 +177,8 @@ __global__ void __launch_bounds__(128) k_msm_accumulate(const uint4* __restrict_
         if (slice_off[mid] <= s) lo = mid; else hi = mid;
     }
     const uint32_t b = lo;
-    const uint32_t begin = off[b] + (s - slice_off[b]) * MSM_SLICE;
-    const uint32_t end = min(off[b + 1], begin + MSM_SLICE);
+    const uint32_t begin = off[b] + (s - slice_off[b]) * slice;
+    const uint32_t end = min(off[b + 1], begin + slice);
     Xyzz<FP> acc = xyzz_identity<FP>();
     for (uint32_t k = begin; k < end; ++k) {
         const uint32_t ent = sorted[k];
@@ -192,26 +192,25 @@ __global__ void __launch_bounds__(128) k_msm_accumulate(const uint4* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// reduction  sum_d d * bucket_d
+// reduction  sum_d d * bucket_d   (replaces the serial Yao tail of curve_msm.rs:149-154)
 // ---------------------------------------------------------------------------------------------
-// level 0: chunk t of L = 2^chunk_log buckets:  S_t = sum_l B,  R_t = sum_l (l+1) B  (running sums)
+// Everything here is latency bound (few points, long dependent chains), so the structure is
+// chosen for depth, not work:  bucket_b = sum of its slice partials (<= n*W / (D * SLICE) + 1
+// serial additions);  sum_b (b+1) * bucket_b = sum_p 2^p * P_p with P_p the plain sum of the
+// buckets whose weight b+1 has bit p set, each P_p a block-parallel tree sum (c planes,
+// c * D / 2 additions in total, ~1.5 % of the accumulation work);  the planes are doubled into
+// place and tree-summed by one block which also normalises the result.
 template <class C>
-__global__ void __launch_bounds__(64) k_msm_chunks(const uint4* __restrict__ partial, const uint32_t* __restrict__ slice_off, uint4* __restrict__ chunk_s,
-                                                   uint4* __restrict__ chunk_r, uint32_t n_chunks, int chunk_log) {
+__global__ void __launch_bounds__(128) k_msm_bucket_sum(const uint4* __restrict__ partial, const uint32_t* __restrict__ slice_off, uint4* __restrict__ bucket,
+                                                        uint32_t buckets) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_chunks) return;
-    Xyzz<FP> run = xyzz_identity<FP>(), acc = xyzz_identity<FP>();
-    const int L = 1 << chunk_log;
-    for (int l = L - 1; l >= 0; --l) {
-        const uint32_t b = (t << chunk_log) + l;
-        const uint32_t s0 = slice_off[b], s1 = slice_off[b + 1];
-        for (uint32_t s = s0; s < s1; ++s) run = xyzz_add<FP>(run, xyzz_load<FP>(partial + (size_t)s * 4 * W));
-        acc = xyzz_add<FP>(acc, run);
-    }
-    xyzz_store<FP>(chunk_s + (size_t)t * 4 * W, run);
-    xyzz_store<FP>(chunk_r + (size_t)t * 4 * W, acc);
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= buckets) return;
+    const uint32_t s0 = slice_off[b], s1 = slice_off[b + 1];
+    Xyzz<FP> acc = xyzz_identity<FP>();
+    for (uint32_t s = s0; s < s1; ++s) acc = xyzz_add<FP>(acc, xyzz_load<FP>(partial + (size_t)s * 4 * W));
+    xyzz_store<FP>(bucket + (size_t)b * 4 * W, acc);
 }
 
 template <class FP> PLK_DI Xyzz<FP> block_sum(Xyzz<FP> v, uint4* s_pts) {
@@ -229,42 +228,61 @@ template <class FP> PLK_DI Xyzz<FP> block_sum(Xyzz<FP> v, uint4* s_pts) {
     return v;
 }
 
-// total = sum_t R_t + L * sum_t t * S_t ;  sum_t t*S_t = sum_b 2^b * (sum over t with bit b set of S_t).
-// plane p < n_bits: tree-sum of {S_t : bit p of t}; plane n_bits: tree-sum of all R_t.
+// plane p: tree-sum of { bucket_b : bit p of (b + 1) }.  grid = (parts, planes)
 template <class C>
-__global__ void __launch_bounds__(128) k_msm_planes(const uint4* __restrict__ chunk_s, const uint4* __restrict__ chunk_r, uint4* __restrict__ plane_part,
-                                                    uint32_t n_chunks, int n_bits) {
+__global__ void __launch_bounds__(256) k_msm_planes(const uint4* __restrict__ bucket, uint4* __restrict__ plane_part, uint32_t buckets) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     extern __shared__ __attribute__((aligned(16))) uint4 s_pts[];
     const int plane = blockIdx.y;
-    const uint4* src = plane == n_bits ? chunk_r : chunk_s;
     Xyzz<FP> acc = xyzz_identity<FP>();
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_chunks; t += gridDim.x * blockDim.x) {
-        if (plane == n_bits || ((t >> plane) & 1u)) acc = xyzz_add<FP>(acc, xyzz_load<FP>(src + (size_t)t * 4 * W));
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < buckets; b += gridDim.x * blockDim.x) {
+        if (((b + 1u) >> plane) & 1u) acc = xyzz_add<FP>(acc, xyzz_load<FP>(bucket + (size_t)b * 4 * W));
     }
     acc = block_sum<FP>(acc, s_pts);
     if (threadIdx.x == 0) xyzz_store<FP>(plane_part + ((size_t)plane * gridDim.x + blockIdx.x) * 4 * W, acc);
 }
 
-// one block: per plane sum the block partials, scale by 2^(plane + chunk_log), add everything, to affine.
+// one block of planes * parts lanes: tree over the parts of each plane, 2^plane by doublings,
+// tree over the planes, to_affine (curve.rs:206-214).
 template <class C>
-__global__ void __launch_bounds__(64) k_msm_final(const uint4* __restrict__ plane_part, int parts_per_plane, int n_bits, int chunk_log, uint4* __restrict__ out_xy,
-                                                  uint8_t* __restrict__ out_zero) {
+__global__ void __launch_bounds__(256) k_msm_final(const uint4* __restrict__ plane_part, int parts, int planes, uint4* __restrict__ out_xy,
+                                                   uint8_t* __restrict__ out_zero) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     extern __shared__ __attribute__((aligned(16))) uint4 s_pts[];
-    const int plane = threadIdx.x;
-    Xyzz<FP> acc = xyzz_identity<FP>();
-    if (plane <= n_bits) {
-        for (int k = 0; k < parts_per_plane; ++k) acc = xyzz_add<FP>(acc, xyzz_load<FP>(plane_part + ((size_t)plane * parts_per_plane + k) * 4 * W));
-        if (plane < n_bits)
-            for (int k = 0; k < plane + chunk_log; ++k) acc = xyzz_dbl<FP>(acc);
+    const int tid = threadIdx.x;
+    const int plane = tid / parts, part = tid % parts;
+    const bool live = plane < planes;
+    Xyzz<FP> acc = live ? xyzz_load<FP>(plane_part + (size_t)tid * 4 * W) : xyzz_identity<FP>();
+    xyzz_store<FP>(s_pts + tid * 4 * W, acc);
+    __syncthreads();
+    for (int d = parts >> 1; d >= 1; d >>= 1) {
+        if (live && part < d) {
+            acc = xyzz_add<FP>(acc, xyzz_load<FP>(s_pts + (tid + d) * 4 * W));
+            xyzz_store<FP>(s_pts + tid * 4 * W, acc);
+        }
+        __syncthreads();
     }
-    acc = block_sum<FP>(acc, s_pts);
-    if (threadIdx.x == 0) {
+    if (live && part == 0)
+        for (int k = 0; k < plane; ++k) acc = xyzz_dbl<FP>(acc);
+    __syncthreads();
+    // compact the plane leaders to the front, then a 32-wide tree
+    if (live && part == 0) xyzz_store<FP>(s_pts + plane * 4 * W, acc);
+    __syncthreads();
+    acc = tid < planes ? xyzz_load<FP>(s_pts + tid * 4 * W) : xyzz_identity<FP>();
+    __syncthreads();
+    for (int d = 16; d >= 1; d >>= 1) {
+        if (tid < d && tid + d < 32) {
+            Xyzz<FP> o = (tid + d) < planes ? xyzz_load<FP>(s_pts + (tid + d) * 4 * W) : xyzz_identity<FP>();
+            acc = xyzz_add<FP>(acc, o);
+            xyzz_store<FP>(s_pts + tid * 4 * W, acc);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
         Fe<FP> x, y;
-        bool ident = xyzz_to_affine<FP>(acc, x, y);
+        bool ident = xyzz_to_affine<FP, true>(acc, x, y);
         fe_store<FP>(out_xy, x);
         fe_store<FP>(out_xy + W, y);
         *out_zero = ident ? 1 : 0;
@@ -289,7 +307,7 @@ __global__ void __launch_bounds__(64) k_sum_affine(const uint4* __restrict__ pts
     acc = block_sum<FP>(acc, s_pts);
     if (threadIdx.x == 0) {
         Fe<FP> x, y;
-        bool ident = xyzz_to_affine<FP>(acc, x, y);
+        bool ident = xyzz_to_affine<FP, true>(acc, x, y);
         fe_store<FP>(out_xy, x);
         fe_store<FP>(out_xy + W, y);
         *out_zero = ident ? 1 : 0;
@@ -330,10 +348,9 @@ struct plk_msm_ctx {
     int c = 0;          // window bits
     int windows = 0;    // ceil((BITS + 1) / c)
     uint32_t buckets = 0;  // 2^(c-1)
-    int chunk_log = 0;
-    uint32_t n_chunks = 0;
-    int n_bits = 0;     // log2(n_chunks)
-    int plane_blocks = 1;
+    uint32_t slice = 32;   // entries per accumulation slice
+    int planes = 0;        // = c: bit-planes of the bucket weights 1 .. 2^(c-1)
+    int plane_blocks = 1;  // blocks (parts) per plane
     size_t max_slices = 0;
     // device memory
     void* tab = nullptr;
@@ -342,8 +359,7 @@ struct plk_msm_ctx {
     void* hist = nullptr;      // hist[buckets] followed by cursor[buckets]
     void* off = nullptr;       // off[buckets+1] followed by slice_off[buckets+1]
     void* partial = nullptr;
-    void* chunk_s = nullptr;
-    void* chunk_r = nullptr;
+    void* bucket = nullptr;    // bucket sums (XYZZ)
     void* plane_part = nullptr;
     std::mutex mu;             // one execution at a time per context (workspace is shared)
     // optional per-kernel timing (HIP events on the launch stream) for bench.py's roofline
@@ -352,7 +368,7 @@ struct plk_msm_ctx {
     std::vector<std::vector<hipEvent_t>> prof_sets;  // each N_STAGES + 1 events, recorded
     std::vector<std::vector<hipEvent_t>> prof_free;
     ~plk_msm_ctx() {
-        for (void* p : {tab, codes, sorted, hist, off, partial, chunk_s, chunk_r, plane_part})
+        for (void* p : {tab, codes, sorted, hist, off, partial, bucket, plane_part})
             if (p) (void)hipFree(p);
         for (auto* v : {&prof_sets, &prof_free})
             for (auto& set : *v)
@@ -367,10 +383,12 @@ static int scalar_bits(int curve) { return curve == PLK_CURVE_BLS12_377 ? 253 : 
 static int choose_window(size_t n) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
-    int c = lg - 3;
+    // ceil(256 / c) windows of work per scalar: 16 and 18..20 are the useful sizes near 2^20; buckets
+    // (2^(c-1)) should stay well below the entry count so that slices are long
+    int c = lg - 4;
     if (const char* e = getenv("PLK_MSM_WINDOW")) c = atoi(e);
     if (c < 3) c = 3;
-    if (c > 18) c = 18;
+    if (c > 16) c = 16;
     return c;
 }
 
@@ -385,11 +403,10 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
     PLK_HIP_TRY(hipMalloc(&ctx->sorted, entries * 4 + 16));
     PLK_HIP_TRY(hipMalloc(&ctx->hist, (size_t)ctx->buckets * 8));
     PLK_HIP_TRY(hipMalloc(&ctx->off, ((size_t)ctx->buckets + 1) * 8));
-    ctx->max_slices = entries / MSM_SLICE + ctx->buckets + 1;
+    ctx->max_slices = entries / ctx->slice + ctx->buckets + 1;
     PLK_HIP_TRY(hipMalloc(&ctx->partial, ctx->max_slices * xyzz_bytes));
-    PLK_HIP_TRY(hipMalloc(&ctx->chunk_s, (size_t)ctx->n_chunks * xyzz_bytes));
-    PLK_HIP_TRY(hipMalloc(&ctx->chunk_r, (size_t)ctx->n_chunks * xyzz_bytes));
-    PLK_HIP_TRY(hipMalloc(&ctx->plane_part, (size_t)(ctx->n_bits + 1) * ctx->plane_blocks * xyzz_bytes));
+    PLK_HIP_TRY(hipMalloc(&ctx->bucket, (size_t)ctx->buckets * xyzz_bytes));
+    PLK_HIP_TRY(hipMalloc(&ctx->plane_part, (size_t)ctx->planes * ctx->plane_blocks * xyzz_bytes));
     if (n) {
         k_msm_table<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)ctx->tab, n, ctx->c,
                                                                        ctx->windows);
@@ -415,13 +432,14 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     ctx->c = c;
     ctx->windows = (scalar_bits(curve) + 1 + c - 1) / c;
     ctx->buckets = 1u << (c - 1);
-    ctx->chunk_log = (c - 1) < MSM_CHUNK_LOG ? (c - 1) : MSM_CHUNK_LOG;
-    ctx->n_chunks = ctx->buckets >> ctx->chunk_log;
-    ctx->n_bits = 0;
-    while ((1u << ctx->n_bits) < ctx->n_chunks) ++ctx->n_bits;
-    ctx->plane_blocks = (int)(ctx->n_chunks / 512);
-    if (ctx->plane_blocks < 1) ctx->plane_blocks = 1;
-    if (ctx->plane_blocks > 32) ctx->plane_blocks = 32;
+    ctx->slice = MSM_SLICE_DEFAULT;
+    if (const char* e = getenv("PLK_MSM_SLICE")) {
+        int v = atoi(e);
+        if (v >= 4 && v <= 4096) ctx->slice = (uint32_t)v;
+    }
+    ctx->planes = c;
+    ctx->plane_blocks = 1;
+    while (ctx->plane_blocks < MSM_MAX_PLANE_PARTS && (uint32_t)ctx->plane_blocks * 2048u < ctx->buckets) ctx->plane_blocks *= 2;
     if (n * (size_t)ctx->windows >= ((size_t)1 << 31)) {
         delete ctx;
         return set_error(PLK_ERR_INVALID_ARG, "n * windows = %zu entries exceeds 2^31", n * (size_t)ctx->windows);
@@ -473,7 +491,7 @@ static int msm_execute_t(plk_msm_ctx* ctx, const void* d_scalars, void* d_out_xy
         PLK_HIP_TRY(hipGetLastError());
     }
     mark();
-    k_msm_scan<<<1, 1024, 0, stream>>>(hist, off, slice_off, buckets);
+    k_msm_scan<<<1, 1024, 0, stream>>>(hist, off, slice_off, buckets, ctx->slice);
     PLK_HIP_TRY(hipGetLastError());
     mark();
     if (entries) {
@@ -483,20 +501,18 @@ static int msm_execute_t(plk_msm_ctx* ctx, const void* d_scalars, void* d_out_xy
     mark();
     // the slice count is only known on the device: launch for the upper bound, lanes past it exit
     k_msm_accumulate<C><<<(unsigned)((ctx->max_slices + 127) / 128), 128, 0, stream>>>((const uint4*)ctx->tab, (const uint32_t*)ctx->sorted, off, slice_off,
-                                                                                       (uint4*)ctx->partial, buckets);
+                                                                                       (uint4*)ctx->partial, buckets, ctx->slice);
     PLK_HIP_TRY(hipGetLastError());
     mark();
-    k_msm_chunks<C><<<(ctx->n_chunks + 63) / 64, 64, 0, stream>>>((const uint4*)ctx->partial, slice_off, (uint4*)ctx->chunk_s, (uint4*)ctx->chunk_r,
-                                                                  ctx->n_chunks, ctx->chunk_log);
+    k_msm_bucket_sum<C><<<(buckets + 127) / 128, 128, 0, stream>>>((const uint4*)ctx->partial, slice_off, (uint4*)ctx->bucket, buckets);
     PLK_HIP_TRY(hipGetLastError());
     mark();
-    dim3 pg(ctx->plane_blocks, ctx->n_bits + 1);
-    k_msm_planes<C><<<pg, 128, 128 * xyzz_bytes, stream>>>((const uint4*)ctx->chunk_s, (const uint4*)ctx->chunk_r, (uint4*)ctx->plane_part, ctx->n_chunks,
-                                                           ctx->n_bits);
+    dim3 pg(ctx->plane_blocks, ctx->planes);
+    k_msm_planes<C><<<pg, 256, 256 * xyzz_bytes, stream>>>((const uint4*)ctx->bucket, (uint4*)ctx->plane_part, buckets);
     PLK_HIP_TRY(hipGetLastError());
     mark();
-    k_msm_final<C><<<1, 64, 64 * xyzz_bytes, stream>>>((const uint4*)ctx->plane_part, ctx->plane_blocks, ctx->n_bits, ctx->chunk_log, (uint4*)d_out_xy,
-                                                       (uint8_t*)d_out_zero);
+    k_msm_final<C><<<1, 256, 256 * xyzz_bytes, stream>>>((const uint4*)ctx->plane_part, ctx->plane_blocks, ctx->planes, (uint4*)d_out_xy,
+                                                         (uint8_t*)d_out_zero);
     PLK_HIP_TRY(hipGetLastError());
     mark();
     if (!ev.empty()) ctx->prof_sets.push_back(ev);
@@ -533,7 +549,7 @@ int msm_set_profiling_impl(plk_msm_ctx* ctx, int enable) {
     ctx->profiling = enable != 0;
     return PLK_OK;
 }
-// sum_ms[7]: digits, scan, scatter, accumulate, chunks, planes, final -- summed over `calls` executions since the last read
+// sum_ms[7]: digits, scan, scatter, accumulate, bucket sums, planes, final -- summed over `calls` executions since the last read
 int msm_get_timings_impl(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls) {
     if (!ctx || !sum_ms) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     std::lock_guard<std::mutex> lk(ctx->mu);

@@ -16,6 +16,7 @@ template <class P> static void run(int op, const uint32_t* a, const uint32_t* b,
             case 4: r = fe_sqr<P>(x); break;
             case 5: r = fe_inv<P>(x); break;
             case 6: r = fe_half<P>(x); break;
+            case 8: r = fe_inv_eea<P>(x); break;
             default: r = fe_neg<P>(x); break;
         }
         for (int k = 0; k < P::NL; ++k) out[i * P::NL + k] = r.v[k];

@@ -66,3 +66,7 @@ def test_device_header_arithmetic_on_host(host_lib, f):
     assert run(host_lib, f, 6, x) == [v * pow(2, -1, p) % p for v in inputs]
     small = ints_to_array([f.to_mont(v) for v in range(0, 25)], n)
     assert run(host_lib, f, 5, small) == [0] + [f.to_mont(pow(v, -1, p)) for v in range(1, 25)]
+    # Euclidean inversion (the reference's algorithm): edge values + random, Montgomery in / Montgomery out
+    nz = [v for v in inputs if v != 0][:120] + inputs[-60:]
+    assert run(host_lib, f, 8, ints_to_array(nz, n)) == [pow(v * Rinv % p, -1, p) * f.R % p for v in nz]
+    assert run(host_lib, f, 8, ints_to_array([0], n)) == [0]
