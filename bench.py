@@ -219,7 +219,7 @@ def main():
         comp["msm_ms"] = tm * 1e3
         comp["msm_mpairs_per_s"] = world * n / tm / 1e6
         comp["msm_window_bits"] = pre.window
-        comp["msm_stage_ms"] = dict(zip(["digits", "scan", "scatter", "accumulate", "bucket_sum", "planes", "final"],
+        comp["msm_stage_ms"] = dict(zip(["digits", "partition", "scan_scatter", "accumulate", "bucket_sum", "planes", "final"],
                                         [round(v, 4) for v in msm_stage_ms]))
 
     # ---- correctness of what was just timed (not in the timed region) ----

@@ -3,7 +3,7 @@
 // Replaces the reference's src/curve/curve_msm.rs (+ curve_summations.rs, curve_adds.rs):
 //   msm_precompute / precompute_single_generator  curve_msm.rs:27-52  -> k_msm_table (device tables)
 //   to_digits                                     curve_msm.rs:159-180 -> k_msm_digits (signed, carry based)
-//   digit_occurrences scatter (serial in the ref) curve_msm.rs:117-126 -> histogram + scan + scatter
+//   digit_occurrences scatter (serial in the ref) curve_msm.rs:117-126 -> two-level LDS partition (k_part*)
 //   per-digit affine multi-summation              curve_msm.rs:131-145 -> k_msm_accumulate (XYZZ mixed adds)
 //   serial Yao tail  u += acc[d]; y += u          curve_msm.rs:149-154 -> k_msm_bucket_sum + k_msm_planes + k_msm_final
 //   msm_execute / msm_execute_parallel            curve_msm.rs:63-157  -> msm_execute_dev_impl
@@ -29,7 +29,7 @@ namespace plk {
 
 constexpr int MSM_SLICE_DEFAULT = 32;  // entries per accumulation slice (PLK_MSM_SLICE overrides)
 constexpr int MSM_MAX_PLANE_PARTS = 8;  // blocks per bit-plane in the reduction
-constexpr int MSM_MAX_WINDOW = 22;
+constexpr int MSM_MAX_WINDOW = 17;   // c - 1 <= 8 fine + 8 coarse bits in the partition
 constexpr uint32_t CODE_INVALID = 0xFFFFFFFFu;
 
 // ---------------------------------------------------------------------------------------------
@@ -56,11 +56,10 @@ __global__ void __launch_bounds__(128) k_msm_table(const uint4* __restrict__ bas
 }
 
 // ---------------------------------------------------------------------------------------------
-// scalars -> signed window digits + bucket histogram  (curve_msm.rs:159-180, :121-126)
+// scalars -> signed window digits  (curve_msm.rs:159-180)
 // ---------------------------------------------------------------------------------------------
 template <class C>
-__global__ void __launch_bounds__(256) k_msm_digits(const uint4* __restrict__ scalars, uint32_t* __restrict__ codes, uint32_t* __restrict__ hist,
-                                                    size_t n, int c, int windows) {
+__global__ void __launch_bounds__(256) k_msm_digits(const uint4* __restrict__ scalars, uint32_t* __restrict__ codes, size_t n, int c, int windows) {
     using SP = typename C::SP;
     static_assert(SP::NL == 8, "scalar fields are 256-bit");
     // Scalars are staged through LDS: the block reads its 256 * 32 B with fully coalesced 16-byte
@@ -99,10 +98,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint4* __restrict__ sc
         uint32_t mag = neg ? (1u << c) - v : v;
         carry = neg;
         uint32_t code = CODE_INVALID;
-        if (mag != 0) {
-            code = ((mag - 1u) << 1) | neg;
-            atomicAdd(&hist[mag - 1u], 1u);
-        }
+        if (mag != 0) code = ((mag - 1u) << 1) | neg;
         codes[(size_t)j * n + i] = code;
     }
 }
@@ -147,15 +143,174 @@ __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ 
     }
 }
 
-__global__ void __launch_bounds__(256) k_msm_scatter(const uint32_t* __restrict__ codes, const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor,
-                                                     uint32_t* __restrict__ sorted, size_t entries) {
-    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= entries) return;
-    uint32_t code = codes[e];
-    if (code == CODE_INVALID) return;
-    uint32_t b = code >> 1;
-    uint32_t pos = off[b] + atomicAdd(&cursor[b], 1u);
-    sorted[pos] = ((uint32_t)e << 1) | (code & 1u);
+// ---------------------------------------------------------------------------------------------
+// entries -> bucket order: two-level MSD partition in LDS  (replaces the reference's serial
+// digit_occurrences scatter, curve_msm.rs:117-126)
+// ---------------------------------------------------------------------------------------------
+// A bucket id has c-1 bits = [coarse | fine], fine = min(8, c-1) bits.  Level 1 splits the entry
+// stream into <= 256 coarse bins, level 2 splits every coarse bin into its <= 256 buckets.  Both
+// levels are the same three steps on tiles of PART_TILE entries: per-tile LDS histogram ->
+// global [bin][tile] counts -> scan -> per-tile LDS cursors, so every global write is a run of
+// consecutive slots and the only atomics are LDS atomics.  Counts, not capacities, drive the
+// layout: any digit distribution works (hot buckets just make long runs).
+constexpr int PART_TILE_LOG = 12;
+constexpr int PART_TILE = 1 << PART_TILE_LOG;   // entries per tile
+constexpr int PART_THREADS = 256;
+constexpr int PART_PER_THREAD = PART_TILE / PART_THREADS;
+
+// level 1, step 1: cnt1[bin * nt1 + tile] = number of entries of `tile` falling in coarse bin `bin`
+__global__ void __launch_bounds__(PART_THREADS) k_part1_count(const uint32_t* __restrict__ codes, size_t entries, uint32_t* __restrict__ cnt1, uint32_t nt1,
+                                                              int fine_bits, int nbins) {
+    __shared__ uint32_t s_hist[256];
+    const uint32_t tile = blockIdx.x;
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t base = (size_t)tile << PART_TILE_LOG;
+#pragma unroll
+    for (int k = 0; k < PART_PER_THREAD; ++k) {
+        const size_t e = base + k * PART_THREADS + threadIdx.x;
+        if (e < entries) {
+            const uint32_t code = codes[e];
+            if (code != CODE_INVALID) atomicAdd(&s_hist[code >> (fine_bits + 1)], 1u);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nbins) cnt1[(size_t)threadIdx.x * nt1 + tile] = s_hist[threadIdx.x];
+}
+
+// one block per row: in-place exclusive scan of `len` counters, total to totals[row]
+__global__ void __launch_bounds__(256) k_part_rowscan(uint32_t* __restrict__ cnt, uint32_t len, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_sum[256];
+    uint32_t* row = cnt + (size_t)blockIdx.x * len;
+    const uint32_t per = (len + 255) / 256;
+    const uint32_t lo = threadIdx.x * per, hi = min(len, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += row[i];
+    s_sum[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        uint32_t v = (int)threadIdx.x >= d ? s_sum[threadIdx.x - d] : 0;
+        __syncthreads();
+        s_sum[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[threadIdx.x] - sum;
+    for (uint32_t i = lo; i < hi; ++i) {
+        uint32_t v = row[i];
+        row[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 255) totals[blockIdx.x] = s_sum[255];
+}
+
+// layout of the intermediate array: every coarse bin starts on a tile boundary (so level-2 tiles
+// never straddle bins).  meta[0] = number of level-2 tiles.
+__global__ void __launch_bounds__(256) k_part_bases(const uint32_t* __restrict__ bin_total, int nbins, uint32_t* __restrict__ bin_base_pad,
+                                                    uint32_t* __restrict__ tile2bin, uint32_t* __restrict__ meta) {
+    __shared__ uint32_t s_pad[257];
+    if (threadIdx.x == 0) {
+        uint32_t pad = 0;
+        for (int b = 0; b < nbins; ++b) {
+            s_pad[b] = pad;
+            pad += (bin_total[b] + PART_TILE - 1) >> PART_TILE_LOG << PART_TILE_LOG;
+        }
+        s_pad[nbins] = pad;
+        meta[0] = pad >> PART_TILE_LOG;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= nbins; b += blockDim.x) bin_base_pad[b] = s_pad[b];
+    for (int b = 0; b < nbins; ++b) {
+        const uint32_t t0 = s_pad[b] >> PART_TILE_LOG, t1 = s_pad[b + 1] >> PART_TILE_LOG;
+        for (uint32_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) tile2bin[t] = (uint32_t)b;
+    }
+}
+
+// level 1, step 3: move (code, entry id) to its coarse bin
+__global__ void __launch_bounds__(PART_THREADS) k_part1_scatter(const uint32_t* __restrict__ codes, size_t entries, const uint32_t* __restrict__ cnt1,
+                                                                uint32_t nt1, const uint32_t* __restrict__ bin_base_pad, int fine_bits, int nbins,
+                                                                uint32_t* __restrict__ tmp_code, uint32_t* __restrict__ tmp_val) {
+    __shared__ uint32_t s_cur[256];
+    const uint32_t tile = blockIdx.x;
+    if ((int)threadIdx.x < nbins) s_cur[threadIdx.x] = bin_base_pad[threadIdx.x] + cnt1[(size_t)threadIdx.x * nt1 + tile];
+    __syncthreads();
+    const size_t base = (size_t)tile << PART_TILE_LOG;
+#pragma unroll
+    for (int k = 0; k < PART_PER_THREAD; ++k) {
+        const size_t e = base + k * PART_THREADS + threadIdx.x;
+        if (e < entries) {
+            const uint32_t code = codes[e];
+            if (code != CODE_INVALID) {
+                const uint32_t pos = atomicAdd(&s_cur[code >> (fine_bits + 1)], 1u);
+                tmp_code[pos] = code;
+                tmp_val[pos] = (uint32_t)e;
+            }
+        }
+    }
+}
+
+// level 2, step 1: cnt2[fine * nt2max + tile2]  (row = bucket-within-bin, so a row scan over the
+// tiles of one bin gives the within-bucket offsets)
+__global__ void __launch_bounds__(PART_THREADS) k_part2_count(const uint32_t* __restrict__ tmp_code, const uint32_t* __restrict__ bin_total,
+                                                              const uint32_t* __restrict__ bin_base_pad, const uint32_t* __restrict__ tile2bin,
+                                                              const uint32_t* __restrict__ meta, uint32_t* __restrict__ cnt2, uint32_t nt2max, int fine_bits) {
+    __shared__ uint32_t s_hist[256];
+    const uint32_t tile = blockIdx.x;
+    if (tile >= meta[0]) return;
+    const uint32_t bin = tile2bin[tile];
+    const uint32_t valid_end = bin_base_pad[bin] + bin_total[bin];
+    s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = tile << PART_TILE_LOG, fmask = (1u << fine_bits) - 1u;
+#pragma unroll
+    for (int k = 0; k < PART_PER_THREAD; ++k) {
+        const uint32_t p = base + k * PART_THREADS + threadIdx.x;
+        if (p < valid_end) atomicAdd(&s_hist[(tmp_code[p] >> 1) & fmask], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x <= fmask) cnt2[(size_t)threadIdx.x * nt2max + tile] = s_hist[threadIdx.x];
+}
+
+// level 2, step 2: one block per coarse bin, lane = fine bucket: walk the bin's tiles, turn the counts
+// into within-bucket offsets and publish the bucket sizes (hist) for the global bucket scan
+__global__ void __launch_bounds__(256) k_part2_scan(uint32_t* __restrict__ cnt2, uint32_t nt2max, const uint32_t* __restrict__ bin_base_pad, int fine_bits,
+                                                    uint32_t* __restrict__ hist) {
+    const uint32_t bin = blockIdx.x, fine = threadIdx.x;
+    if (fine >= (1u << fine_bits)) return;
+    const uint32_t t0 = bin_base_pad[bin] >> PART_TILE_LOG, t1 = bin_base_pad[bin + 1] >> PART_TILE_LOG;
+    uint32_t run = 0;
+    uint32_t* row = cnt2 + (size_t)fine * nt2max;
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t v = row[t];
+        row[t] = run;
+        run += v;
+    }
+    hist[(bin << fine_bits) + fine] = run;
+}
+
+// level 2, step 3: final position = off[bucket] + within-bucket offset of this tile + LDS rank
+__global__ void __launch_bounds__(PART_THREADS) k_part2_scatter(const uint32_t* __restrict__ tmp_code, const uint32_t* __restrict__ tmp_val,
+                                                                const uint32_t* __restrict__ bin_total, const uint32_t* __restrict__ bin_base_pad,
+                                                                const uint32_t* __restrict__ tile2bin, const uint32_t* __restrict__ meta,
+                                                                const uint32_t* __restrict__ cnt2, uint32_t nt2max, int fine_bits,
+                                                                const uint32_t* __restrict__ off, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t s_cur[256];
+    const uint32_t tile = blockIdx.x;
+    if (tile >= meta[0]) return;
+    const uint32_t bin = tile2bin[tile];
+    const uint32_t valid_end = bin_base_pad[bin] + bin_total[bin];
+    const uint32_t fmask = (1u << fine_bits) - 1u;
+    if (threadIdx.x <= fmask) s_cur[threadIdx.x] = off[(bin << fine_bits) + threadIdx.x] + cnt2[(size_t)threadIdx.x * nt2max + tile];
+    __syncthreads();
+    const uint32_t base = tile << PART_TILE_LOG;
+#pragma unroll
+    for (int k = 0; k < PART_PER_THREAD; ++k) {
+        const uint32_t p = base + k * PART_THREADS + threadIdx.x;
+        if (p < valid_end) {
+            const uint32_t code = tmp_code[p];
+            const uint32_t pos = atomicAdd(&s_cur[(code >> 1) & fmask], 1u);
+            sorted[pos] = (tmp_val[p] << 1) | (code & 1u);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -356,7 +511,15 @@ struct plk_msm_ctx {
     void* tab = nullptr;
     void* codes = nullptr;
     void* sorted = nullptr;
-    void* hist = nullptr;      // hist[buckets] followed by cursor[buckets]
+    void* hist = nullptr;      // bucket sizes
+    // two-level partition workspace
+    int fine_bits = 0, nbins = 1;
+    uint32_t nt1 = 0, nt2max = 0;
+    void* cnt1 = nullptr;      // [nbins][nt1]
+    void* cnt2 = nullptr;      // [2^fine_bits][nt2max]
+    void* tmp_code = nullptr;  // entries + nbins * PART_TILE
+    void* tmp_val = nullptr;
+    void* part_meta = nullptr; // bin_total[256] | bin_base_pad[257] | meta[1] | tile2bin[nt2max]
     void* off = nullptr;       // off[buckets+1] followed by slice_off[buckets+1]
     void* partial = nullptr;
     void* bucket = nullptr;    // bucket sums (XYZZ)
@@ -368,7 +531,7 @@ struct plk_msm_ctx {
     std::vector<std::vector<hipEvent_t>> prof_sets;  // each N_STAGES + 1 events, recorded
     std::vector<std::vector<hipEvent_t>> prof_free;
     ~plk_msm_ctx() {
-        for (void* p : {tab, codes, sorted, hist, off, partial, bucket, plane_part})
+        for (void* p : {tab, codes, sorted, hist, off, partial, bucket, plane_part, cnt1, cnt2, tmp_code, tmp_val, part_meta})
             if (p) (void)hipFree(p);
         for (auto* v : {&prof_sets, &prof_free})
             for (auto& set : *v)
@@ -401,7 +564,17 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
     PLK_HIP_TRY(hipMalloc(&ctx->tab, entries * pt_bytes + 16));
     PLK_HIP_TRY(hipMalloc(&ctx->codes, entries * 4 + 16));
     PLK_HIP_TRY(hipMalloc(&ctx->sorted, entries * 4 + 16));
-    PLK_HIP_TRY(hipMalloc(&ctx->hist, (size_t)ctx->buckets * 8));
+    PLK_HIP_TRY(hipMalloc(&ctx->hist, (size_t)ctx->buckets * 4 + 16));
+    ctx->fine_bits = (ctx->c - 1) < 8 ? (ctx->c - 1) : 8;
+    ctx->nbins = 1 << (ctx->c - 1 - ctx->fine_bits);
+    ctx->nt1 = (uint32_t)((entries + PART_TILE - 1) >> PART_TILE_LOG);
+    if (ctx->nt1 == 0) ctx->nt1 = 1;
+    ctx->nt2max = ctx->nt1 + ctx->nbins;
+    PLK_HIP_TRY(hipMalloc(&ctx->cnt1, (size_t)ctx->nbins * ctx->nt1 * 4));
+    PLK_HIP_TRY(hipMalloc(&ctx->cnt2, ((size_t)1 << ctx->fine_bits) * ctx->nt2max * 4));
+    PLK_HIP_TRY(hipMalloc(&ctx->tmp_code, ((size_t)ctx->nt2max << PART_TILE_LOG) * 4));
+    PLK_HIP_TRY(hipMalloc(&ctx->tmp_val, ((size_t)ctx->nt2max << PART_TILE_LOG) * 4));
+    PLK_HIP_TRY(hipMalloc(&ctx->part_meta, (size_t)(256 + 257 + 1 + ctx->nt2max) * 4));
     PLK_HIP_TRY(hipMalloc(&ctx->off, ((size_t)ctx->buckets + 1) * 8));
     ctx->max_slices = entries / ctx->slice + ctx->buckets + 1;
     PLK_HIP_TRY(hipMalloc(&ctx->partial, ctx->max_slices * xyzz_bytes));
@@ -466,9 +639,12 @@ static int msm_execute_t(plk_msm_ctx* ctx, const void* d_scalars, void* d_out_xy
     const uint32_t buckets = ctx->buckets;
     const size_t xyzz_bytes = (size_t)4 * FP::NL * 4;
     uint32_t* hist = (uint32_t*)ctx->hist;
-    uint32_t* cursor = hist + buckets;
     uint32_t* off = (uint32_t*)ctx->off;
     uint32_t* slice_off = off + buckets + 1;
+    uint32_t* bin_total = (uint32_t*)ctx->part_meta;
+    uint32_t* bin_base_pad = bin_total + 256;
+    uint32_t* meta = bin_base_pad + 257;
+    uint32_t* tile2bin = meta + 1;
     std::vector<hipEvent_t> ev;
     if (ctx->profiling) {
         if (!ctx->prof_free.empty()) {
@@ -484,20 +660,28 @@ static int msm_execute_t(plk_msm_ctx* ctx, const void* d_scalars, void* d_out_xy
         if (!ev.empty()) (void)hipEventRecord(ev[stage], stream);
         ++stage;
     };
-    PLK_HIP_TRY(hipMemsetAsync(ctx->hist, 0, (size_t)buckets * 8, stream));
     mark();
     if (n) {
-        k_msm_digits<C><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const uint4*)d_scalars, (uint32_t*)ctx->codes, hist, n, ctx->c, ctx->windows);
+        k_msm_digits<C><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const uint4*)d_scalars, (uint32_t*)ctx->codes, n, ctx->c, ctx->windows);
         PLK_HIP_TRY(hipGetLastError());
     }
     mark();
-    k_msm_scan<<<1, 1024, 0, stream>>>(hist, off, slice_off, buckets, ctx->slice);
+    // partition level 1 (coarse bins)
+    k_part1_count<<<ctx->nt1, PART_THREADS, 0, stream>>>((const uint32_t*)ctx->codes, entries, (uint32_t*)ctx->cnt1, ctx->nt1, ctx->fine_bits, ctx->nbins);
+    k_part_rowscan<<<ctx->nbins, 256, 0, stream>>>((uint32_t*)ctx->cnt1, ctx->nt1, bin_total);
+    k_part_bases<<<1, 256, 0, stream>>>(bin_total, ctx->nbins, bin_base_pad, tile2bin, meta);
+    k_part1_scatter<<<ctx->nt1, PART_THREADS, 0, stream>>>((const uint32_t*)ctx->codes, entries, (const uint32_t*)ctx->cnt1, ctx->nt1, bin_base_pad,
+                                                           ctx->fine_bits, ctx->nbins, (uint32_t*)ctx->tmp_code, (uint32_t*)ctx->tmp_val);
+    // partition level 2 (buckets inside each coarse bin) + bucket offsets / slice offsets
+    k_part2_count<<<ctx->nt2max, PART_THREADS, 0, stream>>>((const uint32_t*)ctx->tmp_code, bin_total, bin_base_pad, tile2bin, meta, (uint32_t*)ctx->cnt2,
+                                                            ctx->nt2max, ctx->fine_bits);
+    k_part2_scan<<<ctx->nbins, 256, 0, stream>>>((uint32_t*)ctx->cnt2, ctx->nt2max, bin_base_pad, ctx->fine_bits, hist);
     PLK_HIP_TRY(hipGetLastError());
     mark();
-    if (entries) {
-        k_msm_scatter<<<(unsigned)((entries + 255) / 256), 256, 0, stream>>>((const uint32_t*)ctx->codes, off, cursor, (uint32_t*)ctx->sorted, entries);
-        PLK_HIP_TRY(hipGetLastError());
-    }
+    k_msm_scan<<<1, 1024, 0, stream>>>(hist, off, slice_off, buckets, ctx->slice);
+    k_part2_scatter<<<ctx->nt2max, PART_THREADS, 0, stream>>>((const uint32_t*)ctx->tmp_code, (const uint32_t*)ctx->tmp_val, bin_total, bin_base_pad, tile2bin,
+                                                              meta, (const uint32_t*)ctx->cnt2, ctx->nt2max, ctx->fine_bits, off, (uint32_t*)ctx->sorted);
+    PLK_HIP_TRY(hipGetLastError());
     mark();
     // the slice count is only known on the device: launch for the upper bound, lanes past it exit
     k_msm_accumulate<C><<<(unsigned)((ctx->max_slices + 127) / 128), 128, 0, stream>>>((const uint4*)ctx->tab, (const uint32_t*)ctx->sorted, off, slice_off,
@@ -549,7 +733,7 @@ int msm_set_profiling_impl(plk_msm_ctx* ctx, int enable) {
     ctx->profiling = enable != 0;
     return PLK_OK;
 }
-// sum_ms[7]: digits, scan, scatter, accumulate, bucket sums, planes, final -- summed over `calls` executions since the last read
+// sum_ms[7]: digits, partition (counts), bucket scan + final scatter, accumulate, bucket sums, planes, final -- summed over `calls` executions since the last read
 int msm_get_timings_impl(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls) {
     if (!ctx || !sum_ms) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     std::lock_guard<std::mutex> lk(ctx->mu);
