@@ -1,0 +1,80 @@
+// ecz.cuh -- XYZZ mixed addition on lazily reduced 29-bit-limb coordinates (fz.cuh): the inner
+// loop of the MSM bucket accumulation.  Same formulas as ec.cuh (EFD madd-2008-s, mdbl-2008-s-1,
+// a = 0), same group law as the reference's P + A addition (curve_adds.rs:50-90); coordinates are
+// in R'-form (x 2^(29 NZ)) and only congruent mod p.  Value bounds (multiples of p) are tracked in
+// the comments; a Montgomery product of values a p and b p comes back below (a b / 128 + 1) p for
+// the 255-bit fields (p / R' <= 2^-7), far less for the others.
+//
+// Invariant of an accumulator:  X < 8p, Y < 4p, ZZ < 2p, ZZZ < 2p, limbs < 2^29 + 8,
+// or inf = true (the identity; the reference's `zero` flag, curve.rs:176-181).
+#pragma once
+#include "fz.cuh"
+
+namespace plk {
+
+template <class FP> struct XyzzZ {
+    Fz<FP> x, y, zz, zzz;
+    bool inf;
+};
+
+template <class FP> PLK_DI Fz<FP> fz_zero() {
+    Fz<FP> r;
+#pragma unroll
+    for (int i = 0; i < FzCfg<FP>::NZ; ++i) r.l[i] = 0;
+    return r;
+}
+
+// -y for a canonical y (< p): 2p - y, in (p, 2p]
+template <class FP> PLK_DI Fz<FP> fz_neg_canonical(const Fz<FP>& y) { return fz_sub<FP, 1>(fz_zero<FP>(), y); }
+
+// 2 * (x, y), affine operand with x, y < 2p  (y = 0 mod p gives the identity)
+template <class FP> PLK_DNI void xyzzz_mdbl(XyzzZ<FP>& r, const Fz<FP>& x, const Fz<FP>& y) {
+    Fz<FP> u = fz_dbl<FP>(y);                                // < 4
+    Fz<FP> v = fz_sqr<FP>(u);                                // < 2
+    Fz<FP> w = fz_mul<FP>(u, v);                             // < 2
+    Fz<FP> s = fz_mul<FP>(x, v);                             // < 2
+    Fz<FP> xx = fz_sqr<FP>(x);                               // < 2
+    Fz<FP> m = fz_add<FP>(fz_dbl<FP>(xx), xx);               // < 6
+    Fz<FP> mm = fz_sqr<FP>(m);                               // < 2
+    r.x = fz_sub<FP, 2>(mm, fz_dbl<FP>(s));                  // < 2 + 4 = 6   (2s < 4 <= 4p - margin)
+    Fz<FP> t = fz_sub<FP, 3>(s, r.x);                        // < 2 + 8 = 10
+    r.y = fz_sub<FP, 1>(fz_mul<FP>(m, t), fz_mul<FP>(w, y));  // < 2 + 2 = 4   (m t / 128 + 1 < 1.5)
+    r.zz = v;
+    r.zzz = w;
+    r.inf = fz_is_zero_mod_p<FP>(v);
+}
+
+// acc += (x2, y2); x2 < p canonical, y2 < 2p (a negated canonical y is 2p - y)
+template <class FP> PLK_DI void xyzzz_madd(XyzzZ<FP>& acc, const Fz<FP>& x2, const Fz<FP>& y2) {
+    if (acc.inf) {
+        acc.x = x2;
+        acc.y = y2;
+        acc.zz = fz_one_rprime<FP>();
+        acc.zzz = acc.zz;
+        acc.inf = false;
+        return;
+    }
+    Fz<FP> u2 = fz_mul<FP>(x2, acc.zz);                      // < 2
+    Fz<FP> s2 = fz_mul<FP>(y2, acc.zzz);                     // < 2
+    Fz<FP> p = fz_sub<FP, 4>(u2, acc.x);                     // < 2 + 16 = 18      (X < 8 <= 16 - margin)
+    Fz<FP> r = fz_sub<FP, 2>(s2, acc.y);                     // < 2 + 4 = 6        (Y < 3.4)
+    Fz<FP> pp = fz_sqr<FP>(p);                               // < 18^2/128 + 1 < 3.6
+    Fz<FP> ppp = fz_mul<FP>(p, pp);                          // < 18*3.6/128 + 1 < 1.6
+    Fz<FP> q = fz_mul<FP>(acc.x, pp);                        // < 8*3.6/128 + 1 < 1.3
+    Fz<FP> rr = fz_sqr<FP>(r);                               // < 36/128 + 1 < 1.3
+    Fz<FP> zz3 = fz_mul<FP>(acc.zz, pp);                     // < 1.1
+    if (fz_is_zero_mod_p<FP>(zz3)) {
+        // p = 0 mod p: the operands share x.  Same point -> double it; opposite points -> identity.
+        if (fz_is_zero_mod_p<FP>(rr)) xyzzz_mdbl<FP>(acc, x2, y2);
+        else acc.inf = true;
+        return;
+    }
+    Fz<FP> x3 = fz_sub<FP, 2>(fz_sub<FP, 1>(rr, ppp), fz_dbl<FP>(q));  // (1.3 + 2) + 4 < 7.3 < 8
+    Fz<FP> t = fz_sub<FP, 3>(q, x3);                                    // < 1.3 + 8 = 9.3
+    acc.y = fz_sub<FP, 1>(fz_mul<FP>(r, t), fz_mul<FP>(acc.y, ppp));    // < (6*9.3/128 + 1) + 2 < 3.5 < 4
+    acc.x = x3;
+    acc.zz = zz3;
+    acc.zzz = fz_mul<FP>(acc.zzz, ppp);                                 // < 1.1
+}
+
+}  // namespace plk

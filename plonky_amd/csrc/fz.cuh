@@ -1,0 +1,294 @@
+// fz.cuh -- lazily reduced field elements on 29-bit limbs: the arithmetic the hot kernels run on.
+//
+// fp.cuh keeps the reference's representation (32-bit words, R = 2^(32 NL), fully reduced) and is
+// what crosses every interface.  Inside a kernel that representation is expensive on gfx950:
+// every carry is a 4-cycle instruction and every product has to be brought back below p.  Fz is
+// the working form of the inner loops:
+//   * NZ = ceil(32 NL / 29) limbs of 29 bits in 32-bit registers (9 for the 256-bit fields, 14 for
+//     Bls12377Base), so a 64-bit accumulator sums a whole product column (<= 2 NZ terms < 2^58)
+//     with plain v_mad_u64_u32 chains - no carry flags anywhere;
+//   * Montgomery radix R' = 2^(29 NZ) (2^261 / 2^406): p / R' <= 2^-7, so a product of two values
+//     below 16p comes back below (1 + 256/128) p ... in practice < 2p, without any final
+//     conditional subtraction;
+//   * values are only congruent mod p ("< k p" for a small tracked k), limbs only almost
+//     normalised (< 2^29 + 8); subtraction adds a multiple of p laid out so no limb goes negative.
+// Conversions: fz_from_words() re-slices 32-bit words (the value is kept, so data in R-form stays
+// in R-form; tables that multiply such data are stored in R'-form, see ntt.hip / msm.hip);
+// fz_to_words_canonical() reduces fully and re-slices back, giving the unique representative.
+//
+// Bounds, stated once.  "limb bound" L: every limb <= L.  mul/sqr accept L <= 2^29 + 2^27 on
+// both operands (column sum <= NZ (2^29+2^27)^2 + NZ 2^58 + 2^36 < 2^64 for NZ <= 14) and any
+// value < 2^(29 NZ - 3) = R'/8.  mul/sqr return exactly normalised limbs (< 2^29, top limb takes
+// the rest) and a value < a b / R' + p.  add/sub return limbs < 2^29 + 8.
+#pragma once
+#include <stdint.h>
+
+#include "fp.cuh"
+
+namespace plk {
+
+template <class P> struct FzCfg {
+    static constexpr int NZ = (32 * P::NL + 28) / 29;
+    static constexpr uint32_t M = 0x1FFFFFFFu;
+    static constexpr uint32_t plimb(int j) { return Mod29<P>::limb(j); }
+    // limb j of (2^k p) in "borrowed" form: every limb below the top carries an extra 2^30 taken from
+    // the limb above, so that (a - b + this) has no negative limb for any b with limbs < 2^30.
+    static constexpr uint32_t kp_limb(int k, int j) {
+        // 2^k p as NZ 29-bit limbs (top limb unbounded)
+        uint64_t carry = 0;
+        uint32_t c = 0;
+        for (int i = 0; i <= j; ++i) {
+            uint64_t v = ((uint64_t)plimb(i) << k) + carry;
+            if (i == NZ - 1) {
+                c = (uint32_t)v;
+                carry = 0;
+            } else {
+                c = (uint32_t)(v & M);
+                carry = v >> 29;
+            }
+        }
+        if (j == 0) return c + (1u << 30);
+        if (j == NZ - 1) return c - 2u;
+        return c + (1u << 30) - 2u;
+    }
+};
+
+template <class P> struct Fz {
+    uint32_t l[FzCfg<P>::NZ];
+};
+
+// ---- conversions -----------------------------------------------------------------------------
+template <class P> PLK_DI Fz<P> fz_from_words(const uint32_t (&a)[P::NL]) {
+    constexpr int NZ = FzCfg<P>::NZ;
+    Fz<P> r;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        const int off = 29 * i, w = off >> 5, sh = off & 31;
+        uint32_t v;
+        if (sh == 0) v = a[w];
+        else if (sh + 29 <= 32 || w + 1 >= P::NL) v = a[w] >> sh;
+        else v = (a[w] >> sh) | (a[w + 1] << (32 - sh));  // 32-bit funnel shift (v_alignbit_b32)
+        r.l[i] = v & FzCfg<P>::M;
+    }
+    return r;
+}
+template <class P> PLK_DI Fz<P> fz_from_fe(const Fe<P>& a) { return fz_from_words<P>(a.v); }
+
+// exact limb normalisation (sequential carry chain): limbs < 2^29, top limb takes the rest
+template <class P> PLK_DI void fz_normalize(Fz<P>& a) {
+    constexpr int NZ = FzCfg<P>::NZ;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NZ - 1; ++i) {
+        const uint32_t t = a.l[i] + c;
+        a.l[i] = t & FzCfg<P>::M;
+        c = t >> 29;
+    }
+    a.l[NZ - 1] += c;
+}
+
+// value < 2p, any limbs  ->  the unique representative in the reference's 32-bit words
+template <class P> PLK_DI Fe<P> fz_to_fe_canonical(Fz<P> a) {
+    constexpr int NZ = FzCfg<P>::NZ;
+    fz_normalize<P>(a);
+    Fe<P> r;
+#pragma unroll
+    for (int t = 0; t < P::NL; ++t) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int m = 0; m < NZ; ++m) {
+            const int s = 29 * m, lo = 32 * t, hi = 32 * t + 32;
+            if (s < hi && s + 32 > lo) {  // the top limb may be wider than 29 bits: treat every limb as 32 wide
+                if (s >= lo) word |= a.l[m] << (s - lo);
+                else if (lo - s < 32) word |= a.l[m] >> (lo - s);
+            }
+        }
+        r.v[t] = word;
+    }
+    fe_cond_sub_p<P>(r.v);
+    return r;
+}
+
+// ---- add / sub -------------------------------------------------------------------------------
+// parallel carry pass: limbs <= L < 2^32  ->  limbs < 2^29 + (L >> 29) + 1
+template <class P> PLK_DI void fz_carry(Fz<P>& a) {
+    constexpr int NZ = FzCfg<P>::NZ;
+    uint32_t c[NZ];
+#pragma unroll
+    for (int i = 0; i < NZ - 1; ++i) c[i] = a.l[i] >> 29;
+    a.l[0] &= FzCfg<P>::M;
+#pragma unroll
+    for (int i = 1; i < NZ - 1; ++i) a.l[i] = (a.l[i] & FzCfg<P>::M) + c[i - 1];
+    a.l[NZ - 1] += c[NZ - 2];
+}
+template <class P> PLK_DI Fz<P> fz_add(const Fz<P>& a, const Fz<P>& b) {
+    Fz<P> r;
+#pragma unroll
+    for (int i = 0; i < FzCfg<P>::NZ; ++i) r.l[i] = a.l[i] + b.l[i];
+    fz_carry<P>(r);
+    return r;
+}
+// a - b + 2^K p.  Needs value(b) <= 2^K p - 2^(29 (NZ - 1) + 2) (any honest bound k p with k < 2^K
+// satisfies it) and limbs of b <= 2^30 - 2.  Result value < value(a) + 2^K p, limbs < 2^29 + 8.
+template <class P, int K> PLK_DI Fz<P> fz_sub(const Fz<P>& a, const Fz<P>& b) {
+    Fz<P> r;
+#pragma unroll
+    for (int i = 0; i < FzCfg<P>::NZ; ++i) r.l[i] = a.l[i] - b.l[i] + FzCfg<P>::kp_limb(K, i);
+    fz_carry<P>(r);
+    return r;
+}
+template <class P> PLK_DI Fz<P> fz_dbl(const Fz<P>& a) { return fz_add<P>(a, a); }
+
+// ---- multiplication --------------------------------------------------------------------------
+// Montgomery product a b / R' mod p (lazy): product scanning, quotient digits folded in as they
+// become known (q_k = -column_k mod 2^29 because p = 1 mod 2^29).
+template <class P> PLK_DI Fz<P> fz_mul(const Fz<P>& a, const Fz<P>& b) {
+    constexpr int NZ = FzCfg<P>::NZ;
+    constexpr uint32_t M = FzCfg<P>::M;
+    static_assert(Mod29<P>::limb(0) == 1u, "needs p = 1 (mod 2^29)");
+    uint32_t q[NZ];
+    Fz<P> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k <= 2 * NZ - 2; ++k) {
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            const int j = k - i;
+            if (j >= 0 && j < NZ) acc = (uint64_t)a.l[i] * b.l[j] + acc;
+        }
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            const int j = k - i;
+            if (i < k && j >= 1 && j < NZ && FzCfg<P>::plimb(j) != 0u) acc = (uint64_t)q[i] * FzCfg<P>::plimb(j) + acc;
+        }
+        if (k < NZ) {
+            q[k] = (0u - (uint32_t)acc) & M;
+            acc += q[k];  // + q_k p_0 with p_0 = 1: the low 29 bits vanish
+        } else {
+            r.l[k - NZ] = (uint32_t)acc & M;
+        }
+        acc >>= 29;
+    }
+    r.l[NZ - 1] = (uint32_t)acc;
+    return r;
+}
+
+// a^2 / R': the 2 a_i a_j cross terms are formed once from a doubled copy of a (NZ (NZ+1) / 2 products)
+template <class P> PLK_DI Fz<P> fz_sqr(const Fz<P>& a) {
+    constexpr int NZ = FzCfg<P>::NZ;
+    constexpr uint32_t M = FzCfg<P>::M;
+    uint32_t q[NZ], a2[NZ];
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) a2[i] = a.l[i] << 1;
+    Fz<P> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k <= 2 * NZ - 2; ++k) {
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            const int j = k - i;
+            if (j > i && j < NZ) acc = (uint64_t)a.l[i] * a2[j] + acc;
+            if (j == i) acc = (uint64_t)a.l[i] * a.l[i] + acc;
+        }
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            const int j = k - i;
+            if (i < k && j >= 1 && j < NZ && FzCfg<P>::plimb(j) != 0u) acc = (uint64_t)q[i] * FzCfg<P>::plimb(j) + acc;
+        }
+        if (k < NZ) {
+            q[k] = (0u - (uint32_t)acc) & M;
+            acc += q[k];
+        } else {
+            r.l[k - NZ] = (uint32_t)acc & M;
+        }
+        acc >>= 29;
+    }
+    r.l[NZ - 1] = (uint32_t)acc;
+    return r;
+}
+
+// ---- predicates --------------------------------------------------------------------------------
+// value == 0 mod p for a value < 2p with exactly normalised limbs (what fz_mul / fz_sqr return)
+template <class P> PLK_DI bool fz_is_zero_mod_p(const Fz<P>& a) {
+    constexpr int NZ = FzCfg<P>::NZ;
+    uint32_t z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        z |= a.l[i];
+        e |= a.l[i] ^ FzCfg<P>::plimb(i);
+    }
+    return z == 0 || e == 0;
+}
+
+// ---- constants (R'-form), derived at compile time from the modulus ------------------------------
+// 2^e mod p as 29-bit limbs, by repeated doubling of 1 (constexpr, host side of the compiler only)
+template <class P> struct FzConst {
+    static constexpr int NZ = FzCfg<P>::NZ;
+    struct Limbs {
+        uint32_t l[NZ];
+    };
+    static constexpr bool geq_p(const Limbs& x) {
+        for (int i = NZ - 1; i >= 0; --i) {
+            if (x.l[i] != FzCfg<P>::plimb(i)) return x.l[i] > FzCfg<P>::plimb(i);
+        }
+        return true;
+    }
+    static constexpr Limbs dbl_mod(Limbs x) {
+        uint32_t c = 0;
+        for (int i = 0; i < NZ; ++i) {
+            uint32_t t = (x.l[i] << 1) + c;
+            if (i < NZ - 1) {
+                x.l[i] = t & FzCfg<P>::M;
+                c = t >> 29;
+            } else {
+                x.l[i] = t;
+            }
+        }
+        if (geq_p(x)) {
+            uint32_t borrow = 0;
+            for (int i = 0; i < NZ; ++i) {
+                uint32_t t = x.l[i] - FzCfg<P>::plimb(i) - borrow;
+                if (i < NZ - 1) {
+                    x.l[i] = t & FzCfg<P>::M;
+                    borrow = (t >> 31) & 1u;
+                } else {
+                    x.l[i] = t;
+                }
+            }
+        }
+        return x;
+    }
+    static constexpr Limbs pow2(int e) {
+        Limbs x{};
+        x.l[0] = 1;
+        for (int i = 0; i < e; ++i) x = dbl_mod(x);
+        return x;
+    }
+};
+
+// multiply by this to take an R-form value (x 2^(32 NL)) into R'-form (x 2^(29 NZ)):  2^(2*29 NZ - 32 NL)
+template <class P> PLK_DI Fz<P> fz_const_r_to_rprime() {
+    constexpr auto c = FzConst<P>::pow2(2 * 29 * FzCfg<P>::NZ - 32 * P::NL);
+    Fz<P> r;
+#pragma unroll
+    for (int i = 0; i < FzCfg<P>::NZ; ++i) r.l[i] = c.l[i];
+    return r;
+}
+// multiply by this to take an R'-form value back to R-form:  2^(32 NL)
+template <class P> PLK_DI Fz<P> fz_const_rprime_to_r() {
+    constexpr auto c = FzConst<P>::pow2(32 * P::NL);
+    Fz<P> r;
+#pragma unroll
+    for (int i = 0; i < FzCfg<P>::NZ; ++i) r.l[i] = c.l[i];
+    return r;
+}
+// 1 in R'-form: 2^(29 NZ)
+template <class P> PLK_DI Fz<P> fz_one_rprime() {
+    constexpr auto c = FzConst<P>::pow2(29 * FzCfg<P>::NZ);
+    Fz<P> r;
+#pragma unroll
+    for (int i = 0; i < FzCfg<P>::NZ; ++i) r.l[i] = c.l[i];
+    return r;
+}
+
+}  // namespace plk

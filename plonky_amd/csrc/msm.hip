@@ -24,6 +24,7 @@
 
 #include "common.h"
 #include "ec.cuh"
+#include "ecz.cuh"
 
 namespace plk {
 
@@ -35,6 +36,16 @@ constexpr uint32_t CODE_INVALID = 0xFFFFFFFFu;
 // ---------------------------------------------------------------------------------------------
 // table construction: tab[j*n + i] = [2^(c j)] G_i, affine  (curve_msm.rs:40-52)
 // ---------------------------------------------------------------------------------------------
+// The table is what the accumulation kernel multiplies with, so it is stored in the working form of
+// that kernel (ecz.cuh / fz.cuh): coordinates in R'-form (x 2^(29 NZ)), canonical, packed in the
+// same 32-bit words.  The generators arrive in the reference's R-form.
+template <class FP> PLK_DI void affine_store_rprime(uint4* dst, const Fe<FP>& x, const Fe<FP>& y, bool identity) {
+    const Fz<FP> k = fz_const_r_to_rprime<FP>();
+    Fe<FP> xr = fz_to_fe_canonical<FP>(fz_mul<FP>(fz_from_fe<FP>(x), k));
+    Fe<FP> yr = fz_to_fe_canonical<FP>(fz_mul<FP>(fz_from_fe<FP>(y), k));
+    affine_store<FP>(dst, xr, yr, identity);
+}
+
 template <class C>
 __global__ void __launch_bounds__(128) k_msm_table(const uint4* __restrict__ bases, const uint8_t* __restrict__ base_zero, uint4* __restrict__ tab,
                                                    size_t n, int c, int windows) {
@@ -44,14 +55,14 @@ __global__ void __launch_bounds__(128) k_msm_table(const uint4* __restrict__ bas
     if (i >= n) return;
     Fe<FP> x = fe_load<FP>(bases + i * 2 * W), y = fe_load<FP>(bases + i * 2 * W + W);
     bool ident = base_zero ? base_zero[i] != 0 : false;
-    affine_store<FP>(tab + i * 2 * W, x, y, ident);
+    affine_store_rprime<FP>(tab + i * 2 * W, x, y, ident);
     for (int j = 1; j < windows; ++j) {
         if (!ident) {
             Xyzz<FP> p = xyzz_mdbl<FP>(x, y);
             for (int k = 1; k < c; ++k) p = xyzz_dbl<FP>(p);
             ident = xyzz_to_affine<FP>(p, x, y);
         }
-        affine_store<FP>(tab + ((size_t)j * n + i) * 2 * W, x, y, ident);
+        affine_store_rprime<FP>(tab + ((size_t)j * n + i) * 2 * W, x, y, ident);
     }
 }
 
@@ -334,16 +345,29 @@ __global__ void __launch_bounds__(128, 4) k_msm_accumulate(const uint4* __restri
     const uint32_t b = lo;
     const uint32_t begin = off[b] + (s - slice_off[b]) * slice;
     const uint32_t end = min(off[b + 1], begin + slice);
-    Xyzz<FP> acc = xyzz_identity<FP>();
+    // lazy 29-bit-limb accumulator (ecz.cuh); table coordinates are R'-form
+    XyzzZ<FP> acc;
+    acc.inf = true;
+    acc.x = acc.y = acc.zz = acc.zzz = fz_zero<FP>();
     for (uint32_t k = begin; k < end; ++k) {
         const uint32_t ent = sorted[k];
         Fe<FP> x, y;
         const bool ident = affine_load<FP>(tab + (size_t)(ent >> 1) * 2 * W, x, y);
         if (ident) continue;
-        if (ent & 1u) y = fe_neg<FP>(y);
-        xyzz_madd<FP>(acc, x, y);
+        Fz<FP> xz = fz_from_fe<FP>(x), yz = fz_from_fe<FP>(y);
+        if (ent & 1u) yz = fz_neg_canonical<FP>(yz);
+        xyzzz_madd<FP>(acc, xz, yz);
     }
-    xyzz_store<FP>(partial + (size_t)s * 4 * W, acc);
+    // hand the partial sum to the reduction kernels in the reference's form (R-form, canonical)
+    Xyzz<FP> o = xyzz_identity<FP>();
+    if (!acc.inf) {
+        const Fz<FP> back = fz_const_rprime_to_r<FP>();
+        o.x = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.x, back));
+        o.y = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.y, back));
+        o.zz = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zz, back));
+        o.zzz = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zzz, back));
+    }
+    xyzz_store<FP>(partial + (size_t)s * 4 * W, o);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -2,6 +2,8 @@
 // under hipcc) with g++ so the CPU test suite can sweep it against Python integers.
 #include <cstddef>
 #include "../plonky_amd/csrc/fp.cuh"
+#include "../plonky_amd/csrc/fz.cuh"
+#include "../plonky_amd/csrc/ecz.cuh"
 using namespace plk;
 
 template <class P> static void run(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
@@ -17,6 +19,32 @@ template <class P> static void run(int op, const uint32_t* a, const uint32_t* b,
             case 5: r = fe_inv<P>(x); break;
             case 6: r = fe_half<P>(x); break;
             case 8: r = fe_inv_eea<P>(x); break;
+            // ---- lazy 29-bit-limb arithmetic (fz.cuh): results brought back to canonical words ----
+            case 10: r = fz_to_fe_canonical<P>(fz_from_fe<P>(x)); break;
+            case 11: r = fz_to_fe_canonical<P>(fz_mul<P>(fz_from_fe<P>(x), fz_from_fe<P>(y))); break;
+            case 12: r = fz_to_fe_canonical<P>(fz_sqr<P>(fz_from_fe<P>(x))); break;
+            case 13: {  // (x + y - 2y) * 1  through add / dbl / sub / mul by one'
+                Fz<P> a = fz_from_fe<P>(x), b = fz_from_fe<P>(y);
+                Fz<P> t = fz_sub<P, 2>(fz_add<P>(a, b), fz_dbl<P>(b));
+                r = fz_to_fe_canonical<P>(fz_mul<P>(t, fz_one_rprime<P>()));
+            } break;
+            case 14: r = fz_to_fe_canonical<P>(fz_mul<P>(fz_from_fe<P>(x), fz_const_r_to_rprime<P>())); break;
+            case 15: r = fz_to_fe_canonical<P>(fz_mul<P>(fz_from_fe<P>(x), fz_const_rprime_to_r<P>())); break;
+            case 16: {  // a longer lazy chain: ((x - y)^2 - (x + y) * y) * (x - 2y + 4p-ish) ...
+                Fz<P> a = fz_from_fe<P>(x), b = fz_from_fe<P>(y);
+                Fz<P> d = fz_sub<P, 1>(a, b);                    // x - y          (< 3p)
+                Fz<P> s = fz_add<P>(a, b);                       // x + y          (< 2p)
+                Fz<P> u = fz_sqr<P>(d);                          // (x-y)^2 / R'   (< 2p)
+                Fz<P> v = fz_mul<P>(s, b);                       // (x+y) y / R'   (< 2p)
+                Fz<P> w = fz_sub<P, 2>(u, fz_dbl<P>(v));         // u - 2v         (< 6p)
+                Fz<P> z = fz_mul<P>(w, d);                       // (u - 2v)(x-y) / R'
+                r = fz_to_fe_canonical<P>(z);
+            } break;
+            case 17: {
+                Fz<P> m = fz_mul<P>(fz_from_fe<P>(x), fz_from_fe<P>(y));
+                r = fe_zero<P>();
+                r.v[0] = fz_is_zero_mod_p<P>(m) ? 1u : 0u;
+            } break;
             default: r = fe_neg<P>(x); break;
         }
         for (int k = 0; k < P::NL; ++k) out[i * P::NL + k] = r.v[k];
@@ -28,6 +56,42 @@ extern "C" int fp_host_op(int field, int op, const uint32_t* a, const uint32_t* 
         case 1: run<TweedledumBaseParams>(op, a, b, out, n); return 0;
         case 2: run<Bls12377ScalarParams>(op, a, b, out, n); return 0;
         case 3: run<Bls12377BaseParams>(op, a, b, out, n); return 0;
+    }
+    return -1;
+}
+
+// Lazy XYZZ accumulation (ecz.cuh): acc = sum of +-(x_i, y_i); points given as canonical words of the
+// R'-form coordinates; out = X, Y, ZZ, ZZZ (canonical words, R'-form) followed by one word: inf flag.
+template <class P> static void ecz_sum(size_t n, const uint32_t* xs, const uint32_t* ys, const uint8_t* negs, uint32_t* out) {
+    XyzzZ<P> acc;
+    acc.inf = true;
+    acc.x = acc.y = acc.zz = acc.zzz = fz_zero<P>();
+    for (size_t i = 0; i < n; ++i) {
+        Fe<P> x, y;
+        for (int k = 0; k < P::NL; ++k) { x.v[k] = xs[i * P::NL + k]; y.v[k] = ys[i * P::NL + k]; }
+        Fz<P> xz = fz_from_fe<P>(x), yz = fz_from_fe<P>(y);
+        if (negs[i]) yz = fz_neg_canonical<P>(yz);
+        xyzzz_madd<P>(acc, xz, yz);
+    }
+    Fz<P> one = fz_one_rprime<P>();
+    Fe<P> c[4];
+    if (acc.inf) { for (auto& e : c) e = fe_zero<P>(); }
+    else {
+        // multiply by one' to bring every coordinate below 2p before the canonical conversion
+        c[0] = fz_to_fe_canonical<P>(fz_mul<P>(acc.x, one));
+        c[1] = fz_to_fe_canonical<P>(fz_mul<P>(acc.y, one));
+        c[2] = fz_to_fe_canonical<P>(fz_mul<P>(acc.zz, one));
+        c[3] = fz_to_fe_canonical<P>(fz_mul<P>(acc.zzz, one));
+    }
+    for (int j = 0; j < 4; ++j)
+        for (int k = 0; k < P::NL; ++k) out[j * P::NL + k] = c[j].v[k];
+    out[4 * P::NL] = acc.inf ? 1u : 0u;
+}
+extern "C" int ecz_host_sum(int field, size_t n, const uint32_t* xs, const uint32_t* ys, const uint8_t* negs, uint32_t* out) {
+    switch (field) {
+        case 0: ecz_sum<TweedledeeBaseParams>(n, xs, ys, negs, out); return 0;
+        case 1: ecz_sum<TweedledumBaseParams>(n, xs, ys, negs, out); return 0;
+        case 3: ecz_sum<Bls12377BaseParams>(n, xs, ys, negs, out); return 0;
     }
     return -1;
 }

@@ -70,3 +70,91 @@ def test_device_header_arithmetic_on_host(host_lib, f):
     nz = [v for v in inputs if v != 0][:120] + inputs[-60:]
     assert run(host_lib, f, 8, ints_to_array(nz, n)) == [pow(v * Rinv % p, -1, p) * f.R % p for v in nz]
     assert run(host_lib, f, 8, ints_to_array([0], n)) == [0]
+
+
+@pytest.mark.parametrize("f", FIELDS, ids=lambda f: f.name)
+def test_lazy_29bit_arithmetic_on_host(host_lib, f):
+    """fz.cuh (the working form of the hot kernels): 29-bit limbs, R' = 2^(29 NZ), lazily reduced."""
+    p, n = f.p, f.n_limbs
+    nz = (64 * n + 28) // 29
+    Rp_inv = pow(1 << (29 * nz), -1, p)
+    inputs = reference_test_inputs(p)
+    inputs += [synth.to_int(r) for r in synth.rand_field(f.field_id, 77, 150)]
+    m = len(inputs)
+    x = ints_to_array(inputs, n)
+    assert run(host_lib, f, 10, x) == inputs
+    assert run(host_lib, f, 12, x) == [v * v * Rp_inv % p for v in inputs]
+    assert run(host_lib, f, 14, x) == [v * pow(2, 2 * 29 * nz - 64 * n, p) * Rp_inv % p for v in inputs]
+    assert run(host_lib, f, 15, x) == [v * pow(2, 64 * n, p) * Rp_inv % p for v in inputs]
+    ia = np.repeat(np.arange(m), m)
+    ib = np.tile(np.arange(m), m)
+    a, b = x[ia], x[ib]
+    got_mul = run(host_lib, f, 11, a, b)
+    got_lin = run(host_lib, f, 13, a, b)
+    got_chain = run(host_lib, f, 16, a, b)
+    got_zero = run(host_lib, f, 17, a, b)
+    k = 0
+    for i in range(m):
+        ai = inputs[i]
+        for j in range(m):
+            bj = inputs[j]
+            assert got_mul[k] == ai * bj * Rp_inv % p
+            assert got_lin[k] == (ai - bj) % p
+            u = (ai - bj) ** 2 * Rp_inv
+            v = (ai + bj) * bj * Rp_inv
+            assert got_chain[k] == (u - 2 * v) * (ai - bj) * Rp_inv % p
+            assert got_zero[k] == (1 if ai * bj % p == 0 else 0)
+            k += 1
+    # the value p itself (== 0 mod p) as an operand exercises the second branch of the zero test
+    pw = ints_to_array([p] * 3, n)
+    yw = ints_to_array([1, 12345, p - 1], n)
+    assert run(host_lib, f, 17, pw, yw) == [1, 1, 1]
+
+
+@pytest.mark.parametrize("c", [br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377], ids=lambda c: c.name)
+def test_lazy_xyzz_accumulation_on_host(host_lib, c):
+    """ecz.cuh: the bucket-accumulation inner loop (mixed XYZZ additions on lazy coordinates), incl. the
+    exceptional cases of curve_adds.rs:50-90 (identity accumulator, P + P, P + (-P)) and long chains."""
+    import random
+    f = c.base
+    n = f.n_limbs
+    nz = (64 * n + 28) // 29
+    Rp = pow(2, 29 * nz, f.p)
+    host_lib.ecz_host_sum.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    G = (c.gx, c.gy)
+    rng = random.Random(5)
+    pts = [br.ec_mul(c, rng.randrange(1, 1 << 64), G) for _ in range(40)]
+
+    def run_sum(points, negs):
+        xs = ints_to_array([P[0] * Rp % f.p for P in points], n)
+        ys = ints_to_array([P[1] * Rp % f.p for P in points], n)
+        ng = np.array(negs, dtype=np.uint8)
+        out = np.zeros(4 * n + 1, dtype=np.uint64)
+        out32 = np.zeros(4 * 2 * n + 2, dtype=np.uint32)
+        assert host_lib.ecz_host_sum(f.field_id, len(points), xs.ctypes.data, ys.ctypes.data, ng.ctypes.data, out32.ctypes.data) == 0
+        inf = int(out32[4 * 2 * n])
+        if inf:
+            return None
+        w = out32[: 4 * 2 * n].reshape(4, 2 * n)
+        X, Y, ZZ, ZZZ = [sum(int(v) << (32 * i) for i, v in enumerate(row)) for row in w]
+        assert ZZ % f.p != 0 and pow(ZZ, 3, f.p) == ZZZ * ZZZ * Rp % f.p  # ZZ^3 = ZZZ^2 (in R'-form: extra R')
+        return (X * pow(ZZ, -1, f.p) % f.p, Y * pow(ZZZ, -1, f.p) % f.p)
+
+    def expect(points, negs):
+        acc = None
+        for P, ng in zip(points, negs):
+            acc = br.ec_add(c, acc, br.ec_neg(c, P) if ng else P)
+        return acc
+
+    cases = [
+        ([pts[0]], [0]), ([pts[0]], [1]),
+        ([pts[0], pts[0]], [0, 0]),                     # doubling branch
+        ([pts[0], pts[0]], [0, 1]),                     # P + (-P) = identity
+        ([pts[0], pts[0], pts[1]], [0, 1, 0]),          # identity accumulator picks up the next point
+        ([pts[0], pts[1], br.ec_add(c, pts[0], pts[1])], [0, 0, 0]),   # acc == operand after two adds -> double
+        ([pts[0], pts[1], br.ec_add(c, pts[0], pts[1])], [0, 0, 1]),   # acc == -operand -> identity
+        (pts, [rng.randrange(2) for _ in pts]),
+        (pts * 8, [rng.randrange(2) for _ in range(len(pts) * 8)]),    # 320-long chain: bounds hold
+    ]
+    for points, negs in cases:
+        assert run_sum(points, negs) == expect(points, negs)
