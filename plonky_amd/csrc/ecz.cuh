@@ -28,7 +28,10 @@ template <class FP> PLK_DI Fz<FP> fz_zero() {
 template <class FP> PLK_DI Fz<FP> fz_neg_canonical(const Fz<FP>& y) { return fz_sub<FP, 1>(fz_zero<FP>(), y); }
 
 // 2 * (x, y), affine operand with x, y < 2p  (y = 0 mod p gives the identity)
-template <class FP> PLK_DNI void xyzzz_mdbl(XyzzZ<FP>& r, const Fz<FP>& x, const Fz<FP>& y) {
+// Operands by value (they travel in VGPRs) and result by value: nothing of the hot loop has its
+// address taken, so the accumulator and the current point stay in registers.
+template <class FP> PLK_DNI XyzzZ<FP> xyzzz_mdbl(Fz<FP> x, Fz<FP> y) {
+    XyzzZ<FP> r;
     Fz<FP> u = fz_dbl<FP>(y);                                // < 4
     Fz<FP> v = fz_sqr<FP>(u);                                // < 2
     Fz<FP> w = fz_mul<FP>(u, v);                             // < 2
@@ -42,6 +45,7 @@ template <class FP> PLK_DNI void xyzzz_mdbl(XyzzZ<FP>& r, const Fz<FP>& x, const
     r.zz = v;
     r.zzz = w;
     r.inf = fz_is_zero_mod_p<FP>(v);
+    return r;
 }
 
 // acc += (x2, y2); x2 < p canonical, y2 < 2p (a negated canonical y is 2p - y)
@@ -65,8 +69,11 @@ template <class FP> PLK_DI void xyzzz_madd(XyzzZ<FP>& acc, const Fz<FP>& x2, con
     Fz<FP> zz3 = fz_mul<FP>(acc.zz, pp);                     // < 1.1
     if (fz_is_zero_mod_p<FP>(zz3)) {
         // p = 0 mod p: the operands share x.  Same point -> double it; opposite points -> identity.
-        if (fz_is_zero_mod_p<FP>(rr)) xyzzz_mdbl<FP>(acc, x2, y2);
-        else acc.inf = true;
+        if (fz_is_zero_mod_p<FP>(rr)) {
+            acc = xyzzz_mdbl<FP>(x2, y2);  // rare, out of line
+        } else {
+            acc.inf = true;
+        }
         return;
     }
     Fz<FP> x3 = fz_sub<FP, 2>(fz_sub<FP, 1>(rr, ppp), fz_dbl<FP>(q));  // (1.3 + 2) + 4 < 7.3 < 8

@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_part2_scatter(const uint32_t* 
 // bucket accumulation: one lane per slice of <= `slice` sorted entries
 // ---------------------------------------------------------------------------------------------
 template <class C>
-__global__ void __launch_bounds__(128, 4) k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(128) k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
                                                            const uint32_t* __restrict__ off, const uint32_t* __restrict__ slice_off,
                                                            uint4* __restrict__ partial, uint32_t buckets, uint32_t slice) {
     using FP = typename C::FP;
@@ -349,13 +349,27 @@ __global__ void __launch_bounds__(128, 4) k_msm_accumulate(const uint4* __restri
     XyzzZ<FP> acc;
     acc.inf = true;
     acc.x = acc.y = acc.zz = acc.zzz = fz_zero<FP>();
+    // Software pipeline: the table gather for entry k+1 (two dependent loads: index, then a random
+    // 64/96-byte point) is issued before the ~10^4-cycle addition of entry k, so the few resident
+    // waves (the lazy arithmetic wants ~180 VGPRs) never wait on HBM.
+    uint32_t ent = 0;
+    Fe<FP> x = fe_zero<FP>(), y = fe_zero<FP>();
+    bool ident = true;
+    if (begin < end) {
+        ent = sorted[begin];
+        ident = affine_load<FP>(tab + (size_t)(ent >> 1) * 2 * W, x, y);
+    }
     for (uint32_t k = begin; k < end; ++k) {
-        const uint32_t ent = sorted[k];
-        Fe<FP> x, y;
-        const bool ident = affine_load<FP>(tab + (size_t)(ent >> 1) * 2 * W, x, y);
-        if (ident) continue;
-        Fz<FP> xz = fz_from_fe<FP>(x), yz = fz_from_fe<FP>(y);
-        if (ent & 1u) yz = fz_neg_canonical<FP>(yz);
+        const uint32_t cur = ent;
+        const Fe<FP> cx = x, cy = y;
+        const bool cident = ident;
+        if (k + 1 < end) {
+            ent = sorted[k + 1];
+            ident = affine_load<FP>(tab + (size_t)(ent >> 1) * 2 * W, x, y);
+        }
+        if (cident) continue;
+        Fz<FP> xz = fz_from_fe<FP>(cx), yz = fz_from_fe<FP>(cy);
+        if (cur & 1u) yz = fz_neg_canonical<FP>(yz);
         xyzzz_madd<FP>(acc, xz, yz);
     }
     // hand the partial sum to the reduction kernels in the reference's form (R-form, canonical)

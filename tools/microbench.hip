@@ -47,6 +47,19 @@ template <int OP> __global__ void __launch_bounds__(256) probe(uint32_t* out, ui
                 b[k] = b[k] + (uint32_t)(x >> 32) + 1u;
             } else if (OP == 8) {  // v_mul_hi_u32_u24 + v_mul_u32_u24
                 a[k] = __umul24(a[k], b[k]) ^ __mul24(a[k] >> 3, b[k] >> 5);
+            } else if (OP == 9) {  // v_lshrrev_b64 (+ 64-bit or to keep it alive)
+                acc[k] = (acc[k] >> 29) | ((uint64_t)b[k] << 35);
+            } else if (OP == 10) {  // v_lshlrev_b64
+                acc[k] = (acc[k] << 22) ^ (uint64_t)a[k];
+            } else if (OP == 11) {  // v_alignbit_b32
+                a[k] = __builtin_amdgcn_alignbit(a[k], b[k], 29) + 1u;
+            } else if (OP == 12) {  // mad with inline/literal constant multiplier
+                acc[k] = (uint64_t)(uint32_t)acc[k] * 0x1657ea0u + acc[k];
+            } else if (OP == 13) {  // column step of the 29-bit multiply: mad, mad, shift, mask
+                uint64_t t = (uint64_t)a[k] * b[k] + acc[k];
+                t = (uint64_t)b[k] * 0x18a1b261u + t;
+                a[k] = (uint32_t)t & 0x1fffffffu;
+                acc[k] = t >> 29;
             }
         }
     }
@@ -90,6 +103,11 @@ int main() {
         run<6>("v_add_u32 + v_xor", 2, d_out, w);
         run<7>("add_co + add3", 2, d_out, w);
         run<8>("mul24 x2 + xor", 3, d_out, w);
+        run<9>("v_lshrrev_b64 (+or64)", 1, d_out, w);
+        run<10>("v_lshlrev_b64 (+xor)", 1, d_out, w);
+        run<11>("v_alignbit_b32 (+add)", 1, d_out, w);
+        run<12>("v_mad_u64_u32 const", 1, d_out, w);
+        run<13>("column: 2 mad + and + lshr64", 4, d_out, w);
         printf("\n");
     }
     return 0;
