@@ -12,8 +12,9 @@
 // inter-pass twiddle w_{N_t}^(r k) and stores in place; the last pass works on contiguous
 // blocks and scatters to the digit-reversed final position.  Each workgroup owns a
 // [A_t x Q] tile (1024 elements, 32 KiB of LDS) so that every global access is a run of
-// Q * 32 B (>= 256 B) contiguous bytes; the A_t-point NTTs run as radix-2 DIF stages inside
-// LDS with the stage twiddles staged in LDS, output un-bit-reversed by the store indexing.
+// Q * 32 B (>= 256 B) contiguous bytes; the A_t-point NTTs run as radix-2 stages inside
+// LDS with the stage twiddles staged in LDS (decimation in time on lazily reduced 29-bit limbs,
+// fz.cuh; input placed bit-reversed by the load indexing, output in natural order).
 // out[j] = sum_k in[k] w^(jk), w = primitive_root_of_unity(log n) (field.rs:429-435): the same
 // function the reference computes, and field elements have a unique representation, so the
 // limbs are bit-identical.  iNTT = the same passes with w^-1 tables and n^-1 folded into the
@@ -27,6 +28,7 @@
 
 #include "common.h"
 #include "fp.cuh"
+#include "fz.cuh"
 
 namespace plk {
 
@@ -53,7 +55,13 @@ struct NttPassArgs {
 // ---------------------------------------------------------------------------------------------
 // pw[b]      = w^(2^b),   b < log_t, w = primitive 2^log_t-th root (ROOT_2ADIC^(2^(adicity-log_t)))
 // pw[32+b]   = w^-(2^b)
-// pw[64]     = 2^-log_n in Montgomery form (n^-1)
+// pw[64]     = 2^-log_n in Montgomery form (n^-1)              -- all of the above in R-form
+// pw[65]     = 1 and pw[66] = n^-1 in R'-form (the form every twiddle TABLE is stored in: the pass
+//              kernel multiplies R-form data by R'-form twiddles on 29-bit limbs, fz.cuh, and the
+//              product x 2^256 * w 2^261 / 2^261 stays in the reference's R-form)
+template <class P> PLK_DI Fe<P> to_rprime(const Fe<P>& v) {
+    return fz_to_fe_canonical<P>(fz_mul<P>(fz_from_fe<P>(v), fz_const_r_to_rprime<P>()));
+}
 template <class P> __global__ void k_ntt_pow2(uint4* pw, int log_t, int log_n) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Fe<P> w;
@@ -74,6 +82,8 @@ template <class P> __global__ void k_ntt_pow2(uint4* pw, int log_t, int log_n) {
     Fe<P> ninv = fe_one<P>();
     for (int i = 0; i < log_n; ++i) ninv = fe_half<P>(ninv);
     fe_store<P>(pw + 64 * 2, ninv);
+    fe_store<P>(pw + 65 * 2, fz_to_fe_canonical<P>(fz_one_rprime<P>()));
+    fe_store<P>(pw + 66 * 2, to_rprime<P>(ninv));
 }
 
 template <class P> PLK_DI Fe<P> pow_from_table(const uint4* pw, int base_off, uint64_t e, int log_t) {
@@ -88,7 +98,7 @@ template <class P> __global__ void k_ntt_fill_inner(uint4* tw, const uint4* pw, 
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (1 << (INNER_LOG - 1))) return;
     uint64_t ex = (uint64_t)e << (log_t - INNER_LOG);
-    fe_store<P>(tw + e * 2, pow_from_table<P>(pw, inverse ? 32 : 0, ex, log_t));
+    fe_store<P>(tw + e * 2, to_rprime<P>(pow_from_table<P>(pw, inverse ? 32 : 0, ex, log_t)));
 }
 // outer table of a pass: W[k * S + r] = w_{N_t}^(+- r k) (* n^-1 when scale != 0)
 template <class P> __global__ void k_ntt_fill_outer(uint4* tw, const uint4* pw, int log_t, int log_nt, int log_s, int inverse, int scale) {
@@ -100,7 +110,7 @@ template <class P> __global__ void k_ntt_fill_outer(uint4* tw, const uint4* pw, 
     ex <<= (log_t - log_nt);
     Fe<P> v = pow_from_table<P>(pw, inverse ? 32 : 0, ex, log_t);
     if (scale) v = fe_mul<P>(v, fe_load<P>(pw + 64 * 2));
-    fe_store<P>(tw + idx * 2, v);
+    fe_store<P>(tw + idx * 2, to_rprime<P>(v));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -108,25 +118,42 @@ template <class P> __global__ void k_ntt_fill_outer(uint4* tw, const uint4* pw, 
 // ---------------------------------------------------------------------------------------------
 PLK_DI uint32_t bitrev(uint32_t x, int bits) { return bits == 0 ? 0u : (__brev(x) >> (32 - bits)); }
 
+// LDS layout: limb-major planes, plane l of the tile at s_mem[l * TILE + e], then the stage twiddles at
+// s_mem[NZ * TILE + l * (A/2) + e]: consecutive lanes touch consecutive dwords (conflict-free ds_*_b32).
+template <class P> PLK_DI Fz<P> lds_load(const uint32_t* base, int stride, int idx) {
+    Fz<P> r;
+#pragma unroll
+    for (int l = 0; l < FzCfg<P>::NZ; ++l) r.l[l] = base[l * stride + idx];
+    return r;
+}
+template <class P> PLK_DI void lds_store(uint32_t* base, int stride, int idx, const Fz<P>& v) {
+#pragma unroll
+    for (int l = 0; l < FzCfg<P>::NZ; ++l) base[l * stride + idx] = v.l[l];
+}
+
+// One pass = for every tile: A-point NTTs on Q columns, decimation in time on lazily reduced 29-bit
+// limbs (fz.cuh).  DIT is chosen for its bounds: the butterfly (a, b) -> (a + w b, a - w b + 2p) only
+// ADDS 2p per stage to a value (the product w b is always < 1.2p), so no reduction is needed inside
+// a tile (< (2 log A + 1) p after the last stage, far below R' = 128p); the input goes to the
+// bit-reversed LDS slot (free: it is just the store index), the output comes out in natural order.
 template <class P>
 __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restrict__ in, uint4* __restrict__ out,
                                                           const uint4* __restrict__ inner_tw, const uint4* __restrict__ outer_tw,
                                                           const uint4* __restrict__ scale_ptr, NttPassArgs a) {
     static_assert(P::NL == 8, "NTT kernels are written for the 256-bit fields");
-    // element e of the tile lives in lo[e] (limbs 0-3) and hi[e] (limbs 4-7): consecutive lanes
-    // touch consecutive 16-byte slots -> conflict-free ds_read_b128 / ds_write_b128
-    __shared__ uint4 s_lo[TILE];
-    __shared__ uint4 s_hi[TILE];
-    __shared__ uint4 s_tw[TILE];  // A/2 stage twiddles (lo at [2e], hi at [2e+1])
+    constexpr int NZ = FzCfg<P>::NZ;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
 
     const int tid = threadIdx.x;
     const int log_a = a.log_a, log_q = a.log_q;
     const int A = 1 << log_a, Q = 1 << log_q;
     const int tile_elems = A << log_q;
+    const int half_a = A >> 1;
     const size_t n = (size_t)1 << a.log_n;
+    uint32_t* s_dat = s_mem;
+    uint32_t* s_tw = s_mem + NZ * TILE;
 
     // ---- which tile ----
-    // tiles per transform = n / tile_elems; blockIdx.x enumerates (batch, tile)
     const size_t tiles_per = n >> (log_a + log_q);
     const size_t b = blockIdx.x / tiles_per;
     const size_t tile = blockIdx.x % tiles_per;
@@ -135,7 +162,6 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restric
 
     size_t blk_base = 0, r0 = 0, ol0 = 0;
     if (!a.last) {
-        // tile -> (kprev, rtile): rtile fastest
         const size_t rtiles = ((size_t)1 << a.log_s) >> log_q;
         const size_t kprev = tile / rtiles;
         r0 = (tile % rtiles) << log_q;
@@ -144,14 +170,13 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restric
         ol0 = tile << log_q;
     }
 
-    // stage twiddles: w_A^e = inner[e * (1024 / A)], e < A/2
-    for (int e = tid; e < (A >> 1); e += NTT_THREADS) {
-        const uint4* src = inner_tw + ((size_t)e << (INNER_LOG - log_a)) * 2;
-        s_tw[2 * e] = src[0];
-        s_tw[2 * e + 1] = src[1];
+    // stage twiddles (R'-form): w_A^e = inner[e * (1024 / A)], e < A/2
+    for (int e = tid; e < half_a; e += NTT_THREADS) {
+        const Fe<P> w = fe_load<P>(inner_tw + ((size_t)e << (INNER_LOG - log_a)) * 2);
+        lds_store<P>(s_tw, half_a, e, fz_from_fe<P>(w));
     }
 
-    // ---- load ----
+    // ---- load: element (p, q) of the tile goes to row bitrev(p) ----
     for (int e = tid; e < tile_elems; e += NTT_THREADS) {
         const int q = e & (Q - 1), p = e >> log_q;
         size_t g;
@@ -167,75 +192,46 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restric
             }
             g = (kprev << log_a) + p;
         }
-        s_lo[e] = inb[g * 2];
-        s_hi[e] = inb[g * 2 + 1];
+        const Fe<P> v = fe_load<P>(inb + g * 2);
+        const int row = (int)bitrev((uint32_t)p, log_a);
+        lds_store<P>(s_dat, TILE, (row << log_q) + q, fz_from_fe<P>(v));
     }
     __syncthreads();
 
-    // ---- A-point radix-2 DIF NTT on each of the Q columns ----
-    for (int log_h = log_a - 1; log_h >= 0; --log_h) {
+    // ---- stages: h = 1, 2, .., A/2 ----
+    for (int log_h = 0; log_h < log_a; ++log_h) {
         const int h = 1 << log_h;
         for (int bf = tid; bf < (tile_elems >> 1); bf += NTT_THREADS) {
             const int q = bf & (Q - 1), pb = bf >> log_q;
             const int j = pb & (h - 1), blk = pb >> log_h;
-            const int p0 = (blk << (log_h + 1)) + j;
-            const int i0 = (p0 << log_q) + q, i1 = i0 + (h << log_q);
-            Fe<P> x, y;
-            {
-                uint4 l0 = s_lo[i0], h0 = s_hi[i0], l1 = s_lo[i1], h1 = s_hi[i1];
-                x.v[0] = l0.x; x.v[1] = l0.y; x.v[2] = l0.z; x.v[3] = l0.w;
-                x.v[4] = h0.x; x.v[5] = h0.y; x.v[6] = h0.z; x.v[7] = h0.w;
-                y.v[0] = l1.x; y.v[1] = l1.y; y.v[2] = l1.z; y.v[3] = l1.w;
-                y.v[4] = h1.x; y.v[5] = h1.y; y.v[6] = h1.z; y.v[7] = h1.w;
-            }
-            Fe<P> s = fe_add<P>(x, y);
-            Fe<P> d = fe_sub<P>(x, y);
+            const int i0 = (((blk << (log_h + 1)) + j) << log_q) + q, i1 = i0 + (h << log_q);
+            const Fz<P> x = lds_load<P>(s_dat, TILE, i0);
+            Fz<P> t = lds_load<P>(s_dat, TILE, i1);
             if (log_h > 0) {
-                const int te = j << (log_a - 1 - log_h);  // w_{2h}^j = w_A^(j * A / 2h)
-                uint4 tl = s_tw[2 * te], th = s_tw[2 * te + 1];
-                Fe<P> w;
-                w.v[0] = tl.x; w.v[1] = tl.y; w.v[2] = tl.z; w.v[3] = tl.w;
-                w.v[4] = th.x; w.v[5] = th.y; w.v[6] = th.z; w.v[7] = th.w;
-                d = fe_mul<P>(d, w);
+                const Fz<P> w = lds_load<P>(s_tw, half_a, j << (log_a - 1 - log_h));  // w_{2h}^j
+                t = fz_mul<P>(t, w);                                                   // < 1.2p
             }
-            s_lo[i0] = make_uint4(s.v[0], s.v[1], s.v[2], s.v[3]);
-            s_hi[i0] = make_uint4(s.v[4], s.v[5], s.v[6], s.v[7]);
-            s_lo[i1] = make_uint4(d.v[0], d.v[1], d.v[2], d.v[3]);
-            s_hi[i1] = make_uint4(d.v[4], d.v[5], d.v[6], d.v[7]);
+            lds_store<P>(s_dat, TILE, i0, fz_add<P>(x, t));
+            lds_store<P>(s_dat, TILE, i1, fz_sub<P, 1>(x, t));  // t < 2p - margin in both cases
         }
         __syncthreads();
     }
 
-    // ---- store: position p holds output index k = bitrev(p) ----
+    // ---- store: row k holds output index k; last multiplication brings the value below 2p ----
+    const Fz<P> scale = fz_from_fe<P>(fe_load<P>(scale_ptr));
     for (int e = tid; e < tile_elems; e += NTT_THREADS) {
-        const int q = e & (Q - 1), p = e >> log_q;
-        const uint32_t k = bitrev((uint32_t)p, log_a);
-        uint4 l = s_lo[e], hh = s_hi[e];
+        const int q = e & (Q - 1), k = e >> log_q;
+        Fz<P> v = lds_load<P>(s_dat, TILE, e);
         size_t g;
         if (!a.last) {
             const size_t r = r0 + q;
             g = blk_base + ((size_t)k << a.log_s) + r;
-            Fe<P> v, w;
-            v.v[0] = l.x; v.v[1] = l.y; v.v[2] = l.z; v.v[3] = l.w;
-            v.v[4] = hh.x; v.v[5] = hh.y; v.v[6] = hh.z; v.v[7] = hh.w;
-            w = fe_load<P>(outer_tw + (((size_t)k << a.log_s) + r) * 2);
-            v = fe_mul<P>(v, w);
-            l = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
-            hh = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+            v = fz_mul<P>(v, fz_from_fe<P>(fe_load<P>(outer_tw + (((size_t)k << a.log_s) + r) * 2)));
         } else {
             g = (ol0 + q) + ((size_t)k << (a.log_n - log_a));
-            if (a.scale) {
-                Fe<P> v, w;
-                v.v[0] = l.x; v.v[1] = l.y; v.v[2] = l.z; v.v[3] = l.w;
-                v.v[4] = hh.x; v.v[5] = hh.y; v.v[6] = hh.z; v.v[7] = hh.w;
-                w = fe_load<P>(scale_ptr);
-                v = fe_mul<P>(v, w);
-                l = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
-                hh = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
-            }
+            v = fz_mul<P>(v, scale);  // 1 or n^-1 (R'-form)
         }
-        outb[g * 2] = l;
-        outb[g * 2 + 1] = hh;
+        fe_store<P>(outb + g * 2, fz_to_fe_canonical<P>(v));
     }
 }
 
@@ -339,7 +335,7 @@ template <class P> static int build_plan_t(NttPlan& pl) {
     const int log_n = pl.log_n;
     const int log_t = log_n > INNER_LOG ? log_n : INNER_LOG;
     if (log_t > P::TWO_ADICITY) return set_error(PLK_ERR_TWO_ADICITY, "log_n %d exceeds the field's 2-adicity %d", log_n, P::TWO_ADICITY);
-    PLK_HIP_TRY(hipMalloc(&pl.pw, 65 * 32));
+    PLK_HIP_TRY(hipMalloc(&pl.pw, 67 * 32));
     k_ntt_pow2<P><<<1, 64>>>((uint4*)pl.pw, log_t, log_n);
     PLK_HIP_TRY(hipGetLastError());
     const int m = (int)pl.pass_log.size();
@@ -447,8 +443,10 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
         void* dst = a.last ? d_out : scratch;
         std::pair<hipEvent_t, hipEvent_t> pev;
         const bool prof = prof_begin(stream, pev);
-        k_ntt_pass<P><<<(unsigned)tiles, NTT_THREADS, 0, stream>>>((const uint4*)src, (uint4*)dst, (const uint4*)pl.inner[dir],
-                                                                 (const uint4*)outer, (const uint4*)pl.pw + 64 * 2, a);
+        const size_t lds_bytes = ((size_t)FzCfg<P>::NZ * TILE + (size_t)FzCfg<P>::NZ * ((size_t)1 << a.log_a) / 2) * 4;
+        const uint4* scale = (const uint4*)pl.pw + (a.scale ? 66 : 65) * 2;
+        k_ntt_pass<P><<<(unsigned)tiles, NTT_THREADS, lds_bytes, stream>>>((const uint4*)src, (uint4*)dst, (const uint4*)pl.inner[dir],
+                                                                         (const uint4*)outer, scale, a);
         if (prof) prof_end(stream, pev);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
