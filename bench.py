@@ -112,7 +112,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from plonky_amd import device as dev, lib, synth
+    from plonky_amd import device as dev, lib, parallel, synth
     from plonky_amd.selfcheck import closed_form_msm, _mul, _add
     from plonky_amd.synth import MODULI
     dev.init(local_rank)
@@ -142,9 +142,7 @@ def main():
         pre = dev.msm_precompute_dev(CURVE, bases)
         oxy = torch.empty((1, 2, 4), dtype=torch.int64, device="cuda")
         oz = torch.empty((1,), dtype=torch.uint8, device="cuda")
-        if world > 1:
-            g_xy = torch.empty((world, 2, 4), dtype=torch.int64, device="cuda")
-            g_z = torch.empty((world,), dtype=torch.uint8, device="cuda")
+        g_pair = [None, None]  # the gathered partial points of the base-range shards
 
     def step():
         if do_ntt:
@@ -153,8 +151,7 @@ def main():
             dev.msm_execute_dev(pre, s, oxy, oz)
             if world > 1:
                 # the one exchange step of the path: partial results of the base-range shards
-                dist.all_gather_into_tensor(g_xy, oxy)
-                dist.all_gather_into_tensor(g_z, oz)
+                g_pair[0], g_pair[1] = parallel.all_gather_points(oxy, oz)
 
     def sync():
         torch.cuda.synchronize()
@@ -236,7 +233,7 @@ def main():
             if world > 1:
                 tot_xy = torch.empty((1, 2, 4), dtype=torch.int64, device="cuda")
                 tot_z = torch.empty((1,), dtype=torch.uint8, device="cuda")
-                hx, hz = dev.to_host(g_xy).reshape(world, 2, 4), g_z.cpu().numpy()
+                hx, hz = dev.to_host(g_pair[0]).reshape(world, 2, 4), g_pair[1].cpu().numpy().reshape(world)
                 from plonky_amd import api
                 tot, tz = api.curve_sum_affine(CURVE, hx, hz)
                 checks["msm_global_sum_is_point"] = bool(tz == 0)

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz: small committed input/expected-output vectors for the NTT and
+MSM path.  The reference is Rust and cannot run here, so the expected values come from the
+independent big-integer maths of oracle/bigint_ref.py (NOT from the C++ restatement and NOT from
+the HIP code): both of those are then checked against these files
+(tests/test_golden.py on CPU, tests/test_gpu_parity.py::test_golden_vectors on the GPU).
+Run from the repo root:  python tests/golden/make_golden.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import bigint_ref as br  # noqa: E402
+from plonky_amd import synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def arr(vals, n):
+    return np.array([[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)] for v in vals], dtype=np.uint64)
+
+
+def main():
+    # NTT: 2^6 points per field, seeded Montgomery-limb inputs, forward and inverse
+    for f in (br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR):
+        x = synth.rand_field(f.field_id, 0x601D0000 + f.field_id, 64)
+        xi = [f.from_mont(synth.to_int(r)) for r in x]
+        fwd = arr([f.to_mont(v) for v in br.ntt(f, xi)], 4)
+        inv = arr([f.to_mont(v) for v in br.intt(f, xi)], 4)
+        np.savez(os.path.join(OUT, "ntt_%s_2p6.npz" % f.name), field=f.field_id, input=x, forward=fwd, inverse=inv)
+    # MSM: 24 generators G0 + i D, seeded scalars with the edge values 0, 1, r-1 and a duplicated base
+    for c in (br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377):
+        n = 24
+        G = (c.gx, c.gy)
+        D = br.ec_mul(c, 0x5EED + c.curve_id, G)
+        pts, P = [], G
+        for _ in range(n):
+            pts.append(P)
+            P = br.ec_add(c, P, D)
+        pts[5] = pts[4]
+        s = synth.rand_field(c.scalar.field_id, 0x601D1000 + c.curve_id, n)
+        sc = [c.scalar.from_mont(synth.to_int(r)) for r in s]
+        sc[0], sc[1], sc[2] = 0, 1, c.scalar.p - 1
+        s = arr([c.scalar.to_mont(v) for v in sc], 4)
+        res = br.msm(c, sc, pts)
+        L = c.base.n_limbs
+        bases = np.stack([arr([c.base.to_mont(P[0]), c.base.to_mont(P[1])], L) for P in pts])
+        expect = arr([c.base.to_mont(res[0]), c.base.to_mont(res[1])], L)
+        np.savez(os.path.join(OUT, "msm_%s_24.npz" % c.name), curve=c.curve_id, bases=bases, scalars=s, expected_xy=expect, expected_zero=0)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
