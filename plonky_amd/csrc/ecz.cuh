@@ -9,6 +9,9 @@
 // or inf = true (the identity; the reference's `zero` flag, curve.rs:176-181).
 #pragma once
 #include "fz.cuh"
+#ifdef __HIPCC__
+#include "ec.cuh"
+#endif
 
 namespace plk {
 
@@ -83,5 +86,101 @@ template <class FP> PLK_DI void xyzzz_madd(XyzzZ<FP>& acc, const Fz<FP>& x2, con
     acc.zz = zz3;
     acc.zzz = fz_mul<FP>(acc.zzz, ppp);                                 // < 1.1
 }
+
+// 2 * a, XYZZ operand within the accumulator invariant (EFD dbl-2008-s-1, a = 0)
+template <class FP> PLK_DI XyzzZ<FP> xyzzz_dbl(const XyzzZ<FP>& a) {
+    if (a.inf) return a;
+    XyzzZ<FP> r;
+    Fz<FP> u = fz_dbl<FP>(a.y);                              // < 8
+    Fz<FP> v = fz_sqr<FP>(u);                                // < 1.5
+    Fz<FP> w = fz_mul<FP>(u, v);                             // < 1.1
+    Fz<FP> s = fz_mul<FP>(a.x, v);                           // < 1.1
+    Fz<FP> xx = fz_sqr<FP>(a.x);                             // < 1.5
+    Fz<FP> m = fz_add<FP>(fz_dbl<FP>(xx), xx);               // < 4.5
+    Fz<FP> mm = fz_sqr<FP>(m);                               // < 1.2
+    r.x = fz_sub<FP, 2>(mm, fz_dbl<FP>(s));                  // < 1.2 + 4 = 5.2
+    Fz<FP> t = fz_sub<FP, 3>(s, r.x);                        // < 9.1
+    r.y = fz_sub<FP, 1>(fz_mul<FP>(m, t), fz_mul<FP>(w, a.y));  // < 3.4
+    r.zz = fz_mul<FP>(v, a.zz);
+    r.zzz = fz_mul<FP>(w, a.zzz);
+    r.inf = fz_is_zero_mod_p<FP>(r.zz);                      // 2-torsion point
+    return r;
+}
+
+// a + b, both XYZZ within the invariant (EFD add-2008-s + the exceptional cases of curve_adds.rs:5-48)
+template <class FP> PLK_DI XyzzZ<FP> xyzzz_add(const XyzzZ<FP>& a, const XyzzZ<FP>& b) {
+    if (a.inf) return b;
+    if (b.inf) return a;
+    Fz<FP> u1 = fz_mul<FP>(a.x, b.zz);                       // < 1.2
+    Fz<FP> u2 = fz_mul<FP>(b.x, a.zz);
+    Fz<FP> s1 = fz_mul<FP>(a.y, b.zzz);
+    Fz<FP> s2 = fz_mul<FP>(b.y, a.zzz);
+    Fz<FP> p = fz_sub<FP, 1>(u2, u1);                        // < 3.2
+    Fz<FP> r = fz_sub<FP, 1>(s2, s1);                        // < 3.2
+    Fz<FP> pp = fz_sqr<FP>(p);                               // < 1.1
+    Fz<FP> ppp = fz_mul<FP>(p, pp);
+    Fz<FP> q = fz_mul<FP>(u1, pp);
+    Fz<FP> rr = fz_sqr<FP>(r);
+    XyzzZ<FP> o;
+    o.zz = fz_mul<FP>(fz_mul<FP>(a.zz, b.zz), pp);
+    if (fz_is_zero_mod_p<FP>(o.zz)) {
+        if (fz_is_zero_mod_p<FP>(rr)) return xyzzz_dbl<FP>(a);
+        o = a;
+        o.inf = true;
+        return o;
+    }
+    o.x = fz_sub<FP, 2>(fz_sub<FP, 1>(rr, ppp), fz_dbl<FP>(q));        // < 7.3
+    Fz<FP> t = fz_sub<FP, 3>(q, o.x);                                  // < 9.3
+    o.y = fz_sub<FP, 1>(fz_mul<FP>(r, t), fz_mul<FP>(s1, ppp));        // < 3.3
+    o.zzz = fz_mul<FP>(fz_mul<FP>(a.zzz, b.zzz), ppp);
+    o.inf = false;
+    return o;
+}
+
+template <class FP> PLK_DI XyzzZ<FP> xyzzz_identity() {
+    XyzzZ<FP> r;
+    r.x = r.y = r.zz = r.zzz = fz_zero<FP>();
+    r.inf = true;
+    return r;
+}
+
+#ifdef __HIPCC__
+// Exchange format between the MSM kernels: X, Y, ZZ, ZZZ in R'-form, canonical, packed in 32-bit
+// words (the layout of Xyzz<FP>); the identity is ZZ = 0.
+template <class FP> PLK_DI void xyzzz_store_packed(uint4* dst, const XyzzZ<FP>& a) {
+    Xyzz<FP> o = xyzz_identity<FP>();
+    if (!a.inf) {
+        const Fz<FP> one = fz_one_rprime<FP>();  // the extra product brings every coordinate below 2p
+        o.x = fz_to_fe_canonical<FP>(fz_mul<FP>(a.x, one));
+        o.y = fz_to_fe_canonical<FP>(fz_mul<FP>(a.y, one));
+        o.zz = fz_to_fe_canonical<FP>(fz_mul<FP>(a.zz, one));
+        o.zzz = fz_to_fe_canonical<FP>(fz_mul<FP>(a.zzz, one));
+    }
+    xyzz_store<FP>(dst, o);
+}
+template <class FP> PLK_DI XyzzZ<FP> xyzzz_load_packed(const uint4* src) {
+    const Xyzz<FP> p = xyzz_load<FP>(src);
+    XyzzZ<FP> r;
+    r.x = fz_from_fe<FP>(p.x);
+    r.y = fz_from_fe<FP>(p.y);
+    r.zz = fz_from_fe<FP>(p.zz);
+    r.zzz = fz_from_fe<FP>(p.zzz);
+    r.inf = fe_is_zero<FP>(p.zz);
+    return r;
+}
+// the other lane's point (xor butterfly inside a wave)
+template <class FP> PLK_DI XyzzZ<FP> xyzzz_shfl_xor(const XyzzZ<FP>& a, int mask) {
+    XyzzZ<FP> r;
+#pragma unroll
+    for (int i = 0; i < FzCfg<FP>::NZ; ++i) {
+        r.x.l[i] = __shfl_xor(a.x.l[i], mask);
+        r.y.l[i] = __shfl_xor(a.y.l[i], mask);
+        r.zz.l[i] = __shfl_xor(a.zz.l[i], mask);
+        r.zzz.l[i] = __shfl_xor(a.zzz.l[i], mask);
+    }
+    r.inf = __shfl_xor((int)a.inf, mask) != 0;
+    return r;
+}
+#endif
 
 }  // namespace plk

@@ -372,38 +372,103 @@ __global__ void __launch_bounds__(128) k_msm_accumulate(const uint4* __restrict_
         if (cur & 1u) yz = fz_neg_canonical<FP>(yz);
         xyzzz_madd<FP>(acc, xz, yz);
     }
-    // hand the partial sum to the reduction kernels in the reference's form (R-form, canonical)
-    Xyzz<FP> o = xyzz_identity<FP>();
-    if (!acc.inf) {
-        const Fz<FP> back = fz_const_rprime_to_r<FP>();
-        o.x = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.x, back));
-        o.y = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.y, back));
-        o.zz = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zz, back));
-        o.zzz = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zzz, back));
-    }
-    xyzz_store<FP>(partial + (size_t)s * 4 * W, o);
+    xyzzz_store_packed<FP>(partial + (size_t)s * 4 * W, acc);  // R'-form, canonical (exchange format of ecz.cuh)
 }
 
 // ---------------------------------------------------------------------------------------------
 // reduction  sum_d d * bucket_d   (replaces the serial Yao tail of curve_msm.rs:149-154)
 // ---------------------------------------------------------------------------------------------
 // Everything here is latency bound (few points, long dependent chains), so the structure is
-// chosen for depth, not work:  bucket_b = sum of its slice partials (<= n*W / (D * SLICE) + 1
-// serial additions);  sum_b (b+1) * bucket_b = sum_p 2^p * P_p with P_p the plain sum of the
-// buckets whose weight b+1 has bit p set, each P_p a block-parallel tree sum (c planes,
-// c * D / 2 additions in total, ~1.5 % of the accumulation work);  the planes are doubled into
-// place and tree-summed by one block which also normalises the result.
+// chosen for depth, not work, and runs on the lazy arithmetic (ecz.cuh, fully inlined):
+//  * bucket_b = sum of its slice partials: 4 lanes per bucket, each sums every 4th slice, two
+//    xor-shuffle additions combine them;
+//  * sum_b (b+1) bucket_b = sum_p 2^p P_p with P_p the plain sum of the buckets whose weight b+1 has
+//    bit p set: c planes, each a tree sum (serial part per lane, 6 shuffle levels per wave, LDS
+//    across waves), c * D / 2 additions in total (~1.5 % of the accumulation work);
+//  * one block sums the parts of every plane, doubles the planes into place, adds them and
+//    normalises the result (to_affine, curve.rs:206-214).
+constexpr int BUCKET_LANES = 4;
+
+template <class FP> PLK_DI XyzzZ<FP> wave_sum(XyzzZ<FP> v, int width) {
+    for (int m = 1; m < width; m <<= 1) v = xyzzz_add<FP>(v, xyzzz_shfl_xor<FP>(v, m));
+    return v;
+}
+
 template <class C>
-__global__ void __launch_bounds__(128) k_msm_bucket_sum(const uint4* __restrict__ partial, const uint32_t* __restrict__ slice_off, uint4* __restrict__ bucket,
+__global__ void __launch_bounds__(256) k_msm_bucket_sum(const uint4* __restrict__ partial, const uint32_t* __restrict__ slice_off, uint4* __restrict__ bucket,
                                                         uint32_t buckets) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= buckets) return;
-    const uint32_t s0 = slice_off[b], s1 = slice_off[b + 1];
-    Xyzz<FP> acc = xyzz_identity<FP>();
-    for (uint32_t s = s0; s < s1; ++s) acc = xyzz_add<FP>(acc, xyzz_load<FP>(partial + (size_t)s * 4 * W));
-    xyzz_store<FP>(bucket + (size_t)b * 4 * W, acc);
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = gid / BUCKET_LANES, part = gid % BUCKET_LANES;
+    XyzzZ<FP> acc = xyzzz_identity<FP>();
+    if (b < buckets) {
+        const uint32_t s0 = slice_off[b], s1 = slice_off[b + 1];
+        for (uint32_t s = s0 + part; s < s1; s += BUCKET_LANES) acc = xyzzz_add<FP>(acc, xyzzz_load_packed<FP>(partial + (size_t)s * 4 * W));
+    }
+    acc = wave_sum<FP>(acc, BUCKET_LANES);  // lanes of a bucket are adjacent; every lane takes part in the shuffles
+    if (b < buckets && part == 0) xyzzz_store_packed<FP>(bucket + (size_t)b * 4 * W, acc);
+}
+
+// plane p: tree-sum of { bucket_b : bit p of (b + 1) }.  grid = (parts, planes), 256 lanes.
+template <class C>
+__global__ void __launch_bounds__(256) k_msm_planes(const uint4* __restrict__ bucket, uint4* __restrict__ plane_part, uint32_t buckets) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    __shared__ uint4 s_pts[4 * 4 * W];  // one packed point per wave
+    const int plane = blockIdx.y;
+    XyzzZ<FP> acc = xyzzz_identity<FP>();
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < buckets; b += gridDim.x * blockDim.x) {
+        if (((b + 1u) >> plane) & 1u) acc = xyzzz_add<FP>(acc, xyzzz_load_packed<FP>(bucket + (size_t)b * 4 * W));
+    }
+    acc = wave_sum<FP>(acc, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) xyzzz_store_packed<FP>(s_pts + wave * 4 * W, acc);
+    __syncthreads();
+    if (wave == 0) {
+        acc = lane < 4 ? xyzzz_load_packed<FP>(s_pts + lane * 4 * W) : xyzzz_identity<FP>();
+        acc = wave_sum<FP>(acc, 4);
+        if (lane == 0) xyzzz_store_packed<FP>(plane_part + ((size_t)plane * gridDim.x + blockIdx.x) * 4 * W, acc);
+    }
+}
+
+// one block of planes * parts lanes (parts a power of two <= 8, planes <= 32)
+template <class C>
+__global__ void __launch_bounds__(256) k_msm_final(const uint4* __restrict__ plane_part, int parts, int planes, uint4* __restrict__ out_xy,
+                                                   uint8_t* __restrict__ out_zero) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    __shared__ uint4 s_pts[32 * 4 * W];
+    const int tid = threadIdx.x;
+    const int plane = tid / parts, part = tid % parts;
+    const bool live = plane < planes;
+    XyzzZ<FP> acc = live ? xyzzz_load_packed<FP>(plane_part + (size_t)tid * 4 * W) : xyzzz_identity<FP>();
+    acc = wave_sum<FP>(acc, parts);  // the parts of a plane are adjacent lanes of one wave
+    if (live && part == 0) {
+        for (int k = 0; k < plane; ++k) acc = xyzzz_dbl<FP>(acc);
+        xyzzz_store_packed<FP>(s_pts + plane * 4 * W, acc);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        acc = tid < planes ? xyzzz_load_packed<FP>(s_pts + tid * 4 * W) : xyzzz_identity<FP>();
+        acc = wave_sum<FP>(acc, 32);
+        if (tid == 0) {
+            // back to the reference's form, then ProjectivePoint::to_affine (curve.rs:206-214)
+            Xyzz<FP> r = xyzz_identity<FP>();
+            if (!acc.inf) {
+                const Fz<FP> back = fz_const_rprime_to_r<FP>();
+                r.x = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.x, back));
+                r.y = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.y, back));
+                r.zz = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zz, back));
+                r.zzz = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zzz, back));
+            }
+            Fe<FP> x, y;
+            bool ident = xyzz_to_affine<FP, true>(r, x, y);
+            fe_store<FP>(out_xy, x);
+            fe_store<FP>(out_xy + W, y);
+            *out_zero = ident ? 1 : 0;
+        }
+    }
 }
 
 template <class FP> PLK_DI Xyzz<FP> block_sum(Xyzz<FP> v, uint4* s_pts) {
@@ -419,67 +484,6 @@ template <class FP> PLK_DI Xyzz<FP> block_sum(Xyzz<FP> v, uint4* s_pts) {
         __syncthreads();
     }
     return v;
-}
-
-// plane p: tree-sum of { bucket_b : bit p of (b + 1) }.  grid = (parts, planes)
-template <class C>
-__global__ void __launch_bounds__(256) k_msm_planes(const uint4* __restrict__ bucket, uint4* __restrict__ plane_part, uint32_t buckets) {
-    using FP = typename C::FP;
-    constexpr int W = FP::NL / 4;
-    extern __shared__ __attribute__((aligned(16))) uint4 s_pts[];
-    const int plane = blockIdx.y;
-    Xyzz<FP> acc = xyzz_identity<FP>();
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < buckets; b += gridDim.x * blockDim.x) {
-        if (((b + 1u) >> plane) & 1u) acc = xyzz_add<FP>(acc, xyzz_load<FP>(bucket + (size_t)b * 4 * W));
-    }
-    acc = block_sum<FP>(acc, s_pts);
-    if (threadIdx.x == 0) xyzz_store<FP>(plane_part + ((size_t)plane * gridDim.x + blockIdx.x) * 4 * W, acc);
-}
-
-// one block of planes * parts lanes: tree over the parts of each plane, 2^plane by doublings,
-// tree over the planes, to_affine (curve.rs:206-214).
-template <class C>
-__global__ void __launch_bounds__(256) k_msm_final(const uint4* __restrict__ plane_part, int parts, int planes, uint4* __restrict__ out_xy,
-                                                   uint8_t* __restrict__ out_zero) {
-    using FP = typename C::FP;
-    constexpr int W = FP::NL / 4;
-    extern __shared__ __attribute__((aligned(16))) uint4 s_pts[];
-    const int tid = threadIdx.x;
-    const int plane = tid / parts, part = tid % parts;
-    const bool live = plane < planes;
-    Xyzz<FP> acc = live ? xyzz_load<FP>(plane_part + (size_t)tid * 4 * W) : xyzz_identity<FP>();
-    xyzz_store<FP>(s_pts + tid * 4 * W, acc);
-    __syncthreads();
-    for (int d = parts >> 1; d >= 1; d >>= 1) {
-        if (live && part < d) {
-            acc = xyzz_add<FP>(acc, xyzz_load<FP>(s_pts + (tid + d) * 4 * W));
-            xyzz_store<FP>(s_pts + tid * 4 * W, acc);
-        }
-        __syncthreads();
-    }
-    if (live && part == 0)
-        for (int k = 0; k < plane; ++k) acc = xyzz_dbl<FP>(acc);
-    __syncthreads();
-    // compact the plane leaders to the front, then a 32-wide tree
-    if (live && part == 0) xyzz_store<FP>(s_pts + plane * 4 * W, acc);
-    __syncthreads();
-    acc = tid < planes ? xyzz_load<FP>(s_pts + tid * 4 * W) : xyzz_identity<FP>();
-    __syncthreads();
-    for (int d = 16; d >= 1; d >>= 1) {
-        if (tid < d && tid + d < 32) {
-            Xyzz<FP> o = (tid + d) < planes ? xyzz_load<FP>(s_pts + (tid + d) * 4 * W) : xyzz_identity<FP>();
-            acc = xyzz_add<FP>(acc, o);
-            xyzz_store<FP>(s_pts + tid * 4 * W, acc);
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        Fe<FP> x, y;
-        bool ident = xyzz_to_affine<FP, true>(acc, x, y);
-        fe_store<FP>(out_xy, x);
-        fe_store<FP>(out_xy + W, y);
-        *out_zero = ident ? 1 : 0;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -675,7 +679,6 @@ static int msm_execute_t(plk_msm_ctx* ctx, const void* d_scalars, void* d_out_xy
     const size_t n = ctx->n;
     const size_t entries = n * ctx->windows;
     const uint32_t buckets = ctx->buckets;
-    const size_t xyzz_bytes = (size_t)4 * FP::NL * 4;
     uint32_t* hist = (uint32_t*)ctx->hist;
     uint32_t* off = (uint32_t*)ctx->off;
     uint32_t* slice_off = off + buckets + 1;
@@ -726,15 +729,14 @@ static int msm_execute_t(plk_msm_ctx* ctx, const void* d_scalars, void* d_out_xy
                                                                                        (uint4*)ctx->partial, buckets, ctx->slice);
     PLK_HIP_TRY(hipGetLastError());
     mark();
-    k_msm_bucket_sum<C><<<(buckets + 127) / 128, 128, 0, stream>>>((const uint4*)ctx->partial, slice_off, (uint4*)ctx->bucket, buckets);
+    k_msm_bucket_sum<C><<<(buckets * BUCKET_LANES + 255) / 256, 256, 0, stream>>>((const uint4*)ctx->partial, slice_off, (uint4*)ctx->bucket, buckets);
     PLK_HIP_TRY(hipGetLastError());
     mark();
     dim3 pg(ctx->plane_blocks, ctx->planes);
-    k_msm_planes<C><<<pg, 256, 256 * xyzz_bytes, stream>>>((const uint4*)ctx->bucket, (uint4*)ctx->plane_part, buckets);
+    k_msm_planes<C><<<pg, 256, 0, stream>>>((const uint4*)ctx->bucket, (uint4*)ctx->plane_part, buckets);
     PLK_HIP_TRY(hipGetLastError());
     mark();
-    k_msm_final<C><<<1, 256, 256 * xyzz_bytes, stream>>>((const uint4*)ctx->plane_part, ctx->plane_blocks, ctx->planes, (uint4*)d_out_xy,
-                                                         (uint8_t*)d_out_zero);
+    k_msm_final<C><<<1, 256, 0, stream>>>((const uint4*)ctx->plane_part, ctx->plane_blocks, ctx->planes, (uint4*)d_out_xy, (uint8_t*)d_out_zero);
     PLK_HIP_TRY(hipGetLastError());
     mark();
     if (!ev.empty()) ctx->prof_sets.push_back(ev);

@@ -1,6 +1,7 @@
 // Host-side harness: compiles the device field arithmetic (plonky_amd/csrc/fp.cuh, plain C++ when not
 // under hipcc) with g++ so the CPU test suite can sweep it against Python integers.
 #include <cstddef>
+#include <vector>
 #include "../plonky_amd/csrc/fp.cuh"
 #include "../plonky_amd/csrc/fz.cuh"
 #include "../plonky_amd/csrc/ecz.cuh"
@@ -86,6 +87,47 @@ template <class P> static void ecz_sum(size_t n, const uint32_t* xs, const uint3
     for (int j = 0; j < 4; ++j)
         for (int k = 0; k < P::NL; ++k) out[j * P::NL + k] = c[j].v[k];
     out[4 * P::NL] = acc.inf ? 1u : 0u;
+}
+// Same sum, but as a balanced tree of full XYZZ additions (xyzzz_add / xyzzz_dbl): the reduction kernels' shape.
+template <class P> static void ecz_tree(size_t n, const uint32_t* xs, const uint32_t* ys, const uint8_t* negs, uint32_t* out) {
+    std::vector<XyzzZ<P>> v;
+    for (size_t i = 0; i < n; ++i) {
+        Fe<P> x, y;
+        for (int k = 0; k < P::NL; ++k) { x.v[k] = xs[i * P::NL + k]; y.v[k] = ys[i * P::NL + k]; }
+        XyzzZ<P> a = xyzzz_identity<P>();
+        Fz<P> yz = fz_from_fe<P>(y);
+        if (negs[i]) yz = fz_neg_canonical<P>(yz);
+        xyzzz_madd<P>(a, fz_from_fe<P>(x), yz);
+        v.push_back(a);
+    }
+    if (v.empty()) v.push_back(xyzzz_identity<P>());
+    while (v.size() > 1) {
+        std::vector<XyzzZ<P>> w;
+        for (size_t i = 0; i + 1 < v.size(); i += 2) w.push_back(xyzzz_add<P>(v[i], v[i + 1]));
+        if (v.size() & 1) w.push_back(v.back());
+        v.swap(w);
+    }
+    XyzzZ<P> acc = v[0];
+    Fz<P> one = fz_one_rprime<P>();
+    Fe<P> c[4];
+    if (acc.inf) { for (auto& e : c) e = fe_zero<P>(); }
+    else {
+        c[0] = fz_to_fe_canonical<P>(fz_mul<P>(acc.x, one));
+        c[1] = fz_to_fe_canonical<P>(fz_mul<P>(acc.y, one));
+        c[2] = fz_to_fe_canonical<P>(fz_mul<P>(acc.zz, one));
+        c[3] = fz_to_fe_canonical<P>(fz_mul<P>(acc.zzz, one));
+    }
+    for (int j = 0; j < 4; ++j)
+        for (int k = 0; k < P::NL; ++k) out[j * P::NL + k] = c[j].v[k];
+    out[4 * P::NL] = acc.inf ? 1u : 0u;
+}
+extern "C" int ecz_host_tree(int field, size_t n, const uint32_t* xs, const uint32_t* ys, const uint8_t* negs, uint32_t* out) {
+    switch (field) {
+        case 0: ecz_tree<TweedledeeBaseParams>(n, xs, ys, negs, out); return 0;
+        case 1: ecz_tree<TweedledumBaseParams>(n, xs, ys, negs, out); return 0;
+        case 3: ecz_tree<Bls12377BaseParams>(n, xs, ys, negs, out); return 0;
+    }
+    return -1;
 }
 extern "C" int ecz_host_sum(int field, size_t n, const uint32_t* xs, const uint32_t* ys, const uint8_t* negs, uint32_t* out) {
     switch (field) {

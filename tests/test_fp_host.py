@@ -125,13 +125,14 @@ def test_lazy_xyzz_accumulation_on_host(host_lib, c):
     rng = random.Random(5)
     pts = [br.ec_mul(c, rng.randrange(1, 1 << 64), G) for _ in range(40)]
 
-    def run_sum(points, negs):
+    def run_sum(points, negs, fn="ecz_host_sum"):
+        getattr(host_lib, fn).argtypes = host_lib.ecz_host_sum.argtypes
         xs = ints_to_array([P[0] * Rp % f.p for P in points], n)
         ys = ints_to_array([P[1] * Rp % f.p for P in points], n)
         ng = np.array(negs, dtype=np.uint8)
         out = np.zeros(4 * n + 1, dtype=np.uint64)
         out32 = np.zeros(4 * 2 * n + 2, dtype=np.uint32)
-        assert host_lib.ecz_host_sum(f.field_id, len(points), xs.ctypes.data, ys.ctypes.data, ng.ctypes.data, out32.ctypes.data) == 0
+        assert getattr(host_lib, fn)(f.field_id, len(points), xs.ctypes.data, ys.ctypes.data, ng.ctypes.data, out32.ctypes.data) == 0
         inf = int(out32[4 * 2 * n])
         if inf:
             return None
@@ -158,3 +159,8 @@ def test_lazy_xyzz_accumulation_on_host(host_lib, c):
     ]
     for points, negs in cases:
         assert run_sum(points, negs) == expect(points, negs)
+        # balanced tree of full XYZZ additions (the reduction kernels): same group element
+        assert run_sum(points, negs, "ecz_host_tree") == expect(points, negs)
+    # trees that hit a + a (doubling) and a + (-a) at inner nodes
+    assert run_sum([pts[0], pts[1], pts[0], pts[1]], [0, 0, 0, 0], "ecz_host_tree") == expect([pts[0], pts[1]] * 2, [0] * 4)
+    assert run_sum([pts[0], pts[1], pts[0], pts[1]], [0, 0, 1, 1], "ecz_host_tree") is None
