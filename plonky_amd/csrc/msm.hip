@@ -28,7 +28,7 @@
 
 namespace plk {
 
-constexpr int MSM_SLICE_DEFAULT = 32;  // entries per accumulation slice (PLK_MSM_SLICE overrides)
+constexpr int MSM_SLICE_DEFAULT = 24;  // entries per accumulation slice (PLK_MSM_SLICE overrides)
 constexpr int MSM_MAX_PLANE_PARTS = 8;  // blocks per bit-plane in the reduction
 constexpr int MSM_MAX_WINDOW = 17;   // c - 1 <= 8 fine + 8 coarse bits in the partition
 constexpr uint32_t CODE_INVALID = 0xFFFFFFFFu;
@@ -114,20 +114,17 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint4* __restrict__ sc
     }
 }
 
-// single block: exclusive scans of the bucket sizes and of the per-bucket slice counts
-__global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ off, uint32_t* __restrict__ slice_off,
-                                                   uint32_t buckets, uint32_t slice) {
+// exclusive scans of the bucket sizes (off) and of the per-bucket slice counts (slice_off), two steps:
+// every block scans 1024 buckets and publishes its totals, then every block adds the totals of the
+// blocks before it (<= 64 of them: a serial walk by one lane is cheaper than another launch).
+__global__ void __launch_bounds__(1024) k_msm_scan_local(const uint32_t* __restrict__ hist, uint32_t* __restrict__ off, uint32_t* __restrict__ slice_off,
+                                                         uint32_t* __restrict__ block_tot, uint32_t buckets, uint32_t slice) {
     __shared__ uint32_t s_a[1024], s_b[1024];
-    const uint32_t per = (buckets + 1023) / 1024;
-    const uint32_t lo = threadIdx.x * per, hi = min(buckets, lo + per);
-    uint32_t sa = 0, sb = 0;
-    for (uint32_t b = lo; b < hi; ++b) {
-        uint32_t h = hist[b];
-        sa += h;
-        sb += (h + slice - 1) / slice;
-    }
-    s_a[threadIdx.x] = sa;
-    s_b[threadIdx.x] = sb;
+    const uint32_t b = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t h = b < buckets ? hist[b] : 0u;
+    const uint32_t sl = (h + slice - 1) / slice;
+    s_a[threadIdx.x] = h;
+    s_b[threadIdx.x] = sl;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
         uint32_t va = 0, vb = 0;
@@ -140,17 +137,36 @@ __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ 
         s_b[threadIdx.x] += vb;
         __syncthreads();
     }
-    uint32_t ra = s_a[threadIdx.x] - sa, rb = s_b[threadIdx.x] - sb;  // exclusive prefix of this lane's range
-    for (uint32_t b = lo; b < hi; ++b) {
-        uint32_t h = hist[b];
-        off[b] = ra;
-        slice_off[b] = rb;
-        ra += h;
-        rb += (h + slice - 1) / slice;
+    if (b < buckets) {
+        off[b] = s_a[threadIdx.x] - h;
+        slice_off[b] = s_b[threadIdx.x] - sl;
     }
     if (threadIdx.x == 1023) {
-        off[buckets] = s_a[1023];
-        slice_off[buckets] = s_b[1023];
+        block_tot[2 * blockIdx.x] = s_a[1023];
+        block_tot[2 * blockIdx.x + 1] = s_b[1023];
+    }
+}
+__global__ void __launch_bounds__(1024) k_msm_scan_add(uint32_t* __restrict__ off, uint32_t* __restrict__ slice_off, const uint32_t* __restrict__ block_tot,
+                                                       uint32_t buckets) {
+    __shared__ uint32_t s_add[2];
+    if (threadIdx.x == 0) {
+        uint32_t a = 0, c = 0;
+        for (uint32_t k = 0; k < blockIdx.x; ++k) {
+            a += block_tot[2 * k];
+            c += block_tot[2 * k + 1];
+        }
+        s_add[0] = a;
+        s_add[1] = c;
+        if (blockIdx.x == gridDim.x - 1) {  // grand totals close both arrays
+            off[buckets] = a + block_tot[2 * blockIdx.x];
+            slice_off[buckets] = c + block_tot[2 * blockIdx.x + 1];
+        }
+    }
+    __syncthreads();
+    const uint32_t b = blockIdx.x * 1024 + threadIdx.x;
+    if (b < buckets) {
+        off[b] += s_add[0];
+        slice_off[b] += s_add[1];
     }
 }
 
@@ -236,25 +252,65 @@ __global__ void __launch_bounds__(256) k_part_bases(const uint32_t* __restrict__
     }
 }
 
+// Shared by both scatter steps: the tile is first ordered by bin inside LDS (returning LDS atomics give
+// the rank inside the (tile, bin) run, a 256-wide scan gives the run starts), then written out in
+// that order, so consecutive lanes store to consecutive addresses of the same run.
+PLK_DI void part_scan256(uint32_t* s_cnt, uint32_t* s_base) {
+    // exclusive scan of s_cnt[0..255] into s_base (Hillis-Steele, blockDim.x == 256)
+    const int t = threadIdx.x;
+    uint32_t v = s_cnt[t];
+    s_base[t] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t u = t >= d ? s_base[t - d] : 0u;
+        __syncthreads();
+        s_base[t] += u;
+        __syncthreads();
+    }
+    const uint32_t incl = s_base[t];
+    __syncthreads();
+    s_base[t] = incl - v;
+    __syncthreads();
+}
+
 // level 1, step 3: move (code, entry id) to its coarse bin
 __global__ void __launch_bounds__(PART_THREADS) k_part1_scatter(const uint32_t* __restrict__ codes, size_t entries, const uint32_t* __restrict__ cnt1,
                                                                 uint32_t nt1, const uint32_t* __restrict__ bin_base_pad, int fine_bits, int nbins,
                                                                 uint32_t* __restrict__ tmp_code, uint32_t* __restrict__ tmp_val) {
-    __shared__ uint32_t s_cur[256];
+    __shared__ uint32_t s_cnt[256], s_base[256], s_gbase[256];
+    __shared__ uint32_t s_code[PART_TILE], s_val[PART_TILE];
     const uint32_t tile = blockIdx.x;
-    if ((int)threadIdx.x < nbins) s_cur[threadIdx.x] = bin_base_pad[threadIdx.x] + cnt1[(size_t)threadIdx.x * nt1 + tile];
+    s_cnt[threadIdx.x] = 0;
+    s_gbase[threadIdx.x] = (int)threadIdx.x < nbins ? bin_base_pad[threadIdx.x] + cnt1[(size_t)threadIdx.x * nt1 + tile] : 0u;
     __syncthreads();
     const size_t base = (size_t)tile << PART_TILE_LOG;
+    uint32_t code[PART_PER_THREAD], rank[PART_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < PART_PER_THREAD; ++k) {
         const size_t e = base + k * PART_THREADS + threadIdx.x;
-        if (e < entries) {
-            const uint32_t code = codes[e];
-            if (code != CODE_INVALID) {
-                const uint32_t pos = atomicAdd(&s_cur[code >> (fine_bits + 1)], 1u);
-                tmp_code[pos] = code;
-                tmp_val[pos] = (uint32_t)e;
-            }
+        code[k] = e < entries ? codes[e] : CODE_INVALID;
+        rank[k] = code[k] != CODE_INVALID ? atomicAdd(&s_cnt[code[k] >> (fine_bits + 1)], 1u) : 0u;
+    }
+    __syncthreads();
+    part_scan256(s_cnt, s_base);
+#pragma unroll
+    for (int k = 0; k < PART_PER_THREAD; ++k) {
+        if (code[k] != CODE_INVALID) {
+            const uint32_t sidx = s_base[code[k] >> (fine_bits + 1)] + rank[k];
+            s_code[sidx] = code[k];
+            s_val[sidx] = (uint32_t)(base + k * PART_THREADS + threadIdx.x);
+        }
+    }
+    __syncthreads();
+    const uint32_t total = s_base[255] + s_cnt[255];
+#pragma unroll
+    for (int k = 0; k < PART_PER_THREAD; ++k) {
+        const uint32_t sidx = k * PART_THREADS + threadIdx.x;
+        if (sidx < total) {
+            const uint32_t c = s_code[sidx], bin = c >> (fine_bits + 1);
+            const uint32_t pos = s_gbase[bin] + (sidx - s_base[bin]);
+            tmp_code[pos] = c;
+            tmp_val[pos] = s_val[sidx];
         }
     }
 }
@@ -298,28 +354,54 @@ __global__ void __launch_bounds__(256) k_part2_scan(uint32_t* __restrict__ cnt2,
     hist[(bin << fine_bits) + fine] = run;
 }
 
-// level 2, step 3: final position = off[bucket] + within-bucket offset of this tile + LDS rank
+// level 2, step 3: final position = off[bucket] + within-bucket offset of this tile + rank in the tile
 __global__ void __launch_bounds__(PART_THREADS) k_part2_scatter(const uint32_t* __restrict__ tmp_code, const uint32_t* __restrict__ tmp_val,
                                                                 const uint32_t* __restrict__ bin_total, const uint32_t* __restrict__ bin_base_pad,
                                                                 const uint32_t* __restrict__ tile2bin, const uint32_t* __restrict__ meta,
                                                                 const uint32_t* __restrict__ cnt2, uint32_t nt2max, int fine_bits,
                                                                 const uint32_t* __restrict__ off, uint32_t* __restrict__ sorted) {
-    __shared__ uint32_t s_cur[256];
+    __shared__ uint32_t s_cnt[256], s_base[256], s_gbase[256];
+    __shared__ uint32_t s_out[PART_TILE];
+    __shared__ uint8_t s_fine[PART_TILE];
     const uint32_t tile = blockIdx.x;
     if (tile >= meta[0]) return;
     const uint32_t bin = tile2bin[tile];
     const uint32_t valid_end = bin_base_pad[bin] + bin_total[bin];
     const uint32_t fmask = (1u << fine_bits) - 1u;
-    if (threadIdx.x <= fmask) s_cur[threadIdx.x] = off[(bin << fine_bits) + threadIdx.x] + cnt2[(size_t)threadIdx.x * nt2max + tile];
+    s_cnt[threadIdx.x] = 0;
+    s_gbase[threadIdx.x] = threadIdx.x <= fmask ? off[(bin << fine_bits) + threadIdx.x] + cnt2[(size_t)threadIdx.x * nt2max + tile] : 0u;
     __syncthreads();
     const uint32_t base = tile << PART_TILE_LOG;
+    uint32_t word[PART_PER_THREAD], fine[PART_PER_THREAD], rank[PART_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < PART_PER_THREAD; ++k) {
         const uint32_t p = base + k * PART_THREADS + threadIdx.x;
+        fine[k] = 0xFFFFFFFFu;
         if (p < valid_end) {
-            const uint32_t code = tmp_code[p];
-            const uint32_t pos = atomicAdd(&s_cur[(code >> 1) & fmask], 1u);
-            sorted[pos] = (tmp_val[p] << 1) | (code & 1u);
+            const uint32_t c = tmp_code[p];
+            fine[k] = (c >> 1) & fmask;
+            word[k] = (tmp_val[p] << 1) | (c & 1u);
+            rank[k] = atomicAdd(&s_cnt[fine[k]], 1u);
+        }
+    }
+    __syncthreads();
+    part_scan256(s_cnt, s_base);
+#pragma unroll
+    for (int k = 0; k < PART_PER_THREAD; ++k) {
+        if (fine[k] != 0xFFFFFFFFu) {
+            const uint32_t sidx = s_base[fine[k]] + rank[k];
+            s_out[sidx] = word[k];
+            s_fine[sidx] = (uint8_t)fine[k];
+        }
+    }
+    __syncthreads();
+    const uint32_t total = s_base[255] + s_cnt[255];
+#pragma unroll
+    for (int k = 0; k < PART_PER_THREAD; ++k) {
+        const uint32_t sidx = k * PART_THREADS + threadIdx.x;
+        if (sidx < total) {
+            const uint32_t f = s_fine[sidx];
+            sorted[s_gbase[f] + (sidx - s_base[f])] = s_out[sidx];
         }
     }
 }
@@ -561,7 +643,7 @@ struct plk_msm_ctx {
     void* cnt2 = nullptr;      // [2^fine_bits][nt2max]
     void* tmp_code = nullptr;  // entries + nbins * PART_TILE
     void* tmp_val = nullptr;
-    void* part_meta = nullptr; // bin_total[256] | bin_base_pad[257] | meta[1] | tile2bin[nt2max]
+    void* part_meta = nullptr; // bin_total[256] | bin_base_pad[257] | meta[1] | tile2bin[nt2max] | scan block totals[128]
     void* off = nullptr;       // off[buckets+1] followed by slice_off[buckets+1]
     void* partial = nullptr;
     void* bucket = nullptr;    // bucket sums (XYZZ)
@@ -616,7 +698,7 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
     PLK_HIP_TRY(hipMalloc(&ctx->cnt2, ((size_t)1 << ctx->fine_bits) * ctx->nt2max * 4));
     PLK_HIP_TRY(hipMalloc(&ctx->tmp_code, ((size_t)ctx->nt2max << PART_TILE_LOG) * 4));
     PLK_HIP_TRY(hipMalloc(&ctx->tmp_val, ((size_t)ctx->nt2max << PART_TILE_LOG) * 4));
-    PLK_HIP_TRY(hipMalloc(&ctx->part_meta, (size_t)(256 + 257 + 1 + ctx->nt2max) * 4));
+    PLK_HIP_TRY(hipMalloc(&ctx->part_meta, (size_t)(256 + 257 + 1 + ctx->nt2max + 2 * 64 + 2) * 4));  // + block totals of the bucket scan
     PLK_HIP_TRY(hipMalloc(&ctx->off, ((size_t)ctx->buckets + 1) * 8));
     ctx->max_slices = entries / ctx->slice + ctx->buckets + 1;
     PLK_HIP_TRY(hipMalloc(&ctx->partial, ctx->max_slices * xyzz_bytes));
@@ -675,7 +757,6 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
 
 template <class C>
 static int msm_execute_t(plk_msm_ctx* ctx, const void* d_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream) {
-    using FP = typename C::FP;
     const size_t n = ctx->n;
     const size_t entries = n * ctx->windows;
     const uint32_t buckets = ctx->buckets;
@@ -719,7 +800,11 @@ static int msm_execute_t(plk_msm_ctx* ctx, const void* d_scalars, void* d_out_xy
     k_part2_scan<<<ctx->nbins, 256, 0, stream>>>((uint32_t*)ctx->cnt2, ctx->nt2max, bin_base_pad, ctx->fine_bits, hist);
     PLK_HIP_TRY(hipGetLastError());
     mark();
-    k_msm_scan<<<1, 1024, 0, stream>>>(hist, off, slice_off, buckets, ctx->slice);
+    {
+        const unsigned sb = (buckets + 1023) / 1024;
+        k_msm_scan_local<<<sb, 1024, 0, stream>>>(hist, off, slice_off, meta + 1 + ctx->nt2max, buckets, ctx->slice);
+        k_msm_scan_add<<<sb, 1024, 0, stream>>>(off, slice_off, meta + 1 + ctx->nt2max, buckets);
+    }
     k_part2_scatter<<<ctx->nt2max, PART_THREADS, 0, stream>>>((const uint32_t*)ctx->tmp_code, (const uint32_t*)ctx->tmp_val, bin_total, bin_base_pad, tile2bin,
                                                               meta, (const uint32_t*)ctx->cnt2, ctx->nt2max, ctx->fine_bits, off, (uint32_t*)ctx->sorted);
     PLK_HIP_TRY(hipGetLastError());
