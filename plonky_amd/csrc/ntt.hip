@@ -198,8 +198,38 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restric
     }
     __syncthreads();
 
-    // ---- stages: h = 1, 2, .., A/2 ----
-    for (int log_h = 0; log_h < log_a; ++log_h) {
+    // ---- stages: h = 1, 2, .., A/2, two at a time (radix-4 in registers: half the LDS round trips and
+    //      barriers of a radix-2 sweep, same multiplications) ----
+    int log_h = 0;
+    for (; log_h + 1 < log_a; log_h += 2) {
+        const int h = 1 << log_h;
+        for (int qd = tid; qd < (tile_elems >> 2); qd += NTT_THREADS) {
+            const int q = qd & (Q - 1), pq = qd >> log_q;
+            const int j = pq & (h - 1), blk = pq >> log_h;
+            const int i0 = (((blk << (log_h + 2)) + j) << log_q) + q, st = h << log_q;
+            Fz<P> x0 = lds_load<P>(s_dat, TILE, i0), x1 = lds_load<P>(s_dat, TILE, i0 + st);
+            Fz<P> x2 = lds_load<P>(s_dat, TILE, i0 + 2 * st), x3 = lds_load<P>(s_dat, TILE, i0 + 3 * st);
+            // stage with half-size h: pairs (x0, x1), (x2, x3), twiddle w_{2h}^j for both
+            if (log_h > 0) {
+                const Fz<P> wa = lds_load<P>(s_tw, half_a, j << (log_a - 1 - log_h));
+                x1 = fz_mul<P>(x1, wa);
+                x3 = fz_mul<P>(x3, wa);
+            }
+            Fz<P> y0 = fz_add<P>(x0, x1), y1 = fz_sub<P, 1>(x0, x1);
+            Fz<P> y2 = fz_add<P>(x2, x3), y3 = fz_sub<P, 1>(x2, x3);
+            // stage with half-size 2h: pairs (y0, y2) with w_{4h}^j and (y1, y3) with w_{4h}^(j+h)
+            const Fz<P> wb0 = lds_load<P>(s_tw, half_a, j << (log_a - 2 - log_h));
+            const Fz<P> wb1 = lds_load<P>(s_tw, half_a, (j + h) << (log_a - 2 - log_h));
+            y2 = fz_mul<P>(y2, wb0);
+            y3 = fz_mul<P>(y3, wb1);
+            lds_store<P>(s_dat, TILE, i0, fz_add<P>(y0, y2));
+            lds_store<P>(s_dat, TILE, i0 + 2 * st, fz_sub<P, 1>(y0, y2));
+            lds_store<P>(s_dat, TILE, i0 + st, fz_add<P>(y1, y3));
+            lds_store<P>(s_dat, TILE, i0 + 3 * st, fz_sub<P, 1>(y1, y3));
+        }
+        __syncthreads();
+    }
+    if (log_h < log_a) {  // odd log A: one radix-2 stage left
         const int h = 1 << log_h;
         for (int bf = tid; bf < (tile_elems >> 1); bf += NTT_THREADS) {
             const int q = bf & (Q - 1), pb = bf >> log_q;
@@ -207,10 +237,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restric
             const int i0 = (((blk << (log_h + 1)) + j) << log_q) + q, i1 = i0 + (h << log_q);
             const Fz<P> x = lds_load<P>(s_dat, TILE, i0);
             Fz<P> t = lds_load<P>(s_dat, TILE, i1);
-            if (log_h > 0) {
-                const Fz<P> w = lds_load<P>(s_tw, half_a, j << (log_a - 1 - log_h));  // w_{2h}^j
-                t = fz_mul<P>(t, w);                                                   // < 1.2p
-            }
+            if (log_h > 0) t = fz_mul<P>(t, lds_load<P>(s_tw, half_a, j << (log_a - 1 - log_h)));  // w_{2h}^j, product < 1.2p
             lds_store<P>(s_dat, TILE, i0, fz_add<P>(x, t));
             lds_store<P>(s_dat, TILE, i1, fz_sub<P, 1>(x, t));  // t < 2p - margin in both cases
         }
