@@ -34,7 +34,7 @@ namespace plk {
 
 constexpr int TILE_LOG = 10;             // elements per workgroup tile
 constexpr int TILE = 1 << TILE_LOG;
-constexpr int NTT_THREADS = 512;
+constexpr int NTT_THREADS = 256;
 constexpr int MAX_PASSES = 6;
 constexpr int INNER_LOG = 10;            // inner twiddle table: w_1024^e, e < 512
 
