@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Turns the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) into
+profiles/rNN_pmc_traffic.json: HBM-side bytes per launch for the dominant kernels.
+Corrections follow MI355X_MICROARCH.md: the counters are in KiB (x1024); on gfx950 FETCH_SIZE reads
+exactly 1/2 of a wide coalesced 16-byte-per-lane stream - that is the NTT pass kernel's access
+pattern, so its fetch figure is doubled; the MSM accumulation gathers 64-byte points at random
+(4 x 16 B per lane), an uncalibrated pattern, so its raw figure is kept and flagged.
+Usage: python tools/pmc_traffic.py <fetch.db> <write.db> <log_n> <out.json>"""
+import json
+import sqlite3
+import sys
+
+
+def per_kernel(path, counter):
+    c = sqlite3.connect(path)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [x for x in tabs if x.startswith("rocpd_kernel_dispatch")][0]
+    ks = [x for x in tabs if x.startswith("rocpd_info_kernel_symbol")][0]
+    pm = [x for x in tabs if x.startswith("rocpd_pmc_event")][0]
+    pi = [x for x in tabs if x.startswith("rocpd_info_pmc")][0]
+    out = {}
+    q = (f"select s.display_name, sum(e.value), count(distinct d.id) from {kd} d join {ks} s on d.kernel_id = s.id "
+         f"join {pm} e on e.event_id = d.event_id join {pi} i on e.pmc_id = i.id where i.name = ? group by s.display_name")
+    for name, total, n in c.execute(q, (counter,)):
+        out[name] = (total, n)
+    return out
+
+
+def main(fetch_db, write_db, log_n, out_path):
+    f = per_kernel(fetch_db, "FETCH_SIZE")
+    w = per_kernel(write_db, "WRITE_SIZE")
+    res = {}
+    for short, fetch_factor, note in (("k_ntt_pass", 2.0, "FETCH_SIZE x2 (wide coalesced stream, gfx950 correction)"),
+                                      ("k_msm_accumulate", 1.0, "FETCH_SIZE uncorrected (random 64-byte gathers, uncalibrated pattern)")):
+        fk = [k for k in f if short in k]
+        wk = [k for k in w if short in k]
+        if not fk or not wk:
+            continue
+        fb = f[fk[0]][0] / f[fk[0]][1] * 1024.0 * fetch_factor
+        wb = w[wk[0]][0] / w[wk[0]][1] * 1024.0
+        res[short] = {"log_n": int(log_n), "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "bytes_per_launch": fb + wb,
+                      "launches_sampled": f[fk[0]][1], "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), " + note}
+    json.dump(res, open(out_path, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])
