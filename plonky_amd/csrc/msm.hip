@@ -476,6 +476,77 @@ template <class FP> PLK_DI XyzzZ<FP> wave_sum(XyzzZ<FP> v, int width) {
     return v;
 }
 
+// A bucket with more than HEAVY_SLICES slice partials (a hot digit of a skewed witness) would make its
+// 4 lanes walk thousands of additions.  Such buckets are listed as (bucket, chunk) work items of
+// HEAVY_CHUNK slices, each summed by a whole workgroup, then their chunk partials are summed.
+constexpr uint32_t HEAVY_SLICES = 256;
+constexpr uint32_t HEAVY_CHUNK = 2048;
+
+// heavy[0] = number of work items, heavy[1] = number of heavy buckets;
+// items at heavy[2 + 2k] = bucket, heavy[3 + 2k] = chunk index; heavy bucket ids at heavy[2 + 2 cap + k]
+__global__ void __launch_bounds__(256) k_msm_heavy_list(const uint32_t* __restrict__ slice_off, uint32_t buckets, uint32_t* __restrict__ heavy, uint32_t cap) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= buckets) return;
+    const uint32_t ns = slice_off[b + 1] - slice_off[b];
+    if (ns <= HEAVY_SLICES) return;
+    const uint32_t chunks = (ns + HEAVY_CHUNK - 1) / HEAVY_CHUNK;
+    const uint32_t at = atomicAdd(&heavy[0], chunks);
+    const uint32_t hb = atomicAdd(&heavy[1], 1u);
+    if (hb < cap) heavy[2 + 2 * cap + hb] = b;
+    for (uint32_t k = 0; k < chunks; ++k)
+        if (at + k < cap) {
+            heavy[2 + 2 * (at + k)] = b;
+            heavy[3 + 2 * (at + k)] = k;
+        }
+}
+
+template <class FP> PLK_DI XyzzZ<FP> block256_sum(XyzzZ<FP> acc, uint4* s_pts) {
+    constexpr int W = FP::NL / 4;
+    acc = wave_sum<FP>(acc, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) xyzzz_store_packed<FP>(s_pts + wave * 4 * W, acc);
+    __syncthreads();
+    acc = (wave == 0 && lane < 4) ? xyzzz_load_packed<FP>(s_pts + lane * 4 * W) : xyzzz_identity<FP>();
+    if (wave == 0) acc = wave_sum<FP>(acc, 4);
+    __syncthreads();
+    return acc;  // valid in thread 0
+}
+
+// one workgroup per (bucket, chunk) item: chunk partial -> heavy_part[item]
+template <class C>
+__global__ void __launch_bounds__(256) k_msm_heavy_chunks(const uint4* __restrict__ partial, const uint32_t* __restrict__ slice_off,
+                                                          const uint32_t* __restrict__ heavy, uint32_t cap, uint4* __restrict__ heavy_part) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    __shared__ uint4 s_pts[4 * 4 * W];
+    const uint32_t items = min(heavy[0], cap);
+    for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const uint32_t b = heavy[2 + 2 * it], k = heavy[3 + 2 * it];
+        const uint32_t s0 = slice_off[b] + k * HEAVY_CHUNK, s1 = min(slice_off[b + 1], s0 + HEAVY_CHUNK);
+        XyzzZ<FP> acc = xyzzz_identity<FP>();
+        for (uint32_t s = s0 + threadIdx.x; s < s1; s += 256) acc = xyzzz_add<FP>(acc, xyzzz_load_packed<FP>(partial + (size_t)s * 4 * W));
+        acc = block256_sum<FP>(acc, s_pts);
+        if (threadIdx.x == 0) xyzzz_store_packed<FP>(heavy_part + (size_t)it * 4 * W, acc);
+    }
+}
+// one workgroup per heavy bucket: sum of its chunk partials -> bucket[b].  Items of one bucket are contiguous.
+template <class C>
+__global__ void __launch_bounds__(256) k_msm_heavy_final(const uint32_t* __restrict__ slice_off, const uint32_t* __restrict__ heavy, uint32_t cap,
+                                                         const uint4* __restrict__ heavy_part, uint4* __restrict__ bucket) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    __shared__ uint4 s_pts[4 * 4 * W];
+    const uint32_t items = min(heavy[0], cap), nb = min(heavy[1], cap);
+    for (uint32_t hb = blockIdx.x; hb < nb; hb += gridDim.x) {
+        const uint32_t b = heavy[2 + 2 * cap + hb];
+        XyzzZ<FP> acc = xyzzz_identity<FP>();
+        for (uint32_t it = threadIdx.x; it < items; it += 256)
+            if (heavy[2 + 2 * it] == b) acc = xyzzz_add<FP>(acc, xyzzz_load_packed<FP>(heavy_part + (size_t)it * 4 * W));
+        acc = block256_sum<FP>(acc, s_pts);
+        if (threadIdx.x == 0) xyzzz_store_packed<FP>(bucket + (size_t)b * 4 * W, acc);
+    }
+}
+
 template <class C>
 __global__ void __launch_bounds__(256) k_msm_bucket_sum(const uint4* __restrict__ partial, const uint32_t* __restrict__ slice_off, uint4* __restrict__ bucket,
                                                         uint32_t buckets) {
@@ -484,12 +555,15 @@ __global__ void __launch_bounds__(256) k_msm_bucket_sum(const uint4* __restrict_
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = gid / BUCKET_LANES, part = gid % BUCKET_LANES;
     XyzzZ<FP> acc = xyzzz_identity<FP>();
+    bool mine = false;
     if (b < buckets) {
         const uint32_t s0 = slice_off[b], s1 = slice_off[b + 1];
-        for (uint32_t s = s0 + part; s < s1; s += BUCKET_LANES) acc = xyzzz_add<FP>(acc, xyzzz_load_packed<FP>(partial + (size_t)s * 4 * W));
+        mine = s1 - s0 <= HEAVY_SLICES;  // heavier buckets are summed by k_msm_heavy_*
+        if (mine)
+            for (uint32_t s = s0 + part; s < s1; s += BUCKET_LANES) acc = xyzzz_add<FP>(acc, xyzzz_load_packed<FP>(partial + (size_t)s * 4 * W));
     }
     acc = wave_sum<FP>(acc, BUCKET_LANES);  // lanes of a bucket are adjacent; every lane takes part in the shuffles
-    if (b < buckets && part == 0) xyzzz_store_packed<FP>(bucket + (size_t)b * 4 * W, acc);
+    if (mine && part == 0) xyzzz_store_packed<FP>(bucket + (size_t)b * 4 * W, acc);
 }
 
 // plane p: tree-sum of { bucket_b : bit p of (b + 1) }.  grid = (parts, planes), 256 lanes.
@@ -647,6 +721,9 @@ struct plk_msm_ctx {
     void* off = nullptr;       // off[buckets+1] followed by slice_off[buckets+1]
     void* partial = nullptr;
     void* bucket = nullptr;    // bucket sums (XYZZ)
+    void* heavy = nullptr;     // heavy-bucket work list (see k_msm_heavy_list)
+    void* heavy_part = nullptr;
+    uint32_t heavy_cap = 0;
     void* plane_part = nullptr;
     std::mutex mu;             // one execution at a time per context (workspace is shared)
     // optional per-kernel timing (HIP events on the launch stream) for bench.py's roofline
@@ -655,7 +732,7 @@ struct plk_msm_ctx {
     std::vector<std::vector<hipEvent_t>> prof_sets;  // each N_STAGES + 1 events, recorded
     std::vector<std::vector<hipEvent_t>> prof_free;
     ~plk_msm_ctx() {
-        for (void* p : {tab, codes, sorted, hist, off, partial, bucket, plane_part, cnt1, cnt2, tmp_code, tmp_val, part_meta})
+        for (void* p : {tab, codes, sorted, hist, off, partial, bucket, plane_part, cnt1, cnt2, tmp_code, tmp_val, part_meta, heavy, heavy_part})
             if (p) (void)hipFree(p);
         for (auto* v : {&prof_sets, &prof_free})
             for (auto& set : *v)
@@ -703,6 +780,10 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
     ctx->max_slices = entries / ctx->slice + ctx->buckets + 1;
     PLK_HIP_TRY(hipMalloc(&ctx->partial, ctx->max_slices * xyzz_bytes));
     PLK_HIP_TRY(hipMalloc(&ctx->bucket, (size_t)ctx->buckets * xyzz_bytes));
+    // at most max_slices / HEAVY_SLICES heavy buckets, max_slices / HEAVY_CHUNK + that many chunk items
+    ctx->heavy_cap = (uint32_t)(ctx->max_slices / HEAVY_SLICES + ctx->max_slices / HEAVY_CHUNK + 2);
+    PLK_HIP_TRY(hipMalloc(&ctx->heavy, (size_t)(2 + 3 * ctx->heavy_cap) * 4));
+    PLK_HIP_TRY(hipMalloc(&ctx->heavy_part, (size_t)ctx->heavy_cap * xyzz_bytes));
     PLK_HIP_TRY(hipMalloc(&ctx->plane_part, (size_t)ctx->planes * ctx->plane_blocks * xyzz_bytes));
     if (n) {
         k_msm_table<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)ctx->tab, n, ctx->c,
@@ -815,6 +896,11 @@ static int msm_execute_t(plk_msm_ctx* ctx, const void* d_scalars, void* d_out_xy
     PLK_HIP_TRY(hipGetLastError());
     mark();
     k_msm_bucket_sum<C><<<(buckets * BUCKET_LANES + 255) / 256, 256, 0, stream>>>((const uint4*)ctx->partial, slice_off, (uint4*)ctx->bucket, buckets);
+    // hot buckets of a skewed scalar distribution (none for uniform scalars: the three launches then exit at once)
+    PLK_HIP_TRY(hipMemsetAsync(ctx->heavy, 0, 8, stream));
+    k_msm_heavy_list<<<(buckets + 255) / 256, 256, 0, stream>>>(slice_off, buckets, (uint32_t*)ctx->heavy, ctx->heavy_cap);
+    k_msm_heavy_chunks<C><<<256, 256, 0, stream>>>((const uint4*)ctx->partial, slice_off, (const uint32_t*)ctx->heavy, ctx->heavy_cap, (uint4*)ctx->heavy_part);
+    k_msm_heavy_final<C><<<64, 256, 0, stream>>>(slice_off, (const uint32_t*)ctx->heavy, ctx->heavy_cap, (const uint4*)ctx->heavy_part, (uint4*)ctx->bucket);
     PLK_HIP_TRY(hipGetLastError());
     mark();
     dim3 pg(ctx->plane_blocks, ctx->planes);

@@ -324,3 +324,29 @@ def test_golden_vectors():
             pre = pa.msm_precompute(int(g["curve"]), g["bases"], 11, device_window=win)
             xy, z = pa.msm_execute_parallel(pre, g["scalars"])
             assert z == int(g["expected_zero"]) and np.array_equal(xy, g["expected_xy"]), (path, win)
+
+
+def test_msm_heavy_buckets_closed_form():
+    """Extremely skewed scalars (most of them identical, the rest tiny): a few buckets receive ~10^5
+    entries each - the heavy-bucket path of the reduction (multi-chunk) - checked with the closed form."""
+    torch = pytest.importorskip("torch")
+    from plonky_amd import device as dev
+    from plonky_amd.selfcheck import closed_form_msm
+    dev.init(0)
+    c = br.TWEEDLEDEE
+    n = 1 << 17
+    G = (c.gx, c.gy)
+    D = br.ec_mul(c, 987654321, G)
+    bases = dev.gen_bases_dev(0, n, _bases(c, [G])[0], _bases(c, [D])[0])
+    hot = synth.rand_field(1, 4242, 1)[0]
+    scal = np.tile(hot, (n, 1))
+    small = mont_arr(c.scalar, [0, 1, 2, 3])
+    idx = np.arange(n)
+    sel = idx % 10 >= 7
+    scal[sel] = small[idx[sel] % 4]
+    pre = dev.msm_precompute_dev(0, bases)
+    oxy, oz = dev.msm_execute_dev(pre, dev.to_device(scal))
+    torch.cuda.synchronize()
+    got = dev.to_host(oxy).reshape(2, 4)
+    exp = closed_form_msm(0, scal, G, D)
+    assert int(oz.cpu()[0]) == 0 and tuple(from_mont_arr(c.base, got)) == exp
