@@ -57,6 +57,29 @@ template <class P> struct Fz {
     uint32_t l[FzCfg<P>::NZ];
 };
 
+// A code-generation nudge for gfx950, kept because it measured faster (profiles/r01_field_op_costs.txt):
+// a modulus limb that is a power of two (2^22 for the Tweedle fields) makes the compiler replace
+// q * p_j + acc by a 64-bit shift and a 64-bit add; keeping the constant opaque (in an SGPR) keeps
+// it one v_mad_u64_u32 (fz_mul 890 -> 835 cycles).  The opposite experiment - replacing the
+// column carry acc >> 29 (v_lshrrev_b64) by v_alignbit_b32 + v_lshrrev_b32 - measured slower.
+PLK_DI uint64_t fz_shr29(uint64_t acc) { return acc >> 29; }
+PLK_DI uint32_t fz_opaque(uint32_t c) {
+#ifdef __HIPCC__
+    asm volatile("" : "+s"(c));
+#endif
+    return c;
+}
+template <class P> struct FzPow2Limb {
+    // index of a modulus limb (j >= 1) that is a power of two, or -1
+    static constexpr int index() {
+        for (int j = 1; j < FzCfg<P>::NZ; ++j) {
+            const uint32_t v = FzCfg<P>::plimb(j);
+            if (v != 0u && (v & (v - 1u)) == 0u) return j;
+        }
+        return -1;
+    }
+};
+
 // ---- conversions -----------------------------------------------------------------------------
 template <class P> PLK_DI Fz<P> fz_from_words(const uint32_t (&a)[P::NL]) {
     constexpr int NZ = FzCfg<P>::NZ;
@@ -149,6 +172,7 @@ template <class P> PLK_DI Fz<P> fz_mul(const Fz<P>& a, const Fz<P>& b) {
     uint32_t q[NZ];
     Fz<P> r;
     uint64_t acc = 0;
+    const uint32_t p_pow2 = FzPow2Limb<P>::index() >= 0 ? fz_opaque(FzCfg<P>::plimb(FzPow2Limb<P>::index() >= 0 ? FzPow2Limb<P>::index() : 0)) : 0u;
 #pragma unroll
     for (int k = 0; k <= 2 * NZ - 2; ++k) {
 #pragma unroll
@@ -159,7 +183,8 @@ template <class P> PLK_DI Fz<P> fz_mul(const Fz<P>& a, const Fz<P>& b) {
 #pragma unroll
         for (int i = 0; i < NZ; ++i) {
             const int j = k - i;
-            if (i < k && j >= 1 && j < NZ && FzCfg<P>::plimb(j) != 0u) acc = (uint64_t)q[i] * FzCfg<P>::plimb(j) + acc;
+            if (i < k && j >= 1 && j < NZ && FzCfg<P>::plimb(j) != 0u)
+                acc = (uint64_t)q[i] * (j == FzPow2Limb<P>::index() ? p_pow2 : FzCfg<P>::plimb(j)) + acc;
         }
         if (k < NZ) {
             q[k] = (0u - (uint32_t)acc) & M;
@@ -167,7 +192,7 @@ template <class P> PLK_DI Fz<P> fz_mul(const Fz<P>& a, const Fz<P>& b) {
         } else {
             r.l[k - NZ] = (uint32_t)acc & M;
         }
-        acc >>= 29;
+        acc = fz_shr29(acc);
     }
     r.l[NZ - 1] = (uint32_t)acc;
     return r;
@@ -182,6 +207,7 @@ template <class P> PLK_DI Fz<P> fz_sqr(const Fz<P>& a) {
     for (int i = 0; i < NZ; ++i) a2[i] = a.l[i] << 1;
     Fz<P> r;
     uint64_t acc = 0;
+    const uint32_t p_pow2 = FzPow2Limb<P>::index() >= 0 ? fz_opaque(FzCfg<P>::plimb(FzPow2Limb<P>::index() >= 0 ? FzPow2Limb<P>::index() : 0)) : 0u;
 #pragma unroll
     for (int k = 0; k <= 2 * NZ - 2; ++k) {
 #pragma unroll
@@ -193,7 +219,8 @@ template <class P> PLK_DI Fz<P> fz_sqr(const Fz<P>& a) {
 #pragma unroll
         for (int i = 0; i < NZ; ++i) {
             const int j = k - i;
-            if (i < k && j >= 1 && j < NZ && FzCfg<P>::plimb(j) != 0u) acc = (uint64_t)q[i] * FzCfg<P>::plimb(j) + acc;
+            if (i < k && j >= 1 && j < NZ && FzCfg<P>::plimb(j) != 0u)
+                acc = (uint64_t)q[i] * (j == FzPow2Limb<P>::index() ? p_pow2 : FzCfg<P>::plimb(j)) + acc;
         }
         if (k < NZ) {
             q[k] = (0u - (uint32_t)acc) & M;
@@ -201,7 +228,7 @@ template <class P> PLK_DI Fz<P> fz_sqr(const Fz<P>& a) {
         } else {
             r.l[k - NZ] = (uint32_t)acc & M;
         }
-        acc >>= 29;
+        acc = fz_shr29(acc);
     }
     r.l[NZ - 1] = (uint32_t)acc;
     return r;
