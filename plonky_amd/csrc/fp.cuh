@@ -240,10 +240,12 @@ template <class P> PLK_DNI Fe<P> fe_inv_eea(const Fe<P>& a) {
         }
     };
     auto less = [](const uint32_t (&x)[N], const uint32_t (&y)[N]) {
-        for (int i = N - 1; i >= 0; --i) {
-            if (x[i] != y[i]) return x[i] < y[i];
-        }
-        return false;
+        // x < y  <=>  x - y borrows.  Fully unrolled borrow chain: an early-exit loop would index the
+        // arrays dynamically and push u, v, b, c out of registers into scratch memory.
+        uint64_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) bw = (((uint64_t)x[i] - y[i] - bw) >> 32) & 1;
+        return bw != 0;
     };
     auto sub = [](uint32_t (&x)[N], const uint32_t (&y)[N]) {  // x -= y (x >= y)
         uint64_t bw = 0;
