@@ -320,3 +320,54 @@ def rand_field_limbs(f: FieldSpec, seed, count):
         if limbs_to_int(limbs) < f.p:
             out.append(limbs)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# polynomial callers of the NTT (src/polynomial.rs) -- independent of the NTT: exact arithmetic
+# ---------------------------------------------------------------------------------------------
+def poly_trim(coeffs):
+    """Polynomial::trim (src/polynomial.rs:178-180)."""
+    k = len(coeffs)
+    while k and coeffs[k - 1] == 0:
+        k -= 1
+    return list(coeffs[:k])
+
+
+def poly_mul_schoolbook(f: FieldSpec, a, b):
+    """Plain O(n m) product of canonical-int coefficient lists (what Polynomial::mul computes)."""
+    if not a or not b:
+        return []
+    out = [0] * (len(a) + len(b) - 1)
+    for i, x in enumerate(a):
+        if x:
+            for j, y in enumerate(b):
+                out[i + j] = (out[i + j] + x * y) % f.p
+    return out
+
+
+def poly_divide_by_z_h_exact(f: FieldSpec, a, n):
+    """a / (X^n - 1) by synthetic division, canonical ints; raises if the division is not exact.
+    This is the mathematical meaning of Polynomial::divide_by_z_h (src/polynomial.rs:329-330)."""
+    a = poly_trim(a)
+    if not a:
+        return []
+    if len(a) <= n:
+        raise ValueError("not divisible by Z_H")
+    q = [0] * (len(a) - n)
+    rem = list(a)
+    for i in range(len(a) - 1, n - 1, -1):
+        c = rem[i]
+        q[i - n] = c
+        rem[i] = 0
+        rem[i - n] = (rem[i - n] + c) % f.p
+    if any(rem):
+        raise ValueError("not divisible by Z_H")
+    return q
+
+
+def poly_eval(f: FieldSpec, a, x):
+    """Polynomial::eval (src/polynomial.rs:124-126), Horner."""
+    acc = 0
+    for c in reversed(a):
+        acc = (acc * x + c) % f.p
+    return acc

@@ -64,6 +64,11 @@ def lib():
         L.orc_to_digits.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_gen_bases.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_rand_field.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_void_p]
+        L.orc_poly_divide_by_z_h.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_int]
+        L.orc_poly_mul.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_int]
+        L.orc_poly_to_values_padded.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -165,6 +170,39 @@ class FftPrecomputation:
             lib().orc_fft_free(self.h)
         except Exception:
             pass
+
+
+def _pow2_ceil(n):
+    return 1 << max(0, (n - 1).bit_length())
+
+
+def poly_divide_by_z_h(field, coeffs, n, threads=1):
+    """Polynomial::divide_by_z_h (src/polynomial.rs:330-380)."""
+    a = _u64(coeffs).reshape(-1, FIELD_LIMBS[field])
+    out = np.zeros((max(a.shape[0], _pow2_ceil(max(a.shape[0], 1))), FIELD_LIMBS[field]), dtype=np.uint64)
+    out_len = ctypes.c_size_t(0)
+    assert lib().orc_poly_divide_by_z_h(field, _p(a), a.shape[0], n, _p(out), ctypes.byref(out_len), threads) == 0
+    return out[: out_len.value].copy()
+
+
+def poly_mul(field, a, b, threads=1):
+    """Polynomial::mul (src/polynomial.rs:208-226)."""
+    a = _u64(a).reshape(-1, FIELD_LIMBS[field])
+    b = _u64(b).reshape(-1, FIELD_LIMBS[field])
+    out = np.zeros((_pow2_ceil(max(a.shape[0] + b.shape[0], 1)), FIELD_LIMBS[field]), dtype=np.uint64)
+    out_len = ctypes.c_size_t(0)
+    assert lib().orc_poly_mul(field, _p(a), a.shape[0], _p(b), b.shape[0], _p(out), ctypes.byref(out_len), threads) == 0
+    return out[: out_len.value].copy()
+
+
+def poly_to_values_padded(pre, coeffs, threads=1):
+    """One polynomial of polynomials_to_values_padded (src/plonk_util.rs:179-190) against an FftPrecomputation."""
+    a = _u64(coeffs).reshape(-1, FIELD_LIMBS[pre.field])
+    out = np.zeros((pre.size(), FIELD_LIMBS[pre.field]), dtype=np.uint64)
+    rc = lib().orc_poly_to_values_padded(pre.h, _p(a), a.shape[0], _p(out), threads)
+    if rc != 0:
+        raise ValueError("polynomial of length %d does not fit the domain (8x blow-up)" % a.shape[0])
+    return out
 
 
 def curve_generator(curve):

@@ -194,6 +194,7 @@ template <class P, int N = P::N> static inline Limbs<N> L(const u64 (&a)[N]) {
 // Field element -- src/field/monty.rs (4 limbs), bls12_377_base.rs:58-98 (6 limbs), field.rs
 // =============================================================================================
 template <class P> struct Fp {
+    using Params = P;
     static constexpr int N = P::N;
     Limbs<N> limbs;  // Montgomery form, fully reduced (tweedledee_base.rs:14-18)
 
@@ -528,6 +529,90 @@ static std::vector<F> ifft_with_precomputation_power_of_2(const std::vector<F>& 
         result[j] = rj;
     }
     return result;
+}
+
+// =============================================================================================
+// Polynomial callers of the NTT -- src/polynomial.rs, src/plonk_util.rs
+// =============================================================================================
+template <class F> static bool poly_is_zero(const std::vector<F>& a) {  // polynomial.rs:88-90
+    for (const F& x : a)
+        if (!x.is_zero()) return false;
+    return true;
+}
+template <class F> static size_t poly_degree_plus_one(const std::vector<F>& a) {  // polynomial.rs:108-113
+    for (size_t i = a.size(); i-- > 0;)
+        if (!a[i].is_zero()) return i + 1;
+    return 0;
+}
+template <class F> static void poly_trim(std::vector<F>& a) { a.resize(poly_degree_plus_one(a)); }  // :178-180
+template <class F> static void poly_pad(std::vector<F>& a, size_t len) {  // :194-198 (asserts trimmed len <= len)
+    poly_trim(a);
+    if (a.size() < len) a.resize(len, F::zero());
+}
+// polynomial.rs:135-143
+template <class F> static std::vector<F> poly_eval_domain(const std::vector<F>& a, const FftPrecomputation<F>& pre, int threads) {
+    size_t domain_size = pre.size();
+    if (a.size() < domain_size) {
+        std::vector<F> p = a;
+        poly_pad(p, domain_size);
+        return fft_with_precomputation(p, pre, threads);
+    }
+    return fft_with_precomputation(a, pre, threads);
+}
+// polynomial.rs:330-380
+template <class F> static std::vector<F> poly_divide_by_z_h(const std::vector<F>& self, size_t n, int threads) {
+    if (poly_is_zero(self)) return self;
+    std::vector<F> a_trim = self;
+    poly_trim(a_trim);
+    F g;
+    g.limbs = L<typename F::Params>(F::Params::GENERATOR);
+    F g_pow = F::one();
+    for (F& x : a_trim) {
+        x = x * g_pow;
+        g_pow = g * g_pow;
+    }
+    size_t d = poly_degree_plus_one(a_trim) - 1;
+    F root = F::primitive_root_of_unity((int)log2_ceil(d + 1));
+    FftPrecomputation<F> pre = fft_precompute<F>(d + 1);
+    std::vector<F> a_eval = poly_eval_domain(a_trim, pre, threads);
+    F denominator_g = g.exp(F::from_canonical_u64((u64)n));
+    F root_n = root.exp(F::from_canonical_u64((u64)n));
+    F root_pow = F::one();
+    std::vector<F> denominators(a_eval.size());
+    for (size_t i = 0; i < a_eval.size(); ++i) {
+        if (i != 0) root_pow = root_pow * root_n;
+        denominators[i] = denominator_g * root_pow - F::one();
+    }
+    std::vector<F> denominators_inv = F::batch_multiplicative_inverse(denominators);
+    for (size_t i = 0; i < a_eval.size(); ++i) a_eval[i] = a_eval[i] * denominators_inv[i];
+    std::vector<F> p = ifft_with_precomputation_power_of_2(a_eval, pre, threads);
+    F g_inv = g.inverse_assuming_nonzero();
+    F g_inv_pow = F::one();
+    for (F& x : p) {
+        x = x * g_inv_pow;
+        g_inv_pow = g_inv_pow * g_inv;
+    }
+    return p;
+}
+// polynomial.rs:208-226
+template <class F> static std::vector<F> poly_mul(const std::vector<F>& a, const std::vector<F>& b, int threads) {
+    if (poly_is_zero(a) || poly_is_zero(b)) return std::vector<F>(1, F::zero());
+    size_t a_deg = poly_degree_plus_one(a) - 1, b_deg = poly_degree_plus_one(b) - 1;
+    std::vector<F> a_pad = a, b_pad = b;
+    poly_pad(a_pad, a_deg + b_deg + 1);
+    poly_pad(b_pad, a_deg + b_deg + 1);
+    FftPrecomputation<F> pre = fft_precompute<F>(a_deg + b_deg + 1);
+    std::vector<F> a_evals = fft_with_precomputation(a_pad, pre, threads);
+    std::vector<F> b_evals = fft_with_precomputation(b_pad, pre, threads);
+    std::vector<F> m(a_evals.size());
+    for (size_t i = 0; i < m.size(); ++i) m[i] = a_evals[i] * b_evals[i];
+    return ifft_with_precomputation_power_of_2(m, pre, threads);
+}
+// plonk_util.rs:179-190, one polynomial: padded(len * 8) then eval_domain
+template <class F> static std::vector<F> poly_to_values_padded(const std::vector<F>& poly, const FftPrecomputation<F>& pre, int threads) {
+    std::vector<F> padded = poly;
+    poly_pad(padded, poly.size() * 8);
+    return poly_eval_domain(padded, pre, threads);
 }
 
 // =============================================================================================
@@ -1102,6 +1187,47 @@ int orc_fft(void* hv, int mode, const u64* in, size_t n, u64* out, int threads) 
         else if (mode == 1) r = fft_with_precomputation_power_of_2(c, pre, threads);
         else if (mode == 2) r = ifft_with_precomputation_power_of_2(c, pre, threads);
         else return -1;
+        for (size_t i = 0; i < r.size(); ++i) st(out + i * F::N, r[i]);
+        return 0;
+    });
+    return -1;
+}
+
+// ---- polynomial callers ----
+// out must hold max(len, 2^ceil(log2(len))) elements; *out_len receives the result length
+int orc_poly_divide_by_z_h(int field, const u64* in, size_t len, size_t n, u64* out, size_t* out_len, int threads) {
+    FIELD_DISPATCH(field, {
+        std::vector<F> a(len);
+        for (size_t i = 0; i < len; ++i) a[i] = ld<F>(in + i * F::N);
+        std::vector<F> r = poly_divide_by_z_h(a, n, threads);
+        for (size_t i = 0; i < r.size(); ++i) st(out + i * F::N, r[i]);
+        *out_len = r.size();
+        return 0;
+    });
+    return -1;
+}
+// out must hold 2^ceil(log2(la + lb)) elements
+int orc_poly_mul(int field, const u64* a_in, size_t la, const u64* b_in, size_t lb, u64* out, size_t* out_len, int threads) {
+    FIELD_DISPATCH(field, {
+        std::vector<F> a(la), b(lb);
+        for (size_t i = 0; i < la; ++i) a[i] = ld<F>(a_in + i * F::N);
+        for (size_t i = 0; i < lb; ++i) b[i] = ld<F>(b_in + i * F::N);
+        std::vector<F> r = poly_mul(a, b, threads);
+        for (size_t i = 0; i < r.size(); ++i) st(out + i * F::N, r[i]);
+        *out_len = r.size();
+        return 0;
+    });
+    return -1;
+}
+// polynomials_to_values_padded for one polynomial against an orc_fft_precompute handle; out holds the domain size
+int orc_poly_to_values_padded(void* hv, const u64* in, size_t len, u64* out, int threads) {
+    AnyHandle* h = (AnyHandle*)hv;
+    FIELD_DISPATCH(h->id, {
+        auto& pre = ((FftHandle<F>*)h->ptr)->pre;
+        if (len * 8 > pre.size()) return -2;  // the reference debug-asserts the table size (fft.rs:107-111)
+        std::vector<F> a(len);
+        for (size_t i = 0; i < len; ++i) a[i] = ld<F>(in + i * F::N);
+        std::vector<F> r = poly_to_values_padded(a, pre, threads);
         for (size_t i = 0; i < r.size(); ++i) st(out + i * F::N, r[i]);
         return 0;
     });
