@@ -82,6 +82,34 @@ int plk_ntt_batch(int field, unsigned log_n, int inverse, unsigned batch, const 
 int plk_ntt_dev(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, void* stream);
 /* fft_with_precomputation (fft.rs:61-80): zero-pad n_in <= 2^log_n coefficients, then transform. */
 int plk_ntt_padded(int field, unsigned log_n, const uint64_t* in, size_t n_in, uint64_t* out);
+/* polynomials_to_values_padded (plonk_util.rs:179-190) / Polynomial::eval_domain (polynomial.rs:135-143):
+ * `batch` polynomials of n_in[b] <= 2^log_n coefficients each, zero-padded to the domain and transformed.
+ * The padding is never materialised: the first pass reads only the stored coefficients. */
+int plk_ntt_padded_batch(int field, unsigned log_n, unsigned batch, const uint64_t* const* in, const size_t* n_in, uint64_t* const* out);
+/* Device form: polynomial b starts at d_in + b * in_stride elements and has in_len coefficients; outputs are
+ * stored back to back (batch * 2^log_n elements).  d_out must not overlap d_in unless batch == 1 and
+ * in_stride == 2^log_n.  Asynchronous on `stream`. */
+int plk_ntt_padded_dev(int field, unsigned log_n, unsigned batch, const void* d_in, size_t in_len, size_t in_stride, void* d_out,
+                       void* stream);
+
+/* ---- polynomial callers of the NTT  (src/polynomial.rs) ------------------------------------- */
+/* Polynomial::divide_by_z_h (polynomial.rs:330-380): coeffs / (X^n - 1), assuming the division is exact
+ * (otherwise the result is as meaningless as the reference's).  The result has 2^ceil(log2(degree + 1))
+ * coefficients (the reference returns the untrimmed inverse transform); the zero polynomial comes back
+ * unchanged with its `len` coefficients.  out_cap: capacity of `out` in elements, at least
+ * max(len, 2^ceil(log2(len))) is always enough; *out_len receives the result length.
+ * Coset scaling, denominators and their inversion are fused into the two transforms (poly.hip). */
+int plk_poly_divide_by_z_h(int field, const uint64_t* coeffs, size_t len, size_t n, uint64_t* out, size_t out_cap, size_t* out_len);
+/* Same on device-resident coefficients.  Synchronises `stream` once (the degree decides the domain
+ * size, as in the reference); d_out may alias d_coeffs. */
+int plk_poly_divide_by_z_h_dev(int field, const void* d_coeffs, size_t len, size_t n, void* d_out, size_t out_cap, size_t* out_len,
+                               void* stream);
+/* Polynomial::mul (polynomial.rs:208-226): product through three transforms of size
+ * 2^ceil(log2(deg a + deg b + 1)), which is also the result length; a zero operand gives the single
+ * coefficient 0 (Polynomial::zero(1)).  The pointwise product is fused into the second transform. */
+int plk_poly_mul(int field, const uint64_t* a, size_t la, const uint64_t* b, size_t lb, uint64_t* out, size_t out_cap, size_t* out_len);
+int plk_poly_mul_dev(int field, const void* d_a, size_t la, const void* d_b, size_t lb, void* d_out, size_t out_cap, size_t* out_len,
+                     void* stream);
 
 /* ---- MSM  (src/curve/curve_msm.rs) -------------------------------------------------------- */
 typedef struct plk_msm_ctx plk_msm_ctx;

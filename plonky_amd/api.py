@@ -132,6 +132,59 @@ def fft_batch(field, polys, inverse=False):
     return out
 
 
+# ---- polynomial callers of the NTT (src/polynomial.rs, src/plonk_util.rs) ----
+def _pow2_ceil(n):
+    return 1 << log2_ceil(max(n, 1))
+
+
+def polynomial_divide_by_z_h(field, coeffs, n):
+    """Polynomial::divide_by_z_h (polynomial.rs:330-380): coeffs / (X^n - 1).  Returns the
+    2^ceil(log2(degree + 1)) untrimmed coefficients the reference returns; the zero polynomial
+    comes back unchanged."""
+    x = _elems(field, coeffs)
+    assert n >= 1
+    cap = max(x.shape[0], _pow2_ceil(x.shape[0]))
+    out = np.zeros((cap, x.shape[1]), dtype=np.uint64)
+    out_len = ctypes.c_size_t(0)
+    _lib.check(_lib.load().plk_poly_divide_by_z_h(field, _ptr(x), x.shape[0], n, _ptr(out), cap, ctypes.byref(out_len)))
+    return out[: out_len.value].copy()
+
+
+def polynomial_mul(field, a, b):
+    """Polynomial::mul (polynomial.rs:208-226)."""
+    x, y = _elems(field, a), _elems(field, b)
+    cap = _pow2_ceil(x.shape[0] + y.shape[0])
+    out = np.zeros((cap, x.shape[1]), dtype=np.uint64)
+    out_len = ctypes.c_size_t(0)
+    _lib.check(_lib.load().plk_poly_mul(field, _ptr(x), x.shape[0], _ptr(y), y.shape[0], _ptr(out), cap, ctypes.byref(out_len)))
+    return out[: out_len.value].copy()
+
+
+def polynomials_to_values_padded(polys, precomputation):
+    """plonk_util.rs:179-190: every polynomial padded to 8x its length, then evaluated on the
+    precomputation's domain (eval_domain pads further when the domain is larger).  polys: sequence of
+    (len_b, 4) arrays; returns (batch, domain, 4)."""
+    field = precomputation.field
+    ps = [_elems(field, p) for p in polys]
+    n = precomputation.size()
+    for p in ps:
+        assert p.shape[0] * 8 <= n, "fft.rs:107-111: the table is too small for the padded polynomial"
+    batch = len(ps)
+    out = np.empty((batch, n, 4), dtype=np.uint64)
+    if batch == 0:
+        return out
+    ins = (ctypes.c_void_p * batch)(*[p.ctypes.data for p in ps])
+    lens = (ctypes.c_size_t * batch)(*[p.shape[0] for p in ps])
+    outs = (ctypes.c_void_p * batch)(*[out[b].ctypes.data for b in range(batch)])
+    _lib.check(_lib.load().plk_ntt_padded_batch(field, precomputation.degree_pow, batch, ins, lens, outs))
+    return out
+
+
+def values_to_polynomials(values_vec, precomputation):
+    """plonk_util.rs:169-177: Polynomial::from_evaluations over a batch."""
+    return fft_batch(precomputation.field, values_vec, inverse=True)
+
+
 class MsmPrecomputation:
     """curve_msm.rs:16-25.  Owns a device context holding the generators and the window tables
     [2^(c j)] G_i.  `w` is kept because it is part of the reference struct; the device window c

@@ -21,6 +21,13 @@ int msm_set_profiling_impl(plk_msm_ctx* ctx, int enable);
 int msm_get_timings_impl(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls);
 int ntt_set_profiling_impl(int enable);
 int ntt_get_timings_impl(double* sum_ms, unsigned* launches);
+int poly_clear_cache_impl();
+int poly_divide_by_z_h_dev_impl(int field, const void* d_coeffs, size_t len, size_t n, void* d_out, size_t out_cap, size_t* out_len,
+                                hipStream_t stream);
+int poly_mul_dev_impl(int field, const void* d_a, size_t la, const void* d_b, size_t lb, void* d_out, size_t out_cap, size_t* out_len,
+                      hipStream_t stream);
+int ntt_padded_dev_impl(int field, unsigned log_n, unsigned batch, const void* d_in, size_t in_len, size_t in_stride, void* d_out,
+                        hipStream_t stream);
 size_t msm_ctx_len(const plk_msm_ctx* ctx);
 unsigned msm_ctx_window(const plk_msm_ctx* ctx);
 int msm_ctx_curve(const plk_msm_ctx* ctx);
@@ -180,6 +187,7 @@ int plk_init(int device) {
 }
 
 void plk_shutdown(void) {
+    (void)poly_clear_cache_impl();
     (void)ntt_clear_cache_impl();
     scratch_clear();
     g_device.store(-1);
@@ -192,7 +200,10 @@ int plk_curve_scalar_field(int curve) { return curve_scalar_field(curve); }
 
 // ---- NTT ----
 int plk_ntt_precompute(int field, unsigned log_n) { return ntt_precompute_impl(field, log_n); }
-int plk_ntt_clear_cache(void) { return ntt_clear_cache_impl(); }
+int plk_ntt_clear_cache(void) {
+    (void)poly_clear_cache_impl();
+    return ntt_clear_cache_impl();
+}
 
 int plk_ntt_dev(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, void* stream) {
     return ntt_dev_impl(field, log_n, inverse, batch, d_in, d_out, as_stream(stream));
@@ -221,20 +232,98 @@ int plk_ntt(int field, unsigned log_n, int inverse, const uint64_t* in, uint64_t
     return plk_ntt_batch(field, log_n, inverse, 1, &in, &out);
 }
 
-int plk_ntt_padded(int field, unsigned log_n, const uint64_t* in, size_t n_in, uint64_t* out) {
+int plk_ntt_padded_dev(int field, unsigned log_n, unsigned batch, const void* d_in, size_t in_len, size_t in_stride, void* d_out,
+                       void* stream) {
+    if (batch == 0) return PLK_OK;
+    return ntt_padded_dev_impl(field, log_n, batch, d_in, in_len, in_stride, d_out, as_stream(stream));
+}
+
+int plk_ntt_padded_batch(int field, unsigned log_n, unsigned batch, const uint64_t* const* in, const size_t* n_in, uint64_t* const* out) {
     if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
     if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
+    if (batch == 0) return PLK_OK;
+    if (!in || !n_in || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     const size_t n = (size_t)1 << log_n;
-    if (n_in > n) return set_error(PLK_ERR_INVALID_ARG, "n_in %zu exceeds 2^%u", n_in, log_n);
-    if ((n_in && !in) || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    size_t max_in = 0;
+    for (unsigned b = 0; b < batch; ++b) {
+        if (n_in[b] > n) return set_error(PLK_ERR_INVALID_ARG, "n_in[%u] = %zu exceeds 2^%u", b, n_in[b], log_n);
+        if ((n_in[b] && !in[b]) || !out[b]) return set_error(PLK_ERR_INVALID_ARG, "null pointer in batch slot %u", b);
+        if (n_in[b] > max_in) max_in = n_in[b];
+    }
     PLK_TRY(ensure_device());
-    DevBuf buf;
-    PLK_TRY(buf.alloc(n * 32));
-    PLK_HIP_TRY(hipMemset(buf.p, 0, n * 32));  // F::ZERO is all-zero limbs in Montgomery form too
-    if (n_in) PLK_HIP_TRY(hipMemcpy(buf.p, in, n_in * 32, hipMemcpyHostToDevice));
-    PLK_TRY(ntt_dev_impl(field, log_n, 0, 1, buf.p, buf.p, nullptr));
+    DevBuf din, dout;
+    PLK_TRY(din.alloc(max_in * 32 * batch));
+    PLK_TRY(dout.alloc(n * 32 * batch));
+    for (unsigned b = 0; b < batch; ++b) {
+        uint8_t* slot = (uint8_t*)din.p + (size_t)b * max_in * 32;
+        if (n_in[b]) PLK_HIP_TRY(hipMemcpy(slot, in[b], n_in[b] * 32, hipMemcpyHostToDevice));
+        // shorter polynomials of the batch: F::ZERO is all-zero limbs in Montgomery form too
+        if (n_in[b] < max_in) PLK_HIP_TRY(hipMemset(slot + n_in[b] * 32, 0, (max_in - n_in[b]) * 32));
+    }
+    PLK_TRY(ntt_padded_dev_impl(field, log_n, batch, din.p, max_in, max_in, dout.p, nullptr));
     PLK_HIP_TRY(hipStreamSynchronize(nullptr));
-    PLK_HIP_TRY(hipMemcpy(out, buf.p, n * 32, hipMemcpyDeviceToHost));
+    for (unsigned b = 0; b < batch; ++b) PLK_HIP_TRY(hipMemcpy(out[b], (uint8_t*)dout.p + (size_t)b * n * 32, n * 32, hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+
+int plk_ntt_padded(int field, unsigned log_n, const uint64_t* in, size_t n_in, uint64_t* out) {
+    return plk_ntt_padded_batch(field, log_n, 1, &in, &n_in, &out);
+}
+
+// ---- polynomial callers ----
+static size_t pow2_ceil_sz(size_t v) {
+    size_t s = 1;
+    while (s < v) s <<= 1;
+    return s;
+}
+
+int plk_poly_divide_by_z_h_dev(int field, const void* d_coeffs, size_t len, size_t n, void* d_out, size_t out_cap, size_t* out_len,
+                               void* stream) {
+    return poly_divide_by_z_h_dev_impl(field, d_coeffs, len, n, d_out, out_cap, out_len, as_stream(stream));
+}
+
+int plk_poly_divide_by_z_h(int field, const uint64_t* coeffs, size_t len, size_t n, uint64_t* out, size_t out_cap, size_t* out_len) {
+    if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
+    if (!out_len || (len && !coeffs)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    const size_t cap = len > pow2_ceil_sz(len) ? len : pow2_ceil_sz(len);
+    DevBuf din, dout;
+    PLK_TRY(din.alloc(len * 32));
+    PLK_TRY(dout.alloc(cap * 32));
+    if (len) PLK_HIP_TRY(hipMemcpy(din.p, coeffs, len * 32, hipMemcpyHostToDevice));
+    size_t got = 0;
+    PLK_TRY(poly_divide_by_z_h_dev_impl(field, din.p, len, n, dout.p, cap, &got, nullptr));
+    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
+    if (got > out_cap) return set_error(PLK_ERR_INVALID_ARG, "output capacity %zu < result length %zu", out_cap, got);
+    if (got && !out) return set_error(PLK_ERR_INVALID_ARG, "null output");
+    if (got) PLK_HIP_TRY(hipMemcpy(out, dout.p, got * 32, hipMemcpyDeviceToHost));
+    *out_len = got;
+    return PLK_OK;
+}
+
+int plk_poly_mul_dev(int field, const void* d_a, size_t la, const void* d_b, size_t lb, void* d_out, size_t out_cap, size_t* out_len,
+                     void* stream) {
+    return poly_mul_dev_impl(field, d_a, la, d_b, lb, d_out, out_cap, out_len, as_stream(stream));
+}
+
+int plk_poly_mul(int field, const uint64_t* a, size_t la, const uint64_t* b, size_t lb, uint64_t* out, size_t out_cap, size_t* out_len) {
+    if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
+    if (!out_len || (la && !a) || (lb && !b)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    const size_t cap = pow2_ceil_sz(la + lb);
+    DevBuf da, db, dout;
+    PLK_TRY(da.alloc(la * 32));
+    PLK_TRY(db.alloc(lb * 32));
+    PLK_TRY(dout.alloc(cap * 32));
+    if (la) PLK_HIP_TRY(hipMemcpy(da.p, a, la * 32, hipMemcpyHostToDevice));
+    if (lb) PLK_HIP_TRY(hipMemcpy(db.p, b, lb * 32, hipMemcpyHostToDevice));
+    size_t got = 0;
+    PLK_TRY(poly_mul_dev_impl(field, da.p, la, db.p, lb, dout.p, cap, &got, nullptr));
+    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
+    if (got > out_cap) return set_error(PLK_ERR_INVALID_ARG, "output capacity %zu < result length %zu", out_cap, got);
+    if (got && !out) return set_error(PLK_ERR_INVALID_ARG, "null output");
+    if (got) PLK_HIP_TRY(hipMemcpy(out, dout.p, got * 32, hipMemcpyDeviceToHost));
+    *out_len = got;
     return PLK_OK;
 }
 

@@ -61,10 +61,30 @@ void* scratch_acquire(size_t bytes, hipStream_t stream);  // nullptr on allocati
 void scratch_release(void* p, hipStream_t stream);       // call after the last kernel using p is enqueued
 void scratch_clear();
 
+// Optional element-wise work fused into the first pass's loads and the last pass's stores of a transform
+// (poly.hip: coset scaling, zero padding, division by the vanishing polynomial).  Tables hold canonical
+// R'-form words (the form of the twiddle tables, see ntt.hip).  Geometric tables: b^i = hi[i >> 10] * lo[i & 1023].
+constexpr int NTT_POW_LO_LOG = 10;
+struct NttHooks {
+    size_t in_len = 0;            // input elements per transform actually stored; the rest reads as zero
+    size_t in_stride = 0;         // distance between the inputs of a batch, in elements
+    const void* in_lo = nullptr;  // x_i *= b^i on load
+    const void* in_hi = nullptr;
+    const void* out_tab = nullptr;  // y_i *= out_tab[i & out_mask] on store
+    size_t out_mask = 0;
+    const void* out_lo = nullptr;  // y_i *= b^i on store
+    const void* out_hi = nullptr;
+};
+
 // ---- entry points implemented in ntt.hip / msm.hip / fieldops.hip, wrapped by capi.hip ----
 int ntt_precompute_impl(int field, unsigned log_n);
 int ntt_clear_cache_impl();
 int ntt_dev_impl(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, hipStream_t stream);
+int ntt_dev_hooked_impl(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, const NttHooks& hooks,
+                        hipStream_t stream);
+// device pointer to the power table of the (cached) plan: pw[b] = w^(2^b), b < log_t, w the primitive 2^log_t-th root
+// (log_t = max(log_n, 10)), R-form
+int ntt_plan_pow_table(int field, unsigned log_n, const void** pw, int* log_t);
 
 int field_limbs(int field);
 int curve_limbs(int curve);

@@ -20,13 +20,6 @@ template <class FP> struct XyzzZ {
     bool inf;
 };
 
-template <class FP> PLK_DI Fz<FP> fz_zero() {
-    Fz<FP> r;
-#pragma unroll
-    for (int i = 0; i < FzCfg<FP>::NZ; ++i) r.l[i] = 0;
-    return r;
-}
-
 // -y for a canonical y (< p): 2p - y, in (p, 2p]
 template <class FP> PLK_DI Fz<FP> fz_neg_canonical(const Fz<FP>& y) { return fz_sub<FP, 1>(fz_zero<FP>(), y); }
 

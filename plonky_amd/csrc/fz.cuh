@@ -294,6 +294,13 @@ template <class P> struct FzConst {
 };
 
 // multiply by this to take an R-form value (x 2^(32 NL)) into R'-form (x 2^(29 NZ)):  2^(2*29 NZ - 32 NL)
+template <class P> PLK_DI Fz<P> fz_zero() {
+    Fz<P> r;
+#pragma unroll
+    for (int i = 0; i < FzCfg<P>::NZ; ++i) r.l[i] = 0;
+    return r;
+}
+
 template <class P> PLK_DI Fz<P> fz_const_r_to_rprime() {
     constexpr auto c = FzConst<P>::pow2(2 * 29 * FzCfg<P>::NZ - 32 * P::NL);
     Fz<P> r;

@@ -29,6 +29,7 @@
 #include "common.h"
 #include "fp.cuh"
 #include "fz.cuh"
+#include "tables.cuh"
 
 namespace plk {
 
@@ -44,6 +45,7 @@ struct NttPassArgs {
     int log_q;        // columns per tile, Q = 2^log_q
     int log_nt;       // N_t: size of the contiguous sub-problem blocks of this pass
     int log_s;        // S_t = N_t / A_t
+    int first;        // 1: first pass (reads the caller's input)
     int last;         // 1: last pass (contiguous blocks in, digit-reversed scatter out)
     int n_prev;       // number of earlier passes (last pass only)
     int prev_log[MAX_PASSES];  // their log sizes a_1..a_{m-1}
@@ -59,9 +61,6 @@ struct NttPassArgs {
 // pw[65]     = 1 and pw[66] = n^-1 in R'-form (the form every twiddle TABLE is stored in: the pass
 //              kernel multiplies R-form data by R'-form twiddles on 29-bit limbs, fz.cuh, and the
 //              product x 2^256 * w 2^261 / 2^261 stays in the reference's R-form)
-template <class P> PLK_DI Fe<P> to_rprime(const Fe<P>& v) {
-    return fz_to_fe_canonical<P>(fz_mul<P>(fz_from_fe<P>(v), fz_const_r_to_rprime<P>()));
-}
 template <class P> __global__ void k_ntt_pow2(uint4* pw, int log_t, int log_n) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Fe<P> w;
@@ -84,13 +83,6 @@ template <class P> __global__ void k_ntt_pow2(uint4* pw, int log_t, int log_n) {
     fe_store<P>(pw + 64 * 2, ninv);
     fe_store<P>(pw + 65 * 2, fz_to_fe_canonical<P>(fz_one_rprime<P>()));
     fe_store<P>(pw + 66 * 2, to_rprime<P>(ninv));
-}
-
-template <class P> PLK_DI Fe<P> pow_from_table(const uint4* pw, int base_off, uint64_t e, int log_t) {
-    Fe<P> r = fe_one<P>();
-    for (int b = 0; b < log_t; ++b)
-        if ((e >> b) & 1) r = fe_mul<P>(r, fe_load<P>(pw + (base_off + b) * 2));
-    return r;
 }
 
 // inner table: tw[e] = w_1024^(+-e), e < 512, expressed through the 2^log_t-th root
@@ -136,10 +128,17 @@ template <class P> PLK_DI void lds_store(uint32_t* base, int stride, int idx, co
 // ADDS 2p per stage to a value (the product w b is always < 1.2p), so no reduction is needed inside
 // a tile (< (2 log A + 1) p after the last stage, far below R' = 128p); the input goes to the
 // bit-reversed LDS slot (free: it is just the store index), the output comes out in natural order.
-template <class P>
+// b^i from a two-level geometric table (R'-form): hi[i >> 10] * lo[i & 1023], < 1.01p
+template <class P> PLK_DI Fz<P> geom_pow(const void* lo, const void* hi, size_t i) {
+    const Fz<P> l = fz_from_fe<P>(fe_load<P>((const uint4*)lo + (i & ((1u << NTT_POW_LO_LOG) - 1)) * 2));
+    const Fz<P> h = fz_from_fe<P>(fe_load<P>((const uint4*)hi + (i >> NTT_POW_LO_LOG) * 2));
+    return fz_mul<P>(l, h);
+}
+
+template <class P, bool HOOKS>
 __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restrict__ in, uint4* __restrict__ out,
                                                           const uint4* __restrict__ inner_tw, const uint4* __restrict__ outer_tw,
-                                                          const uint4* __restrict__ scale_ptr, NttPassArgs a) {
+                                                          const uint4* __restrict__ scale_ptr, NttPassArgs a, NttHooks hk) {
     static_assert(P::NL == 8, "NTT kernels are written for the 256-bit fields");
     constexpr int NZ = FzCfg<P>::NZ;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
@@ -157,7 +156,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restric
     const size_t tiles_per = n >> (log_a + log_q);
     const size_t b = blockIdx.x / tiles_per;
     const size_t tile = blockIdx.x % tiles_per;
-    const uint4* inb = in + b * n * 2;
+    const uint4* inb = in + b * ((HOOKS && a.first) ? hk.in_stride : n) * 2;
     uint4* outb = out + b * n * 2;
 
     size_t blk_base = 0, r0 = 0, ol0 = 0;
@@ -192,9 +191,19 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restric
             }
             g = (kprev << log_a) + p;
         }
-        const Fe<P> v = fe_load<P>(inb + g * 2);
         const int row = (int)bitrev((uint32_t)p, log_a);
-        lds_store<P>(s_dat, TILE, (row << log_q) + q, fz_from_fe<P>(v));
+        if constexpr (HOOKS) {
+            // first pass: g is the natural input index
+            Fz<P> v = fz_zero<P>();
+            if (!a.first || g < hk.in_len) {
+                v = fz_from_fe<P>(fe_load<P>(inb + g * 2));
+                if (a.first && hk.in_lo) v = fz_mul<P>(v, geom_pow<P>(hk.in_lo, hk.in_hi, g));
+            }
+            lds_store<P>(s_dat, TILE, (row << log_q) + q, v);
+        } else {
+            const Fe<P> v = fe_load<P>(inb + g * 2);
+            lds_store<P>(s_dat, TILE, (row << log_q) + q, fz_from_fe<P>(v));
+        }
     }
     __syncthreads();
 
@@ -256,7 +265,19 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restric
             v = fz_mul<P>(v, fz_from_fe<P>(fe_load<P>(outer_tw + (((size_t)k << a.log_s) + r) * 2)));
         } else {
             g = (ol0 + q) + ((size_t)k << (a.log_n - log_a));
-            v = fz_mul<P>(v, scale);  // 1 or n^-1 (R'-form)
+            Fz<P> mult = scale;  // 1 or n^-1 (R'-form)
+            if constexpr (HOOKS) {
+                // g is the natural output index; every factor is an R'-form value below 2p
+                if (hk.out_tab) {
+                    const Fz<P> t = fz_from_fe<P>(fe_load<P>((const uint4*)hk.out_tab + (g & hk.out_mask) * 2));
+                    mult = a.scale ? fz_mul<P>(t, scale) : t;
+                }
+                if (hk.out_lo) {
+                    const Fz<P> pw = geom_pow<P>(hk.out_lo, hk.out_hi, g);
+                    mult = (a.scale || hk.out_tab) ? fz_mul<P>(mult, pw) : pw;
+                }
+            }
+            v = fz_mul<P>(v, mult);
         }
         fe_store<P>(outb + g * 2, fz_to_fe_canonical<P>(v));
     }
@@ -429,11 +450,11 @@ int ntt_clear_cache_impl() {
 }
 
 template <class P>
-static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void* d_in, void* d_out, hipStream_t stream) {
+static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void* d_in, void* d_out, const NttHooks* hooks, hipStream_t stream) {
     const int log_n = pl.log_n;
     const int m = (int)pl.pass_log.size();
     const int dir = inverse ? 1 : 0;
-    if (log_n == 0) {
+    if (log_n == 0 && !hooks) {
         if (d_in != d_out) PLK_HIP_TRY(hipMemcpyAsync(d_out, d_in, (size_t)batch * 32, hipMemcpyDeviceToDevice, stream));
         return PLK_OK;
     }
@@ -454,6 +475,7 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
         a.log_a = pl.pass_log[t];
         a.log_nt = log_nt;
         a.log_s = log_nt - a.log_a;
+        a.first = (t == 0) ? 1 : 0;
         a.last = (t == m - 1) ? 1 : 0;
         a.log_q = TILE_LOG - a.log_a;
         if (a.last) {
@@ -472,8 +494,12 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
         const bool prof = prof_begin(stream, pev);
         const size_t lds_bytes = ((size_t)FzCfg<P>::NZ * TILE + (size_t)FzCfg<P>::NZ * ((size_t)1 << a.log_a) / 2) * 4;
         const uint4* scale = (const uint4*)pl.pw + (a.scale ? 66 : 65) * 2;
-        k_ntt_pass<P><<<(unsigned)tiles, NTT_THREADS, lds_bytes, stream>>>((const uint4*)src, (uint4*)dst, (const uint4*)pl.inner[dir],
-                                                                         (const uint4*)outer, scale, a);
+        if (hooks && (a.first || a.last))
+            k_ntt_pass<P, true><<<(unsigned)tiles, NTT_THREADS, lds_bytes, stream>>>((const uint4*)src, (uint4*)dst, (const uint4*)pl.inner[dir],
+                                                                                   (const uint4*)outer, scale, a, *hooks);
+        else
+            k_ntt_pass<P, false><<<(unsigned)tiles, NTT_THREADS, lds_bytes, stream>>>((const uint4*)src, (uint4*)dst, (const uint4*)pl.inner[dir],
+                                                                                    (const uint4*)outer, scale, a, NttHooks{});
         if (prof) prof_end(stream, pev);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
@@ -487,18 +513,36 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
     return rc;
 }
 
-int ntt_dev_impl(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, hipStream_t stream) {
+static int ntt_dispatch(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, const NttHooks* hooks,
+                        hipStream_t stream) {
     if (!d_in || !d_out) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
     if (batch == 0) return PLK_OK;
     if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
     std::shared_ptr<NttPlan> pl;
     PLK_TRY(get_plan(field, log_n, pl));
     switch (field) {
-        case PLK_FIELD_TWEEDLEDEE_BASE: return run_plan_t<TweedledeeBaseParams>(*pl, inverse, batch, d_in, d_out, stream);
-        case PLK_FIELD_TWEEDLEDUM_BASE: return run_plan_t<TweedledumBaseParams>(*pl, inverse, batch, d_in, d_out, stream);
-        case PLK_FIELD_BLS12_377_SCALAR: return run_plan_t<Bls12377ScalarParams>(*pl, inverse, batch, d_in, d_out, stream);
+        case PLK_FIELD_TWEEDLEDEE_BASE: return run_plan_t<TweedledeeBaseParams>(*pl, inverse, batch, d_in, d_out, hooks, stream);
+        case PLK_FIELD_TWEEDLEDUM_BASE: return run_plan_t<TweedledumBaseParams>(*pl, inverse, batch, d_in, d_out, hooks, stream);
+        case PLK_FIELD_BLS12_377_SCALAR: return run_plan_t<Bls12377ScalarParams>(*pl, inverse, batch, d_in, d_out, hooks, stream);
     }
     return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
+}
+
+int ntt_dev_impl(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, hipStream_t stream) {
+    return ntt_dispatch(field, log_n, inverse, batch, d_in, d_out, nullptr, stream);
+}
+
+int ntt_dev_hooked_impl(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, const NttHooks& hooks,
+                        hipStream_t stream) {
+    return ntt_dispatch(field, log_n, inverse, batch, d_in, d_out, &hooks, stream);
+}
+
+int ntt_plan_pow_table(int field, unsigned log_n, const void** pw, int* log_t) {
+    std::shared_ptr<NttPlan> pl;
+    PLK_TRY(get_plan(field, log_n, pl));
+    *pw = pl->pw;  // owned by the plan cache (alive until plk_ntt_clear_cache / plk_shutdown)
+    *log_t = (int)log_n > INNER_LOG ? (int)log_n : INNER_LOG;
+    return PLK_OK;
 }
 
 }  // namespace plk

@@ -47,6 +47,48 @@ def ntt_dev(field, x, inverse=False, out=None):
     return out
 
 
+def ntt_padded_dev(field, x, log_n, out=None):
+    """polynomials_to_values_padded on device-resident coefficients: x (batch, len, 4) or (len, 4) with
+    len <= 2^log_n; returns (batch, 2^log_n, 4) evaluations.  The zero padding is never stored."""
+    assert x.is_cuda and x.dtype == torch.int64 and x.is_contiguous() and x.shape[-1] == 4
+    length = x.shape[-2]
+    batch = x.numel() // max(length * 4, 1) if length else 1
+    n = 1 << log_n
+    shape = x.shape[:-2] + (n, 4)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.int64, device=x.device)
+    _lib.check(_lib.load().plk_ntt_padded_dev(field, log_n, batch, ctypes.c_void_p(x.data_ptr()), length, length,
+                                              ctypes.c_void_p(out.data_ptr()), _stream()))
+    return out
+
+
+def divide_by_z_h_dev(field, coeffs, n, out=None):
+    """Polynomial::divide_by_z_h on a device-resident (len, 4) coefficient tensor; returns a view of the
+    2^ceil(log2(degree + 1)) result coefficients (one stream synchronisation: the degree picks the domain)."""
+    assert coeffs.is_cuda and coeffs.dtype == torch.int64 and coeffs.is_contiguous() and coeffs.shape[-1] == 4
+    length = coeffs.shape[0]
+    cap = max(length, 1 << max(0, (length - 1).bit_length()))
+    if out is None:
+        out = torch.empty((cap, 4), dtype=torch.int64, device=coeffs.device)
+    assert out.shape[0] >= cap
+    out_len = ctypes.c_size_t(0)
+    _lib.check(_lib.load().plk_poly_divide_by_z_h_dev(field, ctypes.c_void_p(coeffs.data_ptr()), length, n,
+                                                      ctypes.c_void_p(out.data_ptr()), out.shape[0], ctypes.byref(out_len), _stream()))
+    return out[: out_len.value]
+
+
+def poly_mul_dev(field, a, b):
+    """Polynomial::mul on device-resident coefficient tensors."""
+    for t in (a, b):
+        assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.shape[-1] == 4
+    cap = 1 << max(0, (a.shape[0] + b.shape[0] - 1).bit_length())
+    out = torch.empty((cap, 4), dtype=torch.int64, device=a.device)
+    out_len = ctypes.c_size_t(0)
+    _lib.check(_lib.load().plk_poly_mul_dev(field, ctypes.c_void_p(a.data_ptr()), a.shape[0], ctypes.c_void_p(b.data_ptr()), b.shape[0],
+                                            ctypes.c_void_p(out.data_ptr()), cap, ctypes.byref(out_len), _stream()))
+    return out[: out_len.value]
+
+
 def gen_bases_dev(curve, n, g0_xy, d_xy, first=0, device="cuda"):
     """B_i = G0 + (first + i) D on the device: (n, 2, L) int64 tensor."""
     L = _CURVE_LIMBS[curve]

@@ -34,6 +34,12 @@ SYMBOLS = [
     ("plk_ntt_batch", _i, [_i, _u, _i, _u, _vp, _vp]),
     ("plk_ntt_dev", _i, [_i, _u, _i, _u, _vp, _vp, _vp]),
     ("plk_ntt_padded", _i, [_i, _u, _vp, _sz, _vp]),
+    ("plk_ntt_padded_batch", _i, [_i, _u, _u, _vp, _vp, _vp]),
+    ("plk_ntt_padded_dev", _i, [_i, _u, _u, _vp, _sz, _sz, _vp, _vp]),
+    ("plk_poly_divide_by_z_h", _i, [_i, _vp, _sz, _sz, _vp, _sz, _vp]),
+    ("plk_poly_divide_by_z_h_dev", _i, [_i, _vp, _sz, _sz, _vp, _sz, _vp, _vp]),
+    ("plk_poly_mul", _i, [_i, _vp, _sz, _vp, _sz, _vp, _sz, _vp]),
+    ("plk_poly_mul_dev", _i, [_i, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
     ("plk_msm_precompute", _i, [_i, _sz, _vp, _vp, _u, _vp]),
     ("plk_msm_precompute_dev", _i, [_i, _sz, _vp, _vp, _u, _vp, _vp]),
     ("plk_msm_free", _i, [_vp]),
