@@ -123,11 +123,23 @@ template <class P> PLK_DI void lds_store(uint32_t* base, int stride, int idx, co
     for (int l = 0; l < FzCfg<P>::NZ; ++l) base[l * stride + idx] = v.l[l];
 }
 
-// One pass = for every tile: A-point NTTs on Q columns, decimation in time on lazily reduced 29-bit
-// limbs (fz.cuh).  DIT is chosen for its bounds: the butterfly (a, b) -> (a + w b, a - w b + 2p) only
-// ADDS 2p per stage to a value (the product w b is always < 1.2p), so no reduction is needed inside
-// a tile (< (2 log A + 1) p after the last stage, far below R' = 128p); the input goes to the
-// bit-reversed LDS slot (free: it is just the store index), the output comes out in natural order.
+// Timing experiments (tools/ntt_experiments.sh): -DPLK_NTT_EXP=1 replaces the stage multiplications by
+// additions, 2 every multiplication, 3 drops the stage loops.  Results are wrong by construction;
+// the product build leaves PLK_NTT_EXP undefined.
+#ifndef PLK_NTT_EXP
+#define PLK_NTT_EXP 0
+#endif
+#if PLK_NTT_EXP >= 1
+#define STAGE_MUL(P, a, b) fz_add<P>(a, b)
+#else
+#define STAGE_MUL(P, a, b) fz_mul<P>(a, b)
+#endif
+#if PLK_NTT_EXP >= 2
+#define OUT_MUL(P, a, b) fz_add<P>(a, b)
+#else
+#define OUT_MUL(P, a, b) fz_mul<P>(a, b)
+#endif
+
 // b^i from a two-level geometric table (R'-form): hi[i >> 10] * lo[i & 1023], < 1.01p
 template <class P> PLK_DI Fz<P> geom_pow(const void* lo, const void* hi, size_t i) {
     const Fz<P> l = fz_from_fe<P>(fe_load<P>((const uint4*)lo + (i & ((1u << NTT_POW_LO_LOG) - 1)) * 2));
@@ -135,81 +147,69 @@ template <class P> PLK_DI Fz<P> geom_pow(const void* lo, const void* hi, size_t 
     return fz_mul<P>(l, h);
 }
 
-template <class P, bool HOOKS>
-__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restrict__ in, uint4* __restrict__ out,
-                                                          const uint4* __restrict__ inner_tw, const uint4* __restrict__ outer_tw,
-                                                          const uint4* __restrict__ scale_ptr, NttPassArgs a, NttHooks hk) {
-    static_assert(P::NL == 8, "NTT kernels are written for the 256-bit fields");
-    constexpr int NZ = FzCfg<P>::NZ;
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+// One pass = for every tile: A-point NTTs on Q columns, decimation in time on lazily reduced 29-bit
+// limbs (fz.cuh).  DIT is chosen for its bounds: the butterfly (a, b) -> (a + w b, a - w b + 2p) only
+// ADDS 2p per stage to a value (the product w b is always < 1.2p), so no reduction is needed inside
+// a tile (< (2 log A + 1) p after the last stage, far below R' = 128p); the input goes to the
+// bit-reversed LDS slot (free: it is just the store index), the output comes out in natural order.
 
-    const int tid = threadIdx.x;
-    const int log_a = a.log_a, log_q = a.log_q;
-    const int A = 1 << log_a, Q = 1 << log_q;
-    const int tile_elems = A << log_q;
-    const int half_a = A >> 1;
-    const size_t n = (size_t)1 << a.log_n;
-    uint32_t* s_dat = s_mem;
-    uint32_t* s_tw = s_mem + NZ * TILE;
-
-    // ---- which tile ----
-    const size_t tiles_per = n >> (log_a + log_q);
-    const size_t b = blockIdx.x / tiles_per;
-    const size_t tile = blockIdx.x % tiles_per;
-    const uint4* inb = in + b * ((HOOKS && a.first) ? hk.in_stride : n) * 2;
-    uint4* outb = out + b * n * 2;
-
-    size_t blk_base = 0, r0 = 0, ol0 = 0;
+// where a tile lives: which transform of the batch, and its place in this pass's index space
+struct TileGeom {
+    size_t b;         // transform of the batch
+    size_t blk_base;  // first element of the contiguous sub-problem block (non-last passes)
+    size_t r0;        // first column (non-last passes)
+    size_t ol0;       // first output-low index (last pass)
+};
+PLK_DI TileGeom tile_geom(const NttPassArgs& a, size_t t) {
+    const size_t tiles_per = ((size_t)1 << a.log_n) >> (a.log_a + a.log_q);
+    TileGeom g;
+    g.b = t / tiles_per;
+    const size_t tile = t % tiles_per;
+    g.blk_base = g.r0 = g.ol0 = 0;
     if (!a.last) {
-        const size_t rtiles = ((size_t)1 << a.log_s) >> log_q;
-        const size_t kprev = tile / rtiles;
-        r0 = (tile % rtiles) << log_q;
-        blk_base = kprev << a.log_nt;
+        const size_t rtiles = ((size_t)1 << a.log_s) >> a.log_q;
+        g.r0 = (tile % rtiles) << a.log_q;
+        g.blk_base = (tile / rtiles) << a.log_nt;
     } else {
-        ol0 = tile << log_q;
+        g.ol0 = tile << a.log_q;
     }
-
-    // stage twiddles (R'-form): w_A^e = inner[e * (1024 / A)], e < A/2
-    for (int e = tid; e < half_a; e += NTT_THREADS) {
-        const Fe<P> w = fe_load<P>(inner_tw + ((size_t)e << (INNER_LOG - log_a)) * 2);
-        lds_store<P>(s_tw, half_a, e, fz_from_fe<P>(w));
+    return g;
+}
+// input index (within the transform) of tile element e = (p, q)
+PLK_DI size_t tile_in_index(const NttPassArgs& a, const TileGeom& t, int e) {
+    const int q = e & ((1 << a.log_q) - 1), p = e >> a.log_q;
+    if (!a.last) return t.blk_base + ((size_t)p << a.log_s) + t.r0 + q;
+    // column q of the tile is the block whose output-low index is ol0 + q; blocks are stored
+    // with k_1 most significant (kprev), the output wants k_1 least significant
+    size_t ol = t.ol0 + q, kprev = 0;
+    for (int s = 0; s < a.n_prev; ++s) {
+        kprev = (kprev << a.prev_log[s]) | (ol & (((size_t)1 << a.prev_log[s]) - 1));
+        ol >>= a.prev_log[s];
     }
+    return (kprev << a.log_a) + p;
+}
+// LDS slot of tile element e on load: row bitrev(p)
+PLK_DI int tile_in_slot(const NttPassArgs& a, int e) {
+    const int q = e & ((1 << a.log_q) - 1), p = e >> a.log_q;
+    return ((int)bitrev((uint32_t)p, a.log_a) << a.log_q) + q;
+}
+// output index (within the transform) of tile element e = (k, q) on store
+PLK_DI size_t tile_out_index(const NttPassArgs& a, const TileGeom& t, int e) {
+    const int q = e & ((1 << a.log_q) - 1), k = e >> a.log_q;
+    if (!a.last) return t.blk_base + ((size_t)k << a.log_s) + t.r0 + q;
+    return (t.ol0 + q) + ((size_t)k << (a.log_n - a.log_a));
+}
+// index into the outer twiddle table of a non-last pass
+PLK_DI size_t tile_tw_index(const NttPassArgs& a, const TileGeom& t, int e) {
+    const int q = e & ((1 << a.log_q) - 1), k = e >> a.log_q;
+    return ((size_t)k << a.log_s) + t.r0 + q;
+}
 
-    // ---- load: element (p, q) of the tile goes to row bitrev(p) ----
-    for (int e = tid; e < tile_elems; e += NTT_THREADS) {
-        const int q = e & (Q - 1), p = e >> log_q;
-        size_t g;
-        if (!a.last) {
-            g = blk_base + ((size_t)p << a.log_s) + r0 + q;
-        } else {
-            // column q of the tile is the block whose output-low index is ol0 + q; blocks are stored
-            // with k_1 most significant (kprev), the output wants k_1 least significant
-            size_t ol = ol0 + q, kprev = 0;
-            for (int t = 0; t < a.n_prev; ++t) {
-                kprev = (kprev << a.prev_log[t]) | (ol & (((size_t)1 << a.prev_log[t]) - 1));
-                ol >>= a.prev_log[t];
-            }
-            g = (kprev << log_a) + p;
-        }
-        const int row = (int)bitrev((uint32_t)p, log_a);
-        if constexpr (HOOKS) {
-            // first pass: g is the natural input index
-            Fz<P> v = fz_zero<P>();
-            if (!a.first || g < hk.in_len) {
-                v = fz_from_fe<P>(fe_load<P>(inb + g * 2));
-                if (a.first && hk.in_lo) v = fz_mul<P>(v, geom_pow<P>(hk.in_lo, hk.in_hi, g));
-            }
-            lds_store<P>(s_dat, TILE, (row << log_q) + q, v);
-        } else {
-            const Fe<P> v = fe_load<P>(inb + g * 2);
-            lds_store<P>(s_dat, TILE, (row << log_q) + q, fz_from_fe<P>(v));
-        }
-    }
-    __syncthreads();
-
-    // ---- stages: h = 1, 2, .., A/2, two at a time (radix-4 in registers: half the LDS round trips and
-    //      barriers of a radix-2 sweep, same multiplications) ----
-    int log_h = 0;
+// the stages of a tile in LDS: h = 1, 2, .., A/2, two at a time (radix-4 in registers: half the LDS round
+// trips and barriers of a radix-2 sweep, same multiplications).  Ends with a barrier.
+template <class P> PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw, int tid, int log_a, int log_q, int tile_elems) {
+    const int Q = 1 << log_q, half_a = (1 << log_a) >> 1;
+    int log_h = PLK_NTT_EXP == 3 ? log_a : 0;
     for (; log_h + 1 < log_a; log_h += 2) {
         const int h = 1 << log_h;
         for (int qd = tid; qd < (tile_elems >> 2); qd += NTT_THREADS) {
@@ -221,20 +221,27 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restric
             // stage with half-size h: pairs (x0, x1), (x2, x3), twiddle w_{2h}^j for both
             if (log_h > 0) {
                 const Fz<P> wa = lds_load<P>(s_tw, half_a, j << (log_a - 1 - log_h));
-                x1 = fz_mul<P>(x1, wa);
-                x3 = fz_mul<P>(x3, wa);
+                x1 = STAGE_MUL(P, x1, wa);
+                x3 = STAGE_MUL(P, x3, wa);
             }
             Fz<P> y0 = fz_add<P>(x0, x1), y1 = fz_sub<P, 1>(x0, x1);
             Fz<P> y2 = fz_add<P>(x2, x3), y3 = fz_sub<P, 1>(x2, x3);
             // stage with half-size 2h: pairs (y0, y2) with w_{4h}^j and (y1, y3) with w_{4h}^(j+h)
-            const Fz<P> wb0 = lds_load<P>(s_tw, half_a, j << (log_a - 2 - log_h));
             const Fz<P> wb1 = lds_load<P>(s_tw, half_a, (j + h) << (log_a - 2 - log_h));
-            y2 = fz_mul<P>(y2, wb0);
-            y3 = fz_mul<P>(y3, wb1);
-            lds_store<P>(s_dat, TILE, i0, fz_add<P>(y0, y2));
-            lds_store<P>(s_dat, TILE, i0 + 2 * st, fz_sub<P, 1>(y0, y2));
+            y3 = STAGE_MUL(P, y3, wb1);
             lds_store<P>(s_dat, TILE, i0 + st, fz_add<P>(y1, y3));
             lds_store<P>(s_dat, TILE, i0 + 3 * st, fz_sub<P, 1>(y1, y3));
+            if (log_h > 0) {
+                const Fz<P> wb0 = lds_load<P>(s_tw, half_a, j << (log_a - 2 - log_h));
+                y2 = STAGE_MUL(P, y2, wb0);
+                lds_store<P>(s_dat, TILE, i0, fz_add<P>(y0, y2));
+                lds_store<P>(s_dat, TILE, i0 + 2 * st, fz_sub<P, 1>(y0, y2));
+            } else {
+                // first step of a tile: j = 0, w_4^0 = 1, and y2 = x2 + x3 is below 2.1p (the tile's inputs are
+                // canonical, or hooked products below 1.01p): no multiplication, subtract under 4p
+                lds_store<P>(s_dat, TILE, i0, fz_add<P>(y0, y2));
+                lds_store<P>(s_dat, TILE, i0 + 2 * st, fz_sub<P, 2>(y0, y2));
+            }
         }
         __syncthreads();
     }
@@ -246,40 +253,108 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restric
             const int i0 = (((blk << (log_h + 1)) + j) << log_q) + q, i1 = i0 + (h << log_q);
             const Fz<P> x = lds_load<P>(s_dat, TILE, i0);
             Fz<P> t = lds_load<P>(s_dat, TILE, i1);
-            if (log_h > 0) t = fz_mul<P>(t, lds_load<P>(s_tw, half_a, j << (log_a - 1 - log_h)));  // w_{2h}^j, product < 1.2p
+            if (log_h > 0) t = STAGE_MUL(P, t, lds_load<P>(s_tw, half_a, j << (log_a - 1 - log_h)));  // w_{2h}^j, product < 1.2p
             lds_store<P>(s_dat, TILE, i0, fz_add<P>(x, t));
             lds_store<P>(s_dat, TILE, i1, fz_sub<P, 1>(x, t));  // t < 2p - margin in both cases
         }
         __syncthreads();
     }
+}
 
-    // ---- store: row k holds output index k; last multiplication brings the value below 2p ----
+// element from global memory into its working form; hooks of the first pass: zero padding, x_i *= b^i
+template <class P, bool HOOKS> PLK_DI Fz<P> tile_ingest(const NttPassArgs& a, const NttHooks& hk, const Fe<P>& v, size_t g) {
+    Fz<P> x = fz_from_fe<P>(v);
+    if constexpr (HOOKS) {
+        if (a.first) {
+            if (g >= hk.in_len) return fz_zero<P>();
+            if (hk.in_lo) x = fz_mul<P>(x, geom_pow<P>(hk.in_lo, hk.in_hi, g));
+        }
+    }
+    return x;
+}
+// the multiplication every output gets on its way out (brings the value below 2p): the outer twiddle of a
+// non-last pass (tw), or 1 / n^-1 and the hooks of the last pass
+template <class P, bool HOOKS>
+PLK_DI Fe<P> tile_emit(const NttPassArgs& a, const NttHooks& hk, Fz<P> v, const Fe<P>& tw, const Fz<P>& scale, size_t g) {
+    if (!a.last) {
+        v = OUT_MUL(P, v, fz_from_fe<P>(tw));
+    } else {
+        Fz<P> mult = scale;  // 1 or n^-1 (R'-form)
+        if constexpr (HOOKS) {
+            // g is the natural output index; every factor is an R'-form value below 2p
+            if (hk.out_tab) {
+                const Fz<P> t = fz_from_fe<P>(fe_load<P>((const uint4*)hk.out_tab + (g & hk.out_mask) * 2));
+                mult = a.scale ? fz_mul<P>(t, scale) : t;
+            }
+            if (hk.out_lo) {
+                const Fz<P> pw = geom_pow<P>(hk.out_lo, hk.out_hi, g);
+                mult = (a.scale || hk.out_tab) ? fz_mul<P>(mult, pw) : pw;
+            }
+        }
+        v = OUT_MUL(P, v, mult);
+    }
+    return fz_to_fe_canonical<P>(v);
+}
+
+// One tile per workgroup; any tile shape (transforms shorter than a tile included).
+template <class P, bool HOOKS>
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restrict__ in, uint4* __restrict__ out,
+                                                          const uint4* __restrict__ inner_tw, const uint4* __restrict__ outer_tw,
+                                                          const uint4* __restrict__ scale_ptr, NttPassArgs a, NttHooks hk) {
+    static_assert(P::NL == 8, "NTT kernels are written for the 256-bit fields");
+    constexpr int NZ = FzCfg<P>::NZ;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+    const int tid = threadIdx.x;
+    const int log_a = a.log_a, log_q = a.log_q;
+    const int tile_elems = (1 << log_a) << log_q;
+    const int half_a = (1 << log_a) >> 1;
+    const size_t n = (size_t)1 << a.log_n;
+    uint32_t* s_dat = s_mem;
+    uint32_t* s_tw = s_mem + NZ * TILE;
+
+    const TileGeom tg = tile_geom(a, blockIdx.x);
+    const uint4* inb = in + tg.b * ((HOOKS && a.first) ? hk.in_stride : n) * 2;
+    uint4* outb = out + tg.b * n * 2;
+
+    // stage twiddles (R'-form): w_A^e = inner[e * (1024 / A)], e < A/2
+    for (int e = tid; e < half_a; e += NTT_THREADS) {
+        const Fe<P> w = fe_load<P>(inner_tw + ((size_t)e << (INNER_LOG - log_a)) * 2);
+        lds_store<P>(s_tw, half_a, e, fz_from_fe<P>(w));
+    }
+    for (int e = tid; e < tile_elems; e += NTT_THREADS) {
+        const size_t g = tile_in_index(a, tg, e);
+        Fe<P> v = fe_zero<P>();
+#if PLK_NTT_EXP == 6
+        for (int l = 0; l < 8; ++l) {  // no memory traffic, full-entropy limbs
+            uint32_t h = ((uint32_t)g * 8u + l + a.log_s) * 0x9e3779b9u;
+            h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+            v.v[l] = h;
+        }
+        v.v[7] &= 0x0fffffffu;
+#else
+        if (!HOOKS || !a.first || g < hk.in_len) v = fe_load<P>(inb + g * 2);
+#endif
+        lds_store<P>(s_dat, TILE, tile_in_slot(a, e), tile_ingest<P, HOOKS>(a, hk, v, g));
+    }
+    __syncthreads();
+    tile_stages<P>(s_dat, s_tw, tid, log_a, log_q, tile_elems);
     const Fz<P> scale = fz_from_fe<P>(fe_load<P>(scale_ptr));
     for (int e = tid; e < tile_elems; e += NTT_THREADS) {
-        const int q = e & (Q - 1), k = e >> log_q;
-        Fz<P> v = lds_load<P>(s_dat, TILE, e);
-        size_t g;
-        if (!a.last) {
-            const size_t r = r0 + q;
-            g = blk_base + ((size_t)k << a.log_s) + r;
-            v = fz_mul<P>(v, fz_from_fe<P>(fe_load<P>(outer_tw + (((size_t)k << a.log_s) + r) * 2)));
-        } else {
-            g = (ol0 + q) + ((size_t)k << (a.log_n - log_a));
-            Fz<P> mult = scale;  // 1 or n^-1 (R'-form)
-            if constexpr (HOOKS) {
-                // g is the natural output index; every factor is an R'-form value below 2p
-                if (hk.out_tab) {
-                    const Fz<P> t = fz_from_fe<P>(fe_load<P>((const uint4*)hk.out_tab + (g & hk.out_mask) * 2));
-                    mult = a.scale ? fz_mul<P>(t, scale) : t;
-                }
-                if (hk.out_lo) {
-                    const Fz<P> pw = geom_pow<P>(hk.out_lo, hk.out_hi, g);
-                    mult = (a.scale || hk.out_tab) ? fz_mul<P>(mult, pw) : pw;
-                }
-            }
-            v = fz_mul<P>(v, mult);
+        const size_t g = tile_out_index(a, tg, e);
+        Fe<P> tw = fe_zero<P>();
+#if PLK_NTT_EXP == 6
+        for (int l = 0; l < 8; ++l) {
+            uint32_t h = ((uint32_t)g * 8u + l + 77u) * 0x85ebca6bu;
+            h ^= h >> 15; h *= 0x9e3779b9u; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+            tw.v[l] = h;
         }
-        fe_store<P>(outb + g * 2, fz_to_fe_canonical<P>(v));
+        tw.v[7] &= 0x0fffffffu;
+        const Fe<P> r = tile_emit<P, HOOKS>(a, hk, lds_load<P>(s_dat, TILE, e), tw, scale, g);
+        if (r.v[0] == 0x12345678u && r.v[5] == 0x9abcdef0u) fe_store<P>(outb + g * 2, r);  // practically never
+#else
+        if (!a.last) tw = fe_load<P>(outer_tw + tile_tw_index(a, tg, e) * 2);
+        fe_store<P>(outb + g * 2, tile_emit<P, HOOKS>(a, hk, lds_load<P>(s_dat, TILE, e), tw, scale, g));
+#endif
     }
 }
 
@@ -494,12 +569,15 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
         const bool prof = prof_begin(stream, pev);
         const size_t lds_bytes = ((size_t)FzCfg<P>::NZ * TILE + (size_t)FzCfg<P>::NZ * ((size_t)1 << a.log_a) / 2) * 4;
         const uint4* scale = (const uint4*)pl.pw + (a.scale ? 66 : 65) * 2;
-        if (hooks && (a.first || a.last))
+        const bool use_hooks = hooks && (a.first || a.last);
+        const NttHooks hk = use_hooks ? *hooks : NttHooks{};
+        if (use_hooks) {
             k_ntt_pass<P, true><<<(unsigned)tiles, NTT_THREADS, lds_bytes, stream>>>((const uint4*)src, (uint4*)dst, (const uint4*)pl.inner[dir],
-                                                                                   (const uint4*)outer, scale, a, *hooks);
-        else
+                                                                                   (const uint4*)outer, scale, a, hk);
+        } else {
             k_ntt_pass<P, false><<<(unsigned)tiles, NTT_THREADS, lds_bytes, stream>>>((const uint4*)src, (uint4*)dst, (const uint4*)pl.inner[dir],
-                                                                                    (const uint4*)outer, scale, a, NttHooks{});
+                                                                                    (const uint4*)outer, scale, a, hk);
+        }
         if (prof) prof_end(stream, pev);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {

@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SO_PATH = os.path.join(_CSRC, "libplonky_hip.so")
+# PLK_HIP_LIB points the loader at another build of the same library (tools/ntt_experiments.sh)
+SO_PATH = os.environ.get("PLK_HIP_LIB") or os.path.join(_CSRC, "libplonky_hip.so")
 
 PLK_OK = 0
 PLK_ERR_INVALID_ARG = -1
