@@ -240,6 +240,38 @@ def main():
         comp["ntt_batch9_ms"] = tb * 1e3
         comp["ntt_batch9_melems_per_s"] = world * 9 * n / tb / 1e6
         del xb, yb
+        # the quotient path either side of the transforms (polynomial.rs:330-380, plonk_util.rs:179-190)
+        # at the sizes this n implies: divide_by_z_h of a degree < n polynomial by Z_H of n/8, LDE of 9 wires n/8 -> n
+        if args.log_n >= 13:
+            nq = n // 8
+            from plonky_amd import api as _api
+            # m = q0 * (X^nq - 1) for a random q0 of 7 nq coefficients: m[i] = q0[i - nq] - q0[i]
+            q0 = synth.rand_field(NTT_FIELD, SEED_NTT + 100 + rank, 7 * nq)
+            zpad = np.zeros((nq, 4), dtype=np.uint64)
+            m = dev.to_device(_api.field_op(NTT_FIELD, "sub", np.concatenate([zpad, q0]), np.concatenate([q0, zpad])))
+            q_out = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+            dev.divide_by_z_h_dev(NTT_FIELD, m, nq, out=q_out)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                dev.divide_by_z_h_dev(NTT_FIELD, m, nq, out=q_out)
+            sync()
+            comp["divide_by_z_h_ms"] = (time.perf_counter() - t1) / args.steps * 1e3
+            w = dev.to_device(synth.rand_field(NTT_FIELD, SEED_NTT + 200 + rank, 9 * nq)).reshape(9, nq, 4)
+            ev = torch.empty((9, n, 4), dtype=torch.int64, device="cuda")
+            dev.ntt_padded_dev(NTT_FIELD, w, args.log_n, out=ev)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(max(1, args.steps // 2)):
+                dev.ntt_padded_dev(NTT_FIELD, w, args.log_n, out=ev)
+            sync()
+            comp["lde9_ms"] = (time.perf_counter() - t1) / max(1, args.steps // 2) * 1e3
+            comp["quotient_path_note"] = "divide_by_z_h: degree < 2^%d by Z_H of 2^%d (2 fused transforms); lde9: 9 x 2^%d coefficients -> 2^%d evaluations" % (
+                args.log_n, args.log_n - 3, args.log_n - 3, args.log_n)
+            if not args.no_check:
+                q_host = dev.to_host(q_out)
+                comp["_q_check"] = bool(np.array_equal(q_host[: 7 * nq], q0) and not q_host[7 * nq:].any())
+            del m, q_out, ev
     if do_msm_c:
         sync()
         t1 = time.perf_counter()
@@ -260,6 +292,8 @@ def main():
         if do_ntt:
             back = dev.to_host(dev.ntt_dev(NTT_FIELD, y, inverse=True))
             checks["ntt_roundtrip_bit_exact"] = bool(np.array_equal(back, x_host))
+            if "_q_check" in comp:
+                checks["divide_by_z_h_identity"] = comp.pop("_q_check")
         if do_msm:
             got = dev.to_host(oxy).reshape(2, 4)
             exp = closed_form_msm(CURVE, s_host, G, D, first=first)
