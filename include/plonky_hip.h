@@ -148,6 +148,13 @@ int plk_msm(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_z
  * point addition is not an RCCL reduction op).  Host pointers. */
 int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint8_t* pts_zero, uint64_t* out_xy, uint8_t* out_zero);
 
+/* ---- self-test ------------------------------------------------------------------------------ */
+/* Runs the quad-cooperative point arithmetic of the MSM reduction tail (ecz_coop.cuh) against the one-lane
+ * arithmetic on the n affine points pts_xy (n * 2L limbs, Montgomery), `quads` quads cycling through 8 cases
+ * (addition, doubling, doubling inside an addition, opposite points, identity operands, repeated doubling,
+ * wave-wide sum).  mismatches[8] receives the number of disagreements per case: all zero on a healthy build. */
+int plk_selftest_quad(int curve, const uint64_t* pts_xy, size_t n, unsigned quads, unsigned* mismatches);
+
 /* ---- measurement hooks (bench.py's roofline: per-kernel durations from HIP events recorded on the
  *      launch stream around each kernel; no effect on results) ------------------------------- */
 /* NTT pass kernel: enable, run transforms, then read the summed duration and the number of launches

@@ -17,6 +17,7 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void* d_zero, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_gen_bases_dev_impl(int curve, size_t n, uint64_t first, const void* d_g0d, void* d_out, hipStream_t stream);
+int selftest_quad_dev_impl(int curve, const void* d_pts, uint32_t n, uint32_t quads, uint32_t* counts);
 int msm_set_profiling_impl(plk_msm_ctx* ctx, int enable);
 int msm_get_timings_impl(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls);
 int ntt_set_profiling_impl(int enable);
@@ -416,6 +417,18 @@ int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint
     PLK_HIP_TRY(hipMemcpy(out_xy, dxy.p, 2 * L * 8, hipMemcpyDeviceToHost));
     PLK_HIP_TRY(hipMemcpy(out_zero, doz.p, 1, hipMemcpyDeviceToHost));
     return PLK_OK;
+}
+
+// ---- self-test ----
+int plk_selftest_quad(int curve, const uint64_t* pts_xy, size_t n, unsigned quads, unsigned* mismatches) {
+    const int L = curve_limbs(curve);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (!pts_xy || !mismatches || n == 0 || n > 0xffffffffu) return set_error(PLK_ERR_INVALID_ARG, "bad argument");
+    PLK_TRY(ensure_device());
+    DevBuf dp;
+    PLK_TRY(dp.alloc(n * 2 * L * 8));
+    PLK_HIP_TRY(hipMemcpy(dp.p, pts_xy, n * 2 * L * 8, hipMemcpyHostToDevice));
+    return selftest_quad_dev_impl(curve, dp.p, (uint32_t)n, quads, mismatches);
 }
 
 // ---- measurement hooks ----

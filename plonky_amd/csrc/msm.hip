@@ -25,11 +25,12 @@
 #include "common.h"
 #include "ec.cuh"
 #include "ecz.cuh"
+#include "ecz_coop.cuh"
 
 namespace plk {
 
 constexpr int MSM_SLICE_DEFAULT = 24;  // entries per accumulation slice (PLK_MSM_SLICE overrides)
-constexpr int MSM_MAX_PLANE_PARTS = 8;  // blocks per bit-plane in the reduction
+constexpr int MSM_MAX_PLANE_PARTS = 16;  // blocks per bit-plane in the reduction (planes * parts quads must fit the final block)
 constexpr int MSM_MAX_WINDOW = 17;   // c - 1 <= 8 fine + 8 coarse bits in the partition
 constexpr uint32_t CODE_INVALID = 0xFFFFFFFFu;
 
@@ -566,64 +567,106 @@ __global__ void __launch_bounds__(256) k_msm_bucket_sum(const uint4* __restrict_
     if (mine && part == 0) xyzzz_store_packed<FP>(bucket + (size_t)b * 4 * W, acc);
 }
 
-// plane p: tree-sum of { bucket_b : bit p of (b + 1) }.  grid = (parts, planes), 256 lanes.
+// The planes and the final kernel run on quads (ecz_coop.cuh): four lanes per point, a doubling is 3
+// multiplication latencies deep instead of 9, an addition 4 instead of 14.
+//
+// plane p of window z: tree-sum of { bucket_b : bit p of (b + 1) } over the window's buckets.
+// grid = (parts, planes, windows), 128 quads per block.
+constexpr int PLANE_THREADS = 512;
 template <class C>
-__global__ void __launch_bounds__(256) k_msm_planes(const uint4* __restrict__ bucket, uint4* __restrict__ plane_part, uint32_t buckets) {
+__global__ void __launch_bounds__(PLANE_THREADS) k_msm_planes(const uint4* __restrict__ bucket, uint4* __restrict__ plane_part, uint32_t wbuckets) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
-    __shared__ uint4 s_pts[4 * 4 * W];  // one packed point per wave
+    __shared__ uint4 s_pts[(PLANE_THREADS / 64) * 4 * W];  // one packed point per wave
+    const int ql = threadIdx.x & 3, quad = threadIdx.x >> 2;
     const int plane = blockIdx.y;
+    const uint4* wb = bucket + (size_t)blockIdx.z * wbuckets * 4 * W;
     XyzzZ<FP> acc = xyzzz_identity<FP>();
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < buckets; b += gridDim.x * blockDim.x) {
-        if (((b + 1u) >> plane) & 1u) acc = xyzzz_add<FP>(acc, xyzzz_load_packed<FP>(bucket + (size_t)b * 4 * W));
+    for (uint32_t b = blockIdx.x * (PLANE_THREADS / 4) + quad; b < wbuckets; b += gridDim.x * (PLANE_THREADS / 4)) {
+        if (((b + 1u) >> plane) & 1u) acc = xyzzz_add_q<FP>(acc, xyzzz_load_packed<FP>(wb + (size_t)b * 4 * W), ql);
     }
-    acc = wave_sum<FP>(acc, 64);
+    acc = wave_sum_q<FP>(acc, 16, ql);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) xyzzz_store_packed<FP>(s_pts + wave * 4 * W, acc);
     __syncthreads();
     if (wave == 0) {
-        acc = lane < 4 ? xyzzz_load_packed<FP>(s_pts + lane * 4 * W) : xyzzz_identity<FP>();
-        acc = wave_sum<FP>(acc, 4);
-        if (lane == 0) xyzzz_store_packed<FP>(plane_part + ((size_t)plane * gridDim.x + blockIdx.x) * 4 * W, acc);
+        acc = (lane >> 2) < PLANE_THREADS / 64 ? xyzzz_load_packed<FP>(s_pts + (lane >> 2) * 4 * W) : xyzzz_identity<FP>();
+        acc = wave_sum_q<FP>(acc, PLANE_THREADS / 64, ql);
+        if (lane == 0)
+            xyzzz_store_packed<FP>(plane_part + (((size_t)blockIdx.z * gridDim.y + plane) * gridDim.x + blockIdx.x) * 4 * W, acc);
     }
 }
 
-// one block of planes * parts lanes (parts a power of two <= 8, planes <= 32)
+// back to the reference's form, then ProjectivePoint::to_affine (curve.rs:206-214)
+template <class FP> PLK_DI void emit_affine(const XyzzZ<FP>& acc, uint4* out_xy, uint8_t* out_zero) {
+    constexpr int W = FP::NL / 4;
+    Xyzz<FP> r = xyzz_identity<FP>();
+    if (!acc.inf) {
+        const Fz<FP> back = fz_const_rprime_to_r<FP>();
+        r.x = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.x, back));
+        r.y = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.y, back));
+        r.zz = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zz, back));
+        r.zzz = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zzz, back));
+    }
+    Fe<FP> x, y;
+    bool ident = xyzz_to_affine<FP, true>(r, x, y);
+    fe_store<FP>(out_xy, x);
+    fe_store<FP>(out_xy + W, y);
+    *out_zero = ident ? 1 : 0;
+}
+
+// One block per window: sum_p 2^p (sum of the parts of plane p), one quad per (plane, part); parts a power of
+// two <= 16, planes <= 32, planes * parts <= 256.  With one window (tables) the block also normalises the result; with several
+// (table-free mode) it doubles its window into place, 2^(c * window), and k_msm_combine adds the windows.
+constexpr int FINAL_THREADS = 1024;
 template <class C>
-__global__ void __launch_bounds__(256) k_msm_final(const uint4* __restrict__ plane_part, int parts, int planes, uint4* __restrict__ out_xy,
-                                                   uint8_t* __restrict__ out_zero) {
+__global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(const uint4* __restrict__ plane_part, int parts, int planes, int window_bits,
+                                                             uint4* __restrict__ win_out, uint4* __restrict__ out_xy, uint8_t* __restrict__ out_zero) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
-    __shared__ uint4 s_pts[32 * 4 * W];
-    const int tid = threadIdx.x;
-    const int plane = tid / parts, part = tid % parts;
+    __shared__ uint4 s_pts[33 * 4 * W];
+    const int tid = threadIdx.x, ql = tid & 3, item = tid >> 2;
+    const int plane = item / parts, part = item % parts;
+    const int win = blockIdx.x;
     const bool live = plane < planes;
-    XyzzZ<FP> acc = live ? xyzzz_load_packed<FP>(plane_part + (size_t)tid * 4 * W) : xyzzz_identity<FP>();
-    acc = wave_sum<FP>(acc, parts);  // the parts of a plane are adjacent lanes of one wave
+    XyzzZ<FP> acc = live ? xyzzz_load_packed<FP>(plane_part + ((size_t)(win * planes + plane) * parts + part) * 4 * W) : xyzzz_identity<FP>();
+    acc = wave_sum_q<FP>(acc, parts, ql);  // the parts of a plane are adjacent quads of one wave
     if (live && part == 0) {
-        for (int k = 0; k < plane; ++k) acc = xyzzz_dbl<FP>(acc);
-        xyzzz_store_packed<FP>(s_pts + plane * 4 * W, acc);
+        for (int k = 0; k < plane; ++k) acc = xyzzz_dbl_q<FP>(acc, ql);
+        if (ql == 0) xyzzz_store_packed<FP>(s_pts + plane * 4 * W, acc);
     }
     __syncthreads();
-    if (tid < 64) {
-        acc = tid < planes ? xyzzz_load_packed<FP>(s_pts + tid * 4 * W) : xyzzz_identity<FP>();
-        acc = wave_sum<FP>(acc, 32);
+    if (tid < 128) {  // the planes: 32 quads, two waves
+        acc = item < planes ? xyzzz_load_packed<FP>(s_pts + item * 4 * W) : xyzzz_identity<FP>();
+        acc = wave_sum_q<FP>(acc, 16, ql);
+        if (tid == 64) xyzzz_store_packed<FP>(s_pts + 32 * 4 * W, acc);
+    }
+    __syncthreads();
+    if (tid < 4) {
+        if (planes > 16) acc = xyzzz_add_q<FP>(acc, xyzzz_load_packed<FP>(s_pts + 32 * 4 * W), ql);
+        for (int k = 0; k < win * window_bits; ++k) acc = xyzzz_dbl_q<FP>(acc, ql);
         if (tid == 0) {
-            // back to the reference's form, then ProjectivePoint::to_affine (curve.rs:206-214)
-            Xyzz<FP> r = xyzz_identity<FP>();
-            if (!acc.inf) {
-                const Fz<FP> back = fz_const_rprime_to_r<FP>();
-                r.x = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.x, back));
-                r.y = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.y, back));
-                r.zz = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zz, back));
-                r.zzz = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zzz, back));
-            }
-            Fe<FP> x, y;
-            bool ident = xyzz_to_affine<FP, true>(r, x, y);
-            fe_store<FP>(out_xy, x);
-            fe_store<FP>(out_xy + W, y);
-            *out_zero = ident ? 1 : 0;
+            if (gridDim.x > 1) xyzzz_store_packed<FP>(win_out + (size_t)win * 4 * W, acc);
+            else emit_affine<FP>(acc, out_xy, out_zero);
         }
+    }
+}
+
+// table-free mode: the sum of the windows (<= 32 points, already doubled into place), normalised
+template <class C>
+__global__ void __launch_bounds__(128) k_msm_combine(const uint4* __restrict__ win_pts, int windows, uint4* __restrict__ out_xy,
+                                                     uint8_t* __restrict__ out_zero) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    __shared__ uint4 s_pt[4 * W];
+    const int tid = threadIdx.x, ql = tid & 3, item = tid >> 2;
+    XyzzZ<FP> acc = item < windows ? xyzzz_load_packed<FP>(win_pts + (size_t)item * 4 * W) : xyzzz_identity<FP>();
+    acc = wave_sum_q<FP>(acc, 16, ql);
+    if (tid == 64) xyzzz_store_packed<FP>(s_pt, acc);
+    __syncthreads();
+    if (tid < 4) {
+        if (windows > 16) acc = xyzzz_add_q<FP>(acc, xyzzz_load_packed<FP>(s_pt), ql);
+        if (tid == 0) emit_affine<FP>(acc, out_xy, out_zero);
     }
 }
 
@@ -687,6 +730,74 @@ __global__ void __launch_bounds__(128) k_gen_bases(const uint4* __restrict__ g0d
     (void)ident;  // G0 + m D is the identity only for one m in the whole group; callers use small m
     fe_store<FP>(out + i * 2 * W, x);
     fe_store<FP>(out + i * 2 * W + W, y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// self-test: the quad arithmetic (ecz_coop.cuh) against the one-lane arithmetic (ecz.cuh) on the same operands
+// ---------------------------------------------------------------------------------------------
+// same group element: x1 zz2 == x2 zz1 and y1 zzz2 == y2 zzz1 (the projective equality of curve.rs:280-302)
+template <class FP> PLK_DI bool xyzzz_same(const XyzzZ<FP>& a, const XyzzZ<FP>& b) {
+    if (a.inf || b.inf) return a.inf == b.inf;
+    const Fe<FP> l1 = fz_to_fe_canonical<FP>(fz_mul<FP>(a.x, b.zz)), r1 = fz_to_fe_canonical<FP>(fz_mul<FP>(b.x, a.zz));
+    const Fe<FP> l2 = fz_to_fe_canonical<FP>(fz_mul<FP>(a.y, b.zzz)), r2 = fz_to_fe_canonical<FP>(fz_mul<FP>(b.y, a.zzz));
+    bool ok = true;
+    for (int i = 0; i < FP::NL; ++i) ok = ok && (l1.v[i] == r1.v[i]) && (l2.v[i] == r2.v[i]);
+    return ok;
+}
+template <class C>
+__global__ void __launch_bounds__(256) k_selftest_quad(const uint4* __restrict__ pts, uint32_t n, uint32_t* __restrict__ mismatches) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    const uint32_t quad = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const int ql = threadIdx.x & 3;
+    const uint32_t i = quad % n, j = (quad * 7u + 3u) % n;
+    const Fz<FP> k = fz_const_r_to_rprime<FP>();
+    auto load_pt = [&](uint32_t idx, Fz<FP>& x, Fz<FP>& y) {
+        x = fz_from_fe<FP>(fz_to_fe_canonical<FP>(fz_mul<FP>(fz_from_fe<FP>(fe_load<FP>(pts + (size_t)idx * 2 * W)), k)));
+        y = fz_from_fe<FP>(fz_to_fe_canonical<FP>(fz_mul<FP>(fz_from_fe<FP>(fe_load<FP>(pts + (size_t)idx * 2 * W + W)), k)));
+    };
+    Fz<FP> xi, yi, xj, yj;
+    load_pt(i, xi, yi);
+    load_pt(j, xj, yj);
+    XyzzZ<FP> a = xyzzz_identity<FP>(), b = xyzzz_identity<FP>();
+    xyzzz_madd<FP>(a, xi, yi);
+    a = xyzzz_dbl<FP>(a);           // 2 P_i, zz != 1
+    xyzzz_madd<FP>(b, xj, yj);
+    xyzzz_madd<FP>(b, xi, yi);      // P_j + P_i (or 2 P_i / identity when the indices collide)
+    XyzzZ<FP> na = a;
+    na.y = fz_sub<FP, 2>(fz_zero<FP>(), a.y);  // -a, y < 4p
+    bool ok = true;
+    // sum over the 16 quads of the wave against a serial sum of the same 16 points (whole wave active)
+    bool wave_ok;
+    {
+        XyzzZ<FP> tot = wave_sum_q<FP>(a, 16, ql);
+        XyzzZ<FP> ser = xyzzz_identity<FP>();
+        for (int q = 0; q < 16; ++q) {
+            XyzzZ<FP> t = a;  // lane 4q of this wave holds that quad's a
+            const int src = 4 * q;
+#pragma unroll
+            for (int l = 0; l < FzCfg<FP>::NZ; ++l) {
+                t.x.l[l] = __shfl(a.x.l[l], src);
+                t.y.l[l] = __shfl(a.y.l[l], src);
+                t.zz.l[l] = __shfl(a.zz.l[l], src);
+                t.zzz.l[l] = __shfl(a.zzz.l[l], src);
+            }
+            t.inf = __shfl((int)a.inf, src) != 0;
+            ser = xyzzz_add<FP>(ser, t);
+        }
+        wave_ok = xyzzz_same<FP>(tot, ser);
+    }
+    switch (quad & 7u) {
+        case 0: ok = xyzzz_same<FP>(xyzzz_add_q<FP>(a, b, ql), xyzzz_add<FP>(a, b)); break;
+        case 1: ok = xyzzz_same<FP>(xyzzz_dbl_q<FP>(a, ql), xyzzz_dbl<FP>(a)); break;
+        case 2: ok = xyzzz_same<FP>(xyzzz_add_q<FP>(a, a, ql), xyzzz_dbl<FP>(a)); break;          // doubling inside the addition
+        case 3: ok = xyzzz_add_q<FP>(a, na, ql).inf; break;                                          // opposite points
+        case 4: ok = xyzzz_same<FP>(xyzzz_add_q<FP>(xyzzz_identity<FP>(), b, ql), b); break;
+        case 5: ok = xyzzz_same<FP>(xyzzz_add_q<FP>(b, xyzzz_identity<FP>(), ql), b); break;
+        case 6: ok = xyzzz_same<FP>(xyzzz_dbl_q<FP>(xyzzz_dbl_q<FP>(b, ql), ql), xyzzz_dbl<FP>(xyzzz_dbl<FP>(b))); break;
+        default: ok = wave_ok;
+    }
+    if (!ok) atomicAdd(mismatches + (quad & 7u), 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -817,7 +928,9 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     }
     ctx->planes = c;
     ctx->plane_blocks = 1;
-    while (ctx->plane_blocks < MSM_MAX_PLANE_PARTS && (uint32_t)ctx->plane_blocks * 2048u < ctx->buckets) ctx->plane_blocks *= 2;
+    while (ctx->plane_blocks < MSM_MAX_PLANE_PARTS && (uint32_t)ctx->plane_blocks * 2048u < ctx->buckets &&
+           ctx->planes * ctx->plane_blocks * 2 * 4 <= FINAL_THREADS)
+        ctx->plane_blocks *= 2;
     if (n * (size_t)ctx->windows >= ((size_t)1 << 31)) {
         delete ctx;
         return set_error(PLK_ERR_INVALID_ARG, "n * windows = %zu entries exceeds 2^31", n * (size_t)ctx->windows);
@@ -903,11 +1016,12 @@ static int msm_execute_t(plk_msm_ctx* ctx, const void* d_scalars, void* d_out_xy
     k_msm_heavy_final<C><<<64, 256, 0, stream>>>(slice_off, (const uint32_t*)ctx->heavy, ctx->heavy_cap, (const uint4*)ctx->heavy_part, (uint4*)ctx->bucket);
     PLK_HIP_TRY(hipGetLastError());
     mark();
-    dim3 pg(ctx->plane_blocks, ctx->planes);
-    k_msm_planes<C><<<pg, 256, 0, stream>>>((const uint4*)ctx->bucket, (uint4*)ctx->plane_part, buckets);
+    dim3 pg(ctx->plane_blocks, ctx->planes, 1);
+    k_msm_planes<C><<<pg, PLANE_THREADS, 0, stream>>>((const uint4*)ctx->bucket, (uint4*)ctx->plane_part, buckets);
     PLK_HIP_TRY(hipGetLastError());
     mark();
-    k_msm_final<C><<<1, 256, 0, stream>>>((const uint4*)ctx->plane_part, ctx->plane_blocks, ctx->planes, (uint4*)d_out_xy, (uint8_t*)d_out_zero);
+    k_msm_final<C><<<1, FINAL_THREADS, 0, stream>>>((const uint4*)ctx->plane_part, ctx->plane_blocks, ctx->planes, ctx->c, nullptr, (uint4*)d_out_xy,
+                                                    (uint8_t*)d_out_zero);
     PLK_HIP_TRY(hipGetLastError());
     mark();
     if (!ev.empty()) ctx->prof_sets.push_back(ev);
@@ -984,6 +1098,26 @@ int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void
         default: return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     }
     PLK_HIP_TRY(hipGetLastError());
+    return PLK_OK;
+}
+
+// counts[8]: mismatches per case of k_selftest_quad over `quads` quads on the n points d_pts
+int selftest_quad_dev_impl(int curve, const void* d_pts, uint32_t n, uint32_t quads, uint32_t* counts) {
+    if (!d_pts || !counts || n == 0) return set_error(PLK_ERR_INVALID_ARG, "bad argument");
+    PLK_TRY(ensure_device());
+    uint32_t* d_cnt = (uint32_t*)scratch_acquire(32, nullptr);
+    if (!d_cnt) return PLK_ERR_OOM;
+    (void)hipMemsetAsync(d_cnt, 0, 32, nullptr);
+    const unsigned blocks = (quads * 4 + 255) / 256;
+    switch (curve) {
+        case PLK_CURVE_TWEEDLEDEE: k_selftest_quad<TweedledeeCurve><<<blocks, 256>>>((const uint4*)d_pts, n, d_cnt); break;
+        case PLK_CURVE_TWEEDLEDUM: k_selftest_quad<TweedledumCurve><<<blocks, 256>>>((const uint4*)d_pts, n, d_cnt); break;
+        case PLK_CURVE_BLS12_377: k_selftest_quad<Bls12377Curve><<<blocks, 256>>>((const uint4*)d_pts, n, d_cnt); break;
+        default: scratch_release(d_cnt, nullptr); return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    }
+    hipError_t e = hipMemcpy(counts, d_cnt, 32, hipMemcpyDeviceToHost);
+    scratch_release(d_cnt, nullptr);
+    if (e != hipSuccess) return set_error(PLK_ERR_HIP, "selftest failed: %s", hipGetErrorString(e));
     return PLK_OK;
 }
 
