@@ -147,15 +147,15 @@ template <class FP> __device__ __noinline__ Xyzz<FP> xyzz_add(const Xyzz<FP>& a,
 
 // ProjectivePoint::to_affine (curve.rs:206-214): returns true for the identity.
 // x = X/ZZ, y = Y/ZZZ with one inversion: 1/Z = ZZ/ZZZ, 1/ZZ = (1/Z)^2.
-// SINGLE_LANE selects the data-dependent Euclidean inversion (one lane normalising one result)
-// over the branch-free Fermat chain (all lanes normalising table entries in lock step).
+// The inversion is the branch-free division-step one (fp.cuh): a tenth of the instructions of the reference's
+// bit-by-bit Euclid (bigint_inverse.rs:6-55) or of a Fermat chain, for one lane and for a full wave alike.
 template <class FP, bool SINGLE_LANE = false> PLK_DI bool xyzz_to_affine(const Xyzz<FP>& p, Fe<FP>& x, Fe<FP>& y) {
     if (xyzz_is_identity<FP>(p)) {
         x = fe_zero<FP>();
         y = fe_zero<FP>();
         return true;
     }
-    Fe<FP> i3 = SINGLE_LANE ? fe_inv_eea<FP>(p.zzz) : fe_inv<FP>(p.zzz);
+    Fe<FP> i3 = fe_inv_safegcd<FP>(p.zzz);
     Fe<FP> iz = fe_mul<FP>(p.zz, i3);
     Fe<FP> izz = fe_sqr<FP>(iz);
     x = fe_mul<FP>(p.x, izz);

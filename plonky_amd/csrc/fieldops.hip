@@ -20,7 +20,9 @@ template <class P> __global__ void k_field_op(int op, const uint4* a, const uint
         case 4: r = fe_sqr<P>(x); break;
         case 5: r = fe_inv<P>(x); break;
         case 6: r = fe_to_canonical<P>(x); break;
-        default: r = fe_from_canonical<P>(x); break;
+        case 7: r = fe_from_canonical<P>(x); break;
+        case 8: r = fe_inv_eea<P>(x); break;       // the reference's Euclid (bigint_inverse.rs:6-55)
+        default: r = fe_inv_safegcd<P>(x); break;  // what the kernels use
     }
     fe_store<P>(out + i * W, r);
 }
@@ -42,7 +44,7 @@ template <class P> static int field_op_t(int op, const uint64_t* a, const uint64
 }
 
 int field_op_impl(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count) {
-    if (op < 0 || op > 7) return set_error(PLK_ERR_INVALID_ARG, "bad field op %d", op);
+    if (op < 0 || op > 9) return set_error(PLK_ERR_INVALID_ARG, "bad field op %d", op);
     if (!a || !out || (op <= 2 && !b)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     PLK_TRY(ensure_device());
     switch (field) {

@@ -287,6 +287,133 @@ template <class P> PLK_DNI Fe<P> fe_inv_eea(const Fe<P>& a) {
     return fe_mul<P>(r, r3);
 }
 
+// Modular inverse by Bernstein-Yang division steps ("safegcd", half-delta variant) on signed 30-bit limbs,
+// 30 steps at a time on the low words with the transition matrix applied to the full numbers afterwards
+// (the organisation of libsecp256k1's modinv32, restated for these moduli: p = 1 mod 2^32, so p^-1 mod 2^30 = 1).
+// About a tenth of the instructions of the bit-by-bit Euclid above and branch-free, so a wave stays converged.
+// Same contract as fe_inv_eea: Montgomery in, Montgomery out (monty.rs:162-166), 0 -> 0.
+template <class P> PLK_DNI Fe<P> fe_inv_safegcd(const Fe<P>& a) {
+    constexpr int NL = P::NL;
+    constexpr int N = (NL * 32 + 29) / 30;          // 9 limbs for 256 bits, 13 for 384
+    constexpr int ITER = NL == 8 ? 20 : 30;         // 590 steps suffice below 2^256, 886 below 2^384
+    constexpr int32_t M30 = (int32_t)(0xffffffffu >> 2);
+    if (fe_is_zero<P>(a)) return a;
+    int32_t m[N], f[N], g[N], d[N], e[N];
+    // 32-bit limbs -> 30-bit limbs
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int bit = 30 * i, w = bit >> 5, sh = bit & 31;
+        uint64_t mm = w < NL ? P::MOD[w] : 0u, gg = w < NL ? a.v[w] : 0u;
+        if (w + 1 < NL) {
+            mm |= (uint64_t)P::MOD[w + 1] << 32;
+            gg |= (uint64_t)a.v[w + 1] << 32;
+        }
+        m[i] = (int32_t)((uint32_t)(mm >> sh) & (uint32_t)M30);
+        g[i] = (int32_t)((uint32_t)(gg >> sh) & (uint32_t)M30);
+        f[i] = m[i];
+        d[i] = 0;
+        e[i] = 0;
+    }
+    e[0] = 1;
+    int32_t zeta = -1;  // -(delta + 1/2), delta = 1/2
+    for (int it = 0; it < ITER; ++it) {
+        // 30 division steps on the low words; (u v; q r) is 2^30 times the transition matrix
+        uint32_t u = 1, v = 0, q = 0, r = 1, fl = (uint32_t)f[0], gl = (uint32_t)g[0];
+        for (int i = 0; i < 30; ++i) {
+            uint32_t c1 = (uint32_t)(zeta >> 31);           // zeta < 0
+            const uint32_t c2 = (uint32_t)0 - (gl & 1u);     // g odd
+            const uint32_t x = (fl ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;  // +-f, +-u, +-v
+            gl += x & c2;
+            q += y & c2;
+            r += z & c2;
+            c1 &= c2;
+            zeta = (int32_t)((uint32_t)zeta ^ c1) - 1;       // -zeta - 2 or zeta - 1
+            fl += gl & c1;
+            u += q & c1;
+            v += r & c1;
+            gl >>= 1;
+            u <<= 1;
+            v <<= 1;
+        }
+        const int64_t tu = (int32_t)u, tv = (int32_t)v, tq = (int32_t)q, tr = (int32_t)r;
+        // (d, e) <- t (d, e) / 2^30 mod p: a multiple of p makes the low 30 bits vanish first
+        {
+            const int32_t sd = d[N - 1] >> 31, se = e[N - 1] >> 31;
+            int32_t md = ((int32_t)tu & sd) + ((int32_t)tv & se);
+            int32_t me = ((int32_t)tq & sd) + ((int32_t)tr & se);
+            int64_t cd = tu * d[0] + tv * e[0];
+            int64_t ce = tq * d[0] + tr * e[0];
+            md -= (int32_t)(((uint32_t)cd + (uint32_t)md) & (uint32_t)M30);  // p^-1 mod 2^30 = 1
+            me -= (int32_t)(((uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
+            cd += (int64_t)m[0] * md;
+            ce += (int64_t)m[0] * me;
+            cd >>= 30;
+            ce >>= 30;
+#pragma unroll
+            for (int i = 1; i < N; ++i) {
+                cd += tu * d[i] + tv * e[i] + (int64_t)m[i] * md;
+                ce += tq * d[i] + tr * e[i] + (int64_t)m[i] * me;
+                d[i - 1] = (int32_t)cd & M30;
+                e[i - 1] = (int32_t)ce & M30;
+                cd >>= 30;
+                ce >>= 30;
+            }
+            d[N - 1] = (int32_t)cd;
+            e[N - 1] = (int32_t)ce;
+        }
+        // (f, g) <- t (f, g) / 2^30, exact
+        {
+            int64_t cf = tu * f[0] + tv * g[0];
+            int64_t cg = tq * f[0] + tr * g[0];
+            cf >>= 30;
+            cg >>= 30;
+#pragma unroll
+            for (int i = 1; i < N; ++i) {
+                cf += tu * f[i] + tv * g[i];
+                cg += tq * f[i] + tr * g[i];
+                f[i - 1] = (int32_t)cf & M30;
+                g[i - 1] = (int32_t)cg & M30;
+                cf >>= 30;
+                cg >>= 30;
+            }
+            f[N - 1] = (int32_t)cf;
+            g[N - 1] = (int32_t)cg;
+        }
+    }
+    // g = 0, f = +-1 and d = +-a^-1 in (-2p, p): fix the sign, bring into [0, p)
+    {
+        const int32_t neg = f[N - 1] >> 31;
+        int32_t add = d[N - 1] >> 31;
+#pragma unroll
+        for (int i = 0; i < N; ++i) d[i] = ((d[i] + (m[i] & add)) ^ neg) - neg;
+#pragma unroll
+        for (int i = 0; i + 1 < N; ++i) {
+            d[i + 1] += d[i] >> 30;
+            d[i] &= M30;
+        }
+        add = d[N - 1] >> 31;
+#pragma unroll
+        for (int i = 0; i < N; ++i) d[i] += m[i] & add;
+#pragma unroll
+        for (int i = 0; i + 1 < N; ++i) {
+            d[i + 1] += d[i] >> 30;
+            d[i] &= M30;
+        }
+    }
+    // 30-bit limbs -> 32-bit limbs, then x R^3 / R: (a R)^-1 R^2 = a^-1 R
+    Fe<P> r, r3;
+#pragma unroll
+    for (int w = 0; w < NL; ++w) {
+        const int bit = 32 * w, i = bit / 30, sh = bit % 30;
+        uint64_t acc = (uint64_t)(uint32_t)d[i] >> sh;
+        if (i + 1 < N) acc |= (uint64_t)(uint32_t)d[i + 1] << (30 - sh);
+        if (i + 2 < N) acc |= (uint64_t)(uint32_t)d[i + 2] << (60 - sh);
+        r.v[w] = (uint32_t)acc;
+        r3.v[w] = P::R3[w];
+    }
+    return fe_mul<P>(r, r3);
+}
+
 // x/2 mod p for Montgomery or canonical x alike (used to build n^-1 = 2^-log n)
 template <class P> PLK_DI Fe<P> fe_half(const Fe<P>& a) {
     constexpr int N = P::NL;

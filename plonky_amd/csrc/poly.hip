@@ -73,7 +73,7 @@ template <class P> __global__ void __launch_bounds__(64) k_zh_inv_table(const ui
     const Fe<P> wn = pow_from_table<P>(pw, 0, e << (log_t - log_size), log_t);
     const Fe<P> gn = fe_pow_u64<P>(fe_const<P>(P::GEN), n);
     const Fe<P> den = fe_sub<P>(fe_mul<P>(gn, wn), fe_one<P>());
-    fe_store<P>(out + t * 2, to_rprime<P>(fe_inv_eea<P>(den)));
+    fe_store<P>(out + t * 2, to_rprime<P>(fe_inv_safegcd<P>(den)));
 }
 
 struct GeomTables {

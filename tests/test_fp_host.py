@@ -70,6 +70,11 @@ def test_device_header_arithmetic_on_host(host_lib, f):
     nz = [v for v in inputs if v != 0][:120] + inputs[-60:]
     assert run(host_lib, f, 8, ints_to_array(nz, n)) == [pow(v * Rinv % p, -1, p) * f.R % p for v in nz]
     assert run(host_lib, f, 8, ints_to_array([0], n)) == [0]
+    # the division-step inversion (fe_inv_safegcd): same contract, plus the values that stress its sign handling
+    edge = [1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << 30, (1 << 30) - 1, 1 << 60, (1 << 255) % p, f.R % p, f.R2 % p]
+    edge = [v for v in edge if v % p]
+    assert run(host_lib, f, 18, ints_to_array(nz + edge, n)) == [pow(v * Rinv % p, -1, p) * f.R % p for v in nz + edge]
+    assert run(host_lib, f, 18, ints_to_array([0], n)) == [0]
 
 
 @pytest.mark.parametrize("f", FIELDS, ids=lambda f: f.name)

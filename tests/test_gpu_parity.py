@@ -45,6 +45,12 @@ def test_device_field_inverse_and_random(f):
     small = mont_arr(f, list(range(0, 25)))
     assert np.array_equal(api.field_op(f.field_id, "inverse", small), ol.field_unop(f.field_id, "inverse", small))
     assert np.array_equal(api.field_op(f.field_id, "inverse", x[:256]), ol.field_unop(f.field_id, "inverse", x[:256]))
+    # the two other inversion routines of the device code (Euclid as in the reference; division steps, used by the kernels)
+    edge = mont_arr(f, [1, 2, f.p - 1, f.p - 2, (f.p - 1) // 2, (f.p + 1) // 2, 1 << 30, (1 << 60) + 1])
+    for arr in (small, x, edge):
+        want = ol.field_unop(f.field_id, "inverse", arr)
+        assert np.array_equal(api.field_op(f.field_id, "inverse_euclid", arr), want)
+        assert np.array_equal(api.field_op(f.field_id, "inverse_divsteps", arr), want)
 
 
 # ---------------- NTT ----------------
