@@ -618,7 +618,7 @@ template <class FP> PLK_DI void emit_affine(const XyzzZ<FP>& acc, uint4* out_xy,
 // One block per window: sum_p 2^p (sum of the parts of plane p), one quad per (plane, part); parts a power of
 // two <= 16, planes <= 32, planes * parts <= 256.  With one window (tables) the block also normalises the result; with several
 // (table-free mode) it doubles its window into place, 2^(c * window), and k_msm_combine adds the windows.
-constexpr int FINAL_THREADS = 1024;
+constexpr int FINAL_THREADS = 512;  // <= 8 waves, so the compiler may use 256 VGPRs: the point arithmetic must not spill
 template <class C>
 __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(const uint4* __restrict__ plane_part, int parts, int planes, int window_bits,
                                                              uint4* __restrict__ win_out, uint4* __restrict__ out_xy, uint8_t* __restrict__ out_zero) {
@@ -626,12 +626,16 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(const uint4* __rest
     constexpr int W = FP::NL / 4;
     __shared__ uint4 s_pts[33 * 4 * W];
     const int tid = threadIdx.x, ql = tid & 3, item = tid >> 2;
-    const int plane = item / parts, part = item % parts;
+    // a quad takes two parts when there are several (then 4 * planes * parts / 2 <= FINAL_THREADS), else one
+    const int ipq = parts > 1 ? 2 : 1, qpp = parts / ipq;  // quads per plane
+    const int plane = item / qpp, sub = item % qpp;
     const int win = blockIdx.x;
     const bool live = plane < planes;
-    XyzzZ<FP> acc = live ? xyzzz_load_packed<FP>(plane_part + ((size_t)(win * planes + plane) * parts + part) * 4 * W) : xyzzz_identity<FP>();
-    acc = wave_sum_q<FP>(acc, parts, ql);  // the parts of a plane are adjacent quads of one wave
-    if (live && part == 0) {
+    const uint4* src = plane_part + ((size_t)(win * planes + plane) * parts + sub * ipq) * 4 * W;
+    XyzzZ<FP> acc = live ? xyzzz_load_packed<FP>(src) : xyzzz_identity<FP>();
+    if (ipq == 2) acc = xyzzz_add_q<FP>(acc, live ? xyzzz_load_packed<FP>(src + 4 * W) : xyzzz_identity<FP>(), ql);
+    acc = wave_sum_q<FP>(acc, qpp, ql);  // the quads of a plane are adjacent in one wave
+    if (live && sub == 0) {
         for (int k = 0; k < plane; ++k) acc = xyzzz_dbl_q<FP>(acc, ql);
         if (ql == 0) xyzzz_store_packed<FP>(s_pts + plane * 4 * W, acc);
     }
@@ -929,7 +933,7 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     ctx->planes = c;
     ctx->plane_blocks = 1;
     while (ctx->plane_blocks < MSM_MAX_PLANE_PARTS && (uint32_t)ctx->plane_blocks * 2048u < ctx->buckets &&
-           ctx->planes * ctx->plane_blocks * 2 * 4 <= FINAL_THREADS)
+           ctx->planes * ctx->plane_blocks * 4 <= FINAL_THREADS)  // after doubling: planes * parts / 2 quads in the final block
         ctx->plane_blocks *= 2;
     if (n * (size_t)ctx->windows >= ((size_t)1 << 31)) {
         delete ctx;
