@@ -123,6 +123,15 @@ int plk_msm_precompute(int curve, size_t n, const uint64_t* bases_xy, const uint
 /* Same with device-resident bases (n * 2L limbs) and flags (n bytes or NULL). */
 int plk_msm_precompute_dev(int curve, size_t n, const void* d_bases_xy, const void* d_base_zero, unsigned window_bits, void* stream,
                            plk_msm_ctx** out_ctx);
+/* flags for the _ex forms.  PLK_MSM_TABLE_FREE: do not build the window tables -- every window gets its own
+ * buckets and is doubled into place at the end (~250 dependent doublings, ~1 ms).  For generators that are
+ * used once or a few times (msm_parallel, curve_msm.rs:54-61; the IPA rounds of halo.rs:87-91 build a
+ * fresh MsmPrecomputation per round): the table build costs about 30 executions. */
+#define PLK_MSM_TABLE_FREE 1u
+int plk_msm_precompute_ex(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, unsigned window_bits, unsigned flags,
+                          plk_msm_ctx** out_ctx);
+int plk_msm_precompute_dev_ex(int curve, size_t n, const void* d_bases_xy, const void* d_base_zero, unsigned window_bits, unsigned flags,
+                              void* stream, plk_msm_ctx** out_ctx);
 int plk_msm_free(plk_msm_ctx* ctx);
 size_t plk_msm_ctx_len(const plk_msm_ctx* ctx);       /* number of generators n          */
 unsigned plk_msm_ctx_window(const plk_msm_ctx* ctx);  /* window size c actually in use   */

@@ -221,10 +221,14 @@ def _points(curve, generators):
     return g
 
 
-def msm_precompute(curve, generators, w, zero=None, device_window=0):
+MSM_TABLE_FREE = 1  # PLK_MSM_TABLE_FREE
+
+
+def msm_precompute(curve, generators, w, zero=None, device_window=0, table_free=False):
     """generators: (n, 2, L) affine x,y Montgomery limbs; zero: optional n flags (AffinePoint.zero).
     The reference takes ProjectivePoints and only ever passes normalised generators
-    (circuit_builder.rs:1127-1133); the shim in INTEGRATION.md reads powers_per_generator[i][0]."""
+    (circuit_builder.rs:1127-1133); the shim in INTEGRATION.md reads powers_per_generator[i][0].
+    table_free: no window tables on the device (generators used once: msm_parallel, the IPA rounds)."""
     g = _points(curve, generators)
     n = g.shape[0]
     z = None
@@ -232,7 +236,8 @@ def msm_precompute(curve, generators, w, zero=None, device_window=0):
         z = np.ascontiguousarray(zero, dtype=np.uint8)
         assert z.shape[0] == n
     ctx = ctypes.c_void_p()
-    _lib.check(_lib.load().plk_msm_precompute(curve, n, _ptr(g), _ptr(z) if z is not None else None, device_window, ctypes.byref(ctx)))
+    _lib.check(_lib.load().plk_msm_precompute_ex(curve, n, _ptr(g), _ptr(z) if z is not None else None, device_window,
+                                                 MSM_TABLE_FREE if table_free else 0, ctypes.byref(ctx)))
     return MsmPrecomputation(curve, ctx, n, w)
 
 
@@ -266,7 +271,8 @@ def msm_execute_batch(precomputation, scalar_vectors):
 
 
 def msm_parallel(curve, scalars, generators, w, zero=None):
-    pre = msm_precompute(curve, generators, w, zero=zero)
+    """curve_msm.rs:54-61: precompute + execute for generators that are used once -> no device tables."""
+    pre = msm_precompute(curve, generators, w, zero=zero, table_free=True)
     try:
         return msm_execute_parallel(pre, scalars)
     finally:

@@ -13,7 +13,8 @@ struct plk_msm_ctx;
 namespace plk {
 
 int field_op_impl(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count);
-int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, hipStream_t stream, plk_msm_ctx** out_ctx);
+int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, unsigned flags, hipStream_t stream,
+                            plk_msm_ctx** out_ctx);
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void* d_zero, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_gen_bases_dev_impl(int curve, size_t n, uint64_t first, const void* d_g0d, void* d_out, hipStream_t stream);
@@ -329,12 +330,17 @@ int plk_poly_mul(int field, const uint64_t* a, size_t la, const uint64_t* b, siz
 }
 
 // ---- MSM ----
+int plk_msm_precompute_dev_ex(int curve, size_t n, const void* d_bases_xy, const void* d_base_zero, unsigned window_bits, unsigned flags, void* stream,
+                              plk_msm_ctx** out_ctx) {
+    return msm_precompute_dev_impl(curve, n, d_bases_xy, d_base_zero, window_bits, flags, as_stream(stream), out_ctx);
+}
 int plk_msm_precompute_dev(int curve, size_t n, const void* d_bases_xy, const void* d_base_zero, unsigned window_bits, void* stream,
                            plk_msm_ctx** out_ctx) {
-    return msm_precompute_dev_impl(curve, n, d_bases_xy, d_base_zero, window_bits, as_stream(stream), out_ctx);
+    return msm_precompute_dev_impl(curve, n, d_bases_xy, d_base_zero, window_bits, 0, as_stream(stream), out_ctx);
 }
 
-int plk_msm_precompute(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, unsigned window_bits, plk_msm_ctx** out_ctx) {
+int plk_msm_precompute_ex(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, unsigned window_bits, unsigned flags,
+                          plk_msm_ctx** out_ctx) {
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (n && !bases_xy) return set_error(PLK_ERR_INVALID_ARG, "null bases");
@@ -346,7 +352,10 @@ int plk_msm_precompute(int curve, size_t n, const uint64_t* bases_xy, const uint
         PLK_TRY(dz.alloc(n));
         if (n) PLK_HIP_TRY(hipMemcpy(dz.p, base_zero, n, hipMemcpyHostToDevice));
     }
-    return msm_precompute_dev_impl(curve, n, db.p, base_zero ? dz.p : nullptr, window_bits, nullptr, out_ctx);
+    return msm_precompute_dev_impl(curve, n, db.p, base_zero ? dz.p : nullptr, window_bits, flags, nullptr, out_ctx);
+}
+int plk_msm_precompute(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, unsigned window_bits, plk_msm_ctx** out_ctx) {
+    return plk_msm_precompute_ex(curve, n, bases_xy, base_zero, window_bits, 0, out_ctx);
 }
 
 int plk_msm_free(plk_msm_ctx* ctx) {
@@ -392,7 +401,8 @@ int plk_msm_execute(plk_msm_ctx* ctx, const uint64_t* scalars, size_t n_scalars,
 
 int plk_msm(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, const uint64_t* scalars, uint64_t* out_xy, uint8_t* out_zero) {
     plk_msm_ctx* ctx = nullptr;
-    PLK_TRY(plk_msm_precompute(curve, n, bases_xy, base_zero, 0, &ctx));
+    // generators used once: no window tables (their construction costs ~30 executions)
+    PLK_TRY(plk_msm_precompute_ex(curve, n, bases_xy, base_zero, 0, PLK_MSM_TABLE_FREE, &ctx));
     int rc = plk_msm_execute(ctx, scalars, n, out_xy, out_zero);
     msm_ctx_delete(ctx);
     return rc;

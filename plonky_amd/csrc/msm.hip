@@ -71,7 +71,8 @@ __global__ void __launch_bounds__(128) k_msm_table(const uint4* __restrict__ bas
 // scalars -> signed window digits  (curve_msm.rs:159-180)
 // ---------------------------------------------------------------------------------------------
 template <class C>
-__global__ void __launch_bounds__(256) k_msm_digits(const uint4* __restrict__ scalars, uint32_t* __restrict__ codes, size_t n, int c, int windows) {
+__global__ void __launch_bounds__(256) k_msm_digits(const uint4* __restrict__ scalars, uint32_t* __restrict__ codes, size_t n, int c, int windows,
+                                                    uint32_t window_buckets) {
     using SP = typename C::SP;
     static_assert(SP::NL == 8, "scalar fields are 256-bit");
     // Scalars are staged through LDS: the block reads its 256 * 32 B with fully coalesced 16-byte
@@ -110,7 +111,8 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint4* __restrict__ sc
         uint32_t mag = neg ? (1u << c) - v : v;
         carry = neg;
         uint32_t code = CODE_INVALID;
-        if (mag != 0) code = ((mag - 1u) << 1) | neg;
+        // bucket id: |d| - 1, plus the window's own bucket range in table-free mode (window_buckets = 2^(c-1), else 0)
+        if (mag != 0) code = ((mag - 1u + (uint32_t)j * window_buckets) << 1) | neg;
         codes[(size_t)j * n + i] = code;
     }
 }
@@ -413,7 +415,8 @@ __global__ void __launch_bounds__(PART_THREADS) k_part2_scatter(const uint32_t* 
 template <class C>
 __global__ void __launch_bounds__(128) k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
                                                            const uint32_t* __restrict__ off, const uint32_t* __restrict__ slice_off,
-                                                           uint4* __restrict__ partial, uint32_t buckets, uint32_t slice) {
+                                                           uint4* __restrict__ partial, uint32_t buckets, uint32_t slice, int wshift,
+                                                           uint32_t n_sub) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -426,6 +429,9 @@ __global__ void __launch_bounds__(128) k_msm_accumulate(const uint4* __restrict_
         if (slice_off[mid] <= s) lo = mid; else hi = mid;
     }
     const uint32_t b = lo;
+    // entry ids are window * n + generator; with tables that is the table index, without (table-free mode:
+    // n_sub = n, buckets of window w are [w << wshift, (w + 1) << wshift)) the window part is taken off
+    const uint32_t ent_sub = (b >> wshift) * n_sub;
     const uint32_t begin = off[b] + (s - slice_off[b]) * slice;
     const uint32_t end = min(off[b + 1], begin + slice);
     // lazy 29-bit-limb accumulator (ecz.cuh); table coordinates are R'-form
@@ -440,7 +446,7 @@ __global__ void __launch_bounds__(128) k_msm_accumulate(const uint4* __restrict_
     bool ident = true;
     if (begin < end) {
         ent = sorted[begin];
-        ident = affine_load<FP>(tab + (size_t)(ent >> 1) * 2 * W, x, y);
+        ident = affine_load<FP>(tab + (size_t)((ent >> 1) - ent_sub) * 2 * W, x, y);
     }
     for (uint32_t k = begin; k < end; ++k) {
         const uint32_t cur = ent;
@@ -448,7 +454,7 @@ __global__ void __launch_bounds__(128) k_msm_accumulate(const uint4* __restrict_
         const bool cident = ident;
         if (k + 1 < end) {
             ent = sorted[k + 1];
-            ident = affine_load<FP>(tab + (size_t)(ent >> 1) * 2 * W, x, y);
+            ident = affine_load<FP>(tab + (size_t)((ent >> 1) - ent_sub) * 2 * W, x, y);
         }
         if (cident) continue;
         Fz<FP> xz = fz_from_fe<FP>(cx), yz = fz_from_fe<FP>(cy);
@@ -656,20 +662,22 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(const uint4* __rest
     }
 }
 
-// table-free mode: the sum of the windows (<= 32 points, already doubled into place), normalised
+// table-free mode: the sum of the windows (<= 128 points, already doubled into place), normalised
+constexpr int COMBINE_THREADS = 512;
 template <class C>
-__global__ void __launch_bounds__(128) k_msm_combine(const uint4* __restrict__ win_pts, int windows, uint4* __restrict__ out_xy,
-                                                     uint8_t* __restrict__ out_zero) {
+__global__ void __launch_bounds__(COMBINE_THREADS) k_msm_combine(const uint4* __restrict__ win_pts, int windows, uint4* __restrict__ out_xy,
+                                                                 uint8_t* __restrict__ out_zero) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
-    __shared__ uint4 s_pt[4 * W];
+    __shared__ uint4 s_pts[(COMBINE_THREADS / 64) * 4 * W];
     const int tid = threadIdx.x, ql = tid & 3, item = tid >> 2;
     XyzzZ<FP> acc = item < windows ? xyzzz_load_packed<FP>(win_pts + (size_t)item * 4 * W) : xyzzz_identity<FP>();
     acc = wave_sum_q<FP>(acc, 16, ql);
-    if (tid == 64) xyzzz_store_packed<FP>(s_pt, acc);
+    if ((tid & 63) == 0) xyzzz_store_packed<FP>(s_pts + (tid >> 6) * 4 * W, acc);
     __syncthreads();
-    if (tid < 4) {
-        if (windows > 16) acc = xyzzz_add_q<FP>(acc, xyzzz_load_packed<FP>(s_pt), ql);
+    if (tid < 64) {
+        acc = item < COMBINE_THREADS / 64 ? xyzzz_load_packed<FP>(s_pts + item * 4 * W) : xyzzz_identity<FP>();
+        acc = wave_sum_q<FP>(acc, COMBINE_THREADS / 64, ql);
         if (tid == 0) emit_affine<FP>(acc, out_xy, out_zero);
     }
 }
@@ -815,7 +823,10 @@ struct plk_msm_ctx {
     size_t n = 0;
     int c = 0;          // window bits
     int windows = 0;    // ceil((BITS + 1) / c)
-    uint32_t buckets = 0;  // 2^(c-1)
+    uint32_t buckets = 0;  // bucket slots: 2^(c-1) with tables; windows * 2^(c-1) (rounded up to whole partition bins) without
+    uint32_t wbuckets = 0; // 2^(c-1): buckets per window
+    bool table_free = false;  // no window tables: every window has its own buckets and is doubled into place at the end
+    void* win_pts = nullptr;  // table-free: the per-window results
     uint32_t slice = 32;   // entries per accumulation slice
     int planes = 0;        // = c: bit-planes of the bucket weights 1 .. 2^(c-1)
     int plane_blocks = 1;  // blocks (parts) per plane
@@ -847,7 +858,7 @@ struct plk_msm_ctx {
     std::vector<std::vector<hipEvent_t>> prof_sets;  // each N_STAGES + 1 events, recorded
     std::vector<std::vector<hipEvent_t>> prof_free;
     ~plk_msm_ctx() {
-        for (void* p : {tab, codes, sorted, hist, off, partial, bucket, plane_part, cnt1, cnt2, tmp_code, tmp_val, part_meta, heavy, heavy_part})
+        for (void* p : {tab, codes, sorted, hist, off, partial, bucket, plane_part, cnt1, cnt2, tmp_code, tmp_val, part_meta, heavy, heavy_part, win_pts})
             if (p) (void)hipFree(p);
         for (auto* v : {&prof_sets, &prof_free})
             for (auto& set : *v)
@@ -877,12 +888,10 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
     const size_t n = ctx->n;
     const size_t pt_bytes = (size_t)2 * FP::NL * 4, xyzz_bytes = (size_t)4 * FP::NL * 4;
     const size_t entries = n * ctx->windows;
-    PLK_HIP_TRY(hipMalloc(&ctx->tab, entries * pt_bytes + 16));
+    PLK_HIP_TRY(hipMalloc(&ctx->tab, (ctx->table_free ? n : entries) * pt_bytes + 16));
     PLK_HIP_TRY(hipMalloc(&ctx->codes, entries * 4 + 16));
     PLK_HIP_TRY(hipMalloc(&ctx->sorted, entries * 4 + 16));
     PLK_HIP_TRY(hipMalloc(&ctx->hist, (size_t)ctx->buckets * 4 + 16));
-    ctx->fine_bits = (ctx->c - 1) < 8 ? (ctx->c - 1) : 8;
-    ctx->nbins = 1 << (ctx->c - 1 - ctx->fine_bits);
     ctx->nt1 = (uint32_t)((entries + PART_TILE - 1) >> PART_TILE_LOG);
     if (ctx->nt1 == 0) ctx->nt1 = 1;
     ctx->nt2max = ctx->nt1 + ctx->nbins;
@@ -899,32 +908,62 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
     ctx->heavy_cap = (uint32_t)(ctx->max_slices / HEAVY_SLICES + ctx->max_slices / HEAVY_CHUNK + 2);
     PLK_HIP_TRY(hipMalloc(&ctx->heavy, (size_t)(2 + 3 * ctx->heavy_cap) * 4));
     PLK_HIP_TRY(hipMalloc(&ctx->heavy_part, (size_t)ctx->heavy_cap * xyzz_bytes));
-    PLK_HIP_TRY(hipMalloc(&ctx->plane_part, (size_t)ctx->planes * ctx->plane_blocks * xyzz_bytes));
+    const int bucket_windows = ctx->table_free ? ctx->windows : 1;
+    PLK_HIP_TRY(hipMalloc(&ctx->plane_part, (size_t)bucket_windows * ctx->planes * ctx->plane_blocks * xyzz_bytes));
+    if (ctx->table_free) PLK_HIP_TRY(hipMalloc(&ctx->win_pts, (size_t)ctx->windows * xyzz_bytes));
     if (n) {
         k_msm_table<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)ctx->tab, n, ctx->c,
-                                                                       ctx->windows);
+                                                                       ctx->table_free ? 1 : ctx->windows);
         PLK_HIP_TRY(hipGetLastError());
     }
     PLK_HIP_TRY(hipStreamSynchronize(stream));
     return PLK_OK;
 }
 
-int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, hipStream_t stream,
+// table-free window: windows * 2^(c-1) bucket slots must fit the 16 bits of the partition, long slices wanted
+static int choose_window_table_free(size_t n) {
+    int lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) ++lg;
+    int c = lg - 5;
+    if (const char* e = getenv("PLK_MSM_WINDOW_TF")) c = atoi(e);
+    if (c < 3) c = 3;
+    if (c > 12) c = 12;
+    return c;
+}
+
+int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, unsigned flags, hipStream_t stream,
                             plk_msm_ctx** out_ctx) {
     if (!out_ctx) return set_error(PLK_ERR_INVALID_ARG, "null out_ctx");
     *out_ctx = nullptr;
     if (curve < 0 || curve > 2) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (n && !d_bases) return set_error(PLK_ERR_INVALID_ARG, "null bases");
     PLK_TRY(ensure_device());
-    int c = window_bits ? (int)window_bits : choose_window(n ? n : 1);
+    const bool table_free = (flags & PLK_MSM_TABLE_FREE) != 0;
+    int c = window_bits ? (int)window_bits : (table_free ? choose_window_table_free(n ? n : 1) : choose_window(n ? n : 1));
     if (c < 2 || c > MSM_MAX_WINDOW) return set_error(PLK_ERR_INVALID_ARG, "window_bits %d outside [2, %d]", c, MSM_MAX_WINDOW);
+    if (table_free) {
+        const int w = (scalar_bits(curve) + 1 + c - 1) / c;
+        if (((size_t)w << (c - 1)) > 65536 || w > COMBINE_THREADS / 4)
+            return set_error(PLK_ERR_INVALID_ARG, "table-free mode: window_bits %d gives %d windows x %d buckets (limits: 65536 slots, %d windows)", c, w,
+                             1 << (c - 1), COMBINE_THREADS / 4);
+    }
     auto* ctx = new plk_msm_ctx();
+    ctx->table_free = table_free;
     PLK_HIP_TRY(hipGetDevice(&ctx->device));
     ctx->curve = curve;
     ctx->n = n;
     ctx->c = c;
     ctx->windows = (scalar_bits(curve) + 1 + c - 1) / c;
-    ctx->buckets = 1u << (c - 1);
+    ctx->wbuckets = 1u << (c - 1);
+    {
+        // partition geometry from the number of bucket slots: 8 fine bits, <= 256 coarse bins
+        const uint32_t want = ctx->table_free ? ctx->wbuckets * (uint32_t)ctx->windows : ctx->wbuckets;
+        int bits = 0;
+        while (((uint32_t)1 << bits) < want) ++bits;
+        ctx->fine_bits = bits < 8 ? bits : 8;
+        ctx->nbins = (int)((want + (1u << ctx->fine_bits) - 1) >> ctx->fine_bits);
+        ctx->buckets = (uint32_t)ctx->nbins << ctx->fine_bits;
+    }
     ctx->slice = MSM_SLICE_DEFAULT;
     if (const char* e = getenv("PLK_MSM_SLICE")) {
         int v = atoi(e);
@@ -932,7 +971,7 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     }
     ctx->planes = c;
     ctx->plane_blocks = 1;
-    while (ctx->plane_blocks < MSM_MAX_PLANE_PARTS && (uint32_t)ctx->plane_blocks * 2048u < ctx->buckets &&
+    while (ctx->plane_blocks < MSM_MAX_PLANE_PARTS && (uint32_t)ctx->plane_blocks * 2048u < ctx->wbuckets &&
            ctx->planes * ctx->plane_blocks * 4 <= FINAL_THREADS)  // after doubling: planes * parts / 2 quads in the final block
         ctx->plane_blocks *= 2;
     if (n * (size_t)ctx->windows >= ((size_t)1 << 31)) {
@@ -982,7 +1021,8 @@ static int msm_execute_t(plk_msm_ctx* ctx, const void* d_scalars, void* d_out_xy
     };
     mark();
     if (n) {
-        k_msm_digits<C><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const uint4*)d_scalars, (uint32_t*)ctx->codes, n, ctx->c, ctx->windows);
+        k_msm_digits<C><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const uint4*)d_scalars, (uint32_t*)ctx->codes, n, ctx->c, ctx->windows,
+                                                                         ctx->table_free ? ctx->wbuckets : 0u);
         PLK_HIP_TRY(hipGetLastError());
     }
     mark();
@@ -1009,7 +1049,8 @@ static int msm_execute_t(plk_msm_ctx* ctx, const void* d_scalars, void* d_out_xy
     mark();
     // the slice count is only known on the device: launch for the upper bound, lanes past it exit
     k_msm_accumulate<C><<<(unsigned)((ctx->max_slices + 127) / 128), 128, 0, stream>>>((const uint4*)ctx->tab, (const uint32_t*)ctx->sorted, off, slice_off,
-                                                                                       (uint4*)ctx->partial, buckets, ctx->slice);
+                                                                                       (uint4*)ctx->partial, buckets, ctx->slice, ctx->table_free ? ctx->c - 1 : 31,
+                                                                                       ctx->table_free ? (uint32_t)n : 0u);
     PLK_HIP_TRY(hipGetLastError());
     mark();
     k_msm_bucket_sum<C><<<(buckets * BUCKET_LANES + 255) / 256, 256, 0, stream>>>((const uint4*)ctx->partial, slice_off, (uint4*)ctx->bucket, buckets);
@@ -1020,12 +1061,15 @@ static int msm_execute_t(plk_msm_ctx* ctx, const void* d_scalars, void* d_out_xy
     k_msm_heavy_final<C><<<64, 256, 0, stream>>>(slice_off, (const uint32_t*)ctx->heavy, ctx->heavy_cap, (const uint4*)ctx->heavy_part, (uint4*)ctx->bucket);
     PLK_HIP_TRY(hipGetLastError());
     mark();
-    dim3 pg(ctx->plane_blocks, ctx->planes, 1);
-    k_msm_planes<C><<<pg, PLANE_THREADS, 0, stream>>>((const uint4*)ctx->bucket, (uint4*)ctx->plane_part, buckets);
+    const int bucket_windows = ctx->table_free ? ctx->windows : 1;
+    dim3 pg(ctx->plane_blocks, ctx->planes, bucket_windows);
+    k_msm_planes<C><<<pg, PLANE_THREADS, 0, stream>>>((const uint4*)ctx->bucket, (uint4*)ctx->plane_part, ctx->wbuckets);
     PLK_HIP_TRY(hipGetLastError());
     mark();
-    k_msm_final<C><<<1, FINAL_THREADS, 0, stream>>>((const uint4*)ctx->plane_part, ctx->plane_blocks, ctx->planes, ctx->c, nullptr, (uint4*)d_out_xy,
-                                                    (uint8_t*)d_out_zero);
+    k_msm_final<C><<<bucket_windows, FINAL_THREADS, 0, stream>>>((const uint4*)ctx->plane_part, ctx->plane_blocks, ctx->planes, ctx->c, (uint4*)ctx->win_pts,
+                                                                 (uint4*)d_out_xy, (uint8_t*)d_out_zero);
+    if (bucket_windows > 1)
+        k_msm_combine<C><<<1, COMBINE_THREADS, 0, stream>>>((const uint4*)ctx->win_pts, ctx->windows, (uint4*)d_out_xy, (uint8_t*)d_out_zero);
     PLK_HIP_TRY(hipGetLastError());
     mark();
     if (!ev.empty()) ctx->prof_sets.push_back(ev);

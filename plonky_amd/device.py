@@ -100,13 +100,14 @@ def gen_bases_dev(curve, n, g0_xy, d_xy, first=0, device="cuda"):
     return out
 
 
-def msm_precompute_dev(curve, bases, w=11, zero=None, device_window=0):
-    """bases: (n, 2, L) int64 CUDA tensor."""
+def msm_precompute_dev(curve, bases, w=11, zero=None, device_window=0, table_free=False):
+    """bases: (n, 2, L) int64 CUDA tensor.  table_free: no window tables (generators used once or a few times)."""
     assert bases.is_cuda and bases.dtype == torch.int64 and bases.is_contiguous()
     n = bases.shape[0]
     ctx = ctypes.c_void_p()
     zp = ctypes.c_void_p(zero.data_ptr()) if zero is not None else None
-    _lib.check(_lib.load().plk_msm_precompute_dev(curve, n, ctypes.c_void_p(bases.data_ptr()), zp, device_window, _stream(), ctypes.byref(ctx)))
+    _lib.check(_lib.load().plk_msm_precompute_dev_ex(curve, n, ctypes.c_void_p(bases.data_ptr()), zp, device_window, 1 if table_free else 0,
+                                                     _stream(), ctypes.byref(ctx)))
     return MsmPrecomputation(curve, ctx, n, w)
 
 

@@ -43,6 +43,8 @@ SYMBOLS = [
     ("plk_poly_mul_dev", _i, [_i, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
     ("plk_msm_precompute", _i, [_i, _sz, _vp, _vp, _u, _vp]),
     ("plk_msm_precompute_dev", _i, [_i, _sz, _vp, _vp, _u, _vp, _vp]),
+    ("plk_msm_precompute_ex", _i, [_i, _sz, _vp, _vp, _u, _u, _vp]),
+    ("plk_msm_precompute_dev_ex", _i, [_i, _sz, _vp, _vp, _u, _u, _vp, _vp]),
     ("plk_msm_free", _i, [_vp]),
     ("plk_msm_ctx_len", _sz, [_vp]),
     ("plk_msm_ctx_window", _u, [_vp]),

@@ -238,6 +238,36 @@ def test_msm_matches_oracle(c, n, win):
     pre = pa.msm_precompute(c.curve_id, bases, 8, device_window=win)
     got, gz = pa.msm_execute_parallel(pre, scalars)
     assert gz == ez and np.array_equal(got, expected)
+    # the table-free mode (every window its own buckets, doubled into place at the end): same point
+    if win <= 12:
+        pre_tf = pa.msm_precompute(c.curve_id, bases, 8, device_window=win, table_free=True)
+        got, gz = pa.msm_execute_parallel(pre_tf, scalars)
+        assert gz == ez and np.array_equal(got, expected)
+        got, gz = pa.msm_execute_parallel(pre_tf, scalars)  # the context is reusable
+        assert gz == ez and np.array_equal(got, expected)
+
+
+def test_msm_parallel_one_shot():
+    """msm_parallel (curve_msm.rs:54-61; the call of the IPA rounds, halo.rs:87-91, window 8 there): fresh generators,
+    one execution -> the table-free path, against the oracle's msm_parallel at the reference's window."""
+    c = br.TWEEDLEDEE
+    G = (c.gx, c.gy)
+    D = br.ec_mul(c, 99991, G)
+    for n in (2, 64, 1 << 12):
+        bases = ol.gen_bases(0, n, _bases(c, [G])[0], _bases(c, [D])[0])
+        scalars = synth.rand_field(c.scalar.field_id, 0x1A0000 + n, n)
+        expected, ez = ol.MsmPrecomputation(0, bases, 8, threads=8).execute(scalars, parallel=True, threads=8)
+        got, gz = pa.msm_parallel(0, scalars, bases, 8)
+        assert gz == ez and np.array_equal(got, expected)
+    # skewed digits and identity inputs through the table-free buckets
+    n = 1 << 12
+    bases = ol.gen_bases(0, n, _bases(c, [G])[0], _bases(c, [D])[0])
+    scalars = mont_arr(c.scalar, [(i % 3) for i in range(n)])
+    zero = np.zeros(n, dtype=np.uint8)
+    zero[7] = 1
+    expected, ez = ol.MsmPrecomputation(0, bases, 8, zero=zero, threads=8).execute(scalars, parallel=True, threads=8)
+    got, gz = pa.msm_parallel(0, scalars, bases, 8, zero=zero)
+    assert gz == ez and np.array_equal(got, expected)
 
 
 def test_msm_skewed_digits():
@@ -311,6 +341,13 @@ def test_msm_2p20_closed_form():
     torch.cuda.synchronize()
     got = dev.to_host(oxy).reshape(2, 4)
     exp = closed_form_msm(0, scal, G, D)
+    assert int(oz.cpu()[0]) == 0 and tuple(from_mont_arr(c.base, got)) == exp
+    # the same MSM without tables (one-shot mode)
+    pre.free()
+    pre_tf = dev.msm_precompute_dev(0, bases, table_free=True)
+    oxy, oz = dev.msm_execute_dev(pre_tf, dev.to_device(scal))
+    torch.cuda.synchronize()
+    got = dev.to_host(oxy).reshape(2, 4)
     assert int(oz.cpu()[0]) == 0 and tuple(from_mont_arr(c.base, got)) == exp
 
 
