@@ -281,6 +281,35 @@ def main():
         tm = (time.perf_counter() - t1) / args.steps
         comp["msm_ms"] = tm * 1e3
         comp["msm_mpairs_per_s"] = world * n / tm / 1e6
+    if do_msm_c:
+        # commit_polynomials (plonk_util.rs:215-231): the 9 wire polynomials against the same generators, one call
+        sb = s.unsqueeze(0).repeat(9, 1, 1).contiguous()
+        oxy9 = torch.empty((9, 2, 4), dtype=torch.int64, device="cuda")
+        oz9 = torch.empty((9,), dtype=torch.uint8, device="cuda")
+        dev.msm_execute_dev(pre, sb, oxy9, oz9)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(max(1, args.steps // 4)):
+            dev.msm_execute_dev(pre, sb, oxy9, oz9)
+        sync()
+        tb = (time.perf_counter() - t1) / max(1, args.steps // 4)
+        comp["msm_batch9_ms"] = tb * 1e3
+        comp["msm_batch9_mpairs_per_s"] = world * 9 * n / tb / 1e6
+        if not args.no_check:
+            comp["_b9_check"] = bool(torch.equal(oxy9, oxy.expand(9, 2, 4)) and int(oz9.sum().item()) == 0)
+        del sb
+        # msm_parallel (curve_msm.rs:54-61): generators used once -> precompute included, table-free mode
+        sync()
+        t1 = time.perf_counter()
+        reps = max(1, args.steps // 4)
+        for _ in range(reps):
+            pre1 = dev.msm_precompute_dev(CURVE, bases, table_free=True)
+            dev.msm_execute_dev(pre1, s, oxy9[:1], oz9[:1])
+            sync()
+            pre1.free()
+        comp["msm_parallel_one_shot_ms"] = (time.perf_counter() - t1) / reps * 1e3
+        if not args.no_check:
+            comp["_os_check"] = bool(torch.equal(oxy9[:1], oxy) and int(oz9[0].item()) == 0)
     if do_msm:
         comp["msm_window_bits"] = pre.window
         comp["msm_stage_ms"] = dict(zip(["digits", "partition", "scan_scatter", "accumulate", "bucket_sum", "planes", "final"],
@@ -299,6 +328,10 @@ def main():
             exp = closed_form_msm(CURVE, s_host, G, D, first=first)
             gotp = (synth.from_mont(0, got[0]), synth.from_mont(0, got[1]))
             checks["msm_closed_form_bit_exact"] = bool(int(oz.cpu()[0]) == 0 and gotp == exp)
+            if "_b9_check" in comp:
+                checks["msm_batch9_equals_single"] = comp.pop("_b9_check")
+            if "_os_check" in comp:
+                checks["msm_one_shot_equals_tabled"] = comp.pop("_os_check")
             if world > 1:
                 tot_xy = torch.empty((1, 2, 4), dtype=torch.int64, device="cuda")
                 tot_z = torch.empty((1,), dtype=torch.uint8, device="cuda")
