@@ -834,12 +834,13 @@ struct MsmWork {
     void* heavy_part = nullptr;
     void* plane_part = nullptr;
     void* win_pts = nullptr;   // table-free: the per-window results
+    void* slab = nullptr;      // the one allocation all of the above point into
     bool ready = false;
     void release() {
-        for (void** p : {&codes, &sorted, &hist, &cnt1, &cnt2, &tmp_code, &tmp_val, &part_meta, &off, &partial, &bucket, &heavy, &heavy_part, &plane_part, &win_pts}) {
-            if (*p) (void)hipFree(*p);
+        if (slab) (void)hipFree(slab);
+        slab = nullptr;
+        for (void** p : {&codes, &sorted, &hist, &cnt1, &cnt2, &tmp_code, &tmp_val, &part_meta, &off, &partial, &bucket, &heavy, &heavy_part, &plane_part, &win_pts})
             *p = nullptr;
-        }
         ready = false;
     }
 };
@@ -905,32 +906,44 @@ static int choose_window(size_t n) {
     return c;
 }
 
+// One slab per workspace: a single hipMalloc / hipFree instead of fifteen (they dominate a one-shot msm_parallel).
 template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w) {
     using FP = typename C::FP;
     const size_t xyzz_bytes = (size_t)4 * FP::NL * 4;
     const size_t entries = ctx->n * ctx->windows;
-    PLK_HIP_TRY(hipMalloc(&w.codes, entries * 4 + 16));
-    PLK_HIP_TRY(hipMalloc(&w.sorted, entries * 4 + 16));
-    PLK_HIP_TRY(hipMalloc(&w.hist, (size_t)ctx->buckets * 4 + 16));
     ctx->nt1 = (uint32_t)((entries + PART_TILE - 1) >> PART_TILE_LOG);
     if (ctx->nt1 == 0) ctx->nt1 = 1;
     ctx->nt2max = ctx->nt1 + ctx->nbins;
-    PLK_HIP_TRY(hipMalloc(&w.cnt1, (size_t)ctx->nbins * ctx->nt1 * 4));
-    PLK_HIP_TRY(hipMalloc(&w.cnt2, ((size_t)1 << ctx->fine_bits) * ctx->nt2max * 4));
-    PLK_HIP_TRY(hipMalloc(&w.tmp_code, ((size_t)ctx->nt2max << PART_TILE_LOG) * 4));
-    PLK_HIP_TRY(hipMalloc(&w.tmp_val, ((size_t)ctx->nt2max << PART_TILE_LOG) * 4));
-    PLK_HIP_TRY(hipMalloc(&w.part_meta, (size_t)(256 + 257 + 1 + ctx->nt2max + 2 * 64 + 2) * 4));  // + block totals of the bucket scan
-    PLK_HIP_TRY(hipMalloc(&w.off, ((size_t)ctx->buckets + 1) * 8));
     ctx->max_slices = entries / ctx->slice + ctx->buckets + 1;
-    PLK_HIP_TRY(hipMalloc(&w.partial, ctx->max_slices * xyzz_bytes));
-    PLK_HIP_TRY(hipMalloc(&w.bucket, (size_t)ctx->buckets * xyzz_bytes));
     // at most max_slices / HEAVY_SLICES heavy buckets, max_slices / HEAVY_CHUNK + that many chunk items
     ctx->heavy_cap = (uint32_t)(ctx->max_slices / HEAVY_SLICES + ctx->max_slices / HEAVY_CHUNK + 2);
-    PLK_HIP_TRY(hipMalloc(&w.heavy, (size_t)(2 + 3 * ctx->heavy_cap) * 4));
-    PLK_HIP_TRY(hipMalloc(&w.heavy_part, (size_t)ctx->heavy_cap * xyzz_bytes));
     const int bucket_windows = ctx->table_free ? ctx->windows : 1;
-    PLK_HIP_TRY(hipMalloc(&w.plane_part, (size_t)bucket_windows * ctx->planes * ctx->plane_blocks * xyzz_bytes));
-    if (ctx->table_free) PLK_HIP_TRY(hipMalloc(&w.win_pts, (size_t)ctx->windows * xyzz_bytes));
+    struct Part { void** p; size_t bytes; };
+    const Part parts[] = {
+        {&w.codes, entries * 4 + 16},
+        {&w.sorted, entries * 4 + 16},
+        {&w.hist, (size_t)ctx->buckets * 4 + 16},
+        {&w.cnt1, (size_t)ctx->nbins * ctx->nt1 * 4},
+        {&w.cnt2, ((size_t)1 << ctx->fine_bits) * ctx->nt2max * 4},
+        {&w.tmp_code, ((size_t)ctx->nt2max << PART_TILE_LOG) * 4},
+        {&w.tmp_val, ((size_t)ctx->nt2max << PART_TILE_LOG) * 4},
+        {&w.part_meta, (size_t)(256 + 257 + 1 + ctx->nt2max + 2 * 64 + 2) * 4},  // + block totals of the bucket scan
+        {&w.off, ((size_t)ctx->buckets + 1) * 8},
+        {&w.partial, ctx->max_slices * xyzz_bytes},
+        {&w.bucket, (size_t)ctx->buckets * xyzz_bytes},
+        {&w.heavy, (size_t)(2 + 3 * ctx->heavy_cap) * 4},
+        {&w.heavy_part, (size_t)ctx->heavy_cap * xyzz_bytes},
+        {&w.plane_part, (size_t)bucket_windows * ctx->planes * ctx->plane_blocks * xyzz_bytes},
+        {&w.win_pts, ctx->table_free ? (size_t)ctx->windows * xyzz_bytes : 0},
+    };
+    size_t total = 0;
+    for (const Part& pt : parts) total += (pt.bytes + 255) & ~(size_t)255;
+    PLK_HIP_TRY(hipMalloc(&w.slab, total + 256));
+    uint8_t* cur = (uint8_t*)w.slab;
+    for (const Part& pt : parts) {
+        *pt.p = pt.bytes ? cur : nullptr;
+        cur += (pt.bytes + 255) & ~(size_t)255;
+    }
     w.ready = true;
     return PLK_OK;
 }

@@ -393,3 +393,47 @@ def test_msm_heavy_buckets_closed_form():
     got = dev.to_host(oxy).reshape(2, 4)
     exp = closed_form_msm(0, scal, G, D)
     assert int(oz.cpu()[0]) == 0 and tuple(from_mont_arr(c.base, got)) == exp
+
+
+def test_concurrent_callers():
+    """the reference's callers invoke these functions concurrently from Rayon workers
+    (plonk_util.rs:173-189, halo.rs:119-123).  Eight host threads hammer NTTs, a shared MSM context, their own
+    one-shot MSMs and divide_by_z_h at the same time; every result must be the single-threaded one."""
+    import threading
+
+    f = br.TWEEDLEDEE_BASE
+    c = br.TWEEDLEDEE
+    G = (c.gx, c.gy)
+    D = br.ec_mul(c, 424242, G)
+    n = 1 << 10
+    bases = ol.gen_bases(0, n, _bases(c, [G])[0], _bases(c, [D])[0])
+    shared = pa.msm_precompute(0, bases, 8)
+    xs = [synth.rand_field(f.field_id, 0x7000 + t, 1 << (8 + t % 4)) for t in range(8)]
+    ss = [synth.rand_field(c.scalar.field_id, 0x7100 + t, n) for t in range(8)]
+    qs = [synth.rand_field(f.field_id, 0x7200 + t, 300 + 17 * t) for t in range(8)]
+    want_ntt = [pa.fft_with_precomputation_power_of_2(x, pa.fft_precompute(f.field_id, x.shape[0])) for x in xs]
+    want_msm = [pa.msm_execute_parallel(shared, s) for s in ss]
+    from tests.test_gpu_poly import mul_by_z_h_mont
+    ms = [mul_by_z_h_mont(f, q, 64) for q in qs]
+    errors = []
+
+    def worker(t):
+        try:
+            for _ in range(6):
+                x = xs[t]
+                assert np.array_equal(pa.fft_with_precomputation_power_of_2(x, pa.fft_precompute(f.field_id, x.shape[0])), want_ntt[t])
+                got, gz = pa.msm_execute_parallel(shared, ss[t])
+                assert gz == want_msm[t][1] and np.array_equal(got, want_msm[t][0])
+                got, gz = pa.msm_parallel(0, ss[t], bases, 8)
+                assert gz == want_msm[t][1] and np.array_equal(got, want_msm[t][0])
+                q = pa.polynomial_divide_by_z_h(f.field_id, ms[t], 64)
+                assert np.array_equal(q[: qs[t].shape[0]], qs[t]) and not q[qs[t].shape[0]:].any()
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
