@@ -49,6 +49,26 @@ def main():
         bases = np.stack([arr([c.base.to_mont(P[0]), c.base.to_mont(P[1])], L) for P in pts])
         expect = arr([c.base.to_mont(res[0]), c.base.to_mont(res[1])], L)
         np.savez(os.path.join(OUT, "msm_%s_24.npz" % c.name), curve=c.curve_id, bases=bases, scalars=s, expected_xy=expect, expected_zero=0)
+    # polynomial callers: m = q * (X^n - 1) with n = 12 (not a power of two: 64 distinct denominators) and the
+    # product of two short polynomials, per NTT field; expected values by exact synthetic division / schoolbook
+    for f in (br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR):
+        q = [f.from_mont(synth.to_int(r)) for r in synth.rand_field(f.field_id, 0x601D2000 + f.field_id, 37)]
+        n = 12
+        m = [0] * (len(q) + n)
+        for i, cq in enumerate(q):
+            m[i + n] = (m[i + n] + cq) % f.p
+            m[i] = (m[i] - cq) % f.p
+        quot = br.poly_divide_by_z_h_exact(f, m, n)
+        assert quot == q
+        size = 1 << (len(m) - 1).bit_length()
+        a = [f.from_mont(synth.to_int(r)) for r in synth.rand_field(f.field_id, 0x601D3000 + f.field_id, 21)]
+        b = [f.from_mont(synth.to_int(r)) for r in synth.rand_field(f.field_id, 0x601D4000 + f.field_id, 30)]
+        prod = br.poly_mul_schoolbook(f, a, b)
+        psize = 1 << (len(prod) - 1).bit_length()
+        np.savez(os.path.join(OUT, "poly_%s.npz" % f.name), field=f.field_id, n=n,
+                 numerator=arr([f.to_mont(v) for v in m], 4), quotient=arr([f.to_mont(v) for v in quot + [0] * (size - len(quot))], 4),
+                 a=arr([f.to_mont(v) for v in a], 4), b=arr([f.to_mont(v) for v in b], 4),
+                 product=arr([f.to_mont(v) for v in prod + [0] * (psize - len(prod))], 4))
     print("golden vectors written to", OUT)
 
 

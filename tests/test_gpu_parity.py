@@ -356,6 +356,10 @@ def test_golden_vectors():
     import glob
     import os
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for path in sorted(glob.glob(os.path.join(gold, "poly_*.npz"))):
+        g = np.load(path)
+        assert np.array_equal(pa.polynomial_divide_by_z_h(int(g["field"]), g["numerator"], int(g["n"])), g["quotient"]), path
+        assert np.array_equal(pa.polynomial_mul(int(g["field"]), g["a"], g["b"]), g["product"]), path
     for path in sorted(glob.glob(os.path.join(gold, "ntt_*.npz"))):
         g = np.load(path)
         pre = pa.fft_precompute(int(g["field"]), g["input"].shape[0])
