@@ -238,20 +238,29 @@ __global__ void __launch_bounds__(256) k_part_rowscan(uint32_t* __restrict__ cnt
 __global__ void __launch_bounds__(256) k_part_bases(const uint32_t* __restrict__ bin_total, int nbins, uint32_t* __restrict__ bin_base_pad,
                                                     uint32_t* __restrict__ tile2bin, uint32_t* __restrict__ meta) {
     __shared__ uint32_t s_pad[257];
-    if (threadIdx.x == 0) {
-        uint32_t pad = 0;
-        for (int b = 0; b < nbins; ++b) {
-            s_pad[b] = pad;
-            pad += (bin_total[b] + PART_TILE - 1) >> PART_TILE_LOG << PART_TILE_LOG;
-        }
-        s_pad[nbins] = pad;
-        meta[0] = pad >> PART_TILE_LOG;
+    __shared__ uint32_t s_scan[256];
+    // exclusive scan of the bins' sizes rounded up to whole tiles (nbins <= 256 = blockDim.x)
+    const int t = threadIdx.x;
+    const uint32_t mine = t < nbins ? (bin_total[t] + PART_TILE - 1) >> PART_TILE_LOG << PART_TILE_LOG : 0u;
+    s_scan[t] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t u = t >= d ? s_scan[t - d] : 0u;
+        __syncthreads();
+        s_scan[t] += u;
+        __syncthreads();
+    }
+    if (t < nbins) s_pad[t] = s_scan[t] - mine;
+    if (t == nbins - 1) {
+        s_pad[nbins] = s_scan[t];
+        meta[0] = s_scan[t] >> PART_TILE_LOG;
     }
     __syncthreads();
     for (int b = threadIdx.x; b <= nbins; b += blockDim.x) bin_base_pad[b] = s_pad[b];
-    for (int b = 0; b < nbins; ++b) {
-        const uint32_t t0 = s_pad[b] >> PART_TILE_LOG, t1 = s_pad[b + 1] >> PART_TILE_LOG;
-        for (uint32_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) tile2bin[t] = (uint32_t)b;
+    // every thread fills the tiles of its own bin
+    if (t < nbins) {
+        const uint32_t t0 = s_pad[t] >> PART_TILE_LOG, t1 = s_pad[t + 1] >> PART_TILE_LOG;
+        for (uint32_t k = t0; k < t1; ++k) tile2bin[k] = (uint32_t)t;
     }
 }
 
