@@ -157,6 +157,17 @@ int plk_msm(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_z
  * point addition is not an RCCL reduction op).  Host pointers. */
 int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint8_t* pts_zero, uint64_t* out_xy, uint8_t* out_zero);
 
+/* ---- IPA generator fold  (src/halo.rs:119-123) ------------------------------------------------ */
+/* out_i = [scalar_lo] lo_i + [scalar_hi] hi_i for i < m: the fold G' = [u^-1] G_lo + [u] G_hi of an inner-product-
+ * argument round, which the reference computes as m calls of msm_parallel(&[u_inv, u], &[g_lo_i, g_hi_i], 4).
+ * Points are affine (m * 2L limbs, Montgomery) with optional identity flags (m bytes or NULL); the two scalars
+ * are 4 limbs each, Montgomery form in the curve's SCALAR field, host pointers in both forms of the call.
+ * Results are the unique affine points (+ identity flags), as for the MSM. */
+int plk_curve_fold_pairs(int curve, size_t m, const uint64_t* lo_xy, const uint8_t* lo_zero, const uint64_t* hi_xy, const uint8_t* hi_zero,
+                         const uint64_t* scalar_lo, const uint64_t* scalar_hi, uint64_t* out_xy, uint8_t* out_zero);
+int plk_curve_fold_pairs_dev(int curve, size_t m, const void* d_lo_xy, const void* d_lo_zero, const void* d_hi_xy, const void* d_hi_zero,
+                             const uint64_t* scalar_lo, const uint64_t* scalar_hi, void* d_out_xy, void* d_out_zero, void* stream);
+
 /* ---- self-test ------------------------------------------------------------------------------ */
 /* Runs the quad-cooperative point arithmetic of the MSM reduction tail (ecz_coop.cuh) against the one-lane
  * arithmetic on the n affine points pts_xy (n * 2L limbs, Montgomery), `quads` quads cycling through 8 cases

@@ -279,6 +279,24 @@ def msm_parallel(curve, scalars, generators, w, zero=None):
         pre.free()
 
 
+def fold_generators(curve, g_lo, g_hi, scalar_lo, scalar_hi, lo_zero=None, hi_zero=None):
+    """The generator fold of an IPA round (halo.rs:119-123): out_i = [scalar_lo] g_lo_i + [scalar_hi] g_hi_i, where the
+    reference calls msm_parallel(&[u_inv, u], &[g_lo_i, g_hi_i], 4) per pair.  Points (m, 2, L) affine Montgomery
+    limbs, scalars (4,) Montgomery limbs in the curve's scalar field.  Returns (out (m, 2, L), zero flags (m,))."""
+    lo, hi = _points(curve, g_lo), _points(curve, g_hi)
+    m = lo.shape[0]
+    assert hi.shape[0] == m
+    a = np.ascontiguousarray(scalar_lo, dtype=np.uint64).reshape(4)
+    b = np.ascontiguousarray(scalar_hi, dtype=np.uint64).reshape(4)
+    lz = None if lo_zero is None else np.ascontiguousarray(lo_zero, dtype=np.uint8)
+    hz = None if hi_zero is None else np.ascontiguousarray(hi_zero, dtype=np.uint8)
+    out = np.zeros_like(lo)
+    oz = np.zeros(m, dtype=np.uint8)
+    _lib.check(_lib.load().plk_curve_fold_pairs(curve, m, _ptr(lo), _ptr(lz) if lz is not None else None, _ptr(hi),
+                                                _ptr(hz) if hz is not None else None, _ptr(a), _ptr(b), _ptr(out), _ptr(oz)))
+    return out, oz
+
+
 def curve_sum_affine(curve, points, zero=None):
     """Adds k affine points (per-GPU partial MSM results after the all-gather)."""
     p = _points(curve, points)

@@ -18,6 +18,8 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void* d_zero, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_gen_bases_dev_impl(int curve, size_t n, uint64_t first, const void* d_g0d, void* d_out, hipStream_t stream);
+int curve_fold_pairs_dev_impl(int curve, size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero,
+                              const uint64_t* a_mont, const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int selftest_quad_dev_impl(int curve, const void* d_pts, uint32_t n, uint32_t quads, uint32_t* counts);
 int msm_set_profiling_impl(plk_msm_ctx* ctx, int enable);
 int msm_get_timings_impl(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls);
@@ -426,6 +428,46 @@ int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint
     PLK_HIP_TRY(hipStreamSynchronize(nullptr));
     PLK_HIP_TRY(hipMemcpy(out_xy, dxy.p, 2 * L * 8, hipMemcpyDeviceToHost));
     PLK_HIP_TRY(hipMemcpy(out_zero, doz.p, 1, hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+
+// ---- IPA generator fold ----
+int plk_curve_fold_pairs_dev(int curve, size_t m, const void* d_lo_xy, const void* d_lo_zero, const void* d_hi_xy, const void* d_hi_zero,
+                             const uint64_t* scalar_lo, const uint64_t* scalar_hi, void* d_out_xy, void* d_out_zero, void* stream) {
+    return curve_fold_pairs_dev_impl(curve, m, d_lo_xy, d_lo_zero, d_hi_xy, d_hi_zero, scalar_lo, scalar_hi, d_out_xy, d_out_zero, as_stream(stream));
+}
+
+int plk_curve_fold_pairs(int curve, size_t m, const uint64_t* lo_xy, const uint8_t* lo_zero, const uint64_t* hi_xy, const uint8_t* hi_zero,
+                         const uint64_t* scalar_lo, const uint64_t* scalar_hi, uint64_t* out_xy, uint8_t* out_zero) {
+    const int L = curve_limbs(curve);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (m && (!lo_xy || !hi_xy || !out_xy || !out_zero)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    const size_t pb = m * 2 * L * 8;
+    DevBuf dlo, dhi, dlz, dhz, dout, doz;
+    PLK_TRY(dlo.alloc(pb));
+    PLK_TRY(dhi.alloc(pb));
+    PLK_TRY(dout.alloc(pb));
+    PLK_TRY(doz.alloc(m));
+    if (m) {
+        PLK_HIP_TRY(hipMemcpy(dlo.p, lo_xy, pb, hipMemcpyHostToDevice));
+        PLK_HIP_TRY(hipMemcpy(dhi.p, hi_xy, pb, hipMemcpyHostToDevice));
+    }
+    if (lo_zero) {
+        PLK_TRY(dlz.alloc(m));
+        if (m) PLK_HIP_TRY(hipMemcpy(dlz.p, lo_zero, m, hipMemcpyHostToDevice));
+    }
+    if (hi_zero) {
+        PLK_TRY(dhz.alloc(m));
+        if (m) PLK_HIP_TRY(hipMemcpy(dhz.p, hi_zero, m, hipMemcpyHostToDevice));
+    }
+    PLK_TRY(curve_fold_pairs_dev_impl(curve, m, dlo.p, lo_zero ? dlz.p : nullptr, dhi.p, hi_zero ? dhz.p : nullptr, scalar_lo, scalar_hi, dout.p, doz.p,
+                                      nullptr));
+    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
+    if (m) {
+        PLK_HIP_TRY(hipMemcpy(out_xy, dout.p, pb, hipMemcpyDeviceToHost));
+        PLK_HIP_TRY(hipMemcpy(out_zero, doz.p, m, hipMemcpyDeviceToHost));
+    }
     return PLK_OK;
 }
 

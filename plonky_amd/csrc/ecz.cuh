@@ -161,6 +161,24 @@ template <class FP> PLK_DI XyzzZ<FP> xyzzz_load_packed(const uint4* src) {
     r.inf = fe_is_zero<FP>(p.zz);
     return r;
 }
+// back to the reference's form, then ProjectivePoint::to_affine (curve.rs:206-214)
+template <class FP> PLK_DI void emit_affine(const XyzzZ<FP>& acc, uint4* out_xy, uint8_t* out_zero) {
+    constexpr int W = FP::NL / 4;
+    Xyzz<FP> r = xyzz_identity<FP>();
+    if (!acc.inf) {
+        const Fz<FP> back = fz_const_rprime_to_r<FP>();
+        r.x = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.x, back));
+        r.y = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.y, back));
+        r.zz = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zz, back));
+        r.zzz = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zzz, back));
+    }
+    Fe<FP> x, y;
+    bool ident = xyzz_to_affine<FP, true>(r, x, y);
+    fe_store<FP>(out_xy, x);
+    fe_store<FP>(out_xy + W, y);
+    *out_zero = ident ? 1 : 0;
+}
+
 // the other lane's point (xor butterfly inside a wave)
 template <class FP> PLK_DI XyzzZ<FP> xyzzz_shfl_xor(const XyzzZ<FP>& a, int mask) {
     XyzzZ<FP> r;

@@ -1,0 +1,205 @@
+// fold.hip -- the generator fold of an inner-product-argument round:
+//   G'_i = [a] G_lo_i + [b] G_hi_i   for every i, the same two scalars for all pairs
+// (halo.rs:119-123: `msm_parallel(&[u_j_inv, u_j], &[g_lo_i, g_hi_i], 4)` per pair, n/2 pairs per round).
+//
+// One lane per pair, lazy 29-bit-limb arithmetic (ecz.cuh).  The two scalars are recoded ONCE on the host
+// into their joint sparse form (Solinas): digit pairs in {-1,0,1}^2 with on average half of the columns
+// empty; every lane then walks the same columns (no divergence: the branch on the digit pair is uniform),
+// doubling its accumulator and adding one of +-P, +-Q, +-(P+Q), +-(P-Q).  P+Q and P-Q are affine and share
+// one inversion (same denominator x_Q - x_P).  ~255 doublings + ~128 mixed additions + 2 inversions per pair.
+// The result is the unique affine point, as everywhere on this boundary.
+#include <vector>
+
+#include "common.h"
+#include "ec.cuh"
+#include "ecz.cuh"
+#include "tables.cuh"
+
+namespace plk {
+
+constexpr int FOLD_MAX_COLS = 264;
+
+struct FoldDigits {
+    int cols;                       // number of columns, most significant first
+    int8_t d[FOLD_MAX_COLS];        // (da + 1) * 3 + (db + 1): 4 = empty column
+};
+
+template <class FP> struct AffZ {  // affine point in R'-form, canonical; ident = the identity
+    Fz<FP> x, y;
+    bool ident;
+};
+
+// R-form affine pair -> P + Q and P - Q (affine, R'-form) with one inversion
+template <class FP> PLK_DI void sum_and_diff(const Fe<FP>& px, const Fe<FP>& py, bool pi, const Fe<FP>& qx, const Fe<FP>& qy, bool qi, AffZ<FP>& P,
+                                             AffZ<FP>& Q, AffZ<FP>& S, AffZ<FP>& D) {
+    auto rp = [](const Fe<FP>& v) { return fz_from_fe<FP>(to_rprime<FP>(v)); };
+    P.x = rp(px); P.y = rp(py); P.ident = pi;
+    Q.x = rp(qx); Q.y = rp(qy); Q.ident = qi;
+    if (pi || qi) {
+        // P + Q = the other one (or nothing), P - Q = P or -Q
+        S = pi ? Q : P;
+        D = qi ? P : Q;
+        if (!qi) D.y = fz_from_fe<FP>(to_rprime<FP>(fe_neg<FP>(qy)));
+        S.ident = pi && qi;
+        D.ident = pi && qi;
+        return;
+    }
+    const Fe<FP> dx = fe_sub<FP>(qx, px);
+    if (fe_is_zero<FP>(dx)) {
+        // same x: Q = P or Q = -P.  The non-trivial one of P + Q / P - Q is 2P (tangent), the other the identity.
+        const bool same = fe_is_zero<FP>(fe_sub<FP>(qy, py));
+        AffZ<FP> two;
+        if (fe_is_zero<FP>(py)) {
+            two = P;
+            two.ident = true;  // 2-torsion
+        } else {
+            // lambda = 3 x^2 / 2 y  (a = 0, curve.rs:112-135)
+            const Fe<FP> xx = fe_sqr<FP>(px);
+            const Fe<FP> lam = fe_mul<FP>(fe_add<FP>(fe_dbl<FP>(xx), xx), fe_inv_safegcd<FP>(fe_dbl<FP>(py)));
+            const Fe<FP> x3 = fe_sub<FP>(fe_sqr<FP>(lam), fe_dbl<FP>(px));
+            const Fe<FP> y3 = fe_sub<FP>(fe_mul<FP>(lam, fe_sub<FP>(px, x3)), py);
+            two.x = rp(x3); two.y = rp(y3); two.ident = false;
+        }
+        AffZ<FP> none = P;
+        none.ident = true;
+        S = same ? two : none;
+        D = same ? none : two;
+        return;
+    }
+    const Fe<FP> inv = fe_inv_safegcd<FP>(dx);
+    const Fe<FP> lam_s = fe_mul<FP>(fe_sub<FP>(qy, py), inv);                  // (yQ - yP) / (xQ - xP)
+    const Fe<FP> lam_d = fe_mul<FP>(fe_neg<FP>(fe_add<FP>(qy, py)), inv);      // (-yQ - yP) / (xQ - xP)
+    const Fe<FP> xs = fe_sub<FP>(fe_sub<FP>(fe_sqr<FP>(lam_s), px), qx);
+    const Fe<FP> ys = fe_sub<FP>(fe_mul<FP>(lam_s, fe_sub<FP>(px, xs)), py);
+    const Fe<FP> xd = fe_sub<FP>(fe_sub<FP>(fe_sqr<FP>(lam_d), px), qx);
+    const Fe<FP> yd = fe_sub<FP>(fe_mul<FP>(lam_d, fe_sub<FP>(px, xd)), py);
+    S.x = rp(xs); S.y = rp(ys); S.ident = false;
+    D.x = rp(xd); D.y = rp(yd); D.ident = false;
+}
+
+template <class C>
+__global__ void __launch_bounds__(128) k_fold_pairs(const uint4* __restrict__ lo, const uint8_t* __restrict__ lo_zero, const uint4* __restrict__ hi,
+                                                    const uint8_t* __restrict__ hi_zero, size_t m, const FoldDigits* __restrict__ dgp,
+                                                    uint4* __restrict__ out_xy, uint8_t* __restrict__ out_zero) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const Fe<FP> px = fe_load<FP>(lo + i * 2 * W), py = fe_load<FP>(lo + i * 2 * W + W);
+    const Fe<FP> qx = fe_load<FP>(hi + i * 2 * W), qy = fe_load<FP>(hi + i * 2 * W + W);
+    AffZ<FP> P, Q, S, D;
+    sum_and_diff<FP>(px, py, lo_zero ? lo_zero[i] != 0 : false, qx, qy, hi_zero ? hi_zero[i] != 0 : false, P, Q, S, D);
+    XyzzZ<FP> acc = xyzzz_identity<FP>();
+    const int cols = dgp->cols;
+    for (int k = 0; k < cols; ++k) {
+        acc = xyzzz_dbl<FP>(acc);
+        const int code = dgp->d[k];  // uniform over the grid
+        if (code == 4) continue;
+        const int da = code / 3 - 1, db = code % 3 - 1;
+        // +-P, +-Q, +-(P + Q) when the signs agree, +-(P - Q) when they differ
+        const AffZ<FP>& T = db == 0 ? P : (da == 0 ? Q : (da == db ? S : D));
+        const bool neg = da != 0 ? da < 0 : db < 0;  // the table holds the version with a positive first non-zero digit
+        if (T.ident) continue;
+        Fz<FP> y = T.y;
+        if (neg) y = fz_neg_canonical<FP>(y);
+        xyzzz_madd<FP>(acc, T.x, y);
+    }
+    emit_affine<FP>(acc, out_xy + i * 2 * W, out_zero + i);
+}
+
+// joint sparse form (Solinas) of two canonical scalars (8 x 32-bit limbs each), least significant column first
+PLK_DI int joint_sparse_form(const uint32_t* a, const uint32_t* b, int8_t* ua, int8_t* ub) {
+    // 9 limbs so that the shifts never lose a bit; the carries d0, d1 in {0, 1} are added on the fly
+    uint32_t k0[9], k1[9];
+    for (int i = 0; i < 8; ++i) {
+        k0[i] = a[i];
+        k1[i] = b[i];
+    }
+    k0[8] = k1[8] = 0;
+    int d0 = 0, d1 = 0, n = 0;
+    for (;;) {
+        uint32_t nz = (uint32_t)d0 | (uint32_t)d1;
+        for (int i = 0; i < 9; ++i) nz |= k0[i] | k1[i];
+        if (nz == 0) break;
+        const uint32_t l0 = (k0[0] + (uint32_t)d0) & 7u, l1 = (k1[0] + (uint32_t)d1) & 7u;
+        int u0 = 0, u1 = 0;
+        if (l0 & 1) {
+            u0 = 2 - (int)(l0 & 3);
+            if ((l0 == 3 || l0 == 5) && (l1 & 3) == 2) u0 = -u0;
+        }
+        if (l1 & 1) {
+            u1 = 2 - (int)(l1 & 3);
+            if ((l1 == 3 || l1 == 5) && (l0 & 3) == 2) u1 = -u1;
+        }
+        if (2 * d0 == 1 + u0) d0 = 1 - d0;
+        if (2 * d1 == 1 + u1) d1 = 1 - d1;
+        for (int i = 0; i < 8; ++i) {
+            k0[i] = (k0[i] >> 1) | (k0[i + 1] << 31);
+            k1[i] = (k1[i] >> 1) | (k1[i + 1] << 31);
+        }
+        k0[8] >>= 1;
+        k1[8] >>= 1;
+        ua[n] = (int8_t)u0;
+        ub[n] = (int8_t)u1;
+        ++n;
+    }
+    return n;
+}
+
+struct ScalarPair {
+    uint32_t a[8], b[8];  // Montgomery form in the scalar field
+};
+// one thread: Montgomery -> canonical (to_canonical_u64_vec), joint sparse form, most significant column first
+template <class C> __global__ void k_fold_digits(ScalarPair sp, FoldDigits* out) {
+    using SP = typename C::SP;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Fe<SP> a, b;
+    for (int i = 0; i < 8; ++i) {
+        a.v[i] = sp.a[i];
+        b.v[i] = sp.b[i];
+    }
+    a = fe_to_canonical<SP>(a);
+    b = fe_to_canonical<SP>(b);
+    int8_t ua[FOLD_MAX_COLS], ub[FOLD_MAX_COLS];
+    const int n = joint_sparse_form(a.v, b.v, ua, ub);
+    out->cols = n;
+    for (int k = 0; k < n; ++k) out->d[k] = (int8_t)((ua[n - 1 - k] + 1) * 3 + (ub[n - 1 - k] + 1));
+}
+
+template <class C>
+static int fold_pairs_t(size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero, const uint64_t* a_mont,
+                        const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream) {
+    static_assert(C::SP::NL == 8, "scalar fields are 256-bit");
+    if (m == 0) return PLK_OK;
+    ScalarPair sp;
+    for (int i = 0; i < 4; ++i) {
+        sp.a[2 * i] = (uint32_t)a_mont[i];
+        sp.a[2 * i + 1] = (uint32_t)(a_mont[i] >> 32);
+        sp.b[2 * i] = (uint32_t)b_mont[i];
+        sp.b[2 * i + 1] = (uint32_t)(b_mont[i] >> 32);
+    }
+    FoldDigits* d_dg = (FoldDigits*)scratch_acquire(sizeof(FoldDigits), stream);
+    if (!d_dg) return PLK_ERR_OOM;
+    k_fold_digits<C><<<1, 64, 0, stream>>>(sp, d_dg);
+    k_fold_pairs<C><<<(unsigned)((m + 127) / 128), 128, 0, stream>>>((const uint4*)d_lo, (const uint8_t*)d_lo_zero, (const uint4*)d_hi,
+                                                                     (const uint8_t*)d_hi_zero, m, d_dg, (uint4*)d_out_xy, (uint8_t*)d_out_zero);
+    hipError_t e = hipGetLastError();
+    scratch_release(d_dg, stream);
+    if (e != hipSuccess) return set_error(PLK_ERR_HIP, "fold launch failed: %s", hipGetErrorString(e));
+    return PLK_OK;
+}
+
+int curve_fold_pairs_dev_impl(int curve, size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero,
+                              const uint64_t* a_mont, const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream) {
+    if (!a_mont || !b_mont) return set_error(PLK_ERR_INVALID_ARG, "null scalar");
+    if (m && (!d_lo || !d_hi || !d_out_xy || !d_out_zero)) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
+    PLK_TRY(ensure_device());
+    switch (curve) {
+        case PLK_CURVE_TWEEDLEDEE: return fold_pairs_t<TweedledeeCurve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream);
+        case PLK_CURVE_TWEEDLEDUM: return fold_pairs_t<TweedledumCurve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream);
+        case PLK_CURVE_BLS12_377: return fold_pairs_t<Bls12377Curve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream);
+    }
+    return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+}
+
+}  // namespace plk

@@ -612,24 +612,6 @@ __global__ void __launch_bounds__(PLANE_THREADS) k_msm_planes(const uint4* __res
     }
 }
 
-// back to the reference's form, then ProjectivePoint::to_affine (curve.rs:206-214)
-template <class FP> PLK_DI void emit_affine(const XyzzZ<FP>& acc, uint4* out_xy, uint8_t* out_zero) {
-    constexpr int W = FP::NL / 4;
-    Xyzz<FP> r = xyzz_identity<FP>();
-    if (!acc.inf) {
-        const Fz<FP> back = fz_const_rprime_to_r<FP>();
-        r.x = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.x, back));
-        r.y = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.y, back));
-        r.zz = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zz, back));
-        r.zzz = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zzz, back));
-    }
-    Fe<FP> x, y;
-    bool ident = xyzz_to_affine<FP, true>(r, x, y);
-    fe_store<FP>(out_xy, x);
-    fe_store<FP>(out_xy + W, y);
-    *out_zero = ident ? 1 : 0;
-}
-
 // One block per window: sum_p 2^p (sum of the parts of plane p), one quad per (plane, part); parts a power of
 // two <= 16, planes <= 32, planes * parts <= 256.  With one window (tables) the block also normalises the result; with several
 // (table-free mode) it doubles its window into place, 2^(c * window), and k_msm_combine adds the windows.

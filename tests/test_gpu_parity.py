@@ -441,3 +441,37 @@ def test_concurrent_callers():
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+# ---------------- IPA generator fold (halo.rs:119-123) ----------------
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_fold_generators(c):
+    """G'_i = [u_inv] G_lo_i + [u] G_hi_i against the oracle's scalar multiplication (curve_multiplication.rs:5-85) and
+    addition, pair by pair; includes equal / opposite / identity inputs and the scalars 0, 1, r - 1."""
+    G = (c.gx, c.gy)
+    D = br.ec_mul(c, 0xF01D + c.curve_id, G)
+    m = 20
+    pts = ol.gen_bases(c.curve_id, 2 * m, _bases(c, [G])[0], _bases(c, [D])[0])
+    lo, hi = pts[:m].copy(), pts[m:].copy()
+    hi[3] = lo[3]                                   # P == Q
+    neg = list(br.ec_neg(c, tuple(from_mont_arr(c.base, lo[4]))))
+    hi[4] = mont_arr(c.base, neg)                   # Q == -P
+    lz = np.zeros(m, dtype=np.uint8)
+    hz = np.zeros(m, dtype=np.uint8)
+    lz[5] = 1
+    hz[6] = 1
+    lz[7] = hz[7] = 1
+    r = c.scalar.p
+    u = limbs_to_int(synth.rand_field(c.scalar.field_id, 0xF01D, 1)[0]) % r
+    u = c.scalar.from_mont(u) or 3
+    cases = [(pow(u, -1, r), u), (0, 1), (1, 0), (r - 1, 1), (1, r - 1), (5, 5), (0, 0)]
+    for a, b in cases:
+        sa, sb = mont_arr(c.scalar, [a])[0], mont_arr(c.scalar, [b])[0]
+        got, gz = pa.fold_generators(c.curve_id, lo, hi, sa, sb, lo_zero=lz, hi_zero=hz)
+        for i in range(m):
+            p1, z1 = ol.scalar_mul(c.curve_id, sa, lo[i], int(lz[i]))
+            p2, z2 = ol.scalar_mul(c.curve_id, sb, hi[i], int(hz[i]))
+            exp, ez = ol.affine_add(c.curve_id, p1, z1, p2, z2)
+            assert int(gz[i]) == ez, (a, b, i)
+            if not ez:
+                assert np.array_equal(got[i], exp), (a, b, i)
