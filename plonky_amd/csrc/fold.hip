@@ -96,13 +96,19 @@ __global__ void __launch_bounds__(128) k_fold_pairs(const uint4* __restrict__ lo
         const int code = dgp->d[k];  // uniform over the grid
         if (code == 4) continue;
         const int da = code / 3 - 1, db = code % 3 - 1;
-        // +-P, +-Q, +-(P + Q) when the signs agree, +-(P - Q) when they differ
-        const AffZ<FP>& T = db == 0 ? P : (da == 0 ? Q : (da == db ? S : D));
-        const bool neg = da != 0 ? da < 0 : db < 0;  // the table holds the version with a positive first non-zero digit
-        if (T.ident) continue;
-        Fz<FP> y = T.y;
-        if (neg) y = fz_neg_canonical<FP>(y);
-        xyzzz_madd<FP>(acc, T.x, y);
+        // +-P, +-Q, +-(P + Q) when the signs agree, +-(P - Q) when they differ; the table holds the version whose
+        // first non-zero digit is positive.  The digit pair is uniform, so these are scalar selects: the four table
+        // points stay in registers (picking one through a reference would push them to scratch memory).
+        const bool use_q = da == 0, use_s = da != 0 && da == db, use_d = da != 0 && db != 0 && da != db;
+        const bool neg = da != 0 ? da < 0 : db < 0;
+        Fz<FP> tx = P.x, ty = P.y;
+        bool tid = P.ident;
+        if (use_q) { tx = Q.x; ty = Q.y; tid = Q.ident; }
+        if (use_s) { tx = S.x; ty = S.y; tid = S.ident; }
+        if (use_d) { tx = D.x; ty = D.y; tid = D.ident; }
+        if (tid) continue;
+        if (neg) ty = fz_neg_canonical<FP>(ty);
+        xyzzz_madd<FP>(acc, tx, ty);
     }
     emit_affine<FP>(acc, out_xy + i * 2 * W, out_zero + i);
 }
