@@ -33,11 +33,14 @@
 
 namespace plk {
 
-constexpr int TILE_LOG = 10;             // elements per workgroup tile
+#ifndef PLK_NTT_TILE_LOG
+#define PLK_NTT_TILE_LOG 10
+#endif
+constexpr int TILE_LOG = PLK_NTT_TILE_LOG;  // elements per workgroup tile
 constexpr int TILE = 1 << TILE_LOG;
-constexpr int NTT_THREADS = 256;
+constexpr int NTT_THREADS = TILE / 4;        // one radix-4 group per thread and stage pair
 constexpr int MAX_PASSES = 6;
-constexpr int INNER_LOG = 10;            // inner twiddle table: w_1024^e, e < 512
+constexpr int INNER_LOG = TILE_LOG;      // inner twiddle table: w_TILE^e, e < TILE / 2
 
 struct NttPassArgs {
     int log_n;        // whole transform
@@ -124,7 +127,8 @@ template <class P> PLK_DI void lds_store(uint32_t* base, int stride, int idx, co
 }
 
 // Timing experiments (tools/ntt_experiments.sh): -DPLK_NTT_EXP=1 replaces the stage multiplications by
-// additions, 2 every multiplication, 3 drops the stage loops.  Results are wrong by construction;
+// additions, 2 every multiplication, 3 drops the stage loops, 6 replaces all global loads by synthetic values and
+// drops the stores (7: real loads, no stores; 8: synthetic loads, real stores).  Results are wrong by construction;
 // the product build leaves PLK_NTT_EXP undefined.
 #ifndef PLK_NTT_EXP
 #define PLK_NTT_EXP 0
@@ -324,7 +328,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restric
     for (int e = tid; e < tile_elems; e += NTT_THREADS) {
         const size_t g = tile_in_index(a, tg, e);
         Fe<P> v = fe_zero<P>();
-#if PLK_NTT_EXP == 6
+#if PLK_NTT_EXP == 6 || PLK_NTT_EXP == 8
         for (int l = 0; l < 8; ++l) {  // no memory traffic, full-entropy limbs
             uint32_t h = ((uint32_t)g * 8u + l + a.log_s) * 0x9e3779b9u;
             h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
@@ -342,15 +346,23 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restric
     for (int e = tid; e < tile_elems; e += NTT_THREADS) {
         const size_t g = tile_out_index(a, tg, e);
         Fe<P> tw = fe_zero<P>();
-#if PLK_NTT_EXP == 6
+#if PLK_NTT_EXP == 6 || PLK_NTT_EXP == 7 || PLK_NTT_EXP == 8
+#if PLK_NTT_EXP == 7
+        if (!a.last) tw = fe_load<P>(outer_tw + tile_tw_index(a, tg, e) * 2);
+#else
         for (int l = 0; l < 8; ++l) {
             uint32_t h = ((uint32_t)g * 8u + l + 77u) * 0x85ebca6bu;
             h ^= h >> 15; h *= 0x9e3779b9u; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
             tw.v[l] = h;
         }
         tw.v[7] &= 0x0fffffffu;
+#endif
         const Fe<P> r = tile_emit<P, HOOKS>(a, hk, lds_load<P>(s_dat, TILE, e), tw, scale, g);
+#if PLK_NTT_EXP == 8
+        fe_store<P>(outb + g * 2, r);
+#else
         if (r.v[0] == 0x12345678u && r.v[5] == 0x9abcdef0u) fe_store<P>(outb + g * 2, r);  // practically never
+#endif
 #else
         if (!a.last) tw = fe_load<P>(outer_tw + tile_tw_index(a, tg, e) * 2);
         fe_store<P>(outb + g * 2, tile_emit<P, HOOKS>(a, hk, lds_load<P>(s_dat, TILE, e), tw, scale, g));
@@ -464,7 +476,7 @@ template <class P> static int build_plan_t(NttPlan& pl) {
     const int m = (int)pl.pass_log.size();
     for (int dir = 0; dir < 2; ++dir) {
         PLK_HIP_TRY(hipMalloc(&pl.inner[dir], (size_t)(1 << (INNER_LOG - 1)) * 32));
-        k_ntt_fill_inner<P><<<2, 256>>>((uint4*)pl.inner[dir], (const uint4*)pl.pw, log_t, dir);
+        k_ntt_fill_inner<P><<<((1 << (INNER_LOG - 1)) + 255) / 256, 256>>>((uint4*)pl.inner[dir], (const uint4*)pl.pw, log_t, dir);
         PLK_HIP_TRY(hipGetLastError());
         int log_nt = log_n;
         for (int t = 0; t + 1 < m; ++t) {

@@ -7,8 +7,8 @@ cd "$(dirname "$0")/../plonky_amd/csrc"
 if [ "$1" = build ]; then
   make -j4 >/dev/null; mkdir -p ../../build_exp
   for e in ${EXPS:-1 2 3}; do
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DPLK_NTT_EXP=$e -c ntt.hip -o /tmp/ntt_e$e.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_exp/libplonky_hip_e$e.so capi.o /tmp/ntt_e$e.o msm.o fieldops.o poly.o
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DPLK_NTT_EXP=$e $EXTRA -c ntt.hip -o /tmp/ntt_e$e.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_exp/libplonky_hip_e$e.so capi.o /tmp/ntt_e$e.o msm.o fieldops.o poly.o fold.o
   done
 else
   cd ../..
