@@ -7,6 +7,7 @@
 //   per-digit affine multi-summation              curve_msm.rs:131-145 -> k_msm_accumulate (XYZZ mixed adds)
 //   serial Yao tail  u += acc[d]; y += u          curve_msm.rs:149-154 -> k_msm_bucket_sum + k_msm_planes + k_msm_final
 //   msm_execute / msm_execute_parallel            curve_msm.rs:63-157  -> msm_execute_dev_impl
+//   msm_parallel (precompute + execute, one use)  curve_msm.rs:54-61   -> the table-free mode (PLK_MSM_TABLE_FREE)
 // Same mathematical structure as the reference (Yao's method over per-generator power tables
 // [2^(c j)] G_i, one bucket per digit value, result = sum_d d * bucket_d) with two MI355X-first
 // changes: (1) digits are signed (carry-based integer recoding, never s -> r - s, so it is valid
@@ -19,6 +20,12 @@
 // +-table[j*n + i] into bucket |d|-1.  Entries are counting-sorted by bucket; every bucket is
 // cut into slices of <= SLICE entries and one lane accumulates one slice, so the load per lane
 // is bounded whatever the digit distribution (a skewed witness cannot serialise the kernel).
+//
+// Table-free mode (generators used once): only the generators themselves are stored; window j gets its own
+// bucket range [j 2^(c-1), (j+1) 2^(c-1)), the same kernels run over all windows at once, every window's
+// plane sum is doubled into place (2^(c j)) by a quad and k_msm_combine adds the windows.
+// Batches: consecutive MSMs alternate between two workspaces on two internal streams (msm_execute_dev_impl).
+// The reduction kernels run on quads of lanes (ecz_coop.cuh): they are chains of point operations, i.e. latency.
 #include <mutex>
 #include <vector>
 
@@ -26,6 +33,7 @@
 #include "ec.cuh"
 #include "ecz.cuh"
 #include "ecz_coop.cuh"
+#include "tables.cuh"
 
 namespace plk {
 
@@ -40,13 +48,8 @@ constexpr uint32_t CODE_INVALID = 0xFFFFFFFFu;
 // The table is what the accumulation kernel multiplies with, so it is stored in the working form of
 // that kernel (ecz.cuh / fz.cuh): coordinates in R'-form (x 2^(29 NZ)), canonical, packed in the
 // same 32-bit words.  The generators arrive in the reference's R-form.
-template <class FP> PLK_DI void affine_store_rprime(uint4* dst, const Fe<FP>& x, const Fe<FP>& y, bool identity) {
-    const Fz<FP> k = fz_const_r_to_rprime<FP>();
-    Fe<FP> xr = fz_to_fe_canonical<FP>(fz_mul<FP>(fz_from_fe<FP>(x), k));
-    Fe<FP> yr = fz_to_fe_canonical<FP>(fz_mul<FP>(fz_from_fe<FP>(y), k));
-    affine_store<FP>(dst, xr, yr, identity);
-}
-
+// One lane per generator, on the lazy arithmetic of the accumulation kernel (ecz.cuh): c doublings per window,
+// then back to affine with the division-step inversion (about a quarter of a window's work).
 template <class C>
 __global__ void __launch_bounds__(128) k_msm_table(const uint4* __restrict__ bases, const uint8_t* __restrict__ base_zero, uint4* __restrict__ tab,
                                                    size_t n, int c, int windows) {
@@ -54,16 +57,32 @@ __global__ void __launch_bounds__(128) k_msm_table(const uint4* __restrict__ bas
     constexpr int W = FP::NL / 4;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fe<FP> x = fe_load<FP>(bases + i * 2 * W), y = fe_load<FP>(bases + i * 2 * W + W);
+    // R-form (the reference's) -> canonical R'-form, the form the table is stored and consumed in
+    Fe<FP> xr = to_rprime<FP>(fe_load<FP>(bases + i * 2 * W)), yr = to_rprime<FP>(fe_load<FP>(bases + i * 2 * W + W));
     bool ident = base_zero ? base_zero[i] != 0 : false;
-    affine_store_rprime<FP>(tab + i * 2 * W, x, y, ident);
+    affine_store<FP>(tab + i * 2 * W, xr, yr, ident);
+    const Fz<FP> one = fz_one_rprime<FP>();
     for (int j = 1; j < windows; ++j) {
         if (!ident) {
-            Xyzz<FP> p = xyzz_mdbl<FP>(x, y);
-            for (int k = 1; k < c; ++k) p = xyzz_dbl<FP>(p);
-            ident = xyzz_to_affine<FP>(p, x, y);
+            XyzzZ<FP> p;
+            p.x = fz_from_fe<FP>(xr);
+            p.y = fz_from_fe<FP>(yr);
+            p.zz = one;
+            p.zzz = one;
+            p.inf = false;
+            for (int k = 0; k < c; ++k) p = xyzzz_dbl<FP>(p);
+            ident = p.inf;
+            if (!ident) {
+                // x = X / ZZ, y = Y / ZZZ with 1 / Z = ZZ / ZZZ (xyzz_to_affine, ec.cuh), all in R'-form
+                const Fe<FP> zzz_r = fz_to_fe_canonical<FP>(fz_mul<FP>(p.zzz, fz_const_rprime_to_r<FP>()));
+                const Fz<FP> i3 = fz_from_fe<FP>(to_rprime<FP>(fe_inv_safegcd<FP>(zzz_r)));
+                const Fz<FP> iz = fz_mul<FP>(p.zz, i3);
+                const Fz<FP> izz = fz_sqr<FP>(iz);
+                xr = fz_to_fe_canonical<FP>(fz_mul<FP>(p.x, izz));
+                yr = fz_to_fe_canonical<FP>(fz_mul<FP>(p.y, i3));
+            }
         }
-        affine_store_rprime<FP>(tab + ((size_t)j * n + i) * 2 * W, x, y, ident);
+        affine_store<FP>(tab + ((size_t)j * n + i) * 2 * W, xr, yr, ident);
     }
 }
 
