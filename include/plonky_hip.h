@@ -157,6 +157,16 @@ int plk_msm(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_z
  * point addition is not an RCCL reduction op).  Host pointers. */
 int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint8_t* pts_zero, uint64_t* out_xy, uint8_t* out_zero);
 
+/* ---- the reference's own table contents  (curve_msm.rs:16-52) ---------------------------------- */
+/* MsmPrecomputation { powers_per_generator, w } is plain, serde-visible data in the reference (embedded in Circuit,
+ * plonk.rs:64-69).  A caller that wants that struct filled from the device gets exactly its contents here:
+ * out[i * digits + j] = [2^(w j)] G_i, j < digits = ceil(ScalarField::BITS / w) = plk_msm_table_digits(curve, w),
+ * affine Montgomery limbs (n * digits * 2L) plus AffinePoint::zero flags (n * digits bytes). */
+int plk_msm_table_digits(int curve, unsigned w);
+int plk_msm_precompute_table(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, unsigned w, uint64_t* out_xy, uint8_t* out_zero);
+int plk_msm_precompute_table_dev(int curve, size_t n, const void* d_bases_xy, const void* d_base_zero, unsigned w, void* d_out_xy, void* d_out_zero,
+                                 void* stream);
+
 /* ---- IPA generator fold  (src/halo.rs:119-123) ------------------------------------------------ */
 /* out_i = [scalar_lo] lo_i + [scalar_hi] hi_i for i < m: the fold G' = [u^-1] G_lo + [u] G_hi of an inner-product-
  * argument round, which the reference computes as m calls of msm_parallel(&[u_inv, u], &[g_lo_i, g_hi_i], 4).

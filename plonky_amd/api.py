@@ -279,6 +279,21 @@ def msm_parallel(curve, scalars, generators, w, zero=None):
         pre.free()
 
 
+def msm_precompute_table(curve, generators, w, zero=None):
+    """The CONTENTS of the reference's MsmPrecomputation (curve_msm.rs:16-52): powers_per_generator[i][j] = [2^(w j)] G_i,
+    j < ceil(ScalarField::BITS / w).  Returns (table (n, digits, 2, L), zero flags (n, digits))."""
+    g = _points(curve, generators)
+    n = g.shape[0]
+    L = _CURVE_LIMBS[curve]
+    digits = int(_lib.load().plk_msm_table_digits(curve, w))
+    assert digits > 0
+    z = None if zero is None else np.ascontiguousarray(zero, dtype=np.uint8)
+    out = np.zeros((n, digits, 2, L), dtype=np.uint64)
+    oz = np.zeros((n, digits), dtype=np.uint8)
+    _lib.check(_lib.load().plk_msm_precompute_table(curve, n, _ptr(g), _ptr(z) if z is not None else None, w, _ptr(out), _ptr(oz)))
+    return out, oz
+
+
 def fold_generators(curve, g_lo, g_hi, scalar_lo, scalar_hi, lo_zero=None, hi_zero=None):
     """The generator fold of an IPA round (halo.rs:119-123): out_i = [scalar_lo] g_lo_i + [scalar_hi] g_hi_i, where the
     reference calls msm_parallel(&[u_inv, u], &[g_lo_i, g_hi_i], 4) per pair.  Points (m, 2, L) affine Montgomery

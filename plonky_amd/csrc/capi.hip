@@ -20,6 +20,9 @@ int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void
 int curve_gen_bases_dev_impl(int curve, size_t n, uint64_t first, const void* d_g0d, void* d_out, hipStream_t stream);
 int curve_fold_pairs_dev_impl(int curve, size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero,
                               const uint64_t* a_mont, const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream);
+int msm_table_digits(int curve, unsigned w);
+int msm_reference_table_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned w, void* d_out_xy, void* d_out_zero,
+                                 hipStream_t stream);
 int selftest_quad_dev_impl(int curve, const void* d_pts, uint32_t n, uint32_t quads, uint32_t* counts);
 int msm_set_profiling_impl(plk_msm_ctx* ctx, int enable);
 int msm_get_timings_impl(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls);
@@ -428,6 +431,40 @@ int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint
     PLK_HIP_TRY(hipStreamSynchronize(nullptr));
     PLK_HIP_TRY(hipMemcpy(out_xy, dxy.p, 2 * L * 8, hipMemcpyDeviceToHost));
     PLK_HIP_TRY(hipMemcpy(out_zero, doz.p, 1, hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+
+// ---- the reference's own MsmPrecomputation contents ----
+int plk_msm_table_digits(int curve, unsigned w) {
+    if (curve < 0 || curve > 2 || w == 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d or window 0", curve);
+    return msm_table_digits(curve, w);
+}
+int plk_msm_precompute_table_dev(int curve, size_t n, const void* d_bases_xy, const void* d_base_zero, unsigned w, void* d_out_xy, void* d_out_zero,
+                                 void* stream) {
+    return msm_reference_table_dev_impl(curve, n, d_bases_xy, d_base_zero, w, d_out_xy, d_out_zero, as_stream(stream));
+}
+int plk_msm_precompute_table(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, unsigned w, uint64_t* out_xy, uint8_t* out_zero) {
+    const int L = curve_limbs(curve);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (w < 1 || w > 64) return set_error(PLK_ERR_INVALID_ARG, "window size %u outside [1, 64]", w);
+    if (n && (!bases_xy || !out_xy || !out_zero)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    const size_t digits = (size_t)msm_table_digits(curve, w);
+    DevBuf db, dz, dout, doz;
+    PLK_TRY(db.alloc(n * 2 * L * 8));
+    PLK_TRY(dout.alloc(n * digits * 2 * L * 8));
+    PLK_TRY(doz.alloc(n * digits));
+    if (n) PLK_HIP_TRY(hipMemcpy(db.p, bases_xy, n * 2 * L * 8, hipMemcpyHostToDevice));
+    if (base_zero) {
+        PLK_TRY(dz.alloc(n));
+        if (n) PLK_HIP_TRY(hipMemcpy(dz.p, base_zero, n, hipMemcpyHostToDevice));
+    }
+    PLK_TRY(msm_reference_table_dev_impl(curve, n, db.p, base_zero ? dz.p : nullptr, w, dout.p, doz.p, nullptr));
+    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
+    if (n) {
+        PLK_HIP_TRY(hipMemcpy(out_xy, dout.p, n * digits * 2 * L * 8, hipMemcpyDeviceToHost));
+        PLK_HIP_TRY(hipMemcpy(out_zero, doz.p, n * digits, hipMemcpyDeviceToHost));
+    }
     return PLK_OK;
 }
 

@@ -86,6 +86,26 @@ __global__ void __launch_bounds__(128) k_msm_table(const uint4* __restrict__ bas
     }
 }
 
+// The reference's own table (MsmPrecomputation::powers_per_generator, curve_msm.rs:16-52): the device table
+// [j][i] in R'-form becomes [i][j] in the reference's Montgomery form, with AffinePoint::zero flags.
+template <class C>
+__global__ void __launch_bounds__(256) k_msm_table_export(const uint4* __restrict__ tab, size_t n, int digits, uint4* __restrict__ out_xy,
+                                                          uint8_t* __restrict__ out_zero) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // output slot i * digits + j
+    if (e >= n * (size_t)digits) return;
+    const size_t i = e / digits, j = e % digits;
+    Fe<FP> x, y;
+    const bool ident = affine_load<FP>(tab + (j * n + i) * 2 * W, x, y);
+    const Fz<FP> back = fz_const_rprime_to_r<FP>();
+    x = ident ? fe_zero<FP>() : fz_to_fe_canonical<FP>(fz_mul<FP>(fz_from_fe<FP>(x), back));
+    y = ident ? fe_zero<FP>() : fz_to_fe_canonical<FP>(fz_mul<FP>(fz_from_fe<FP>(y), back));
+    fe_store<FP>(out_xy + e * 2 * W, x);
+    fe_store<FP>(out_xy + e * 2 * W + W, y);
+    out_zero[e] = ident ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // scalars -> signed window digits  (curve_msm.rs:159-180)
 // ---------------------------------------------------------------------------------------------
@@ -1240,6 +1260,40 @@ size_t msm_ctx_len(const plk_msm_ctx* ctx) { return ctx->n; }
 unsigned msm_ctx_window(const plk_msm_ctx* ctx) { return (unsigned)ctx->c; }
 int msm_ctx_curve(const plk_msm_ctx* ctx) { return ctx->curve; }
 void msm_ctx_delete(plk_msm_ctx* ctx) { delete ctx; }
+
+// msm_precompute with the reference's output (curve_msm.rs:27-52): powers_per_generator[i][j] = [2^(w j)] G_i, j < ceil(BITS / w)
+int msm_table_digits(int curve, unsigned w) { return w ? (scalar_bits(curve) + (int)w - 1) / (int)w : -1; }
+
+template <class C>
+static int msm_reference_table_t(size_t n, const void* d_bases, const void* d_zero, int w, int digits, void* d_out_xy, void* d_out_zero,
+                                 hipStream_t stream) {
+    using FP = typename C::FP;
+    const size_t pt_bytes = (size_t)2 * FP::NL * 4;
+    void* tab = scratch_acquire(n * digits * pt_bytes + 16, stream);
+    if (!tab) return PLK_ERR_OOM;
+    k_msm_table<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)tab, n, w, digits);
+    const size_t total = n * (size_t)digits;
+    k_msm_table_export<C><<<(unsigned)((total + 255) / 256), 256, 0, stream>>>((const uint4*)tab, n, digits, (uint4*)d_out_xy, (uint8_t*)d_out_zero);
+    hipError_t e = hipGetLastError();
+    scratch_release(tab, stream);
+    if (e != hipSuccess) return set_error(PLK_ERR_HIP, "table launch failed: %s", hipGetErrorString(e));
+    return PLK_OK;
+}
+
+int msm_reference_table_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned w, void* d_out_xy, void* d_out_zero,
+                                 hipStream_t stream) {
+    if (curve < 0 || curve > 2) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (w < 1 || w > 64) return set_error(PLK_ERR_INVALID_ARG, "window size %u outside [1, 64]", w);
+    if (n == 0) return PLK_OK;
+    if (!d_bases || !d_out_xy || !d_out_zero) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
+    PLK_TRY(ensure_device());
+    const int digits = msm_table_digits(curve, w);
+    switch (curve) {
+        case PLK_CURVE_TWEEDLEDEE: return msm_reference_table_t<TweedledeeCurve>(n, d_bases, d_zero, (int)w, digits, d_out_xy, d_out_zero, stream);
+        case PLK_CURVE_TWEEDLEDUM: return msm_reference_table_t<TweedledumCurve>(n, d_bases, d_zero, (int)w, digits, d_out_xy, d_out_zero, stream);
+        default: return msm_reference_table_t<Bls12377Curve>(n, d_bases, d_zero, (int)w, digits, d_out_xy, d_out_zero, stream);
+    }
+}
 
 int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void* d_zero, void* d_out_xy, void* d_out_zero, hipStream_t stream) {
     switch (curve) {

@@ -53,6 +53,9 @@ SYMBOLS = [
     ("plk_msm_execute_dev", _i, [_vp, _u, _vp, _sz, _vp, _vp, _vp]),
     ("plk_msm", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("plk_curve_sum_affine", _i, [_i, _sz, _vp, _vp, _vp, _vp]),
+    ("plk_msm_table_digits", _i, [_i, _u]),
+    ("plk_msm_precompute_table", _i, [_i, _sz, _vp, _vp, _u, _vp, _vp]),
+    ("plk_msm_precompute_table_dev", _i, [_i, _sz, _vp, _vp, _u, _vp, _vp, _vp]),
     ("plk_curve_fold_pairs", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("plk_curve_fold_pairs_dev", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("plk_selftest_quad", _i, [_i, _vp, _sz, _u, _vp]),

@@ -475,3 +475,28 @@ def test_fold_generators(c):
             assert int(gz[i]) == ez, (a, b, i)
             if not ez:
                 assert np.array_equal(got[i], exp), (a, b, i)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_msm_precompute_table_is_the_reference_table(c):
+    """msm_precompute (curve_msm.rs:27-52): the device-built powers_per_generator[i][j] = [2^(w j)] G_i against the
+    oracle's restatement, entry by entry, for the reference's window sizes 4, 8 and 11 and an identity generator."""
+    G = (c.gx, c.gy)
+    D = br.ec_mul(c, 77, G)
+    n = 6
+    bases = ol.gen_bases(c.curve_id, n, _bases(c, [G])[0], _bases(c, [D])[0])
+    zero = np.zeros(n, dtype=np.uint8)
+    zero[2] = 1
+    for w in (4, 8, 11):
+        tab, tz = pa.msm_precompute_table(c.curve_id, bases, w, zero=zero)
+        digits = (c.scalar.bits + w - 1) // w
+        assert tab.shape == (n, digits, 2, c.base.n_limbs)
+        pre = ol.MsmPrecomputation(c.curve_id, bases, w, zero=zero)
+        for i in range(n):
+            for j in range(digits):
+                exp, ez = pre.table_entry(i, j)
+                assert int(tz[i, j]) == ez, (w, i, j)
+                if not ez:
+                    assert np.array_equal(tab[i, j], exp), (w, i, j)
+                else:
+                    assert not tab[i, j].any()
