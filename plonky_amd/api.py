@@ -270,6 +270,27 @@ def msm_execute_batch(precomputation, scalar_vectors):
     return out, oz
 
 
+def commitment_precompute(curve, generators, blinding_point, w, device_window=0):
+    """Device context for PolynomialCommitment::coeffs_vec_to_commitments (poly_commit.rs:31-66): the blinding term
+    [r] H is the (n+1)-th term of the same MSM, so the context simply holds H after the n generators."""
+    g = _points(curve, generators)
+    h = _points(curve, blinding_point)
+    assert h.shape[0] == 1
+    return msm_precompute(curve, np.concatenate([g, h]), w, device_window=device_window)
+
+
+def coeffs_vec_to_commitments(precomputation, coefficients_vec, blinding_factors):
+    """poly_commit.rs:51-66: one commitment per coefficient vector, pedersen_hash(coeffs) + [r] H, already normalised
+    (the reference's batch_to_affine).  blinding_factors: one Montgomery scalar per vector (zeros when blinding is off).
+    precomputation: from commitment_precompute.  Returns (points (k, 2, L), zero flags (k,))."""
+    cv = np.ascontiguousarray(coefficients_vec, dtype=np.uint64)
+    k = cv.shape[0]
+    cv = cv.reshape(k, -1, 4)
+    r = np.ascontiguousarray(blinding_factors, dtype=np.uint64).reshape(k, 1, 4)
+    assert cv.shape[1] + 1 == precomputation.n, "coefficients.len() must equal the number of generators (curve_msm.rs:106)"
+    return msm_execute_batch(precomputation, np.concatenate([cv, r], axis=1))
+
+
 def msm_parallel(curve, scalars, generators, w, zero=None):
     """curve_msm.rs:54-61: precompute + execute for generators that are used once -> no device tables."""
     pre = msm_precompute(curve, generators, w, zero=zero, table_free=True)

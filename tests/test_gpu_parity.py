@@ -500,3 +500,26 @@ def test_msm_precompute_table_is_the_reference_table(c):
                     assert np.array_equal(tab[i, j], exp), (w, i, j)
                 else:
                     assert not tab[i, j].any()
+
+
+def test_coeffs_vec_to_commitments():
+    """PolynomialCommitment::coeffs_vec_to_commitments (poly_commit.rs:51-66): pedersen_hash(coeffs) + [r] H for several
+    polynomials, normalised; against the oracle's MSM, scalar multiplication and addition."""
+    c = br.TWEEDLEDEE
+    G = (c.gx, c.gy)
+    D = br.ec_mul(c, 31337, G)
+    n = 200
+    gens = ol.gen_bases(0, n + 1, _bases(c, [G])[0], _bases(c, [D])[0])
+    g, h = gens[:n], gens[n:]
+    pre = pa.commitment_precompute(0, g, h, 8)
+    k = 5
+    coeffs = np.stack([synth.rand_field(c.scalar.field_id, 0xC0 + t, n) for t in range(k)])
+    blind = synth.rand_field(c.scalar.field_id, 0xB1, k)
+    blind[1] = 0  # blinding off for one of them
+    got, gz = pa.coeffs_vec_to_commitments(pre, coeffs, blind)
+    opre = ol.MsmPrecomputation(0, g, 8)
+    for t in range(k):
+        m, mz = opre.execute(coeffs[t])
+        b, bz = ol.scalar_mul(0, blind[t], h[0], 0)
+        exp, ez = ol.affine_add(0, m, mz, b, bz)
+        assert int(gz[t]) == ez and np.array_equal(got[t], exp), t
