@@ -1,0 +1,101 @@
+"""Randomised parity stress on the GPU (not part of the pytest suites: minutes, not seconds): random sizes, windows,
+identity flags, duplicate / opposite generators, skewed scalars, tables and table-free, all three curves; random
+polynomial divisions and products; random NTT sizes and batches.  Everything against the oracle, bit for bit.
+Usage: python tools/fuzz_gpu.py [seconds]"""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import plonky_amd as pa
+from plonky_amd import synth
+from oracle import bigint_ref as br, oracle_lib as ol
+from tests.util import ints_to_array
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = random.Random(int(os.environ.get("FUZZ_SEED", "12345")))
+CURVES = [br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377]
+FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR]
+t_end = time.time() + budget
+counts = {"msm": 0, "ntt": 0, "poly": 0, "fold": 0}
+
+
+def mont(f, vals):
+    return ints_to_array([f.to_mont(v % f.p) for v in vals], f.n_limbs)
+
+
+while time.time() < t_end:
+    kind = rng.choice(["msm", "msm", "ntt", "poly", "fold"])
+    if kind == "msm":
+        c = rng.choice(CURVES)
+        n = rng.choice([1, 2, 3, 7, 33, 100, 257, 1000, 3000, 5000])
+        G = (c.gx, c.gy)
+        D = br.ec_mul(c, rng.randrange(1, 1 << 40), G)
+        bases = ol.gen_bases(c.curve_id, n, mont(c.base, [G[0], G[1]]).reshape(2, -1), mont(c.base, [D[0], D[1]]).reshape(2, -1))
+        zero = np.zeros(n, dtype=np.uint8)
+        for _ in range(rng.randrange(0, 3)):
+            zero[rng.randrange(n)] = 1
+        if n > 3:
+            bases[1] = bases[0]                                  # duplicate
+            neg = bases[2].copy()
+            neg[1] = ol.field_unop(c.base.field_id, "neg", neg[1:2])[0]
+            bases[3] = neg                                       # opposite of bases[2]
+        style = rng.choice(["uniform", "small", "equal", "edge"])
+        r = c.scalar.p
+        if style == "uniform":
+            sc = synth.rand_field(c.scalar.field_id, rng.randrange(1 << 30), n)
+        elif style == "small":
+            sc = mont(c.scalar, [rng.randrange(0, 4) for _ in range(n)])
+        elif style == "equal":
+            v = rng.randrange(r)
+            sc = mont(c.scalar, [v] * n)
+        else:
+            sc = mont(c.scalar, [rng.choice([0, 1, r - 1, r - 2, (r - 1) // 2, 1 << 200]) for _ in range(n)])
+        exp, ez = ol.MsmPrecomputation(c.curve_id, bases, 8, zero=zero, threads=8).execute(sc, parallel=True, threads=8)
+        tf = rng.random() < 0.5
+        win = rng.choice([0, 0, 3, 5, 8, 11] + ([] if tf else [14, 16]))
+        pre = pa.msm_precompute(c.curve_id, bases, 8, zero=zero, device_window=win, table_free=tf)
+        got, gz = pa.msm_execute_parallel(pre, sc)
+        assert gz == ez and (ez or np.array_equal(got, exp)), ("msm", c.name, n, style, tf, win)
+        pre.free()
+    elif kind == "ntt":
+        f = rng.choice(FIELDS)
+        log_n = rng.randrange(0, 17)
+        batch = rng.choice([1, 1, 2, 5])
+        x = synth.rand_field(f.field_id, rng.randrange(1 << 30), batch << log_n).reshape(batch, 1 << log_n, 4)
+        opre = ol.FftPrecomputation(f.field_id, 1 << log_n)
+        inv = rng.random() < 0.5
+        got = pa.api.fft_batch(f.field_id, x, inverse=inv)
+        for b in range(batch):
+            want = opre.ifft_with_precomputation_power_of_2(x[b], threads=8) if inv else opre.fft_with_precomputation_power_of_2(x[b], threads=8)
+            assert np.array_equal(got[b], want), ("ntt", f.name, log_n, batch, inv)
+    elif kind == "poly":
+        f = rng.choice(FIELDS)
+        la = rng.randrange(1, 6000)
+        a = synth.rand_field(f.field_id, rng.randrange(1 << 30), la)
+        if rng.random() < 0.5:
+            n = rng.choice([1, 2, 3, 8, 64, 100, 1024, rng.randrange(1, 3000)])
+            m = np.zeros((la + n, 4), dtype=np.uint64)
+            m[n:] = a
+            m[:la] = ol.field_binop(f.field_id, "sub", m[:la].copy(), a)
+            if rng.random() < 0.3:
+                m = np.concatenate([m, np.zeros((rng.randrange(1, 9), 4), dtype=np.uint64)])
+            got = pa.polynomial_divide_by_z_h(f.field_id, m, n)
+            assert np.array_equal(got, ol.poly_divide_by_z_h(f.field_id, m, n, threads=8)), ("divide", f.name, la, n)
+        else:
+            b = synth.rand_field(f.field_id, rng.randrange(1 << 30), rng.randrange(1, 3000))
+            assert np.array_equal(pa.polynomial_mul(f.field_id, a, b), ol.poly_mul(f.field_id, a, b, threads=8)), ("mul", f.name, la)
+    else:
+        c = rng.choice(CURVES)
+        m = rng.choice([1, 5, 64])
+        G = (c.gx, c.gy)
+        D = br.ec_mul(c, rng.randrange(1, 1 << 40), G)
+        pts = ol.gen_bases(c.curve_id, 2 * m, mont(c.base, [G[0], G[1]]).reshape(2, -1), mont(c.base, [D[0], D[1]]).reshape(2, -1))
+        sa = synth.rand_field(c.scalar.field_id, rng.randrange(1 << 30), 1)[0]
+        sb = synth.rand_field(c.scalar.field_id, rng.randrange(1 << 30), 1)[0]
+        got, gz = pa.fold_generators(c.curve_id, pts[:m], pts[m:], sa, sb)
+        for i in range(m):
+            p1, z1 = ol.scalar_mul(c.curve_id, sa, pts[i], 0)
+            p2, z2 = ol.scalar_mul(c.curve_id, sb, pts[m + i], 0)
+            exp, ez = ol.affine_add(c.curve_id, p1, z1, p2, z2)
+            assert int(gz[i]) == ez and (ez or np.array_equal(got[i], exp)), ("fold", c.name, m, i)
+    counts[kind] += 1
+print("fuzz ok:", counts)
