@@ -172,3 +172,43 @@ def test_device_resident_divide_by_z_h_large():
     d_p = dv.poly_mul_dev(f.field_id, dv.to_device(a), dv.to_device(b))
     torch.cuda.synchronize()
     assert np.array_equal(dv.to_host(d_p), pa.polynomial_mul(f.field_id, a, b))
+
+
+def test_error_behaviour_of_the_new_entry_points():
+    """Contract violations come back as error codes with a message, never as aborts (include/plonky_hip.h)."""
+    import ctypes
+
+    from plonky_amd import lib
+
+    L = lib.load()
+    f = br.TWEEDLEDEE_BASE
+    a = synth.rand_field(f.field_id, 1, 40)
+    out = np.zeros((64, 4), dtype=np.uint64)
+    n_out = ctypes.c_size_t(0)
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    # Z_H of n = 0 is the zero polynomial
+    assert L.plk_poly_divide_by_z_h(f.field_id, p(a), 40, 0, p(out), 64, ctypes.byref(n_out)) == lib.PLK_ERR_INVALID_ARG
+    assert b"X^0" in L.plk_last_error()
+    # output too small for the 2^6 result
+    assert L.plk_poly_divide_by_z_h(f.field_id, p(a), 40, 3, p(out), 8, ctypes.byref(n_out)) == lib.PLK_ERR_INVALID_ARG
+    # a field without NTT entry points (Bls12377Base) and a bad id
+    assert L.plk_poly_mul(3, p(a), 4, p(a), 4, p(out), 64, ctypes.byref(n_out)) == lib.PLK_ERR_INVALID_ARG
+    assert L.plk_poly_mul(9, p(a), 4, p(a), 4, p(out), 64, ctypes.byref(n_out)) == lib.PLK_ERR_INVALID_ARG
+    # padded transform: more coefficients than the domain holds
+    ins = (ctypes.c_void_p * 1)(a.ctypes.data)
+    lens = (ctypes.c_size_t * 1)(40)
+    outs = (ctypes.c_void_p * 1)(out.ctypes.data)
+    assert L.plk_ntt_padded_batch(f.field_id, 5, 1, ins, lens, outs) == lib.PLK_ERR_INVALID_ARG
+    assert L.plk_ntt_padded_batch(f.field_id, 6, 1, ins, lens, outs) == lib.PLK_OK
+    # table-free MSM: a window whose bucket ranges do not fit the partition
+    c = br.TWEEDLEDEE
+    g = mont_arr(c.base, [c.gx, c.gy]).reshape(1, 2, 4)
+    ctx = ctypes.c_void_p()
+    assert L.plk_msm_precompute_ex(0, 1, p(g), None, 16, 1, ctypes.byref(ctx)) == lib.PLK_ERR_INVALID_ARG
+    assert L.plk_msm_precompute_ex(0, 1, p(g), None, 40, 0, ctypes.byref(ctx)) == lib.PLK_ERR_INVALID_ARG
+    # reference-layout table: window 0
+    assert L.plk_msm_table_digits(0, 0) == lib.PLK_ERR_INVALID_ARG
+    assert L.plk_msm_table_digits(0, 11) == 24 and L.plk_msm_table_digits(2, 11) == 23  # ceil(255 / 11), ceil(253 / 11)
+    # fold: null scalar
+    oz = np.zeros(1, dtype=np.uint8)
+    assert L.plk_curve_fold_pairs(0, 1, p(g), None, p(g), None, None, None, p(g.copy()), p(oz)) == lib.PLK_ERR_INVALID_ARG
