@@ -24,7 +24,7 @@
 // Table-free mode (generators used once): only the generators themselves are stored; window j gets its own
 // bucket range [j 2^(c-1), (j+1) 2^(c-1)), the same kernels run over all windows at once, every window's
 // plane sum is doubled into place (2^(c j)) by a quad and k_msm_combine adds the windows.
-// Batches: consecutive MSMs alternate between two workspaces on two internal streams (msm_execute_dev_impl).
+// Batches: every MSM of a group has its own workspace and the group shares one reduction (msm_execute_dev_impl).
 // The reduction kernels run on quads of lanes (ecz_coop.cuh): they are chains of point operations, i.e. latency.
 #include <mutex>
 #include <vector>
@@ -534,12 +534,33 @@ template <class FP> PLK_DI XyzzZ<FP> wave_sum(XyzzZ<FP> v, int width) {
 // A bucket with more than HEAVY_SLICES slice partials (a hot digit of a skewed witness) would make its
 // 4 lanes walk thousands of additions.  Such buckets are listed as (bucket, chunk) work items of
 // HEAVY_CHUNK slices, each summed by a whole workgroup, then their chunk partials are summed.
+// The reduction kernels serve several MSMs per launch (the executions of a batch share one tail): every MSM brings
+// its own buffers in a slot, blockIdx.y (planes, final: a factor of the grid) picks the slot.
+constexpr int TAIL_MAX = 16;
+struct TailSlot {
+    const uint4* partial;
+    const uint32_t* slice_off;
+    uint4* bucket;
+    uint32_t* heavy;
+    uint4* heavy_part;
+    uint4* plane_part;
+    uint4* win_pts;
+    uint4* out_xy;
+    uint8_t* out_zero;
+};
+struct TailBatch {
+    int count;
+    TailSlot s[TAIL_MAX];
+};
+
 constexpr uint32_t HEAVY_SLICES = 256;
 constexpr uint32_t HEAVY_CHUNK = 2048;
 
 // heavy[0] = number of work items, heavy[1] = number of heavy buckets;
 // items at heavy[2 + 2k] = bucket, heavy[3 + 2k] = chunk index; heavy bucket ids at heavy[2 + 2 cap + k]
-__global__ void __launch_bounds__(256) k_msm_heavy_list(const uint32_t* __restrict__ slice_off, uint32_t buckets, uint32_t* __restrict__ heavy, uint32_t cap) {
+__global__ void __launch_bounds__(256) k_msm_heavy_list(TailBatch tb, uint32_t buckets, uint32_t cap) {
+    const uint32_t* __restrict__ slice_off = tb.s[blockIdx.y].slice_off;
+    uint32_t* __restrict__ heavy = tb.s[blockIdx.y].heavy;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= buckets) return;
     const uint32_t ns = slice_off[b + 1] - slice_off[b];
@@ -569,11 +590,14 @@ template <class FP> PLK_DI XyzzZ<FP> block256_sum(XyzzZ<FP> acc, uint4* s_pts) {
 
 // one workgroup per (bucket, chunk) item: chunk partial -> heavy_part[item]
 template <class C>
-__global__ void __launch_bounds__(256) k_msm_heavy_chunks(const uint4* __restrict__ partial, const uint32_t* __restrict__ slice_off,
-                                                          const uint32_t* __restrict__ heavy, uint32_t cap, uint4* __restrict__ heavy_part) {
+__global__ void __launch_bounds__(256) k_msm_heavy_chunks(TailBatch tb, uint32_t cap) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     __shared__ uint4 s_pts[4 * 4 * W];
+    const uint4* __restrict__ partial = tb.s[blockIdx.y].partial;
+    const uint32_t* __restrict__ slice_off = tb.s[blockIdx.y].slice_off;
+    const uint32_t* __restrict__ heavy = tb.s[blockIdx.y].heavy;
+    uint4* __restrict__ heavy_part = tb.s[blockIdx.y].heavy_part;
     const uint32_t items = min(heavy[0], cap);
     for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
         const uint32_t b = heavy[2 + 2 * it], k = heavy[3 + 2 * it];
@@ -586,11 +610,13 @@ __global__ void __launch_bounds__(256) k_msm_heavy_chunks(const uint4* __restric
 }
 // one workgroup per heavy bucket: sum of its chunk partials -> bucket[b].  Items of one bucket are contiguous.
 template <class C>
-__global__ void __launch_bounds__(256) k_msm_heavy_final(const uint32_t* __restrict__ slice_off, const uint32_t* __restrict__ heavy, uint32_t cap,
-                                                         const uint4* __restrict__ heavy_part, uint4* __restrict__ bucket) {
+__global__ void __launch_bounds__(256) k_msm_heavy_final(TailBatch tb, uint32_t cap) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     __shared__ uint4 s_pts[4 * 4 * W];
+    const uint32_t* __restrict__ heavy = tb.s[blockIdx.y].heavy;
+    const uint4* __restrict__ heavy_part = tb.s[blockIdx.y].heavy_part;
+    uint4* __restrict__ bucket = tb.s[blockIdx.y].bucket;
     const uint32_t items = min(heavy[0], cap), nb = min(heavy[1], cap);
     for (uint32_t hb = blockIdx.x; hb < nb; hb += gridDim.x) {
         const uint32_t b = heavy[2 + 2 * cap + hb];
@@ -603,10 +629,13 @@ __global__ void __launch_bounds__(256) k_msm_heavy_final(const uint32_t* __restr
 }
 
 template <class C>
-__global__ void __launch_bounds__(256) k_msm_bucket_sum(const uint4* __restrict__ partial, const uint32_t* __restrict__ slice_off, uint4* __restrict__ bucket,
-                                                        uint32_t buckets) {
+__global__ void __launch_bounds__(256) k_msm_bucket_sum(TailBatch tb, uint32_t buckets) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
+    const uint4* __restrict__ partial = tb.s[blockIdx.y].partial;
+    const uint32_t* __restrict__ slice_off = tb.s[blockIdx.y].slice_off;
+    uint4* __restrict__ bucket = tb.s[blockIdx.y].bucket;
+    if (blockIdx.x == 0 && threadIdx.x < 2) tb.s[blockIdx.y].heavy[threadIdx.x] = 0;  // counters of k_msm_heavy_list, which runs next
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = gid / BUCKET_LANES, part = gid % BUCKET_LANES;
     XyzzZ<FP> acc = xyzzz_identity<FP>();
@@ -628,13 +657,15 @@ __global__ void __launch_bounds__(256) k_msm_bucket_sum(const uint4* __restrict_
 // grid = (parts, planes, windows), 128 quads per block.
 constexpr int PLANE_THREADS = 512;
 template <class C>
-__global__ void __launch_bounds__(PLANE_THREADS) k_msm_planes(const uint4* __restrict__ bucket, uint4* __restrict__ plane_part, uint32_t wbuckets) {
+__global__ void __launch_bounds__(PLANE_THREADS) k_msm_planes(TailBatch tb, int windows, uint32_t wbuckets) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     __shared__ uint4 s_pts[(PLANE_THREADS / 64) * 4 * W];  // one packed point per wave
     const int ql = threadIdx.x & 3, quad = threadIdx.x >> 2;
     const int plane = blockIdx.y;
-    const uint4* wb = bucket + (size_t)blockIdx.z * wbuckets * 4 * W;
+    const int slot = blockIdx.z / windows, win = blockIdx.z % windows;
+    uint4* __restrict__ plane_part = tb.s[slot].plane_part;
+    const uint4* wb = tb.s[slot].bucket + (size_t)win * wbuckets * 4 * W;
     XyzzZ<FP> acc = xyzzz_identity<FP>();
     for (uint32_t b = blockIdx.x * (PLANE_THREADS / 4) + quad; b < wbuckets; b += gridDim.x * (PLANE_THREADS / 4)) {
         if (((b + 1u) >> plane) & 1u) acc = xyzzz_add_q<FP>(acc, xyzzz_load_packed<FP>(wb + (size_t)b * 4 * W), ql);
@@ -647,7 +678,7 @@ __global__ void __launch_bounds__(PLANE_THREADS) k_msm_planes(const uint4* __res
         acc = (lane >> 2) < PLANE_THREADS / 64 ? xyzzz_load_packed<FP>(s_pts + (lane >> 2) * 4 * W) : xyzzz_identity<FP>();
         acc = wave_sum_q<FP>(acc, PLANE_THREADS / 64, ql);
         if (lane == 0)
-            xyzzz_store_packed<FP>(plane_part + (((size_t)blockIdx.z * gridDim.y + plane) * gridDim.x + blockIdx.x) * 4 * W, acc);
+            xyzzz_store_packed<FP>(plane_part + (((size_t)win * gridDim.y + plane) * gridDim.x + blockIdx.x) * 4 * W, acc);
     }
 }
 
@@ -656,16 +687,17 @@ __global__ void __launch_bounds__(PLANE_THREADS) k_msm_planes(const uint4* __res
 // (table-free mode) it doubles its window into place, 2^(c * window), and k_msm_combine adds the windows.
 constexpr int FINAL_THREADS = 512;  // <= 8 waves, so the compiler may use 256 VGPRs: the point arithmetic must not spill
 template <class C>
-__global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(const uint4* __restrict__ plane_part, int parts, int planes, int window_bits,
-                                                             uint4* __restrict__ win_out, uint4* __restrict__ out_xy, uint8_t* __restrict__ out_zero) {
+__global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int windows, int parts, int planes, int window_bits) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     __shared__ uint4 s_pts[33 * 4 * W];
     const int tid = threadIdx.x, ql = tid & 3, item = tid >> 2;
+    const int slot = blockIdx.x / windows;
+    const uint4* __restrict__ plane_part = tb.s[slot].plane_part;
     // a quad takes two parts when there are several (then 4 * planes * parts / 2 <= FINAL_THREADS), else one
     const int ipq = parts > 1 ? 2 : 1, qpp = parts / ipq;  // quads per plane
     const int plane = item / qpp, sub = item % qpp;
-    const int win = blockIdx.x;
+    const int win = blockIdx.x % windows;
     const bool live = plane < planes;
     const uint4* src = plane_part + ((size_t)(win * planes + plane) * parts + sub * ipq) * 4 * W;
     XyzzZ<FP> acc = live ? xyzzz_load_packed<FP>(src) : xyzzz_identity<FP>();
@@ -686,8 +718,8 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(const uint4* __rest
         if (planes > 16) acc = xyzzz_add_q<FP>(acc, xyzzz_load_packed<FP>(s_pts + 32 * 4 * W), ql);
         for (int k = 0; k < win * window_bits; ++k) acc = xyzzz_dbl_q<FP>(acc, ql);
         if (tid == 0) {
-            if (gridDim.x > 1) xyzzz_store_packed<FP>(win_out + (size_t)win * 4 * W, acc);
-            else emit_affine<FP>(acc, out_xy, out_zero);
+            if (windows > 1) xyzzz_store_packed<FP>(tb.s[slot].win_pts + (size_t)win * 4 * W, acc);
+            else emit_affine<FP>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
         }
     }
 }
@@ -695,11 +727,13 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(const uint4* __rest
 // table-free mode: the sum of the windows (<= 128 points, already doubled into place), normalised
 constexpr int COMBINE_THREADS = 512;
 template <class C>
-__global__ void __launch_bounds__(COMBINE_THREADS) k_msm_combine(const uint4* __restrict__ win_pts, int windows, uint4* __restrict__ out_xy,
-                                                                 uint8_t* __restrict__ out_zero) {
+__global__ void __launch_bounds__(COMBINE_THREADS) k_msm_combine(TailBatch tb, int windows) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     __shared__ uint4 s_pts[(COMBINE_THREADS / 64) * 4 * W];
+    const uint4* __restrict__ win_pts = tb.s[blockIdx.x].win_pts;
+    uint4* __restrict__ out_xy = tb.s[blockIdx.x].out_xy;
+    uint8_t* __restrict__ out_zero = tb.s[blockIdx.x].out_zero;
     const int tid = threadIdx.x, ql = tid & 3, item = tid >> 2;
     XyzzZ<FP> acc = item < windows ? xyzzz_load_packed<FP>(win_pts + (size_t)item * 4 * W) : xyzzz_identity<FP>();
     acc = wave_sum_q<FP>(acc, 16, ql);
@@ -894,10 +928,8 @@ struct plk_msm_ctx {
     int fine_bits = 0, nbins = 1;
     uint32_t nt1 = 0, nt2max = 0;
     uint32_t heavy_cap = 0;
-    MsmWork ws[2];             // ws[1] is allocated by the first batched execution
-    hipStream_t lane[2] = {nullptr, nullptr};  // internal streams of the batched path
-    hipEvent_t lane_ev[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t acc_ev[2] = {nullptr, nullptr};  // accumulation on workspace 0 / 1 has finished
+    std::vector<MsmWork> ws;   // ws[0] at precompute; a batched execution allocates one per MSM of a group (<= TAIL_MAX)
+    size_t ws_bytes = 0;       // size of one workspace slab
     std::mutex mu;             // one execution at a time per context (workspaces are shared)
     // optional per-kernel timing (HIP events on the launch stream) for bench.py's roofline
     bool profiling = false;
@@ -906,14 +938,7 @@ struct plk_msm_ctx {
     std::vector<std::vector<hipEvent_t>> prof_free;
     ~plk_msm_ctx() {
         if (tab) (void)hipFree(tab);
-        ws[0].release();
-        ws[1].release();
-        for (hipStream_t st : lane)
-            if (st) (void)hipStreamDestroy(st);
-        for (hipEvent_t e : lane_ev)
-            if (e) (void)hipEventDestroy(e);
-        for (hipEvent_t e : acc_ev)
-            if (e) (void)hipEventDestroy(e);
+        for (MsmWork& w : ws) w.release();
         for (auto* v : {&prof_sets, &prof_free})
             for (auto& set : *v)
                 for (hipEvent_t e : set) (void)hipEventDestroy(e);
@@ -968,6 +993,7 @@ template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w) {
     };
     size_t total = 0;
     for (const Part& pt : parts) total += (pt.bytes + 255) & ~(size_t)255;
+    ctx->ws_bytes = total + 256;
     PLK_HIP_TRY(hipMalloc(&w.slab, total + 256));
     uint8_t* cur = (uint8_t*)w.slab;
     for (const Part& pt : parts) {
@@ -985,6 +1011,7 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
     const size_t pt_bytes = (size_t)2 * FP::NL * 4;
     const size_t entries = n * ctx->windows;
     PLK_HIP_TRY(hipMalloc(&ctx->tab, (ctx->table_free ? n : entries) * pt_bytes + 16));
+    ctx->ws.resize(1);
     PLK_TRY(msm_alloc_work<C>(ctx, ctx->ws[0]));
     if (n) {
         k_msm_table<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)ctx->tab, n, ctx->c,
@@ -1067,6 +1094,45 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     return PLK_OK;
 }
 
+static TailSlot tail_slot(const MsmWork& w, void* d_out_xy, void* d_out_zero) {
+    TailSlot t;
+    t.partial = (const uint4*)w.partial;
+    t.slice_off = (const uint32_t*)w.off + 0;  // fixed up by the caller: slice_off = off + buckets + 1
+    t.bucket = (uint4*)w.bucket;
+    t.heavy = (uint32_t*)w.heavy;
+    t.heavy_part = (uint4*)w.heavy_part;
+    t.plane_part = (uint4*)w.plane_part;
+    t.win_pts = (uint4*)w.win_pts;
+    t.out_xy = (uint4*)d_out_xy;
+    t.out_zero = (uint8_t*)d_out_zero;
+    return t;
+}
+
+// bucket sums -> bit-plane sums -> result, for the tb.count MSMs of a batch at once (their accumulations have run)
+template <class C, class Mark>
+static int msm_reduce_t(plk_msm_ctx* ctx, TailBatch tb, hipStream_t stream, Mark&& mark) {
+    const uint32_t buckets = ctx->buckets;
+    const unsigned cnt = (unsigned)tb.count;
+    for (unsigned k = 0; k < cnt; ++k) tb.s[k].slice_off += buckets + 1;
+    k_msm_bucket_sum<C><<<dim3((buckets * BUCKET_LANES + 255) / 256, cnt), 256, 0, stream>>>(tb, buckets);
+    // hot buckets of a skewed scalar distribution (none for uniform scalars: the three launches then exit at once)
+    k_msm_heavy_list<<<dim3((buckets + 255) / 256, cnt), 256, 0, stream>>>(tb, buckets, ctx->heavy_cap);
+    k_msm_heavy_chunks<C><<<dim3(256, cnt), 256, 0, stream>>>(tb, ctx->heavy_cap);
+    k_msm_heavy_final<C><<<dim3(64, cnt), 256, 0, stream>>>(tb, ctx->heavy_cap);
+    PLK_HIP_TRY(hipGetLastError());
+    mark();
+    const int bucket_windows = ctx->table_free ? ctx->windows : 1;
+    dim3 pg(ctx->plane_blocks, ctx->planes, bucket_windows * cnt);
+    k_msm_planes<C><<<pg, PLANE_THREADS, 0, stream>>>(tb, bucket_windows, ctx->wbuckets);
+    PLK_HIP_TRY(hipGetLastError());
+    mark();
+    k_msm_final<C><<<bucket_windows * cnt, FINAL_THREADS, 0, stream>>>(tb, bucket_windows, ctx->plane_blocks, ctx->planes, ctx->c);
+    if (bucket_windows > 1) k_msm_combine<C><<<cnt, COMBINE_THREADS, 0, stream>>>(tb, ctx->windows);
+    PLK_HIP_TRY(hipGetLastError());
+    mark();
+    return PLK_OK;
+}
+
 // phases: 1 = digits + bucket ordering, 2 = accumulation, 4 = reduction; 7 = the whole MSM on one stream
 constexpr int PH_ORDER = 1, PH_ACC = 2, PH_REDUCE = 4, PH_ALL = 7;
 template <class C>
@@ -1138,25 +1204,10 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
     }
     mark();
     if (!(phases & PH_REDUCE)) return PLK_OK;
-    k_msm_bucket_sum<C><<<(buckets * BUCKET_LANES + 255) / 256, 256, 0, stream>>>((const uint4*)w.partial, slice_off, (uint4*)w.bucket, buckets);
-    // hot buckets of a skewed scalar distribution (none for uniform scalars: the three launches then exit at once)
-    PLK_HIP_TRY(hipMemsetAsync(w.heavy, 0, 8, stream));
-    k_msm_heavy_list<<<(buckets + 255) / 256, 256, 0, stream>>>(slice_off, buckets, (uint32_t*)w.heavy, ctx->heavy_cap);
-    k_msm_heavy_chunks<C><<<256, 256, 0, stream>>>((const uint4*)w.partial, slice_off, (const uint32_t*)w.heavy, ctx->heavy_cap, (uint4*)w.heavy_part);
-    k_msm_heavy_final<C><<<64, 256, 0, stream>>>(slice_off, (const uint32_t*)w.heavy, ctx->heavy_cap, (const uint4*)w.heavy_part, (uint4*)w.bucket);
-    PLK_HIP_TRY(hipGetLastError());
-    mark();
-    const int bucket_windows = ctx->table_free ? ctx->windows : 1;
-    dim3 pg(ctx->plane_blocks, ctx->planes, bucket_windows);
-    k_msm_planes<C><<<pg, PLANE_THREADS, 0, stream>>>((const uint4*)w.bucket, (uint4*)w.plane_part, ctx->wbuckets);
-    PLK_HIP_TRY(hipGetLastError());
-    mark();
-    k_msm_final<C><<<bucket_windows, FINAL_THREADS, 0, stream>>>((const uint4*)w.plane_part, ctx->plane_blocks, ctx->planes, ctx->c, (uint4*)w.win_pts,
-                                                                 (uint4*)d_out_xy, (uint8_t*)d_out_zero);
-    if (bucket_windows > 1)
-        k_msm_combine<C><<<1, COMBINE_THREADS, 0, stream>>>((const uint4*)w.win_pts, ctx->windows, (uint4*)d_out_xy, (uint8_t*)d_out_zero);
-    PLK_HIP_TRY(hipGetLastError());
-    mark();
+    TailBatch tb;
+    tb.count = 1;
+    tb.s[0] = tail_slot(w, d_out_xy, d_out_zero);
+    PLK_TRY(msm_reduce_t<C>(ctx, tb, stream, mark));
     if (!ev.empty()) ctx->prof_sets.push_back(ev);
     return PLK_OK;
 }
@@ -1180,51 +1231,53 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
             default: return msm_execute_t<Bls12377Curve>(ctx, w, sc, oxy, oz, st, phases);
         }
     };
-    static const bool no_lanes = getenv("PLK_MSM_NO_OVERLAP") != nullptr;
-    if (batch == 1 || ctx->profiling || no_lanes) {
+    static const bool no_batching = getenv("PLK_MSM_NO_OVERLAP") != nullptr;  // every MSM of a batch start to end, one by one
+    if (batch == 1 || ctx->profiling || no_batching) {
         for (unsigned b = 0; b < batch; ++b) PLK_TRY(run_one(b, ctx->ws[0], stream, PH_ALL));
         return PLK_OK;
     }
-    // Several scalar vectors against the same generators (commit_polynomials, plonk_util.rs:215-231): consecutive
-    // MSMs alternate between two workspaces on two internal streams, their accumulations chained (ALU-bound, they
-    // would only slow each other down), so that the memory-bound bucket ordering and the latency-bound reduction
-    // of one MSM can run under the accumulation of its neighbour.  Measured gain 12 % (14.9 vs 16.9 ms for 9 x
-    // 2^20): the accumulation fills every SIMD's register file (3 waves x 168 VGPRs), the neighbour only gets the
-    // wave slots it frees.  Giving the other phases their own CUs (hipExtStreamCreateWithCUMask, 1 CU in 4..16) or
-    // a more urgent stream was measured slower (17.9 / 16.3 ms) and is not kept.
-    if (!ctx->ws[1].ready) {
+    // Several scalar vectors against the same generators (commit_polynomials, plonk_util.rs:215-231), in groups of up
+    // to TAIL_MAX: every MSM of a group has its own workspace, ordering and accumulation run one MSM after the other,
+    // and the latency-bound reduction runs ONCE for the whole group - it is a chain of point operations on few points,
+    // so nine of them cost little more than one (1.2 ms against 9 x 0.44 ms at 2^20).  Measured alternatives: running
+    // consecutive MSMs on two streams so that the ordering of one overlaps the accumulation of its neighbour gains
+    // nothing on top of this (the accumulation fills every SIMD's register file, 3 waves x 168 VGPRs); giving the other
+    // phases their own CUs (CU masks) or a more urgent stream is slower.
+    unsigned group = batch < (unsigned)TAIL_MAX ? batch : (unsigned)TAIL_MAX;
+    const size_t budget = (size_t)16 << 30;  // bytes of workspace a batch may hold
+    while (group > 2 && ctx->ws_bytes * group > budget) --group;
+    while (ctx->ws.size() < group) {
+        ctx->ws.emplace_back();
         int rc;
         switch (ctx->curve) {
-            case PLK_CURVE_TWEEDLEDEE: rc = msm_alloc_work<TweedledeeCurve>(ctx, ctx->ws[1]); break;
-            case PLK_CURVE_TWEEDLEDUM: rc = msm_alloc_work<TweedledumCurve>(ctx, ctx->ws[1]); break;
-            default: rc = msm_alloc_work<Bls12377Curve>(ctx, ctx->ws[1]); break;
+            case PLK_CURVE_TWEEDLEDEE: rc = msm_alloc_work<TweedledeeCurve>(ctx, ctx->ws.back()); break;
+            case PLK_CURVE_TWEEDLEDUM: rc = msm_alloc_work<TweedledumCurve>(ctx, ctx->ws.back()); break;
+            default: rc = msm_alloc_work<Bls12377Curve>(ctx, ctx->ws.back()); break;
         }
         if (rc != PLK_OK) {
-            ctx->ws[1].release();
-            return rc;
+            ctx->ws.pop_back();
+            (void)hipGetLastError();
+            group = (unsigned)ctx->ws.size();  // make do with what fits (at least the workspace of the precomputation)
+            break;
         }
     }
-    if (!ctx->lane[0]) {
-        for (int l = 0; l < 2; ++l) PLK_HIP_TRY(hipStreamCreateWithFlags(&ctx->lane[l], hipStreamNonBlocking));
-        for (int l = 0; l < 3; ++l) PLK_HIP_TRY(hipEventCreateWithFlags(&ctx->lane_ev[l], hipEventDisableTiming));
-        for (int l = 0; l < 2; ++l) PLK_HIP_TRY(hipEventCreateWithFlags(&ctx->acc_ev[l], hipEventDisableTiming));
-    }
-    // fork: both lanes start after whatever the caller queued on `stream` (the scalars may still be in flight)
-    PLK_HIP_TRY(hipEventRecord(ctx->lane_ev[2], stream));
-    for (int l = 0; l < 2; ++l) PLK_HIP_TRY(hipStreamWaitEvent(ctx->lane[l], ctx->lane_ev[2], 0));
-    for (unsigned b = 0; b < batch; ++b) {
-        hipStream_t st = ctx->lane[b & 1];
-        MsmWork& w = ctx->ws[b & 1];
-        PLK_TRY(run_one(b, w, st, PH_ORDER));
-        if (b) PLK_HIP_TRY(hipStreamWaitEvent(st, ctx->acc_ev[(b - 1) & 1], 0));
-        PLK_TRY(run_one(b, w, st, PH_ACC));
-        PLK_HIP_TRY(hipEventRecord(ctx->acc_ev[b & 1], st));
-        PLK_TRY(run_one(b, w, st, PH_REDUCE));
-    }
-    // join: the caller's stream continues after both lanes
-    for (int l = 0; l < 2; ++l) {
-        PLK_HIP_TRY(hipEventRecord(ctx->lane_ev[l], ctx->lane[l]));
-        PLK_HIP_TRY(hipStreamWaitEvent(stream, ctx->lane_ev[l], 0));
+    for (unsigned g0 = 0; g0 < batch; g0 += group) {
+        const unsigned cnt = batch - g0 < group ? batch - g0 : group;
+        TailBatch tb;
+        tb.count = (int)cnt;
+        for (unsigned k = 0; k < cnt; ++k) {
+            const unsigned b = g0 + k;
+            PLK_TRY(run_one(b, ctx->ws[k], stream, PH_ORDER | PH_ACC));
+            tb.s[k] = tail_slot(ctx->ws[k], (uint8_t*)d_out_xy + (size_t)b * 2 * L * 8, (uint8_t*)d_out_zero + b);
+        }
+        int rc;
+        auto nomark = [] {};
+        switch (ctx->curve) {
+            case PLK_CURVE_TWEEDLEDEE: rc = msm_reduce_t<TweedledeeCurve>(ctx, tb, stream, nomark); break;
+            case PLK_CURVE_TWEEDLEDUM: rc = msm_reduce_t<TweedledumCurve>(ctx, tb, stream, nomark); break;
+            default: rc = msm_reduce_t<Bls12377Curve>(ctx, tb, stream, nomark); break;
+        }
+        PLK_TRY(rc);
     }
     return PLK_OK;
 }
