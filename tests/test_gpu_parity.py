@@ -523,3 +523,27 @@ def test_coeffs_vec_to_commitments():
         b, bz = ol.scalar_mul(0, blind[t], h[0], 0)
         exp, ez = ol.affine_add(0, m, mz, b, bz)
         assert int(gz[t]) == ez and np.array_equal(got[t], exp), t
+
+
+@pytest.mark.parametrize("table_free", [False, True])
+def test_msm_batch_larger_than_one_group(table_free):
+    """20 scalar vectors in one call: more than one group of the shared reduction (16 per group), with tables and
+    table-free, skewed vectors included; every result equals the single-vector execution and the oracle."""
+    c = br.TWEEDLEDUM
+    G = (c.gx, c.gy)
+    D = br.ec_mul(c, 271828, G)
+    n = 300
+    bases = ol.gen_bases(c.curve_id, n, _bases(c, [G])[0], _bases(c, [D])[0])
+    vecs = [synth.rand_field(c.scalar.field_id, 0xBA7C0 + t, n) for t in range(20)]
+    vecs[3] = mont_arr(c.scalar, [7] * n)          # one bucket takes everything
+    vecs[11] = mont_arr(c.scalar, [0] * n)         # identity result
+    pre = pa.msm_precompute(c.curve_id, bases, 8, table_free=table_free)
+    out, oz = pa.msm_execute_batch(pre, np.stack(vecs))
+    opre = ol.MsmPrecomputation(c.curve_id, bases, 8, threads=8)
+    for t in range(20):
+        exp, ez = opre.execute(vecs[t], parallel=True, threads=8)
+        assert int(oz[t]) == ez, t
+        if not ez:
+            assert np.array_equal(out[t], exp), t
+        one, z1 = pa.msm_execute_parallel(pre, vecs[t])
+        assert z1 == ez and (ez or np.array_equal(one, exp)), t
