@@ -55,6 +55,14 @@ while time.time() < t_end:
         pre = pa.msm_precompute(c.curve_id, bases, 8, zero=zero, device_window=win, table_free=tf)
         got, gz = pa.msm_execute_parallel(pre, sc)
         assert gz == ez and (ez or np.array_equal(got, exp)), ("msm", c.name, n, style, tf, win)
+        if rng.random() < 0.3:
+            # the same vector inside a batch (shared reduction), next to other vectors
+            k = rng.choice([2, 3, 17])
+            vecs = [synth.rand_field(c.scalar.field_id, rng.randrange(1 << 30), n) for _ in range(k)]
+            at = rng.randrange(k)
+            vecs[at] = sc
+            bo, bz = pa.msm_execute_batch(pre, np.stack(vecs))
+            assert int(bz[at]) == ez and (ez or np.array_equal(bo[at], exp)), ("msm batch", c.name, n, style, tf, win, k)
         pre.free()
     elif kind == "ntt":
         f = rng.choice(FIELDS)
@@ -67,6 +75,13 @@ while time.time() < t_end:
         for b in range(batch):
             want = opre.ifft_with_precomputation_power_of_2(x[b], threads=8) if inv else opre.fft_with_precomputation_power_of_2(x[b], threads=8)
             assert np.array_equal(got[b], want), ("ntt", f.name, log_n, batch, inv)
+        if log_n >= 3 and rng.random() < 0.5:
+            # padded evaluation of shorter polynomials on the same domain (polynomials_to_values_padded)
+            lens = [rng.randrange(1, (1 << log_n) // 8 + 1) for _ in range(batch)]
+            polys = [x[b][: lens[b]] for b in range(batch)]
+            pv = pa.polynomials_to_values_padded(polys, pa.fft_precompute(f.field_id, 1 << log_n))
+            for b in range(batch):
+                assert np.array_equal(pv[b], ol.poly_to_values_padded(opre, polys[b], threads=8)), ("padded", f.name, log_n, lens[b])
     elif kind == "poly":
         f = rng.choice(FIELDS)
         la = rng.randrange(1, 6000)
