@@ -1094,10 +1094,10 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     return PLK_OK;
 }
 
-static TailSlot tail_slot(const MsmWork& w, void* d_out_xy, void* d_out_zero) {
+static TailSlot tail_slot(const plk_msm_ctx* ctx, const MsmWork& w, void* d_out_xy, void* d_out_zero) {
     TailSlot t;
     t.partial = (const uint4*)w.partial;
-    t.slice_off = (const uint32_t*)w.off + 0;  // fixed up by the caller: slice_off = off + buckets + 1
+    t.slice_off = (const uint32_t*)w.off + ctx->buckets + 1;  // off[buckets + 1] is followed by slice_off[buckets + 1]
     t.bucket = (uint4*)w.bucket;
     t.heavy = (uint32_t*)w.heavy;
     t.heavy_part = (uint4*)w.heavy_part;
@@ -1113,7 +1113,6 @@ template <class C, class Mark>
 static int msm_reduce_t(plk_msm_ctx* ctx, TailBatch tb, hipStream_t stream, Mark&& mark) {
     const uint32_t buckets = ctx->buckets;
     const unsigned cnt = (unsigned)tb.count;
-    for (unsigned k = 0; k < cnt; ++k) tb.s[k].slice_off += buckets + 1;
     k_msm_bucket_sum<C><<<dim3((buckets * BUCKET_LANES + 255) / 256, cnt), 256, 0, stream>>>(tb, buckets);
     // hot buckets of a skewed scalar distribution (none for uniform scalars: the three launches then exit at once)
     k_msm_heavy_list<<<dim3((buckets + 255) / 256, cnt), 256, 0, stream>>>(tb, buckets, ctx->heavy_cap);
@@ -1206,7 +1205,7 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
     if (!(phases & PH_REDUCE)) return PLK_OK;
     TailBatch tb;
     tb.count = 1;
-    tb.s[0] = tail_slot(w, d_out_xy, d_out_zero);
+    tb.s[0] = tail_slot(ctx, w, d_out_xy, d_out_zero);
     PLK_TRY(msm_reduce_t<C>(ctx, tb, stream, mark));
     if (!ev.empty()) ctx->prof_sets.push_back(ev);
     return PLK_OK;
@@ -1268,7 +1267,7 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
         for (unsigned k = 0; k < cnt; ++k) {
             const unsigned b = g0 + k;
             PLK_TRY(run_one(b, ctx->ws[k], stream, PH_ORDER | PH_ACC));
-            tb.s[k] = tail_slot(ctx->ws[k], (uint8_t*)d_out_xy + (size_t)b * 2 * L * 8, (uint8_t*)d_out_zero + b);
+            tb.s[k] = tail_slot(ctx, ctx->ws[k], (uint8_t*)d_out_xy + (size_t)b * 2 * L * 8, (uint8_t*)d_out_zero + b);
         }
         int rc;
         auto nomark = [] {};
