@@ -128,7 +128,8 @@ template <class P> PLK_DI void lds_store(uint32_t* base, int stride, int idx, co
 
 // Timing experiments (tools/ntt_experiments.sh): -DPLK_NTT_EXP=1 replaces the stage multiplications by
 // additions, 2 every multiplication, 3 drops the stage loops, 6 replaces all global loads by synthetic values and
-// drops the stores (7: real loads, no stores; 8: synthetic loads, real stores).  Results are wrong by construction;
+// drops the stores (7: real loads, no stores; 8: synthetic loads, real stores; 10 / 11: as 7 / 0 but every pass reads the
+// caller's input, i.e. full-entropy data that no launch has written).  Results are wrong by construction;
 // the product build leaves PLK_NTT_EXP undefined.
 #ifndef PLK_NTT_EXP
 #define PLK_NTT_EXP 0
@@ -346,8 +347,8 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restric
     for (int e = tid; e < tile_elems; e += NTT_THREADS) {
         const size_t g = tile_out_index(a, tg, e);
         Fe<P> tw = fe_zero<P>();
-#if PLK_NTT_EXP == 6 || PLK_NTT_EXP == 7 || PLK_NTT_EXP == 8
-#if PLK_NTT_EXP == 7
+#if PLK_NTT_EXP == 6 || PLK_NTT_EXP == 7 || PLK_NTT_EXP == 8 || PLK_NTT_EXP == 10
+#if PLK_NTT_EXP == 7 || PLK_NTT_EXP == 10
         if (!a.last) tw = fe_load<P>(outer_tw + tile_tw_index(a, tg, e) * 2);
 #else
         for (int l = 0; l < 8; ++l) {
@@ -596,7 +597,11 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
             rc = set_error(PLK_ERR_HIP, "ntt pass launch failed: %s", hipGetErrorString(e));
             break;
         }
+#if PLK_NTT_EXP == 10 || PLK_NTT_EXP == 11
+        src = hooks ? dst : d_in;  // experiment: every pass reads the caller's (random, never modified) input
+#else
         src = dst;
+#endif
         log_nt = a.log_s;
     }
     if (scratch) scratch_release(scratch, stream);
