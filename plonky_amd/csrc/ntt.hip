@@ -134,12 +134,12 @@ template <class P> PLK_DI void lds_store(uint32_t* base, int stride, int idx, co
 #ifndef PLK_NTT_EXP
 #define PLK_NTT_EXP 0
 #endif
-#if PLK_NTT_EXP >= 1
+#if PLK_NTT_EXP >= 1 && PLK_NTT_EXP <= 3
 #define STAGE_MUL(P, a, b) fz_add<P>(a, b)
 #else
 #define STAGE_MUL(P, a, b) fz_mul<P>(a, b)
 #endif
-#if PLK_NTT_EXP >= 2
+#if PLK_NTT_EXP >= 2 && PLK_NTT_EXP <= 3
 #define OUT_MUL(P, a, b) fz_add<P>(a, b)
 #else
 #define OUT_MUL(P, a, b) fz_mul<P>(a, b)
