@@ -2,24 +2,26 @@
 //
 // Replaces the reference's src/curve/curve_msm.rs (+ curve_summations.rs, curve_adds.rs):
 //   msm_precompute / precompute_single_generator  curve_msm.rs:27-52  -> k_msm_table (device tables)
-//   to_digits                                     curve_msm.rs:159-180 -> k_msm_digits (signed, carry based)
-//   digit_occurrences scatter (serial in the ref) curve_msm.rs:117-126 -> two-level LDS partition (k_part*)
-//   per-digit affine multi-summation              curve_msm.rs:131-145 -> k_msm_accumulate (XYZZ mixed adds)
-//   serial Yao tail  u += acc[d]; y += u          curve_msm.rs:149-154 -> k_msm_bucket_sum + k_msm_planes + k_msm_final
+//   to_digits                                     curve_msm.rs:159-180 -> ord_digit (signed, carry based; recomputed where used)
+//   digit_occurrences scatter (serial in the ref) curve_msm.rs:117-126 -> two-level LDS partition (k_ord_*)
+//   per-digit affine multi-summation              curve_msm.rs:131-145 -> k_msm_accumulate (XYZZ mixed adds, equal chunks)
+//   serial Yao tail  u += acc[d]; y += u          curve_msm.rs:149-154 -> k_msm_assemble + k_msm_gsum/lsum + k_msm_planes + k_msm_final
 //   msm_execute / msm_execute_parallel            curve_msm.rs:63-157  -> msm_execute_dev_impl
 //   msm_parallel (precompute + execute, one use)  curve_msm.rs:54-61   -> the table-free mode (PLK_MSM_TABLE_FREE)
 // Same mathematical structure as the reference (Yao's method over per-generator power tables
 // [2^(c j)] G_i, one bucket per digit value, result = sum_d d * bucket_d) with two MI355X-first
 // changes: (1) digits are signed (carry-based integer recoding, never s -> r - s, so it is valid
 // on BLS12-377 G1 whose cofactor is even): half the buckets for the same window; (2) the serial
-// running sum is replaced by bit-plane tree sums (sum_d d B_d = sum_p 2^p sum_{d: bit p} B_d), so
-// the tail is O(log) deep instead of 2 * 2^w sequential additions.  The result is returned as
+// running sum is replaced by a two-level weighting (row / column sums of the bucket grid) followed by
+// bit-plane tree sums (sum_d d B_d = sum_p 2^p sum_{d: bit p} B_d), so the tail is O(log) deep instead of
+// 2 * 2^w sequential additions and costs 2 additions per bucket - which is what makes windows of 18-20 bits
+// (13 additions per scalar at 2^20) affordable.  The result is returned as
 // the unique affine point (to_affine, curve.rs:206-214), on which parity is defined.
 //
 // Work decomposition: every (scalar i, window j) with a non-zero digit is one *entry* that adds
-// +-table[j*n + i] into bucket |d|-1.  Entries are counting-sorted by bucket; every bucket is
-// cut into slices of <= SLICE entries and one lane accumulates one slice, so the load per lane
-// is bounded whatever the digit distribution (a skewed witness cannot serialise the kernel).
+// +-table[j*n + i] into bucket |d|-1.  Entries are counting-sorted by bucket; the sorted list is cut
+// into equal chunks and one lane accumulates one chunk (storing a piece at every bucket boundary), so the
+// load per lane is the same whatever the digit distribution (a skewed witness cannot serialise the kernel).
 //
 // Table-free mode (generators used once): only the generators themselves are stored; window j gets its own
 // bucket range [j 2^(c-1), (j+1) 2^(c-1)), the same kernels run over all windows at once, every window's
@@ -27,6 +29,7 @@
 // Batches: every MSM of a group has its own workspace and the group shares one reduction (msm_execute_dev_impl).
 // The reduction kernels run on quads of lanes (ecz_coop.cuh): they are chains of point operations, i.e. latency.
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -37,9 +40,8 @@
 
 namespace plk {
 
-constexpr int MSM_SLICE_DEFAULT = 24;  // entries per accumulation slice (PLK_MSM_SLICE overrides)
 constexpr int MSM_MAX_PLANE_PARTS = 16;  // blocks per bit-plane in the reduction (planes * parts quads must fit the final block)
-constexpr int MSM_MAX_WINDOW = 17;   // c - 1 <= 8 fine + 8 coarse bits in the partition
+constexpr int MSM_MAX_WINDOW = 21;   // c - 1 <= 10 coarse + 11 fine bits in the partition (ORD_MAX_BINS, ORD_MAX_FINE)
 constexpr uint32_t CODE_INVALID = 0xFFFFFFFFu;
 
 // ---------------------------------------------------------------------------------------------
@@ -107,152 +109,133 @@ __global__ void __launch_bounds__(256) k_msm_table_export(const uint4* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// scalars -> signed window digits  (curve_msm.rs:159-180)
+// scalars -> signed window digits  (curve_msm.rs:159-180), computed where they are consumed
 // ---------------------------------------------------------------------------------------------
-template <class C>
-__global__ void __launch_bounds__(256) k_msm_digits(const uint4* __restrict__ scalars, uint32_t* __restrict__ codes, size_t n, int c, int windows,
-                                                    uint32_t window_buckets) {
-    using SP = typename C::SP;
+// Digits are never stored: the two kernels of the first partition level recompute them from the scalars
+// (one Montgomery -> canonical conversion per scalar and kernel, ~10 instructions per digit), which replaces
+// a 4-byte write and two 4-byte reads per (scalar, window) by two extra reads of the 32-byte scalar.
+// The canonical limbs are parked in LDS (limb-major: conflict-free) so that the window loop can index them.
+constexpr int ORD_THREADS = 256;
+constexpr int ORD_TILE = 4096;      // entries staged per tile of the level-1 scatter
+constexpr int ORD_MAX_BINS = 1024;  // coarse bins
+constexpr int ORD_MAX_FINE = 11;    // fine bits: buckets per coarse bin <= 2048
+constexpr int ORD_BIN_THREADS = 512;
+constexpr uint32_t ORD_SEG = 8192;  // entries per level-2 workgroup
+
+struct OrdCfg {
+    int c;                   // window bits
+    int windows;             // digits per scalar
+    uint32_t window_buckets; // table-free mode: 2^(c-1) (every window has its own bucket range), else 0
+    int fine_bits;           // bucket id = [coarse bin | fine]
+    int nbins;               // coarse bins in use
+    uint32_t spt;            // scalars per sub-tile (<= ORD_THREADS, spt * windows <= ORD_TILE)
+    uint32_t sub;            // sub-tiles per tile (one block walks them in turn)
+    uint32_t nt1;            // tiles
+};
+
+template <class SP> PLK_DI void ord_park_scalar(const uint4* __restrict__ scalars, size_t i, uint32_t* s_lim, int tid) {
     static_assert(SP::NL == 8, "scalar fields are 256-bit");
-    // Scalars are staged through LDS: the block reads its 256 * 32 B with fully coalesced 16-byte
-    // loads, each lane then picks up its own scalar, converts it and parks the canonical limbs
-    // back in LDS so the window loop can index them dynamically.
-    __shared__ uint4 s_sc[512];
-    const size_t base = (size_t)blockIdx.x * 256;
-    for (int k = threadIdx.x; k < 512; k += 256) {
-        size_t g = base * 2 + k;
-        s_sc[k] = g < n * 2 ? scalars[g] : make_uint4(0, 0, 0, 0);
-    }
-    __syncthreads();
-    const size_t i = base + threadIdx.x;
+    const uint4 lo = scalars[i * 2], hi = scalars[i * 2 + 1];
     Fe<SP> s;
-    {
-        uint4 lo = s_sc[2 * threadIdx.x], hi = s_sc[2 * threadIdx.x + 1];
-        s.v[0] = lo.x; s.v[1] = lo.y; s.v[2] = lo.z; s.v[3] = lo.w;
-        s.v[4] = hi.x; s.v[5] = hi.y; s.v[6] = hi.z; s.v[7] = hi.w;
-    }
+    s.v[0] = lo.x; s.v[1] = lo.y; s.v[2] = lo.z; s.v[3] = lo.w;
+    s.v[4] = hi.x; s.v[5] = hi.y; s.v[6] = hi.z; s.v[7] = hi.w;
     // Montgomery -> canonical in the SCALAR field (to_canonical_u64_vec, curve_msm.rs:164)
     s = fe_to_canonical<SP>(s);
-    uint32_t* lim = reinterpret_cast<uint32_t*>(s_sc) + threadIdx.x * 8;
-    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) lim[k] = s.v[k];
-    if (i >= n) return;
+    for (int k = 0; k < 8; ++k) s_lim[k * ORD_THREADS + tid] = s.v[k];
+}
+// digit j of the parked scalar: signed c-bit window by carry-based integer recoding (never s -> r - s, so it is valid on
+// BLS12-377 G1 whose cofactor is even).  Returns (bucket << 1) | negative, or CODE_INVALID for a zero digit.
+PLK_DI uint32_t ord_digit(const uint32_t* s_lim, int tid, int j, const OrdCfg& cfg, uint32_t& carry) {
+    const int c = cfg.c;
     const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
-    uint32_t carry = 0;
-    for (int j = 0; j < windows; ++j) {
-        const int bp = j * c, li = bp >> 5, sh = bp & 31;
-        uint64_t two = li < 8 ? lim[li] : 0u;
-        if (li + 1 < 8) two |= (uint64_t)lim[li + 1] << 32;
-        uint32_t v = ((uint32_t)(two >> sh) & mask) + carry;
-        // signed recoding: v in [0, 2^c]; v > 2^(c-1) becomes v - 2^c with a carry into the next window
-        uint32_t neg = v > half ? 1u : 0u;
-        uint32_t mag = neg ? (1u << c) - v : v;
-        carry = neg;
-        uint32_t code = CODE_INVALID;
-        // bucket id: |d| - 1, plus the window's own bucket range in table-free mode (window_buckets = 2^(c-1), else 0)
-        if (mag != 0) code = ((mag - 1u + (uint32_t)j * window_buckets) << 1) | neg;
-        codes[(size_t)j * n + i] = code;
-    }
+    const int bp = j * c, li = bp >> 5, sh = bp & 31;
+    uint64_t two = li < 8 ? s_lim[li * ORD_THREADS + tid] : 0u;
+    if (li + 1 < 8) two |= (uint64_t)s_lim[(li + 1) * ORD_THREADS + tid] << 32;
+    const uint32_t v = ((uint32_t)(two >> sh) & mask) + carry;
+    // v in [0, 2^c]; v > 2^(c-1) becomes v - 2^c with a carry into the next window
+    const uint32_t neg = v > half ? 1u : 0u;
+    const uint32_t mag = neg ? (1u << c) - v : v;
+    carry = neg;
+    if (mag == 0) return CODE_INVALID;
+    return ((mag - 1u + (uint32_t)j * cfg.window_buckets) << 1) | neg;
 }
 
-// exclusive scans of the bucket sizes (off) and of the per-bucket slice counts (slice_off), two steps:
-// every block scans 1024 buckets and publishes its totals, then every block adds the totals of the
-// blocks before it (<= 64 of them: a serial walk by one lane is cheaper than another launch).
-__global__ void __launch_bounds__(1024) k_msm_scan_local(const uint32_t* __restrict__ hist, uint32_t* __restrict__ off, uint32_t* __restrict__ slice_off,
-                                                         uint32_t* __restrict__ block_tot, uint32_t buckets, uint32_t slice) {
-    __shared__ uint32_t s_a[1024], s_b[1024];
-    const uint32_t b = blockIdx.x * 1024 + threadIdx.x;
-    const uint32_t h = b < buckets ? hist[b] : 0u;
-    const uint32_t sl = (h + slice - 1) / slice;
-    s_a[threadIdx.x] = h;
-    s_b[threadIdx.x] = sl;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        uint32_t va = 0, vb = 0;
-        if ((int)threadIdx.x >= d) {
-            va = s_a[threadIdx.x - d];
-            vb = s_b[threadIdx.x - d];
-        }
-        __syncthreads();
-        s_a[threadIdx.x] += va;
-        s_b[threadIdx.x] += vb;
-        __syncthreads();
-    }
-    if (b < buckets) {
-        off[b] = s_a[threadIdx.x] - h;
-        slice_off[b] = s_b[threadIdx.x] - sl;
-    }
-    if (threadIdx.x == 1023) {
-        block_tot[2 * blockIdx.x] = s_a[1023];
-        block_tot[2 * blockIdx.x + 1] = s_b[1023];
-    }
-}
-__global__ void __launch_bounds__(1024) k_msm_scan_add(uint32_t* __restrict__ off, uint32_t* __restrict__ slice_off, const uint32_t* __restrict__ block_tot,
-                                                       uint32_t buckets) {
-    __shared__ uint32_t s_add[2];
-    if (threadIdx.x == 0) {
-        uint32_t a = 0, c = 0;
-        for (uint32_t k = 0; k < blockIdx.x; ++k) {
-            a += block_tot[2 * k];
-            c += block_tot[2 * k + 1];
-        }
-        s_add[0] = a;
-        s_add[1] = c;
-        if (blockIdx.x == gridDim.x - 1) {  // grand totals close both arrays
-            off[buckets] = a + block_tot[2 * blockIdx.x];
-            slice_off[buckets] = c + block_tot[2 * blockIdx.x + 1];
-        }
-    }
-    __syncthreads();
-    const uint32_t b = blockIdx.x * 1024 + threadIdx.x;
-    if (b < buckets) {
-        off[b] += s_add[0];
-        slice_off[b] += s_add[1];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// entries -> bucket order: two-level MSD partition in LDS  (replaces the reference's serial
-// digit_occurrences scatter, curve_msm.rs:117-126)
-// ---------------------------------------------------------------------------------------------
-// A bucket id has c-1 bits = [coarse | fine], fine = min(8, c-1) bits.  Level 1 splits the entry
-// stream into <= 256 coarse bins, level 2 splits every coarse bin into its <= 256 buckets.  Both
-// levels are the same three steps on tiles of PART_TILE entries: per-tile LDS histogram ->
-// global [bin][tile] counts -> scan -> per-tile LDS cursors, so every global write is a run of
-// consecutive slots and the only atomics are LDS atomics.  Counts, not capacities, drive the
-// layout: any digit distribution works (hot buckets just make long runs).
-constexpr int PART_TILE_LOG = 12;
-constexpr int PART_TILE = 1 << PART_TILE_LOG;   // entries per tile
-constexpr int PART_THREADS = 256;
-constexpr int PART_PER_THREAD = PART_TILE / PART_THREADS;
-
-// level 1, step 1: cnt1[bin * nt1 + tile] = number of entries of `tile` falling in coarse bin `bin`
-__global__ void __launch_bounds__(PART_THREADS) k_part1_count(const uint32_t* __restrict__ codes, size_t entries, uint32_t* __restrict__ cnt1, uint32_t nt1,
-                                                              int fine_bits, int nbins) {
-    __shared__ uint32_t s_hist[256];
-    const uint32_t tile = blockIdx.x;
-    s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    const size_t base = (size_t)tile << PART_TILE_LOG;
+// exclusive scan of s_data[0..count) in place (count <= 4 * blockDim.x); s_tmp: blockDim.x words.  Ends with a barrier.
+PLK_DI void block_excl_scan4(uint32_t* s_data, int count, uint32_t* s_tmp) {
+    const int t = threadIdx.x, nth = blockDim.x;
+    uint32_t v[4], sum = 0;
 #pragma unroll
-    for (int k = 0; k < PART_PER_THREAD; ++k) {
-        const size_t e = base + k * PART_THREADS + threadIdx.x;
-        if (e < entries) {
-            const uint32_t code = codes[e];
-            if (code != CODE_INVALID) atomicAdd(&s_hist[code >> (fine_bits + 1)], 1u);
+    for (int k = 0; k < 4; ++k) {
+        const int idx = t * 4 + k;
+        v[k] = idx < count ? s_data[idx] : 0u;
+        sum += v[k];
+    }
+    s_tmp[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < nth; d <<= 1) {
+        const uint32_t u = t >= d ? s_tmp[t - d] : 0u;
+        __syncthreads();
+        s_tmp[t] += u;
+        __syncthreads();
+    }
+    uint32_t run = s_tmp[t] - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = t * 4 + k;
+        if (idx < count) s_data[idx] = run;
+        run += v[k];
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// entries -> bucket order  (replaces the reference's serial digit_occurrences scatter, curve_msm.rs:117-126)
+// ---------------------------------------------------------------------------------------------
+// Every (scalar i, window j) with a non-zero digit is an entry (id j * n + i = its table index) that goes to bucket
+// |d| - 1.  A bucket id is [coarse bin | fine].  Level 1 moves the entries to their coarse bin (per-tile LDS histogram ->
+// global [bin][tile] counts -> scan -> staged, run-wise writes); level 2 is one workgroup per coarse bin that counts,
+// scans and scatters its bin by the fine bits, producing the bucket offsets on the way.  Only LDS atomics; counts,
+// not capacities, drive the layout, so any digit distribution works.
+
+// level 1, step 1: cnt1[bin * nt1 + tile].  A tile is `sub` consecutive sub-tiles of spt scalars, walked by one block.
+template <class C>
+__global__ void __launch_bounds__(ORD_THREADS) k_ord_count(const uint4* __restrict__ scalars, size_t n, OrdCfg cfg, uint32_t* __restrict__ cnt1) {
+    using SP = typename C::SP;
+    __shared__ uint32_t s_lim[8 * ORD_THREADS];
+    __shared__ uint32_t s_hist[ORD_MAX_BINS];
+    const int tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_hist[k] = 0;
+    for (uint32_t st = 0; st < cfg.sub; ++st) {
+        const size_t i = ((size_t)tile * cfg.sub + st) * cfg.spt + tid;
+        const bool live = (uint32_t)tid < cfg.spt && i < n;
+        __syncthreads();
+        if (live) ord_park_scalar<SP>(scalars, i, s_lim, tid);
+        __syncthreads();
+        if (live) {
+            uint32_t carry = 0;
+            for (int j = 0; j < cfg.windows; ++j) {
+                const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
+                if (code != CODE_INVALID) atomicAdd(&s_hist[code >> (cfg.fine_bits + 1)], 1u);
+            }
         }
     }
     __syncthreads();
-    if ((int)threadIdx.x < nbins) cnt1[(size_t)threadIdx.x * nt1 + tile] = s_hist[threadIdx.x];
+    for (int k = tid; k < cfg.nbins; k += ORD_THREADS) cnt1[(size_t)k * cfg.nt1 + tile] = s_hist[k];
 }
 
-// one block per row: in-place exclusive scan of `len` counters, total to totals[row]
-__global__ void __launch_bounds__(256) k_part_rowscan(uint32_t* __restrict__ cnt, uint32_t len, uint32_t* __restrict__ totals) {
+// level 1, step 2: one block per bin row: in-place exclusive scan over the tiles; the block that finishes last turns the
+// bin totals into the bin offsets bin_base[0..nbins] (exclusive scan; bin_base[nbins] = number of entries) and into the
+// level-2 segment table seg_base[0..nbins] (a bin of t entries has ceil(t / ORD_SEG) segments).
+__global__ void __launch_bounds__(256) k_ord_scan1(uint32_t* __restrict__ cnt1, uint32_t nt1, int nbins, uint32_t* __restrict__ bin_total,
+                                                   uint32_t* __restrict__ bin_base, uint32_t* __restrict__ seg_base, uint32_t* __restrict__ done_counter) {
     __shared__ uint32_t s_sum[256];
-    uint32_t* row = cnt + (size_t)blockIdx.x * len;
-    const uint32_t per = (len + 255) / 256;
-    const uint32_t lo = threadIdx.x * per, hi = min(len, lo + per);
+    __shared__ uint32_t s_bins[ORD_MAX_BINS];
+    __shared__ bool s_last;
+    uint32_t* row = cnt1 + (size_t)blockIdx.x * nt1;
+    const uint32_t per = (nt1 + 255) / 256;
+    const uint32_t lo = min(nt1, threadIdx.x * per), hi = min(nt1, lo + per);
     uint32_t sum = 0;
     for (uint32_t i = lo; i < hi; ++i) sum += row[i];
     s_sum[threadIdx.x] = sum;
@@ -269,280 +252,360 @@ __global__ void __launch_bounds__(256) k_part_rowscan(uint32_t* __restrict__ cnt
         row[i] = run;
         run += v;
     }
-    if (threadIdx.x == 255) totals[blockIdx.x] = s_sum[255];
-}
-
-// layout of the intermediate array: every coarse bin starts on a tile boundary (so level-2 tiles
-// never straddle bins).  meta[0] = number of level-2 tiles.
-__global__ void __launch_bounds__(256) k_part_bases(const uint32_t* __restrict__ bin_total, int nbins, uint32_t* __restrict__ bin_base_pad,
-                                                    uint32_t* __restrict__ tile2bin, uint32_t* __restrict__ meta) {
-    __shared__ uint32_t s_pad[257];
-    __shared__ uint32_t s_scan[256];
-    // exclusive scan of the bins' sizes rounded up to whole tiles (nbins <= 256 = blockDim.x)
-    const int t = threadIdx.x;
-    const uint32_t mine = t < nbins ? (bin_total[t] + PART_TILE - 1) >> PART_TILE_LOG << PART_TILE_LOG : 0u;
-    s_scan[t] = mine;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const uint32_t u = t >= d ? s_scan[t - d] : 0u;
-        __syncthreads();
-        s_scan[t] += u;
-        __syncthreads();
-    }
-    if (t < nbins) s_pad[t] = s_scan[t] - mine;
-    if (t == nbins - 1) {
-        s_pad[nbins] = s_scan[t];
-        meta[0] = s_scan[t] >> PART_TILE_LOG;
+    if (threadIdx.x == 255) {
+        bin_total[blockIdx.x] = s_sum[255];
+        __threadfence();
+        s_last = atomicAdd(done_counter, 1u) == (uint32_t)nbins - 1u;
     }
     __syncthreads();
-    for (int b = threadIdx.x; b <= nbins; b += blockDim.x) bin_base_pad[b] = s_pad[b];
-    // every thread fills the tiles of its own bin
-    if (t < nbins) {
-        const uint32_t t0 = s_pad[t] >> PART_TILE_LOG, t1 = s_pad[t + 1] >> PART_TILE_LOG;
-        for (uint32_t k = t0; k < t1; ++k) tile2bin[k] = (uint32_t)t;
+    if (!s_last) return;
+    __threadfence();
+    const volatile uint32_t* vt = bin_total;
+    for (int k = threadIdx.x; k < nbins; k += 256) s_bins[k] = vt[k];
+    __syncthreads();
+    const uint32_t last_total = s_bins[nbins - 1];
+    block_excl_scan4(s_bins, nbins, s_sum);
+    for (int k = threadIdx.x; k < nbins; k += 256) bin_base[k] = s_bins[k];
+    if (threadIdx.x == 0) bin_base[nbins] = s_bins[nbins - 1] + last_total;
+    __syncthreads();
+    for (int k = threadIdx.x; k < nbins; k += 256) s_bins[k] = (vt[k] + ORD_SEG - 1) / ORD_SEG;
+    __syncthreads();
+    const uint32_t last_segs = s_bins[nbins - 1];
+    block_excl_scan4(s_bins, nbins, s_sum);
+    for (int k = threadIdx.x; k < nbins; k += 256) seg_base[k] = s_bins[k];
+    if (threadIdx.x == 0) {
+        seg_base[nbins] = s_bins[nbins - 1] + last_segs;
+        *done_counter = 0;  // ready for the next execution
     }
 }
 
-// Shared by both scatter steps: the tile is first ordered by bin inside LDS (returning LDS atomics give
-// the rank inside the (tile, bin) run, a 256-wide scan gives the run starts), then written out in
-// that order, so consecutive lanes store to consecutive addresses of the same run.
-PLK_DI void part_scan256(uint32_t* s_cnt, uint32_t* s_base) {
-    // exclusive scan of s_cnt[0..255] into s_base (Hillis-Steele, blockDim.x == 256)
-    const int t = threadIdx.x;
-    uint32_t v = s_cnt[t];
-    s_base[t] = v;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const uint32_t u = t >= d ? s_base[t - d] : 0u;
-        __syncthreads();
-        s_base[t] += u;
-        __syncthreads();
-    }
-    const uint32_t incl = s_base[t];
-    __syncthreads();
-    s_base[t] = incl - v;
-    __syncthreads();
-}
-
-// level 1, step 3: move (code, entry id) to its coarse bin
-__global__ void __launch_bounds__(PART_THREADS) k_part1_scatter(const uint32_t* __restrict__ codes, size_t entries, const uint32_t* __restrict__ cnt1,
-                                                                uint32_t nt1, const uint32_t* __restrict__ bin_base_pad, int fine_bits, int nbins,
-                                                                uint32_t* __restrict__ tmp_code, uint32_t* __restrict__ tmp_val) {
-    __shared__ uint32_t s_cnt[256], s_base[256], s_gbase[256];
-    __shared__ uint32_t s_code[PART_TILE], s_val[PART_TILE];
-    const uint32_t tile = blockIdx.x;
-    s_cnt[threadIdx.x] = 0;
-    s_gbase[threadIdx.x] = (int)threadIdx.x < nbins ? bin_base_pad[threadIdx.x] + cnt1[(size_t)threadIdx.x * nt1 + tile] : 0u;
-    __syncthreads();
-    const size_t base = (size_t)tile << PART_TILE_LOG;
-    uint32_t code[PART_PER_THREAD], rank[PART_PER_THREAD];
-#pragma unroll
-    for (int k = 0; k < PART_PER_THREAD; ++k) {
-        const size_t e = base + k * PART_THREADS + threadIdx.x;
-        code[k] = e < entries ? codes[e] : CODE_INVALID;
-        rank[k] = code[k] != CODE_INVALID ? atomicAdd(&s_cnt[code[k] >> (fine_bits + 1)], 1u) : 0u;
-    }
-    __syncthreads();
-    part_scan256(s_cnt, s_base);
-#pragma unroll
-    for (int k = 0; k < PART_PER_THREAD; ++k) {
-        if (code[k] != CODE_INVALID) {
-            const uint32_t sidx = s_base[code[k] >> (fine_bits + 1)] + rank[k];
-            s_code[sidx] = code[k];
-            s_val[sidx] = (uint32_t)(base + k * PART_THREADS + threadIdx.x);
-        }
-    }
-    __syncthreads();
-    const uint32_t total = s_base[255] + s_cnt[255];
-#pragma unroll
-    for (int k = 0; k < PART_PER_THREAD; ++k) {
-        const uint32_t sidx = k * PART_THREADS + threadIdx.x;
-        if (sidx < total) {
-            const uint32_t c = s_code[sidx], bin = c >> (fine_bits + 1);
-            const uint32_t pos = s_gbase[bin] + (sidx - s_base[bin]);
-            tmp_code[pos] = c;
-            tmp_val[pos] = s_val[sidx];
-        }
-    }
-}
-
-// level 2, step 1: cnt2[fine * nt2max + tile2]  (row = bucket-within-bin, so a row scan over the
-// tiles of one bin gives the within-bucket offsets)
-__global__ void __launch_bounds__(PART_THREADS) k_part2_count(const uint32_t* __restrict__ tmp_code, const uint32_t* __restrict__ bin_total,
-                                                              const uint32_t* __restrict__ bin_base_pad, const uint32_t* __restrict__ tile2bin,
-                                                              const uint32_t* __restrict__ meta, uint32_t* __restrict__ cnt2, uint32_t nt2max, int fine_bits) {
-    __shared__ uint32_t s_hist[256];
-    const uint32_t tile = blockIdx.x;
-    if (tile >= meta[0]) return;
-    const uint32_t bin = tile2bin[tile];
-    const uint32_t valid_end = bin_base_pad[bin] + bin_total[bin];
-    s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t base = tile << PART_TILE_LOG, fmask = (1u << fine_bits) - 1u;
-#pragma unroll
-    for (int k = 0; k < PART_PER_THREAD; ++k) {
-        const uint32_t p = base + k * PART_THREADS + threadIdx.x;
-        if (p < valid_end) atomicAdd(&s_hist[(tmp_code[p] >> 1) & fmask], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x <= fmask) cnt2[(size_t)threadIdx.x * nt2max + tile] = s_hist[threadIdx.x];
-}
-
-// level 2, step 2: one block per coarse bin, lane = fine bucket: walk the bin's tiles, turn the counts
-// into within-bucket offsets and publish the bucket sizes (hist) for the global bucket scan
-__global__ void __launch_bounds__(256) k_part2_scan(uint32_t* __restrict__ cnt2, uint32_t nt2max, const uint32_t* __restrict__ bin_base_pad, int fine_bits,
-                                                    uint32_t* __restrict__ hist) {
-    const uint32_t bin = blockIdx.x, fine = threadIdx.x;
-    if (fine >= (1u << fine_bits)) return;
-    const uint32_t t0 = bin_base_pad[bin] >> PART_TILE_LOG, t1 = bin_base_pad[bin + 1] >> PART_TILE_LOG;
-    uint32_t run = 0;
-    uint32_t* row = cnt2 + (size_t)fine * nt2max;
-    for (uint32_t t = t0; t < t1; ++t) {
-        const uint32_t v = row[t];
-        row[t] = run;
-        run += v;
-    }
-    hist[(bin << fine_bits) + fine] = run;
-}
-
-// level 2, step 3: final position = off[bucket] + within-bucket offset of this tile + rank in the tile
-__global__ void __launch_bounds__(PART_THREADS) k_part2_scatter(const uint32_t* __restrict__ tmp_code, const uint32_t* __restrict__ tmp_val,
-                                                                const uint32_t* __restrict__ bin_total, const uint32_t* __restrict__ bin_base_pad,
-                                                                const uint32_t* __restrict__ tile2bin, const uint32_t* __restrict__ meta,
-                                                                const uint32_t* __restrict__ cnt2, uint32_t nt2max, int fine_bits,
-                                                                const uint32_t* __restrict__ off, uint32_t* __restrict__ sorted) {
-    __shared__ uint32_t s_cnt[256], s_base[256], s_gbase[256];
-    __shared__ uint32_t s_out[PART_TILE];
-    __shared__ uint8_t s_fine[PART_TILE];
-    const uint32_t tile = blockIdx.x;
-    if (tile >= meta[0]) return;
-    const uint32_t bin = tile2bin[tile];
-    const uint32_t valid_end = bin_base_pad[bin] + bin_total[bin];
-    const uint32_t fmask = (1u << fine_bits) - 1u;
-    s_cnt[threadIdx.x] = 0;
-    s_gbase[threadIdx.x] = threadIdx.x <= fmask ? off[(bin << fine_bits) + threadIdx.x] + cnt2[(size_t)threadIdx.x * nt2max + tile] : 0u;
-    __syncthreads();
-    const uint32_t base = tile << PART_TILE_LOG;
-    uint32_t word[PART_PER_THREAD], fine[PART_PER_THREAD], rank[PART_PER_THREAD];
-#pragma unroll
-    for (int k = 0; k < PART_PER_THREAD; ++k) {
-        const uint32_t p = base + k * PART_THREADS + threadIdx.x;
-        fine[k] = 0xFFFFFFFFu;
-        if (p < valid_end) {
-            const uint32_t c = tmp_code[p];
-            fine[k] = (c >> 1) & fmask;
-            word[k] = (tmp_val[p] << 1) | (c & 1u);
-            rank[k] = atomicAdd(&s_cnt[fine[k]], 1u);
-        }
-    }
-    __syncthreads();
-    part_scan256(s_cnt, s_base);
-#pragma unroll
-    for (int k = 0; k < PART_PER_THREAD; ++k) {
-        if (fine[k] != 0xFFFFFFFFu) {
-            const uint32_t sidx = s_base[fine[k]] + rank[k];
-            s_out[sidx] = word[k];
-            s_fine[sidx] = (uint8_t)fine[k];
-        }
-    }
-    __syncthreads();
-    const uint32_t total = s_base[255] + s_cnt[255];
-#pragma unroll
-    for (int k = 0; k < PART_PER_THREAD; ++k) {
-        const uint32_t sidx = k * PART_THREADS + threadIdx.x;
-        if (sidx < total) {
-            const uint32_t f = s_fine[sidx];
-            sorted[s_gbase[f] + (sidx - s_base[f])] = s_out[sidx];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// bucket accumulation: one lane per slice of <= `slice` sorted entries
-// ---------------------------------------------------------------------------------------------
+// level 1, step 3: (code, entry id) to its coarse bin; every sub-tile is ordered by bin inside LDS first, so that consecutive
+// lanes store to consecutive slots of the same (tile, bin) run
 template <class C>
-__global__ void __launch_bounds__(128) k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
-                                                           const uint32_t* __restrict__ off, const uint32_t* __restrict__ slice_off,
-                                                           uint4* __restrict__ partial, uint32_t buckets, uint32_t slice, int wshift,
-                                                           uint32_t n_sub) {
+__global__ void __launch_bounds__(ORD_THREADS) k_ord_scatter(const uint4* __restrict__ scalars, size_t n, OrdCfg cfg, const uint32_t* __restrict__ cnt1,
+                                                             const uint32_t* __restrict__ bin_base, uint2* __restrict__ tmp) {
+    using SP = typename C::SP;
+    __shared__ uint32_t s_lim[8 * ORD_THREADS];
+    __shared__ uint32_t s_cnt[ORD_MAX_BINS], s_base[ORD_MAX_BINS], s_gbase[ORD_MAX_BINS];
+    __shared__ uint32_t s_tmp[ORD_THREADS];
+    __shared__ uint2 s_ent[ORD_TILE];
+    const int tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_gbase[k] = bin_base[k] + cnt1[(size_t)k * cfg.nt1 + tile];
+    for (uint32_t st = 0; st < cfg.sub; ++st) {
+        const size_t i = ((size_t)tile * cfg.sub + st) * cfg.spt + tid;
+        const bool live = (uint32_t)tid < cfg.spt && i < n;
+        __syncthreads();  // the previous sub-tile has been written out
+        for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_cnt[k] = 0;
+        if (live) ord_park_scalar<SP>(scalars, i, s_lim, tid);
+        __syncthreads();
+        if (live) {
+            uint32_t carry = 0;
+            for (int j = 0; j < cfg.windows; ++j) {
+                const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
+                if (code != CODE_INVALID) atomicAdd(&s_cnt[code >> (cfg.fine_bits + 1)], 1u);
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_base[k] = s_cnt[k];
+        __syncthreads();
+        block_excl_scan4(s_base, cfg.nbins, s_tmp);
+        for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_cnt[k] = s_base[k];  // cursors
+        __syncthreads();
+        if (live) {
+            uint32_t carry = 0;
+            for (int j = 0; j < cfg.windows; ++j) {
+                const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
+                if (code != CODE_INVALID) {
+                    const uint32_t sidx = atomicAdd(&s_cnt[code >> (cfg.fine_bits + 1)], 1u);
+                    s_ent[sidx] = make_uint2(code, (uint32_t)((size_t)j * n + i));
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t total = s_cnt[cfg.nbins - 1];  // every cursor now sits at the end of its bin
+        for (uint32_t sidx = tid; sidx < total; sidx += ORD_THREADS) {
+            const uint2 e = s_ent[sidx];
+            const uint32_t bin = e.x >> (cfg.fine_bits + 1);
+            tmp[s_gbase[bin] + (sidx - s_base[bin])] = e;
+        }
+        __syncthreads();
+        for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_gbase[k] += s_cnt[k] - s_base[k];  // this sub-tile's entries of bin k
+    }
+}
+
+// level 2: a coarse bin is cut into segments of <= ORD_SEG entries, one workgroup each (a hot bin - short top window, skewed
+// witness - is shared by many workgroups).  Block -> (bin, segment) by a search in seg_base.
+PLK_DI bool ord_segment(const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ bin_base, int nbins, uint32_t blk, uint32_t& bin,
+                        uint32_t& seg, uint32_t& lo, uint32_t& hi) {
+    if (blk >= seg_base[nbins]) return false;
+    uint32_t a = 0, b = (uint32_t)nbins;  // seg_base[a] <= blk < seg_base[b]
+    while (b - a > 1) {
+        const uint32_t m = (a + b) >> 1;
+        if (seg_base[m] <= blk) a = m; else b = m;
+    }
+    bin = a;
+    seg = blk - seg_base[a];
+    lo = bin_base[a] + seg * ORD_SEG;
+    hi = min(bin_base[a + 1], lo + ORD_SEG);
+    return true;
+}
+// step 1: cnt2[segment][fine]
+__global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_count(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bin_base,
+                                                                   const uint32_t* __restrict__ seg_base, int fine_bits, int nbins,
+                                                                   uint32_t* __restrict__ cnt2) {
+    __shared__ uint32_t s_hist[1 << ORD_MAX_FINE];
+    const int tid = threadIdx.x;
+    uint32_t bin, seg, lo, hi;
+    if (!ord_segment(seg_base, bin_base, nbins, blockIdx.x, bin, seg, lo, hi)) return;
+    const int nf = 1 << fine_bits;
+    const uint32_t fmask = (uint32_t)nf - 1u;
+    for (int k = tid; k < nf; k += ORD_BIN_THREADS) s_hist[k] = 0;
+    __syncthreads();
+    for (uint32_t p = lo + tid; p < hi; p += ORD_BIN_THREADS) atomicAdd(&s_hist[(tmp[p].x >> 1) & fmask], 1u);
+    __syncthreads();
+    for (int k = tid; k < nf; k += ORD_BIN_THREADS) cnt2[((size_t)blockIdx.x << fine_bits) + k] = s_hist[k];
+}
+// step 2: bucket offsets of the bin (sum over its segments, scanned), this segment's start inside every bucket, scatter.
+// The segment is ordered by bucket inside LDS first: its entries of one bucket leave as one run.
+__global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_scatter(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bin_base,
+                                                                     const uint32_t* __restrict__ seg_base, int fine_bits, int nbins, uint32_t buckets,
+                                                                     const uint32_t* __restrict__ cnt2, uint32_t* __restrict__ off,
+                                                                     uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t s_glob[1 << ORD_MAX_FINE], s_loc[1 << ORD_MAX_FINE], s_cur[1 << ORD_MAX_FINE];
+    __shared__ uint32_t s_tmp[ORD_BIN_THREADS];
+    __shared__ uint32_t s_out[ORD_SEG];
+    __shared__ uint16_t s_fine[ORD_SEG];
+    const int tid = threadIdx.x;
+    uint32_t bin, seg, lo, hi;
+    if (!ord_segment(seg_base, bin_base, nbins, blockIdx.x, bin, seg, lo, hi)) {
+        // bins without entries still own bucket offsets: written by the blocks past the last segment, one bin each
+        // (the grid has at least nbins blocks past the segments; see the launch)
+        const uint32_t extra = blockIdx.x - seg_base[nbins];
+        if (extra < (uint32_t)nbins && bin_base[extra + 1] == bin_base[extra]) {
+            const int nf = 1 << fine_bits;
+            for (int k = tid; k < nf; k += ORD_BIN_THREADS) off[((size_t)extra << fine_bits) + k] = bin_base[extra];
+        }
+        if (extra == 0 && tid == 0) off[buckets] = bin_base[nbins];
+        return;
+    }
+    const int nf = 1 << fine_bits;
+    const uint32_t fmask = (uint32_t)nf - 1u;
+    const uint32_t s0 = seg_base[bin], s1 = seg_base[bin + 1];
+    for (int k = tid; k < nf; k += ORD_BIN_THREADS) {
+        uint32_t tot = 0, before = 0, own = 0;
+        for (uint32_t sg = s0; sg < s1; ++sg) {
+            const uint32_t v = cnt2[((size_t)sg << fine_bits) + k];
+            if (sg - s0 < seg) before += v;
+            if (sg - s0 == seg) own = v;
+            tot += v;
+        }
+        s_glob[k] = tot;
+        s_cur[k] = before;
+        s_loc[k] = own;
+    }
+    __syncthreads();
+    block_excl_scan4(s_glob, nf, s_tmp);
+    block_excl_scan4(s_loc, nf, s_tmp);
+    const uint32_t bb = bin_base[bin];
+    for (int k = tid; k < nf; k += ORD_BIN_THREADS) {
+        const uint32_t o = bb + s_glob[k];
+        if (seg == 0) off[((size_t)bin << fine_bits) + k] = o;
+        s_glob[k] = o + s_cur[k];  // where this segment's entries of bucket k start
+        s_cur[k] = s_loc[k];       // LDS cursor
+    }
+    __syncthreads();
+    for (uint32_t p = lo + tid; p < hi; p += ORD_BIN_THREADS) {
+        const uint2 e = tmp[p];
+        const uint32_t f = (e.x >> 1) & fmask;
+        const uint32_t idx = atomicAdd(&s_cur[f], 1u);
+        s_out[idx] = (e.y << 1) | (e.x & 1u);
+        s_fine[idx] = (uint16_t)f;
+    }
+    __syncthreads();
+    const uint32_t count = hi - lo;
+    for (uint32_t i = tid; i < count; i += ORD_BIN_THREADS) {
+        const uint32_t f = s_fine[i];
+        sorted[s_glob[f] + (i - s_loc[f])] = s_out[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bucket accumulation: every lane adds exactly `chunk` consecutive sorted entries
+// ---------------------------------------------------------------------------------------------
+// The sorted entry list is cut into chunks of `chunk` entries regardless of the bucket boundaries, one lane per chunk:
+// perfectly balanced whatever the digit distribution and whatever the bucket sizes (26 entries on average at c = 20).  A
+// lane that crosses a bucket boundary stores what it has and starts over: the piece of the bucket that STARTS inside the
+// chunk goes to p_start[bucket], the piece of the bucket that was already running at the chunk's first entry goes to
+// p_head[lane].  bucket b = p_start[b] + sum of p_head[l] for the lanes l0 < l <= l1, l0 = off[b] / chunk,
+// l1 = (off[b+1] - 1) / chunk (k_msm_assemble).  Pieces are stored as they are (lazy 29-bit limbs, accumulator invariant of
+// ecz.cuh; the identity is all-zero): a store inside the loop must be cheap, because some lane of the wave has one almost every round.
+template <class FP> constexpr int raw_u4() { return FzCfg<FP>::NZ; }  // uint4 per raw point: 4 NZ words
+
+template <class FP> PLK_DI void xyzzz_store_raw(uint4* dst, const XyzzZ<FP>& a) {
+    constexpr int NZ = FzCfg<FP>::NZ;
+    uint32_t w[4 * NZ];
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        w[i] = a.inf ? 0u : a.x.l[i];
+        w[NZ + i] = a.inf ? 0u : a.y.l[i];
+        w[2 * NZ + i] = a.inf ? 0u : a.zz.l[i];
+        w[3 * NZ + i] = a.inf ? 0u : a.zzz.l[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+template <class FP> PLK_DI XyzzZ<FP> xyzzz_load_raw(const uint4* src) {
+    constexpr int NZ = FzCfg<FP>::NZ;
+    uint32_t w[4 * NZ];
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        const uint4 v = src[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    XyzzZ<FP> r;
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        r.x.l[i] = w[i];
+        r.y.l[i] = w[NZ + i];
+        r.zz.l[i] = w[2 * NZ + i];
+        r.zzz.l[i] = w[3 * NZ + i];
+        any |= w[2 * NZ + i];
+    }
+    r.inf = any == 0;  // a live accumulator never has ZZ = 0 (that case is caught as the identity in ecz.cuh)
+    return r;
+}
+
+// Head pieces are mostly short-lived: the head piece of lane l (closed at l's first bucket boundary) belongs to the last
+// bucket of lane l - 1, whose piece is still in registers when the loop ends.  Lanes therefore park a closed head piece in
+// LDS and their predecessor in the block adds it to its last piece before storing it: at c = 20 (26 entries per bucket,
+// 24 per lane) almost every bucket leaves the kernel whole, and k_msm_assemble only finds the head pieces of the first lane
+// of a block and of lanes that lie entirely inside one bucket (head_live[lane] = 1).
+constexpr int ACC_THREADS = 128;
+template <class C>
+PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ off,
+                                uint4* __restrict__ p_start, uint4* __restrict__ p_head, uint8_t* __restrict__ head_live, uint32_t buckets, uint32_t chunk,
+                                int wshift, uint32_t n_sub, uint4* s_head, uint8_t* s_parked) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t total = slice_off[buckets];
-    if (s >= total) return;
-    // bucket of slice s: largest b with slice_off[b] <= s
-    uint32_t lo = 0, hi = buckets;
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (slice_off[mid] <= s) lo = mid; else hi = mid;
-    }
-    const uint32_t b = lo;
-    // entry ids are window * n + generator; with tables that is the table index, without (table-free mode:
-    // n_sub = n, buckets of window w are [w << wshift, (w + 1) << wshift)) the window part is taken off
-    const uint32_t ent_sub = (b >> wshift) * n_sub;
-    const uint32_t begin = off[b] + (s - slice_off[b]) * slice;
-    const uint32_t end = min(off[b + 1], begin + slice);
-    // lazy 29-bit-limb accumulator (ecz.cuh); table coordinates are R'-form
-    XyzzZ<FP> acc;
-    acc.inf = true;
-    acc.x = acc.y = acc.zz = acc.zzz = fz_zero<FP>();
-    // Software pipeline: the table gather for entry k+1 (two dependent loads: index, then a random
-    // 64/96-byte point) is issued before the ~10^4-cycle addition of entry k, so the few resident
-    // waves (the lazy arithmetic wants ~180 VGPRs) never wait on HBM.
-    uint32_t ent = 0;
-    Fe<FP> x = fe_zero<FP>(), y = fe_zero<FP>();
-    bool ident = true;
-    if (begin < end) {
-        ent = sorted[begin];
-        ident = affine_load<FP>(tab + (size_t)((ent >> 1) - ent_sub) * 2 * W, x, y);
-    }
-    for (uint32_t k = begin; k < end; ++k) {
-        const uint32_t cur = ent;
-        const Fe<FP> cx = x, cy = y;
-        const bool cident = ident;
-        if (k + 1 < end) {
-            ent = sorted[k + 1];
-            ident = affine_load<FP>(tab + (size_t)((ent >> 1) - ent_sub) * 2 * W, x, y);
+    constexpr int RU = raw_u4<FP>();
+    const int tid = threadIdx.x;
+    const uint32_t lane = blockIdx.x * blockDim.x + tid;
+    const uint32_t total = off[buckets];
+    const uint64_t begin64 = (uint64_t)lane * chunk;
+    const bool active = begin64 < total;
+    XyzzZ<FP> acc = xyzzz_identity<FP>();
+    bool head = false, parked = false;
+    uint32_t b = 0;
+    if (active) {
+        const uint32_t begin = (uint32_t)begin64;
+        const uint32_t end = (uint32_t)min((uint64_t)total, begin64 + chunk);
+        // bucket of the first entry: largest b with off[b] <= begin (empty buckets share an offset with their successor)
+        uint32_t lo = 0, hi = buckets;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (off[mid] <= begin) lo = mid; else hi = mid;
         }
-        if (cident) continue;
-        Fz<FP> xz = fz_from_fe<FP>(cx), yz = fz_from_fe<FP>(cy);
-        if (cur & 1u) yz = fz_neg_canonical<FP>(yz);
-        xyzzz_madd<FP>(acc, xz, yz);
+        b = lo;
+        uint32_t next = off[b + 1];
+        head = off[b] < begin;  // the bucket was already running: this lane's first piece is a head piece
+        // entry ids are window * n + generator; with tables that is the table index, without (table-free mode:
+        // n_sub = n, buckets of window w are [w << wshift, (w + 1) << wshift)) the window part is taken off
+        const uint32_t ent_sub = (b >> wshift) * n_sub;
+        // Software pipeline: the table gather for entry k+1 (two dependent loads: index, then a random
+        // 64/96-byte point) is issued before the ~10^4-cycle addition of entry k.
+        uint32_t ent = sorted[begin];
+        Fe<FP> x, y;
+        bool ident = affine_load<FP>(tab + (size_t)((ent >> 1) - ent_sub) * 2 * W, x, y);
+        for (uint32_t k = begin; k < end; ++k) {
+            if (k == next) {  // entry k opens a new bucket: the piece of the old one is closed
+                if (head) {
+                    xyzzz_store_raw<FP>(s_head + tid * RU, acc);
+                    parked = true;
+                } else {
+                    xyzzz_store_raw<FP>(p_start + (size_t)b * RU, acc);
+                }
+                head = false;
+                acc = xyzzz_identity<FP>();
+                do {
+                    ++b;
+                    next = off[b + 1];
+                } while (next <= k);
+            }
+            const uint32_t cur = ent;
+            const Fe<FP> cx = x, cy = y;
+            const bool cident = ident;
+            if (k + 1 < end) {
+                // the next entry may belong to a later bucket (another window in table-free mode): its bucket is known here
+                uint32_t nb = b;
+                if (k + 1 == next) {
+                    nb = b + 1;
+                    while (off[nb + 1] <= k + 1) ++nb;
+                }
+                const uint32_t nsub = (nb >> wshift) * n_sub;
+                ent = sorted[k + 1];
+                ident = affine_load<FP>(tab + (size_t)((ent >> 1) - nsub) * 2 * W, x, y);
+            }
+            if (cident) continue;
+            Fz<FP> xz = fz_from_fe<FP>(cx), yz = fz_from_fe<FP>(cy);
+            if (cur & 1u) yz = fz_neg_canonical<FP>(yz);
+            xyzzz_madd<FP>(acc, xz, yz);
+        }
     }
-    xyzzz_store_packed<FP>(partial + (size_t)s * 4 * W, acc);  // R'-form, canonical (exchange format of ecz.cuh)
+    s_parked[tid] = parked ? 1 : 0;
+    __syncthreads();
+    if (!active) return;
+    // the successor's closed head piece continues this lane's last bucket
+    if (tid + 1 < ACC_THREADS && s_parked[tid + 1]) acc = xyzzz_add<FP>(acc, xyzzz_load_raw<FP>(s_head + (tid + 1) * RU));
+    if (head) {
+        xyzzz_store_raw<FP>(p_head + (size_t)lane * RU, acc);  // the whole chunk lies inside one bucket
+    } else {
+        xyzzz_store_raw<FP>(p_start + (size_t)b * RU, acc);
+        if (parked && tid == 0) {  // no predecessor in this block: the head piece stays a head piece
+            const XyzzZ<FP> h = xyzzz_load_raw<FP>(s_head);
+            xyzzz_store_raw<FP>(p_head + (size_t)lane * RU, h);
+        }
+    }
+    head_live[lane] = (head || (parked && tid == 0)) ? 1 : 0;
+}
+template <class C>
+__global__ void __launch_bounds__(ACC_THREADS) k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
+                                                                const uint32_t* __restrict__ off, uint4* __restrict__ p_start, uint4* __restrict__ p_head,
+                                                                uint8_t* __restrict__ head_live, uint32_t buckets, uint32_t chunk, int wshift, uint32_t n_sub) {
+    __shared__ uint4 s_head[ACC_THREADS * raw_u4<typename C::FP>()];
+    __shared__ uint8_t s_parked[ACC_THREADS];
+    msm_accumulate_body<C>(tab, sorted, off, p_start, p_head, head_live, buckets, chunk, wshift, n_sub, s_head, s_parked);
 }
 
 // ---------------------------------------------------------------------------------------------
 // reduction  sum_d d * bucket_d   (replaces the serial Yao tail of curve_msm.rs:149-154)
 // ---------------------------------------------------------------------------------------------
-// Everything here is latency bound (few points, long dependent chains), so the structure is
-// chosen for depth, not work, and runs on the lazy arithmetic (ecz.cuh, fully inlined):
-//  * bucket_b = sum of its slice partials: 4 lanes per bucket, each sums every 4th slice, two
-//    xor-shuffle additions combine them;
-//  * sum_b (b+1) bucket_b = sum_p 2^p P_p with P_p the plain sum of the buckets whose weight b+1 has
-//    bit p set: c planes, each a tree sum (serial part per lane, 6 shuffle levels per wave, LDS
-//    across waves), c * D / 2 additions in total (~1.5 % of the accumulation work);
-//  * one block sums the parts of every plane, doubles the planes into place, adds them and
-//    normalises the result (to_affine, curve.rs:206-214).
-constexpr int BUCKET_LANES = 4;
-
+// Steps (all batched over the MSMs of a group: blockIdx.y / a factor of blockIdx.z picks the MSM's slot):
+//  * buckets with very many head pieces (a hot digit of a skewed witness) are summed by whole workgroups (k_msm_heavy_*);
+//  * k_msm_assemble: bucket = start piece + head pieces;
+//  * two-level weighting (tabled mode, many buckets): with b = hi 2^L + lo, sum_b (b + 1) B_b =
+//    2^L sum_hi hi R_hi + sum_lo (lo + 1) C_lo, R_hi / C_lo the row / column sums of the 2^H x 2^L bucket grid:
+//    2 additions per bucket at one lane each (k_msm_gsum: groups of G serially; k_msm_lsum: the rest by wave shuffles),
+//    which leaves two weighted sums over 2^H and 2^L points;
+//  * those (or, with few buckets and in table-free mode, the buckets themselves) go through bit-plane tree sums on quads,
+//    sum_d d P_d = sum_p 2^p sum_{d: bit p} P_d, are doubled into place and added (k_msm_planes, k_msm_final, k_msm_combine),
+//    then normalised (to_affine, curve.rs:206-214).
 template <class FP> PLK_DI XyzzZ<FP> wave_sum(XyzzZ<FP> v, int width) {
     for (int m = 1; m < width; m <<= 1) v = xyzzz_add<FP>(v, xyzzz_shfl_xor<FP>(v, m));
     return v;
 }
 
-// A bucket with more than HEAVY_SLICES slice partials (a hot digit of a skewed witness) would make its
-// 4 lanes walk thousands of additions.  Such buckets are listed as (bucket, chunk) work items of
-// HEAVY_CHUNK slices, each summed by a whole workgroup, then their chunk partials are summed.
-// The reduction kernels serve several MSMs per launch (the executions of a batch share one tail): every MSM brings
-// its own buffers in a slot, blockIdx.y (planes, final: a factor of the grid) picks the slot.
 constexpr int TAIL_MAX = 16;
 struct TailSlot {
-    const uint4* partial;
-    const uint32_t* slice_off;
-    uint4* bucket;
+    const uint32_t* off;  // bucket offsets off[buckets + 1]
+    uint4* p_start;       // raw, one per bucket (becomes the assembled bucket)
+    const uint4* p_head;  // raw, one per accumulation lane
+    const uint8_t* head_live;  // 1: p_head[lane] holds a piece that is not part of a start piece yet
+    uint4* bucket;        // packed points: the operands of the plane sums
     uint32_t* heavy;
-    uint4* heavy_part;
+    uint4* heavy_part;    // raw
+    uint4* line_part;     // raw: row partials then column partials
     uint4* plane_part;
     uint4* win_pts;
     uint4* out_xy;
@@ -553,18 +616,31 @@ struct TailBatch {
     TailSlot s[TAIL_MAX];
 };
 
-constexpr uint32_t HEAVY_SLICES = 256;
+constexpr uint32_t HEAVY_HEADS = 32;   // more head pieces than this: the bucket is summed by workgroups
 constexpr uint32_t HEAVY_CHUNK = 2048;
+
+// head pieces of bucket b: lanes first .. first + count - 1
+PLK_DI bool bucket_heads(const uint32_t* __restrict__ off, uint32_t b, uint32_t chunk, uint32_t& first, uint32_t& count) {
+    const uint32_t o0 = off[b], o1 = off[b + 1];
+    first = 0;
+    count = 0;
+    if (o1 == o0) return false;
+    const uint32_t l0 = o0 / chunk, l1 = (o1 - 1) / chunk;
+    first = l0 + 1;
+    count = l1 - l0;
+    return true;
+}
 
 // heavy[0] = number of work items, heavy[1] = number of heavy buckets;
 // items at heavy[2 + 2k] = bucket, heavy[3 + 2k] = chunk index; heavy bucket ids at heavy[2 + 2 cap + k]
-__global__ void __launch_bounds__(256) k_msm_heavy_list(TailBatch tb, uint32_t buckets, uint32_t cap) {
-    const uint32_t* __restrict__ slice_off = tb.s[blockIdx.y].slice_off;
+__global__ void __launch_bounds__(256) k_msm_heavy_list(TailBatch tb, uint32_t buckets, uint32_t chunk, uint32_t cap) {
+    const uint32_t* __restrict__ off = tb.s[blockIdx.y].off;
     uint32_t* __restrict__ heavy = tb.s[blockIdx.y].heavy;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= buckets) return;
-    const uint32_t ns = slice_off[b + 1] - slice_off[b];
-    if (ns <= HEAVY_SLICES) return;
+    uint32_t first, ns;
+    bucket_heads(off, b, chunk, first, ns);
+    if (ns <= HEAVY_HEADS) return;
     const uint32_t chunks = (ns + HEAVY_CHUNK - 1) / HEAVY_CHUNK;
     const uint32_t at = atomicAdd(&heavy[0], chunks);
     const uint32_t hb = atomicAdd(&heavy[1], 1u);
@@ -577,12 +653,12 @@ __global__ void __launch_bounds__(256) k_msm_heavy_list(TailBatch tb, uint32_t b
 }
 
 template <class FP> PLK_DI XyzzZ<FP> block256_sum(XyzzZ<FP> acc, uint4* s_pts) {
-    constexpr int W = FP::NL / 4;
+    constexpr int RU = raw_u4<FP>();
     acc = wave_sum<FP>(acc, 64);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) xyzzz_store_packed<FP>(s_pts + wave * 4 * W, acc);
+    if (lane == 0) xyzzz_store_raw<FP>(s_pts + wave * RU, acc);
     __syncthreads();
-    acc = (wave == 0 && lane < 4) ? xyzzz_load_packed<FP>(s_pts + lane * 4 * W) : xyzzz_identity<FP>();
+    acc = (wave == 0 && lane < 4) ? xyzzz_load_raw<FP>(s_pts + lane * RU) : xyzzz_identity<FP>();
     if (wave == 0) acc = wave_sum<FP>(acc, 4);
     __syncthreads();
     return acc;  // valid in thread 0
@@ -590,64 +666,153 @@ template <class FP> PLK_DI XyzzZ<FP> block256_sum(XyzzZ<FP> acc, uint4* s_pts) {
 
 // one workgroup per (bucket, chunk) item: chunk partial -> heavy_part[item]
 template <class C>
-__global__ void __launch_bounds__(256) k_msm_heavy_chunks(TailBatch tb, uint32_t cap) {
+__global__ void __launch_bounds__(256) k_msm_heavy_chunks(TailBatch tb, uint32_t chunk, uint32_t cap) {
     using FP = typename C::FP;
-    constexpr int W = FP::NL / 4;
-    __shared__ uint4 s_pts[4 * 4 * W];
-    const uint4* __restrict__ partial = tb.s[blockIdx.y].partial;
-    const uint32_t* __restrict__ slice_off = tb.s[blockIdx.y].slice_off;
+    constexpr int RU = raw_u4<FP>();
+    __shared__ uint4 s_pts[4 * RU];
+    const uint4* __restrict__ p_head = tb.s[blockIdx.y].p_head;
+    const uint32_t* __restrict__ off = tb.s[blockIdx.y].off;
     const uint32_t* __restrict__ heavy = tb.s[blockIdx.y].heavy;
     uint4* __restrict__ heavy_part = tb.s[blockIdx.y].heavy_part;
     const uint32_t items = min(heavy[0], cap);
     for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
         const uint32_t b = heavy[2 + 2 * it], k = heavy[3 + 2 * it];
-        const uint32_t s0 = slice_off[b] + k * HEAVY_CHUNK, s1 = min(slice_off[b + 1], s0 + HEAVY_CHUNK);
+        uint32_t first, ns;
+        bucket_heads(off, b, chunk, first, ns);
+        const uint32_t s0 = first + k * HEAVY_CHUNK, s1 = min(first + ns, s0 + HEAVY_CHUNK);
         XyzzZ<FP> acc = xyzzz_identity<FP>();
-        for (uint32_t s = s0 + threadIdx.x; s < s1; s += 256) acc = xyzzz_add<FP>(acc, xyzzz_load_packed<FP>(partial + (size_t)s * 4 * W));
+        for (uint32_t s = s0 + threadIdx.x; s < s1; s += 256)
+            if (tb.s[blockIdx.y].head_live[s]) acc = xyzzz_add<FP>(acc, xyzzz_load_raw<FP>(p_head + (size_t)s * RU));
         acc = block256_sum<FP>(acc, s_pts);
-        if (threadIdx.x == 0) xyzzz_store_packed<FP>(heavy_part + (size_t)it * 4 * W, acc);
+        if (threadIdx.x == 0) xyzzz_store_raw<FP>(heavy_part + (size_t)it * RU, acc);
     }
 }
-// one workgroup per heavy bucket: sum of its chunk partials -> bucket[b].  Items of one bucket are contiguous.
+// one workgroup per heavy bucket: its start piece + the sum of its chunk partials -> p_start[b] (the whole bucket)
 template <class C>
 __global__ void __launch_bounds__(256) k_msm_heavy_final(TailBatch tb, uint32_t cap) {
     using FP = typename C::FP;
-    constexpr int W = FP::NL / 4;
-    __shared__ uint4 s_pts[4 * 4 * W];
+    constexpr int RU = raw_u4<FP>();
+    __shared__ uint4 s_pts[4 * RU];
     const uint32_t* __restrict__ heavy = tb.s[blockIdx.y].heavy;
     const uint4* __restrict__ heavy_part = tb.s[blockIdx.y].heavy_part;
-    uint4* __restrict__ bucket = tb.s[blockIdx.y].bucket;
+    uint4* __restrict__ p_start = tb.s[blockIdx.y].p_start;
     const uint32_t items = min(heavy[0], cap), nb = min(heavy[1], cap);
     for (uint32_t hb = blockIdx.x; hb < nb; hb += gridDim.x) {
         const uint32_t b = heavy[2 + 2 * cap + hb];
-        XyzzZ<FP> acc = xyzzz_identity<FP>();
+        XyzzZ<FP> acc = threadIdx.x == 0 ? xyzzz_load_raw<FP>(p_start + (size_t)b * RU) : xyzzz_identity<FP>();
         for (uint32_t it = threadIdx.x; it < items; it += 256)
-            if (heavy[2 + 2 * it] == b) acc = xyzzz_add<FP>(acc, xyzzz_load_packed<FP>(heavy_part + (size_t)it * 4 * W));
+            if (heavy[2 + 2 * it] == b) acc = xyzzz_add<FP>(acc, xyzzz_load_raw<FP>(heavy_part + (size_t)it * RU));
         acc = block256_sum<FP>(acc, s_pts);
-        if (threadIdx.x == 0) xyzzz_store_packed<FP>(bucket + (size_t)b * 4 * W, acc);
+        if (threadIdx.x == 0) xyzzz_store_raw<FP>(p_start + (size_t)b * RU, acc);
     }
 }
 
-template <class C>
-__global__ void __launch_bounds__(256) k_msm_bucket_sum(TailBatch tb, uint32_t buckets) {
+// bucket = start piece + the head pieces that are still live, 2^lpb_log adjacent lanes per bucket (each takes every
+// 2^lpb_log-th head, shuffles combine).  PACKED: the result goes to bucket[] in the packed exchange format (operand of the
+// plane sums); else it stays in p_start[] raw, which is only rewritten when something was added (or the bucket is empty).
+template <class C, bool PACKED>
+__global__ void __launch_bounds__(256) k_msm_assemble(TailBatch tb, uint32_t buckets, uint32_t chunk, int lpb_log) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
-    const uint4* __restrict__ partial = tb.s[blockIdx.y].partial;
-    const uint32_t* __restrict__ slice_off = tb.s[blockIdx.y].slice_off;
-    uint4* __restrict__ bucket = tb.s[blockIdx.y].bucket;
-    if (blockIdx.x == 0 && threadIdx.x < 2) tb.s[blockIdx.y].heavy[threadIdx.x] = 0;  // counters of k_msm_heavy_list, which runs next
+    constexpr int RU = raw_u4<FP>();
+    const TailSlot& sl = tb.s[blockIdx.y];
+    if (blockIdx.x == 0 && threadIdx.x < 2) sl.heavy[threadIdx.x] = 0;  // the counters of k_msm_heavy_list are free again
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t b = gid / BUCKET_LANES, part = gid % BUCKET_LANES;
+    const uint32_t b = gid >> lpb_log, part = gid & ((1u << lpb_log) - 1u);
     XyzzZ<FP> acc = xyzzz_identity<FP>();
-    bool mine = false;
+    bool nonempty = false, touched = false;
     if (b < buckets) {
-        const uint32_t s0 = slice_off[b], s1 = slice_off[b + 1];
-        mine = s1 - s0 <= HEAVY_SLICES;  // heavier buckets are summed by k_msm_heavy_*
-        if (mine)
-            for (uint32_t s = s0 + part; s < s1; s += BUCKET_LANES) acc = xyzzz_add<FP>(acc, xyzzz_load_packed<FP>(partial + (size_t)s * 4 * W));
+        uint32_t first, ns;
+        nonempty = bucket_heads(sl.off, b, chunk, first, ns);
+        uint32_t live = 0;
+        if (ns <= HEAVY_HEADS)  // heavier buckets are already whole (k_msm_heavy_final)
+            for (uint32_t h = part; h < ns; h += 1u << lpb_log) live |= sl.head_live[first + h] ? (1u << (h >> lpb_log)) : 0u;  // ns <= 32
+        touched = live != 0;
+        if (lpb_log > 0 || PACKED || touched) {
+            if (nonempty && part == 0) acc = xyzzz_load_raw<FP>(sl.p_start + (size_t)b * RU);
+            for (uint32_t h = part, k = 0; h < ns && live; h += 1u << lpb_log, ++k)
+                if ((live >> k) & 1u) acc = xyzzz_add<FP>(acc, xyzzz_load_raw<FP>(sl.p_head + (size_t)(first + h) * RU));
+        }
     }
-    acc = wave_sum<FP>(acc, BUCKET_LANES);  // lanes of a bucket are adjacent; every lane takes part in the shuffles
-    if (mine && part == 0) xyzzz_store_packed<FP>(bucket + (size_t)b * 4 * W, acc);
+    if (lpb_log > 0) acc = wave_sum<FP>(acc, 1 << lpb_log);  // the lanes of a bucket are adjacent; every lane takes part in the shuffles
+    if (b < buckets && part == 0) {
+        if constexpr (PACKED) xyzzz_store_packed<FP>(sl.bucket + (size_t)b * 4 * W, acc);
+        else if (lpb_log > 0 || touched || !nonempty) xyzzz_store_raw<FP>(sl.p_start + (size_t)b * RU, acc);
+    }
+}
+
+// Two-level weighting, step 1: partial row and column sums over groups of G = 2^g_log buckets, one lane per group.
+// lanes [0, NB / G): row hi, group g: buckets (hi << L) + g G + k;   lanes [NB / G, 2 NB / G): column lo, group g:
+// buckets ((g G + k) << L) + lo (adjacent lanes = adjacent columns = adjacent addresses).
+template <class C>
+__global__ void __launch_bounds__(128) k_msm_gsum(TailBatch tb, int L, int H, int g_log) {
+    using FP = typename C::FP;
+    constexpr int RU = raw_u4<FP>();
+    const TailSlot& sl = tb.s[blockIdx.y];
+    const uint32_t nbg = (1u << (L + H)) >> g_log;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * nbg) return;
+    const uint32_t G = 1u << g_log;
+    uint32_t b0, bstep;  // first bucket, distance between consecutive buckets of the group
+    uint4* dst;
+    if (t < nbg) {
+        const uint32_t pr = (1u << L) >> g_log;  // groups per row
+        const uint32_t hi = t / pr, g = t % pr;
+        b0 = (hi << L) + (g << g_log);
+        bstep = 1;
+        dst = sl.line_part + (size_t)t * RU;
+    } else {
+        const uint32_t u = t - nbg;
+        const uint32_t lo = u & ((1u << L) - 1u), g = u >> L;
+        const uint32_t pc = (1u << H) >> g_log;  // groups per column
+        b0 = ((g << g_log) << L) + lo;
+        bstep = 1u << L;
+        dst = sl.line_part + ((size_t)nbg + (size_t)lo * pc + g) * RU;
+    }
+    // the load of element k + 1 is in flight while element k is added
+    XyzzZ<FP> acc = xyzzz_identity<FP>();
+    XyzzZ<FP> nxt = xyzzz_load_raw<FP>(sl.p_start + (size_t)b0 * RU);
+    for (uint32_t k = 0; k < G; ++k) {
+        XyzzZ<FP> cur = nxt;
+        const uint32_t b = b0 + k * bstep;
+        if (k + 1 < G) nxt = xyzzz_load_raw<FP>(sl.p_start + (size_t)(b + bstep) * RU);
+        acc = xyzzz_add<FP>(acc, cur);
+    }
+    xyzzz_store_raw<FP>(dst, acc);
+}
+
+// step 2: the lines.  Output slot s of 2 * wb (wb = 2^H): window 0 holds the column sums C_lo at index lo (weight lo + 1),
+// window 1 the row sums R_hi at index hi - 1 (weight hi; R_0 has weight 0 and is dropped); the rest is the identity.
+// A chain of additions on few points, i.e. latency: it runs on quads (ecz_coop.cuh), 2^qpl_log adjacent quads per line (<= 16):
+// each sums its share of the line's partials, quad-wide shuffles combine.
+template <class C>
+__global__ void __launch_bounds__(256) k_msm_lsum(TailBatch tb, int L, int H, int g_log, int qpl_log) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    constexpr int RU = raw_u4<FP>();
+    const TailSlot& sl = tb.s[blockIdx.y];
+    const uint32_t wb = 1u << H;
+    const uint32_t nbg = (1u << (L + H)) >> g_log;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ql = threadIdx.x & 3;
+    const uint32_t quad = gid >> 2;
+    const uint32_t slot = quad >> qpl_log, part = quad & ((1u << qpl_log) - 1u);
+    XyzzZ<FP> acc = xyzzz_identity<FP>();
+    if (slot < 2 * wb) {
+        const uint32_t win = slot >> H, idx = slot & (wb - 1u);
+        const uint4* src = nullptr;
+        uint32_t cnt = 0;
+        if (win == 0 && idx < (1u << L)) {
+            cnt = (1u << H) >> g_log;
+            src = sl.line_part + ((size_t)nbg + (size_t)idx * cnt) * RU;
+        } else if (win == 1 && idx + 1 < wb) {
+            cnt = (1u << L) >> g_log;
+            src = sl.line_part + (size_t)(idx + 1) * cnt * RU;
+        }
+        for (uint32_t k = part; k < cnt; k += 1u << qpl_log) acc = xyzzz_add_q<FP>(acc, xyzzz_load_raw<FP>(src + (size_t)k * RU), ql);
+    }
+    acc = wave_sum_q<FP>(acc, 1 << qpl_log, ql);
+    if (slot < 2 * wb && part == 0 && ql == 0) xyzzz_store_packed<FP>(sl.bucket + (size_t)slot * 4 * W, acc);
 }
 
 // The planes and the final kernel run on quads (ecz_coop.cuh): four lanes per point, a doubling is 3
@@ -881,31 +1046,37 @@ __global__ void __launch_bounds__(256) k_selftest_quad(const uint4* __restrict__
 // ---------------------------------------------------------------------------------------------
 }  // namespace plk
 
-// per-execution device workspace; a context owns two so that consecutive MSMs of a batch can overlap
+// per-execution device workspace; a batched execution owns one per MSM of a group
 struct MsmWork {
-    void* codes = nullptr;
-    void* sorted = nullptr;
-    void* hist = nullptr;      // bucket sizes
+    void* tmp = nullptr;       // uint2 (code, entry id) ordered by coarse bin
+    void* sorted = nullptr;    // (entry id << 1 | negative) ordered by bucket
     void* cnt1 = nullptr;      // [nbins][nt1]
-    void* cnt2 = nullptr;      // [2^fine_bits][nt2max]
-    void* tmp_code = nullptr;  // entries + nbins * PART_TILE
-    void* tmp_val = nullptr;
-    void* part_meta = nullptr; // bin_total[256] | bin_base_pad[257] | meta[1] | tile2bin[nt2max] | scan block totals[128]
-    void* off = nullptr;       // off[buckets+1] followed by slice_off[buckets+1]
-    void* partial = nullptr;
-    void* bucket = nullptr;    // bucket sums (XYZZ)
+    void* meta = nullptr;      // bin_total[1024] | bin_base[1025] | seg_base[1025] | done counter
+    void* cnt2 = nullptr;      // [segment][fine]
+    void* off = nullptr;       // off[buckets + 1]
+    void* p_start = nullptr;   // raw pieces, one per bucket
+    void* p_head = nullptr;    // raw pieces, one per accumulation lane
+    void* head_live = nullptr; // one byte per accumulation lane
+    void* bucket = nullptr;    // packed points: operands of the plane sums
     void* heavy = nullptr;     // heavy-bucket work list (see k_msm_heavy_list)
     void* heavy_part = nullptr;
+    void* line_part = nullptr; // two-level tail: row / column partial sums
     void* plane_part = nullptr;
-    void* win_pts = nullptr;   // table-free: the per-window results
+    void* win_pts = nullptr;   // the per-window results
     void* slab = nullptr;      // the one allocation all of the above point into
     bool ready = false;
+    // executions on different streams share the workspace: the next user waits for the previous one's last kernel
+    hipEvent_t ev = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool used = false;
     void release() {
         if (slab) (void)hipFree(slab);
+        if (ev) (void)hipEventDestroy(ev);
+        ev = nullptr;
         slab = nullptr;
-        for (void** p : {&codes, &sorted, &hist, &cnt1, &cnt2, &tmp_code, &tmp_val, &part_meta, &off, &partial, &bucket, &heavy, &heavy_part, &plane_part, &win_pts})
-            *p = nullptr;
+        for (void** p : {&tmp, &sorted, &cnt1, &cnt2, &meta, &off, &p_start, &p_head, &head_live, &bucket, &heavy, &heavy_part, &line_part, &plane_part, &win_pts}) *p = nullptr;
         ready = false;
+        used = false;
     }
 };
 
@@ -918,22 +1089,27 @@ struct plk_msm_ctx {
     uint32_t buckets = 0;  // bucket slots: 2^(c-1) with tables; windows * 2^(c-1) (rounded up to whole partition bins) without
     uint32_t wbuckets = 0; // 2^(c-1): buckets per window
     bool table_free = false;  // no window tables: every window has its own buckets and is doubled into place at the end
-    uint32_t slice = 32;   // entries per accumulation slice
-    int planes = 0;        // = c: bit-planes of the bucket weights 1 .. 2^(c-1)
+    uint32_t chunk = 24;   // entries per accumulation lane
+    // tail geometry
+    bool two_level = false;  // tabled mode with many buckets: row / column sums first
+    int L = 0, H = 0;        // bucket grid 2^H x 2^L
+    int g_log = 0, lpl_log = 0, lpb_log = 0;
+    int tail_windows = 1;    // windows seen by the plane kernels (2 in two-level mode: columns, rows)
+    uint32_t tail_wbuckets = 0;
+    int tail_shift = 0;      // doublings between consecutive tail windows
+    int planes = 0;
     int plane_blocks = 1;  // blocks (parts) per plane
-    size_t max_slices = 0;
+    size_t max_lanes = 0;
     // device memory
     void* tab = nullptr;
-    // two-level partition workspace
-    int fine_bits = 0, nbins = 1;
-    uint32_t nt1 = 0, nt2max = 0;
+    plk::OrdCfg ord{};
     uint32_t heavy_cap = 0;
     std::vector<MsmWork> ws;   // ws[0] at precompute; a batched execution allocates one per MSM of a group (<= TAIL_MAX)
     size_t ws_bytes = 0;       // size of one workspace slab
-    std::mutex mu;             // one execution at a time per context (workspaces are shared)
+    std::mutex mu;             // one enqueue at a time per context
     // optional per-kernel timing (HIP events on the launch stream) for bench.py's roofline
     bool profiling = false;
-    static constexpr int N_STAGES = 7;  // digits, scan, scatter, accumulate, chunks, planes, final
+    static constexpr int N_STAGES = 7;  // order: count + scan | scatter | bins; accumulate; heavy + assemble + lines; planes; final
     std::vector<std::vector<hipEvent_t>> prof_sets;  // each N_STAGES + 1 events, recorded
     std::vector<std::vector<hipEvent_t>> prof_free;
     ~plk_msm_ctx() {
@@ -948,48 +1124,68 @@ struct plk_msm_ctx {
 namespace plk {
 
 static int scalar_bits(int curve) { return curve == PLK_CURVE_BLS12_377 ? 253 : 255; }
+static int ilog2_ceil(uint64_t v) {
+    int b = 0;
+    while (((uint64_t)1 << b) < v) ++b;
+    return b;
+}
 
-static int choose_window(size_t n) {
+static int choose_window(size_t n, int curve) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
-    // ceil(256 / c) windows of work per scalar: 16 and 18..20 are the useful sizes near 2^20; buckets
-    // (2^(c-1)) should stay well below the entry count so that slices are long
-    int c = lg - 4;
+    // ceil((BITS + 1) / c) additions per scalar against 2 * 2^(c-1) additions in the reduction: c = lg n is the balance point for
+    // the sizes that matter (2^20: 13 windows, 2^19 buckets); small inputs keep the buckets well below the entry count
+    int c = lg >= 18 ? lg : lg - 4 + (lg >= 14 ? (lg - 12) / 2 : 0);
+    if (c < 3) c = 3;
+    if (c > MSM_MAX_WINDOW) c = MSM_MAX_WINDOW;
+    // the smallest window with the same number of digits (fewer buckets for the same additions)
+    const int bits = scalar_bits(curve) + 1;
+    while (c > 3 && (bits + c - 2) / (c - 1) == (bits + c - 1) / c) --c;
     if (const char* e = getenv("PLK_MSM_WINDOW")) c = atoi(e);
     if (c < 3) c = 3;
-    if (c > 16) c = 16;
+    if (c > MSM_MAX_WINDOW) c = MSM_MAX_WINDOW;
     return c;
 }
 
-// One slab per workspace: a single hipMalloc / hipFree instead of fifteen (they dominate a one-shot msm_parallel).
+// accumulation lanes the GPU runs at once (for the chunk size: whole rounds of lanes, no ragged last round)
+template <class C> static size_t accumulate_slots() {
+    static size_t slots = 0;
+    if (slots == 0) {
+        int per_cu = 0, dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_accumulate<C>, ACC_THREADS, 0) != hipSuccess || per_cu <= 0) per_cu = 6;
+        slots = (size_t)per_cu * ACC_THREADS * (size_t)cus;
+    }
+    return slots;
+}
+
+// One slab per workspace: a single hipMalloc / hipFree instead of a dozen (they dominate a one-shot msm_parallel).
 template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w) {
     using FP = typename C::FP;
-    const size_t xyzz_bytes = (size_t)4 * FP::NL * 4;
+    const size_t packed_bytes = (size_t)4 * FP::NL * 4;
+    const size_t raw_bytes = (size_t)raw_u4<FP>() * 16;
     const size_t entries = ctx->n * ctx->windows;
-    ctx->nt1 = (uint32_t)((entries + PART_TILE - 1) >> PART_TILE_LOG);
-    if (ctx->nt1 == 0) ctx->nt1 = 1;
-    ctx->nt2max = ctx->nt1 + ctx->nbins;
-    ctx->max_slices = entries / ctx->slice + ctx->buckets + 1;
-    // at most max_slices / HEAVY_SLICES heavy buckets, max_slices / HEAVY_CHUNK + that many chunk items
-    ctx->heavy_cap = (uint32_t)(ctx->max_slices / HEAVY_SLICES + ctx->max_slices / HEAVY_CHUNK + 2);
-    const int bucket_windows = ctx->table_free ? ctx->windows : 1;
+    const int bucket_windows = ctx->tail_windows;
+    // packed operands of the plane sums: the buckets themselves, or (two-level tail) the column and row sums
+    const size_t tail_slots = ctx->two_level ? (size_t)bucket_windows * ctx->tail_wbuckets : (size_t)ctx->buckets;
     struct Part { void** p; size_t bytes; };
     const Part parts[] = {
-        {&w.codes, entries * 4 + 16},
+        {&w.tmp, entries * 8 + 16},
         {&w.sorted, entries * 4 + 16},
-        {&w.hist, (size_t)ctx->buckets * 4 + 16},
-        {&w.cnt1, (size_t)ctx->nbins * ctx->nt1 * 4},
-        {&w.cnt2, ((size_t)1 << ctx->fine_bits) * ctx->nt2max * 4},
-        {&w.tmp_code, ((size_t)ctx->nt2max << PART_TILE_LOG) * 4},
-        {&w.tmp_val, ((size_t)ctx->nt2max << PART_TILE_LOG) * 4},
-        {&w.part_meta, (size_t)(256 + 257 + 1 + ctx->nt2max + 2 * 64 + 2) * 4},  // + block totals of the bucket scan
-        {&w.off, ((size_t)ctx->buckets + 1) * 8},
-        {&w.partial, ctx->max_slices * xyzz_bytes},
-        {&w.bucket, (size_t)ctx->buckets * xyzz_bytes},
+        {&w.cnt1, (size_t)ctx->ord.nbins * ctx->ord.nt1 * 4},
+        {&w.cnt2, ((entries / ORD_SEG + ctx->ord.nbins + 1) << ctx->ord.fine_bits) * 4},
+        {&w.meta, (size_t)(1024 + 1025 + 1025 + 8) * 4},
+        {&w.off, ((size_t)ctx->buckets + 2) * 4},
+        {&w.p_start, (size_t)ctx->buckets * raw_bytes},
+        {&w.p_head, (ctx->max_lanes + 1) * raw_bytes},
+        {&w.head_live, ctx->max_lanes + ACC_THREADS},
+        {&w.bucket, tail_slots * packed_bytes},
         {&w.heavy, (size_t)(2 + 3 * ctx->heavy_cap) * 4},
-        {&w.heavy_part, (size_t)ctx->heavy_cap * xyzz_bytes},
-        {&w.plane_part, (size_t)bucket_windows * ctx->planes * ctx->plane_blocks * xyzz_bytes},
-        {&w.win_pts, ctx->table_free ? (size_t)ctx->windows * xyzz_bytes : 0},
+        {&w.heavy_part, (size_t)ctx->heavy_cap * raw_bytes},
+        {&w.line_part, ctx->two_level ? (size_t)2 * (ctx->buckets >> ctx->g_log) * raw_bytes : 0},
+        {&w.plane_part, (size_t)bucket_windows * ctx->planes * ctx->plane_blocks * packed_bytes},
+        {&w.win_pts, bucket_windows > 1 ? (size_t)bucket_windows * packed_bytes : 0},
     };
     size_t total = 0;
     for (const Part& pt : parts) total += (pt.bytes + 255) & ~(size_t)255;
@@ -1000,6 +1196,10 @@ template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w) {
         *pt.p = pt.bytes ? cur : nullptr;
         cur += (pt.bytes + 255) & ~(size_t)255;
     }
+    // the "last block" counter of k_ord_scan1 and the heavy-list counters start at zero and are left at zero by their users
+    PLK_HIP_TRY(hipMemset(w.meta, 0, (size_t)(1024 + 1025 + 1025 + 8) * 4));
+    PLK_HIP_TRY(hipMemset(w.heavy, 0, 8));
+    PLK_HIP_TRY(hipEventCreateWithFlags(&w.ev, hipEventDisableTiming));
     w.ready = true;
     return PLK_OK;
 }
@@ -1010,6 +1210,29 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
     const size_t n = ctx->n;
     const size_t pt_bytes = (size_t)2 * FP::NL * 4;
     const size_t entries = n * ctx->windows;
+    // entries per accumulation lane: whole rounds of the lanes the GPU holds, at most 72 entries each (longer chunks: fewer pieces)
+    {
+        const size_t slots = accumulate_slots<C>();
+        const double per_slot = (double)entries / (double)slots;
+        size_t rounds = (size_t)(per_slot / 72.0 + 0.999);
+        if (rounds < 1) rounds = 1;
+        size_t ch = (size_t)(per_slot / (double)rounds + 0.999);
+        if (ch < 8) ch = 8;
+        if (ch > 96) ch = 96;
+        ctx->chunk = (uint32_t)ch;
+        if (const char* e = getenv("PLK_MSM_SLICE")) {
+            int v = atoi(e);
+            if (v >= 2 && v <= 4096) ctx->chunk = (uint32_t)v;
+        }
+    }
+    ctx->max_lanes = entries / ctx->chunk + 2;
+    // at most max_lanes / HEAVY_HEADS heavy buckets, max_lanes / HEAVY_CHUNK + that many chunk items
+    ctx->heavy_cap = (uint32_t)(ctx->max_lanes / HEAVY_HEADS + ctx->max_lanes / HEAVY_CHUNK + 2);
+    // lanes per bucket in k_msm_assemble: from the expected number of head pieces per bucket
+    {
+        const double heads = (double)entries / (double)ctx->buckets / (double)ctx->chunk;
+        ctx->lpb_log = heads > 6.0 ? 3 : heads > 2.0 ? 2 : 0;
+    }
     PLK_HIP_TRY(hipMalloc(&ctx->tab, (ctx->table_free ? n : entries) * pt_bytes + 16));
     ctx->ws.resize(1);
     PLK_TRY(msm_alloc_work<C>(ctx, ctx->ws[0]));
@@ -1022,7 +1245,7 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
     return PLK_OK;
 }
 
-// table-free window: windows * 2^(c-1) bucket slots must fit the 16 bits of the partition, long slices wanted
+// table-free window: windows * 2^(c-1) bucket slots, long chunks wanted
 static int choose_window_table_free(size_t n) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
@@ -1041,45 +1264,71 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     if (n && !d_bases) return set_error(PLK_ERR_INVALID_ARG, "null bases");
     PLK_TRY(ensure_device());
     const bool table_free = (flags & PLK_MSM_TABLE_FREE) != 0;
-    int c = window_bits ? (int)window_bits : (table_free ? choose_window_table_free(n ? n : 1) : choose_window(n ? n : 1));
+    int c = window_bits ? (int)window_bits : (table_free ? choose_window_table_free(n ? n : 1) : choose_window(n ? n : 1, curve));
     if (c < 2 || c > MSM_MAX_WINDOW) return set_error(PLK_ERR_INVALID_ARG, "window_bits %d outside [2, %d]", c, MSM_MAX_WINDOW);
+    const int windows = (scalar_bits(curve) + 1 + c - 1) / c;
     if (table_free) {
-        const int w = (scalar_bits(curve) + 1 + c - 1) / c;
-        if (((size_t)w << (c - 1)) > 65536 || w > COMBINE_THREADS / 4)
-            return set_error(PLK_ERR_INVALID_ARG, "table-free mode: window_bits %d gives %d windows x %d buckets (limits: 65536 slots, %d windows)", c, w,
+        if (((size_t)windows << (c - 1)) > 65536 || windows > COMBINE_THREADS / 4)
+            return set_error(PLK_ERR_INVALID_ARG, "table-free mode: window_bits %d gives %d windows x %d buckets (limits: 65536 slots, %d windows)", c, windows,
                              1 << (c - 1), COMBINE_THREADS / 4);
     }
+    if (n * (size_t)windows >= ((size_t)1 << 31))
+        return set_error(PLK_ERR_INVALID_ARG, "n * windows = %zu entries exceeds 2^31", n * (size_t)windows);
+    int dev = 0;
+    PLK_HIP_TRY(hipGetDevice(&dev));
     auto* ctx = new plk_msm_ctx();
     ctx->table_free = table_free;
-    PLK_HIP_TRY(hipGetDevice(&ctx->device));
+    ctx->device = dev;
     ctx->curve = curve;
     ctx->n = n;
     ctx->c = c;
-    ctx->windows = (scalar_bits(curve) + 1 + c - 1) / c;
+    ctx->windows = windows;
     ctx->wbuckets = 1u << (c - 1);
     {
-        // partition geometry from the number of bucket slots: 8 fine bits, <= 256 coarse bins
+        // partition geometry from the number of bucket slots: <= 512 coarse bins (one workgroup each at level 2), the rest fine
         const uint32_t want = ctx->table_free ? ctx->wbuckets * (uint32_t)ctx->windows : ctx->wbuckets;
-        int bits = 0;
-        while (((uint32_t)1 << bits) < want) ++bits;
-        ctx->fine_bits = bits < 8 ? bits : 8;
-        ctx->nbins = (int)((want + (1u << ctx->fine_bits) - 1) >> ctx->fine_bits);
-        ctx->buckets = (uint32_t)ctx->nbins << ctx->fine_bits;
+        const int bits = ilog2_ceil(want);
+        int coarse = bits < 9 ? bits : 9;
+        if (bits - coarse > ORD_MAX_FINE) coarse = bits - ORD_MAX_FINE;
+        OrdCfg& o = ctx->ord;
+        o.c = c;
+        o.windows = windows;
+        o.window_buckets = ctx->table_free ? ctx->wbuckets : 0u;
+        o.fine_bits = bits - coarse;
+        o.nbins = (int)((want + (1u << o.fine_bits) - 1) >> o.fine_bits);
+        ctx->buckets = (uint32_t)o.nbins << o.fine_bits;
+        o.spt = (uint32_t)(ORD_TILE / windows);
+        if (o.spt > (uint32_t)ORD_THREADS) o.spt = ORD_THREADS;
+        o.sub = n >= ((size_t)1 << 16) ? 4 : 1;
+        o.nt1 = (uint32_t)((n + (size_t)o.spt * o.sub - 1) / ((size_t)o.spt * o.sub));
+        if (o.nt1 == 0) o.nt1 = 1;
     }
-    ctx->slice = MSM_SLICE_DEFAULT;
-    if (const char* e = getenv("PLK_MSM_SLICE")) {
-        int v = atoi(e);
-        if (v >= 4 && v <= 4096) ctx->slice = (uint32_t)v;
+    // tail geometry
+    ctx->two_level = !ctx->table_free && c - 1 >= 12;
+    if (ctx->two_level) {
+        ctx->L = (c - 1) / 2;
+        ctx->H = c - 1 - ctx->L;
+        ctx->g_log = c - 1 >= 17 ? 3 : 2;
+        if (const char* e = getenv("PLK_MSM_GLOG")) ctx->g_log = atoi(e);
+        if (ctx->g_log > ctx->L) ctx->g_log = ctx->L;
+        if (ctx->g_log < 0) ctx->g_log = 0;
+        const int longest = ctx->H - ctx->g_log;  // log2 of the partials per column (rows have L - g_log <= that)
+        ctx->lpl_log = longest < 4 ? longest : 4;  // quads per line
+        ctx->tail_windows = 2;
+        ctx->tail_wbuckets = 1u << ctx->H;
+        ctx->tail_shift = ctx->L;
+        ctx->planes = ctx->H;  // weights up to 2^H - 1 (rows) / 2^L (columns): plane H - 1 is the top one for rows; columns need bit L <= H - 1 or L == H
+        if (ctx->L == ctx->H) ctx->planes = ctx->H + 1;  // column weight 2^L = 2^H needs plane H
+    } else {
+        ctx->tail_windows = ctx->table_free ? ctx->windows : 1;
+        ctx->tail_wbuckets = ctx->wbuckets;
+        ctx->tail_shift = c;
+        ctx->planes = c;
     }
-    ctx->planes = c;
     ctx->plane_blocks = 1;
-    while (ctx->plane_blocks < MSM_MAX_PLANE_PARTS && (uint32_t)ctx->plane_blocks * 2048u < ctx->wbuckets &&
+    while (ctx->plane_blocks < MSM_MAX_PLANE_PARTS && (uint32_t)ctx->plane_blocks * 512u < ctx->tail_wbuckets &&
            ctx->planes * ctx->plane_blocks * 4 <= FINAL_THREADS)  // after doubling: planes * parts / 2 quads in the final block
         ctx->plane_blocks *= 2;
-    if (n * (size_t)ctx->windows >= ((size_t)1 << 31)) {
-        delete ctx;
-        return set_error(PLK_ERR_INVALID_ARG, "n * windows = %zu entries exceeds 2^31", n * (size_t)ctx->windows);
-    }
     int rc;
     switch (curve) {
         case PLK_CURVE_TWEEDLEDEE: rc = msm_precompute_t<TweedledeeCurve>(ctx, d_bases, d_zero, stream); break;
@@ -1095,12 +1344,16 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
 }
 
 static TailSlot tail_slot(const plk_msm_ctx* ctx, const MsmWork& w, void* d_out_xy, void* d_out_zero) {
+    (void)ctx;
     TailSlot t;
-    t.partial = (const uint4*)w.partial;
-    t.slice_off = (const uint32_t*)w.off + ctx->buckets + 1;  // off[buckets + 1] is followed by slice_off[buckets + 1]
+    t.off = (const uint32_t*)w.off;
+    t.p_start = (uint4*)w.p_start;
+    t.p_head = (const uint4*)w.p_head;
+    t.head_live = (const uint8_t*)w.head_live;
     t.bucket = (uint4*)w.bucket;
     t.heavy = (uint32_t*)w.heavy;
     t.heavy_part = (uint4*)w.heavy_part;
+    t.line_part = (uint4*)w.line_part;
     t.plane_part = (uint4*)w.plane_part;
     t.win_pts = (uint4*)w.win_pts;
     t.out_xy = (uint4*)d_out_xy;
@@ -1108,45 +1361,54 @@ static TailSlot tail_slot(const plk_msm_ctx* ctx, const MsmWork& w, void* d_out_
     return t;
 }
 
-// bucket sums -> bit-plane sums -> result, for the tb.count MSMs of a batch at once (their accumulations have run)
+// pieces -> buckets -> (row / column sums ->) bit-plane sums -> result, for the tb.count MSMs of a batch at once
 template <class C, class Mark>
 static int msm_reduce_t(plk_msm_ctx* ctx, TailBatch tb, hipStream_t stream, Mark&& mark) {
     const uint32_t buckets = ctx->buckets;
     const unsigned cnt = (unsigned)tb.count;
-    k_msm_bucket_sum<C><<<dim3((buckets * BUCKET_LANES + 255) / 256, cnt), 256, 0, stream>>>(tb, buckets);
     // hot buckets of a skewed scalar distribution (none for uniform scalars: the three launches then exit at once)
-    k_msm_heavy_list<<<dim3((buckets + 255) / 256, cnt), 256, 0, stream>>>(tb, buckets, ctx->heavy_cap);
-    k_msm_heavy_chunks<C><<<dim3(256, cnt), 256, 0, stream>>>(tb, ctx->heavy_cap);
+    k_msm_heavy_list<<<dim3((buckets + 255) / 256, cnt), 256, 0, stream>>>(tb, buckets, ctx->chunk, ctx->heavy_cap);
+    k_msm_heavy_chunks<C><<<dim3(256, cnt), 256, 0, stream>>>(tb, ctx->chunk, ctx->heavy_cap);
     k_msm_heavy_final<C><<<dim3(64, cnt), 256, 0, stream>>>(tb, ctx->heavy_cap);
+    const unsigned ab = (unsigned)((((size_t)buckets << ctx->lpb_log) + 255) / 256);
+    if (ctx->two_level) {
+        const uint32_t nbg = buckets >> ctx->g_log;
+        k_msm_assemble<C, false><<<dim3(ab, cnt), 256, 0, stream>>>(tb, buckets, ctx->chunk, ctx->lpb_log);
+        k_msm_gsum<C><<<dim3((2 * nbg + 127) / 128, cnt), 128, 0, stream>>>(tb, ctx->L, ctx->H, ctx->g_log);
+        const size_t lanes = ((size_t)2 << ctx->H) << (ctx->lpl_log + 2);
+        k_msm_lsum<C><<<dim3((unsigned)((lanes + 255) / 256), cnt), 256, 0, stream>>>(tb, ctx->L, ctx->H, ctx->g_log, ctx->lpl_log);
+    } else {
+        k_msm_assemble<C, true><<<dim3(ab, cnt), 256, 0, stream>>>(tb, buckets, ctx->chunk, ctx->lpb_log);
+    }
     PLK_HIP_TRY(hipGetLastError());
     mark();
-    const int bucket_windows = ctx->table_free ? ctx->windows : 1;
-    dim3 pg(ctx->plane_blocks, ctx->planes, bucket_windows * cnt);
-    k_msm_planes<C><<<pg, PLANE_THREADS, 0, stream>>>(tb, bucket_windows, ctx->wbuckets);
+    const int tw = ctx->tail_windows;
+    dim3 pg(ctx->plane_blocks, ctx->planes, tw * cnt);
+    k_msm_planes<C><<<pg, PLANE_THREADS, 0, stream>>>(tb, tw, ctx->tail_wbuckets);
     PLK_HIP_TRY(hipGetLastError());
     mark();
-    k_msm_final<C><<<bucket_windows * cnt, FINAL_THREADS, 0, stream>>>(tb, bucket_windows, ctx->plane_blocks, ctx->planes, ctx->c);
-    if (bucket_windows > 1) k_msm_combine<C><<<cnt, COMBINE_THREADS, 0, stream>>>(tb, ctx->windows);
+    k_msm_final<C><<<tw * cnt, FINAL_THREADS, 0, stream>>>(tb, tw, ctx->plane_blocks, ctx->planes, ctx->tail_shift);
+    if (tw > 1) k_msm_combine<C><<<cnt, COMBINE_THREADS, 0, stream>>>(tb, tw);
     PLK_HIP_TRY(hipGetLastError());
     mark();
     return PLK_OK;
 }
 
-// phases: 1 = digits + bucket ordering, 2 = accumulation, 4 = reduction; 7 = the whole MSM on one stream
+// phases: 1 = bucket ordering, 2 = accumulation, 4 = reduction; 7 = the whole MSM on one stream
 constexpr int PH_ORDER = 1, PH_ACC = 2, PH_REDUCE = 4, PH_ALL = 7;
 template <class C>
 static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
                          int phases = PH_ALL) {
     const size_t n = ctx->n;
-    const size_t entries = n * ctx->windows;
     const uint32_t buckets = ctx->buckets;
-    uint32_t* hist = (uint32_t*)w.hist;
+    const OrdCfg& o = ctx->ord;
     uint32_t* off = (uint32_t*)w.off;
-    uint32_t* slice_off = off + buckets + 1;
-    uint32_t* bin_total = (uint32_t*)w.part_meta;
-    uint32_t* bin_base_pad = bin_total + 256;
-    uint32_t* meta = bin_base_pad + 257;
-    uint32_t* tile2bin = meta + 1;
+    uint32_t* bin_total = (uint32_t*)w.meta;
+    uint32_t* bin_base = bin_total + 1024;
+    uint32_t* seg_base = bin_base + 1025;
+    uint32_t* done_counter = seg_base + 1025;
+    // the workspace may still be in use by an execution enqueued on another stream
+    if (w.used && w.last_stream != stream) PLK_HIP_TRY(hipStreamWaitEvent(stream, w.ev, 0));
     std::vector<hipEvent_t> ev;
     if (ctx->profiling && phases == PH_ALL) {
         if (!ctx->prof_free.empty()) {
@@ -1164,51 +1426,49 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
     };
     mark();
     if (phases & PH_ORDER) {
-    if (n) {
-        k_msm_digits<C><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const uint4*)d_scalars, (uint32_t*)w.codes, n, ctx->c, ctx->windows,
-                                                                         ctx->table_free ? ctx->wbuckets : 0u);
+        k_ord_count<C><<<o.nt1, ORD_THREADS, 0, stream>>>((const uint4*)d_scalars, n, o, (uint32_t*)w.cnt1);
+        k_ord_scan1<<<o.nbins, 256, 0, stream>>>((uint32_t*)w.cnt1, o.nt1, o.nbins, bin_total, bin_base, seg_base, done_counter);
         PLK_HIP_TRY(hipGetLastError());
-    }
-    mark();
-    // partition level 1 (coarse bins)
-    k_part1_count<<<ctx->nt1, PART_THREADS, 0, stream>>>((const uint32_t*)w.codes, entries, (uint32_t*)w.cnt1, ctx->nt1, ctx->fine_bits, ctx->nbins);
-    k_part_rowscan<<<ctx->nbins, 256, 0, stream>>>((uint32_t*)w.cnt1, ctx->nt1, bin_total);
-    k_part_bases<<<1, 256, 0, stream>>>(bin_total, ctx->nbins, bin_base_pad, tile2bin, meta);
-    k_part1_scatter<<<ctx->nt1, PART_THREADS, 0, stream>>>((const uint32_t*)w.codes, entries, (const uint32_t*)w.cnt1, ctx->nt1, bin_base_pad,
-                                                           ctx->fine_bits, ctx->nbins, (uint32_t*)w.tmp_code, (uint32_t*)w.tmp_val);
-    // partition level 2 (buckets inside each coarse bin) + bucket offsets / slice offsets
-    k_part2_count<<<ctx->nt2max, PART_THREADS, 0, stream>>>((const uint32_t*)w.tmp_code, bin_total, bin_base_pad, tile2bin, meta, (uint32_t*)w.cnt2,
-                                                            ctx->nt2max, ctx->fine_bits);
-    k_part2_scan<<<ctx->nbins, 256, 0, stream>>>((uint32_t*)w.cnt2, ctx->nt2max, bin_base_pad, ctx->fine_bits, hist);
-    PLK_HIP_TRY(hipGetLastError());
-    mark();
-    {
-        const unsigned sb = (buckets + 1023) / 1024;
-        k_msm_scan_local<<<sb, 1024, 0, stream>>>(hist, off, slice_off, meta + 1 + ctx->nt2max, buckets, ctx->slice);
-        k_msm_scan_add<<<sb, 1024, 0, stream>>>(off, slice_off, meta + 1 + ctx->nt2max, buckets);
-    }
-    k_part2_scatter<<<ctx->nt2max, PART_THREADS, 0, stream>>>((const uint32_t*)w.tmp_code, (const uint32_t*)w.tmp_val, bin_total, bin_base_pad, tile2bin,
-                                                              meta, (const uint32_t*)w.cnt2, ctx->nt2max, ctx->fine_bits, off, (uint32_t*)w.sorted);
-    PLK_HIP_TRY(hipGetLastError());
-    mark();
+        mark();
+        k_ord_scatter<C><<<o.nt1, ORD_THREADS, 0, stream>>>((const uint4*)d_scalars, n, o, (const uint32_t*)w.cnt1, bin_base, (uint2*)w.tmp);
+        PLK_HIP_TRY(hipGetLastError());
+        mark();
+        {
+            // the number of segments is only known on the device: launch for the upper bound (+ nbins blocks that write the
+            // offsets of the empty bins), blocks past the end exit
+            const unsigned segs = (unsigned)(n * (size_t)o.windows / ORD_SEG + o.nbins + 1);
+            k_ord_bin_count<<<segs, ORD_BIN_THREADS, 0, stream>>>((const uint2*)w.tmp, bin_base, seg_base, o.fine_bits, o.nbins, (uint32_t*)w.cnt2);
+            k_ord_bin_scatter<<<segs + o.nbins, ORD_BIN_THREADS, 0, stream>>>((const uint2*)w.tmp, bin_base, seg_base, o.fine_bits, o.nbins, buckets,
+                                                                              (const uint32_t*)w.cnt2, off, (uint32_t*)w.sorted);
+        }
+        PLK_HIP_TRY(hipGetLastError());
+        mark();
     } else {
         stage += 3;
     }
     if (phases & PH_ACC) {
-    // the slice count is only known on the device: launch for the upper bound, lanes past it exit
-    k_msm_accumulate<C><<<(unsigned)((ctx->max_slices + 127) / 128), 128, 0, stream>>>((const uint4*)ctx->tab, (const uint32_t*)w.sorted, off, slice_off,
-                                                                                       (uint4*)w.partial, buckets, ctx->slice, ctx->table_free ? ctx->c - 1 : 31,
-                                                                                       ctx->table_free ? (uint32_t)n : 0u);
-    PLK_HIP_TRY(hipGetLastError());
+        // the entry count is only known on the device: launch for the upper bound, lanes past it exit
+        const unsigned ablocks = (unsigned)((ctx->max_lanes + ACC_THREADS - 1) / ACC_THREADS);
+        k_msm_accumulate<C><<<ablocks, ACC_THREADS, 0, stream>>>((const uint4*)ctx->tab, (const uint32_t*)w.sorted, off, (uint4*)w.p_start, (uint4*)w.p_head,
+                                                                 (uint8_t*)w.head_live, buckets, ctx->chunk, ctx->table_free ? ctx->c - 1 : 31,
+                                                                 ctx->table_free ? (uint32_t)n : 0u);
+        PLK_HIP_TRY(hipGetLastError());
     }
     mark();
-    if (!(phases & PH_REDUCE)) return PLK_OK;
-    TailBatch tb;
-    tb.count = 1;
-    tb.s[0] = tail_slot(ctx, w, d_out_xy, d_out_zero);
-    PLK_TRY(msm_reduce_t<C>(ctx, tb, stream, mark));
-    if (!ev.empty()) ctx->prof_sets.push_back(ev);
+    if (phases & PH_REDUCE) {
+        TailBatch tb;
+        tb.count = 1;
+        tb.s[0] = tail_slot(ctx, w, d_out_xy, d_out_zero);
+        PLK_TRY(msm_reduce_t<C>(ctx, tb, stream, mark));
+        if (!ev.empty()) ctx->prof_sets.push_back(ev);
+    }
     return PLK_OK;
+}
+
+static void work_done(MsmWork& w, hipStream_t stream) {
+    (void)hipEventRecord(w.ev, stream);
+    w.last_stream = stream;
+    w.used = true;
 }
 
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream) {
@@ -1233,15 +1493,13 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
     static const bool no_batching = getenv("PLK_MSM_NO_OVERLAP") != nullptr;  // every MSM of a batch start to end, one by one
     if (batch == 1 || ctx->profiling || no_batching) {
         for (unsigned b = 0; b < batch; ++b) PLK_TRY(run_one(b, ctx->ws[0], stream, PH_ALL));
+        work_done(ctx->ws[0], stream);
         return PLK_OK;
     }
     // Several scalar vectors against the same generators (commit_polynomials, plonk_util.rs:215-231), in groups of up
     // to TAIL_MAX: every MSM of a group has its own workspace, ordering and accumulation run one MSM after the other,
     // and the latency-bound reduction runs ONCE for the whole group - it is a chain of point operations on few points,
-    // so nine of them cost little more than one (1.2 ms against 9 x 0.44 ms at 2^20).  Measured alternatives: running
-    // consecutive MSMs on two streams so that the ordering of one overlaps the accumulation of its neighbour gains
-    // nothing on top of this (the accumulation fills every SIMD's register file, 3 waves x 168 VGPRs); giving the other
-    // phases their own CUs (CU masks) or a more urgent stream is slower.
+    // so nine of them cost little more than one.
     unsigned group = batch < (unsigned)TAIL_MAX ? batch : (unsigned)TAIL_MAX;
     const size_t budget = (size_t)16 << 30;  // bytes of workspace a batch may hold
     while (group > 2 && ctx->ws_bytes * group > budget) --group;
@@ -1254,6 +1512,7 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
             default: rc = msm_alloc_work<Bls12377Curve>(ctx, ctx->ws.back()); break;
         }
         if (rc != PLK_OK) {
+            ctx->ws.back().release();
             ctx->ws.pop_back();
             (void)hipGetLastError();
             group = (unsigned)ctx->ws.size();  // make do with what fits (at least the workspace of the precomputation)
@@ -1277,6 +1536,7 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
             default: rc = msm_reduce_t<Bls12377Curve>(ctx, tb, stream, nomark); break;
         }
         PLK_TRY(rc);
+        for (unsigned k = 0; k < cnt; ++k) work_done(ctx->ws[k], stream);
     }
     return PLK_OK;
 }

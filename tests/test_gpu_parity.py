@@ -220,7 +220,7 @@ def test_msm_summation_edge_cases(c):
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
-@pytest.mark.parametrize("n,win", [(1, 0), (10, 0), (24, 3), (24, 7), (300, 0), (1000, 6), (4096, 0), (4096, 11)])
+@pytest.mark.parametrize("n,win", [(1, 0), (10, 0), (24, 3), (24, 7), (300, 0), (1000, 6), (1000, 14), (4096, 0), (4096, 11), (4096, 13), (4096, 16), (300, 20)])
 def test_msm_matches_oracle(c, n, win):
     """msm_execute_parallel on seeded inputs vs the oracle's restatement of the reference (w = 8 tables)."""
     G = (c.gx, c.gy)
