@@ -111,6 +111,29 @@ int plk_poly_mul(int field, const uint64_t* a, size_t la, const uint64_t* b, siz
 int plk_poly_mul_dev(int field, const void* d_a, size_t la, const void* d_b, size_t lb, void* d_out, size_t out_cap, size_t* out_len,
                      void* stream);
 
+/* ---- the Plonk quotient numerator  (src/plonk.rs, src/gates/) ------------------------------------ */
+/* The 8n-point loop of Prover::vanishing_poly (plonk.rs:392-453): for every point x = g^i of the 8n domain the
+ * vanishing terms [L_1(x) (Z(x) - 1), Z(x) f'(x) - g'(x) Z(g x), evaluate_all_constraints(...)] reduced with powers of
+ * alpha (plonk_util.rs:27-33).  `field` is the circuit's scalar field C::ScalarField, degree = 2^log_degree, n8 = 8 * degree.
+ * Device tables, row-major, n8 elements per row, exactly the prover's own: constants_8n (6 rows, plonk.rs:64-69),
+ * wire_values_8n (9 rows), s_sigma_values_8n (6 rows), plonk_z_points_8n (1 row: the LDE of Z, plonk.rs:388-391 =
+ * plk_ntt_padded_dev).  Host scalars (4 limbs each, Montgomery): k_is[6] = get_subgroup_shift(0..5) (partition.rs:140-153,
+ * ChaCha8 output: an input here), the challenges alpha, beta, gamma, and the two constants through which InnerC enters the
+ * gates, InnerC::ZETA (curve_endo.rs:119) and InnerC::A (curve_dbl.rs:57).  d_out: n8 elements; the closing
+ * Polynomial::from_evaluations (plonk.rs:455) is plk_ntt_dev(inverse = 1) on it.  Asynchronous on `stream`; the first call
+ * for a (field, log_degree) builds and caches the circuit-size tables (L_1 over the domain, powers of g, MDS entries). */
+int plk_plonk_vanishing_points_dev(int field, unsigned log_degree, const void* d_constants_8n, const void* d_wires_8n, const void* d_s_sigma_8n,
+                                   const void* d_plonk_z_8n, const uint64_t* k_is, const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma,
+                                   const uint64_t* inner_zeta, const uint64_t* inner_a, void* d_out, void* stream);
+/* Same with host tables (copied through PCIe). */
+int plk_plonk_vanishing_points(int field, unsigned log_degree, const uint64_t* constants_8n, const uint64_t* wires_8n, const uint64_t* s_sigma_8n,
+                               const uint64_t* plonk_z_8n, const uint64_t* k_is, const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma,
+                               const uint64_t* inner_zeta, const uint64_t* inner_a, uint64_t* out);
+/* evaluate_all_constraints (gates/mod.rs:46-125) at `count` independent points: constants [count][6], local / right / below
+ * wire values [count][9] each, out [count][8] (the unified constraint set: the longest gate has 8 constraints). Host pointers. */
+int plk_plonk_evaluate_all_constraints(int field, size_t count, const uint64_t* constants, const uint64_t* local_wires, const uint64_t* right_wires,
+                                       const uint64_t* below_wires, const uint64_t* inner_zeta, const uint64_t* inner_a, uint64_t* out);
+
 /* ---- MSM  (src/curve/curve_msm.rs) -------------------------------------------------------- */
 typedef struct plk_msm_ctx plk_msm_ctx;
 

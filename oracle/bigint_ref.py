@@ -371,3 +371,122 @@ def poly_eval(f: FieldSpec, a, x):
     for c in reversed(a):
         acc = (acc * x + c) % f.p
     return acc
+
+
+# ---------------------------------------------------------------------------------------------
+# The Plonk quotient numerator, from the mathematics of the gates:
+#   gates/mod.rs:46-125,289-300, gates/*.rs, mds.rs:63-77, plonk_util.rs:7-33, plonk.rs:392-453.
+# Canonical integers mod p, written table-driven (a gate = prefix bits + a function returning its constraint
+# list) so that it shares no structure with oracle/plonk_gates.inc or plonky_amd/csrc/plonk.hip.
+# ---------------------------------------------------------------------------------------------
+NUM_WIRES, NUM_ROUTED_WIRES, NUM_CONSTANTS, GRID_WIDTH = 9, 6, 6, 65  # plonk.rs:21-25
+
+
+def _mds4(p, r, c):
+    return pow(4 + r - c, -1, p)  # Cauchy matrix, x_r = 4 + r, y_c = c (mds.rs:63-77)
+
+
+def _g_curve_add(p, k, l, r, b, zeta, a):
+    x1, y1, acc_old, acc_new, x2, y2, bit, inv, lam = l
+    x4, y4 = r[0], r[1]
+    x3 = lam * lam - x1 - x2
+    y3 = lam * (x1 - x4) - y1
+    return [(y1 - y2) * inv - lam, bit * x3 + (1 - bit) * x1 - x4, bit * y3 + (1 - bit) * y1 - y4, acc_new - (2 * acc_old + bit),
+            bit * (1 - bit), inv * (x1 - x2) - 1]
+
+
+def _g_curve_dbl(p, k, l, r, b, zeta, a):
+    xo, yo, xn, yn, inv, lam = l[:6]
+    return [(3 * xo * xo + a) * inv - lam, lam * lam - 2 * xo - xn, lam * (xo - xn) - yo - yn, 2 * yo * inv - 1]
+
+
+def _g_curve_endo(p, k, l, r, b, zeta, a):
+    x1, y1, un_old, sg_old, x_in, y_in, b0, b1, inv = l
+    x3, y3 = r[0], r[1]
+    mult = (zeta - 1) * b1 + 1
+    x2, y2 = mult * x_in, (2 * b0 - 1) * y_in
+    lam = (y1 - y2) * inv
+    return [lam * lam - x1 - x2 - x3, lam * (x1 - x3) - y1 - y3, b[2] - (4 * un_old + 2 * b1 + b0), b[3] - (2 * sg_old + (2 * b0 - 1) * mult),
+            b0 * (b0 - 1), b1 * (b1 - 1), inv * (x1 - x2) - 1]
+
+
+def _g_base4(p, k, l, r, b, zeta, a):
+    acc = l[0]
+    for limb in l[2:]:
+        acc = 4 * acc + limb
+    return [acc - l[1]] + [limb * (limb - 1) * (limb - 2) * (limb - 3) for limb in l[2:]]
+
+
+def _g_rescue_a(p, k, l, r, b, zeta, a):
+    out = []
+    for i in range(4):
+        out.append(pow(l[4 + i], 5, p) - l[i])
+        out.append(k[2 + i] + sum(_mds4(p, i, j) * l[4 + j] for j in range(4)) - r[i])
+    return out
+
+
+def _g_rescue_b(p, k, l, r, b, zeta, a):
+    return [k[2 + i] + sum(_mds4(p, i, j) * pow(l[j], 5, p) for j in range(4)) - r[i] for i in range(4)]
+
+
+# (prefix bits, constraint function) in the order of evaluate_all_constraints (gates/mod.rs:52-113)
+PLONK_GATES = [
+    ("10101", _g_curve_add), ("10111", _g_curve_dbl), ("11", _g_curve_endo), ("1000", _g_base4),
+    ("101001", lambda p, k, l, r, b, zeta, a: [l[6 + i] - r[i] for i in range(3)]),       # PublicInputGate
+    ("101010", lambda p, k, l, r, b, zeta, a: []),                                           # BufferGate
+    ("10110", lambda p, k, l, r, b, zeta, a: [k[5] - l[0]]),                                 # ConstantGate
+    ("1001", lambda p, k, l, r, b, zeta, a: [k[4] * l[0] * l[1] + k[5] * l[2] - l[3]]),      # ArithmeticGate
+    ("00", _g_rescue_a), ("01", _g_rescue_b),
+]
+
+
+def plonk_gate_filtered(f: FieldSpec, gate, k, l, r, b, zeta, a, unfiltered=False):
+    p = f.p
+    prefix, fn = PLONK_GATES[gate]
+    filt = 1
+    for bit, c in zip(prefix, k):
+        filt = filt * (c if bit == "1" else 1 - c) % p
+    return [(v if unfiltered else filt * v) % p for v in fn(p, k, l, r, b, zeta, a)]
+
+
+def plonk_all_constraints(f: FieldSpec, k, l, r, b, zeta, a):
+    out = []
+    for g in range(len(PLONK_GATES)):
+        cs = plonk_gate_filtered(f, g, k, l, r, b, zeta, a)
+        out += [0] * (len(cs) - len(out))
+        for i, v in enumerate(cs):
+            out[i] = (out[i] + v) % f.p
+    return out
+
+
+def plonk_eval_l_1(f: FieldSpec, n, x):
+    if x % f.p == 1:
+        return 1
+    return (pow(x, n, f.p) - 1) * pow(n * (x - 1), -1, f.p) % f.p
+
+
+def plonk_vanishing_points(f: FieldSpec, degree, constants, wires, s_sigma, z, k_is, alpha, beta, gamma, zeta, a):
+    """plonk.rs:392-453 on canonical integers; tables are lists of rows of 8 * degree values."""
+    p, n8 = f.p, 8 * degree
+    g = f.primitive_root_of_unity(n8.bit_length() - 1)
+    out = []
+    x = 1
+    for i in range(n8):
+        ir, ib = (i + 8) % n8, (i + 8 * GRID_WIDTH) % n8
+        k = [constants[j][i] for j in range(NUM_CONSTANTS)]
+        l = [wires[j][i] for j in range(NUM_WIRES)]
+        r = [wires[j][ir] for j in range(NUM_WIRES)]
+        b = [wires[j][ib] for j in range(NUM_WIRES)]
+        terms = [plonk_eval_l_1(f, degree, x) * (z[i] - 1) % p]
+        fp = gp = 1
+        for j in range(NUM_ROUTED_WIRES):
+            fp = fp * (l[j] + beta * k_is[j] * x + gamma) % p
+            gp = gp * (l[j] + beta * s_sigma[j][i] + gamma) % p
+        terms.append((fp * z[i] - gp * z[ir]) % p)
+        terms += plonk_all_constraints(f, k, l, r, b, zeta, a)
+        acc = 0
+        for t in reversed(terms):
+            acc = (acc * alpha + t) % p
+        out.append(acc)
+        x = x * g % p
+    return out

@@ -21,8 +21,8 @@ CURVE_SCALAR_BITS = {0: 255, 1: 255, 2: 253}
 
 
 def build(force=False):
-    src = os.path.join(_DIR, "plk_oracle.cpp")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_DIR, "plk_oracle.cpp"), os.path.join(_DIR, "plonk_gates.inc")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", _DIR, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -69,6 +69,10 @@ def lib():
         L.orc_poly_mul.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                    ctypes.c_void_p, ctypes.c_int]
         L.orc_poly_to_values_padded.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+        L.orc_gate_constraints.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 8
+        L.orc_eval_l_1.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_mds.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
+        L.orc_vanishing_points.argtypes = [ctypes.c_int, ctypes.c_size_t] + [ctypes.c_void_p] * 11 + [ctypes.c_int]
         _lib = L
     return _lib
 
@@ -307,3 +311,34 @@ class MsmPrecomputation:
             lib().orc_msm_free(self.h)
         except Exception:
             pass
+
+
+# ---- the Plonk quotient numerator (plonk_gates.inc) ----
+def gate_constraints(field, gate, k, l, r, b, zeta, a, unfiltered=False):
+    """gate < 0: evaluate_all_constraints (gates/mod.rs:46-125); else Gate::evaluate_filtered / evaluate_unfiltered of that gate."""
+    k, l, r, b, zeta, a = (_u64(x) for x in (k, l, r, b, zeta, a))
+    out = np.zeros((8, 4), dtype=np.uint64)
+    cnt = ctypes.c_size_t(0)
+    assert lib().orc_gate_constraints(field, gate, 1 if unfiltered else 0, _p(k), _p(l), _p(r), _p(b), _p(zeta), _p(a), _p(out), ctypes.byref(cnt)) == 0
+    return out[: cnt.value]
+
+
+def eval_l_1(field, n, x):
+    x = _u64(x)
+    out = np.zeros(4, dtype=np.uint64)
+    assert lib().orc_eval_l_1(field, n, _p(x), _p(out)) == 0
+    return out
+
+
+def mds(field, n, r, c):
+    out = np.zeros(4, dtype=np.uint64)
+    assert lib().orc_mds(field, n, r, c, _p(out)) == 0
+    return out
+
+
+def vanishing_points(field, degree, constants, wires, s_sigma, z, k_is, alpha, beta, gamma, zeta, a, threads=1):
+    """plonk.rs:392-453: constants (6, 8n, 4), wires (9, 8n, 4), s_sigma (6, 8n, 4), z (8n, 4), k_is (6, 4) -> (8n, 4)."""
+    arrs = [_u64(x) for x in (constants, wires, s_sigma, z, k_is, alpha, beta, gamma, zeta, a)]
+    out = np.zeros((8 * degree, 4), dtype=np.uint64)
+    assert lib().orc_vanishing_points(field, degree, *[_p(x) for x in arrs], _p(out), threads) == 0
+    return out

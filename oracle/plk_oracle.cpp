@@ -1002,6 +1002,8 @@ struct Bls12377 : CurveT<Bls12377BaseP, Bls12377ScalarP> {
     }
 };
 
+#include "plonk_gates.inc"
+
 // =============================================================================================
 // C interface for ctypes (tests / cpu_baseline only)
 // =============================================================================================
@@ -1382,4 +1384,54 @@ int orc_rand_field(int field, u64 seed, size_t count, u64* out) {
     return -1;
 }
 
+
+// ---- Plonk quotient numerator (plonk_gates.inc) ----
+// gate < 0: evaluate_all_constraints; else Gate::evaluate_filtered of that gate (order of gates/mod.rs:52-113).  unfiltered != 0: evaluate_unfiltered.
+int orc_gate_constraints(int field, int gate, int unfiltered, const u64* k, const u64* l, const u64* r, const u64* b, const u64* zeta, const u64* a,
+                         u64* out, size_t* n_out) {
+    FIELD_DISPATCH(field, {
+        if (F::N != 4) return -1;
+        F kv[plonk::NUM_CONSTANTS], lv[plonk::NUM_WIRES], rv[plonk::NUM_WIRES], bv[plonk::NUM_WIRES];
+        for (size_t j = 0; j < plonk::NUM_CONSTANTS; ++j) kv[j] = ld<F>(k + j * F::N);
+        for (size_t j = 0; j < plonk::NUM_WIRES; ++j) {
+            lv[j] = ld<F>(l + j * F::N);
+            rv[j] = ld<F>(r + j * F::N);
+            bv[j] = ld<F>(b + j * F::N);
+        }
+        plonk::GateEnv<F> env{kv, lv, rv, bv, ld<F>(zeta), ld<F>(a)};
+        std::vector<F> c = gate < 0 ? plonk::evaluate_all_constraints(env) : unfiltered ? plonk::gate_unfiltered(gate, env) : plonk::gate_filtered(gate, env);
+        for (size_t i = 0; i < c.size(); ++i) st(out + i * F::N, c[i]);
+        *n_out = c.size();
+        return 0;
+    });
+    return -1;
+}
+int orc_eval_l_1(int field, size_t n, const u64* x, u64* out) {
+    FIELD_DISPATCH(field, { st(out, plonk::eval_l_1(n, ld<F>(x))); return 0; });
+    return -1;
+}
+int orc_mds(int field, size_t n, size_t r, size_t c, u64* out) {
+    FIELD_DISPATCH(field, { st(out, plonk::mds_get<F>(n, r, c)); return 0; });
+    return -1;
+}
+// plonk.rs:392-453; tables row-major: constants 6 x 8n, wires 9 x 8n, s_sigma 6 x 8n, z 8n, k_is 6
+int orc_vanishing_points(int field, size_t degree, const u64* constants, const u64* wires, const u64* s_sigma, const u64* z, const u64* k_is,
+                         const u64* alpha, const u64* beta, const u64* gamma, const u64* zeta, const u64* a, u64* out, int threads) {
+    FIELD_DISPATCH(field, {
+        if (F::N != 4) return -1;
+        const size_t n8 = 8 * degree;
+        auto load = [&](const u64* p, size_t cnt) {
+            std::vector<F> v(cnt);
+            for (size_t i = 0; i < cnt; ++i) v[i] = ld<F>(p + i * F::N);
+            return v;
+        };
+        const std::vector<F> cv = load(constants, plonk::NUM_CONSTANTS * n8), wv = load(wires, plonk::NUM_WIRES * n8),
+                             sv = load(s_sigma, plonk::NUM_ROUTED_WIRES * n8), zv = load(z, n8), kv = load(k_is, plonk::NUM_ROUTED_WIRES);
+        const std::vector<F> res = plonk::vanishing_points<F>(degree, cv.data(), wv.data(), sv.data(), zv.data(), kv.data(), ld<F>(alpha), ld<F>(beta),
+                                                              ld<F>(gamma), ld<F>(zeta), ld<F>(a), threads);
+        for (size_t i = 0; i < n8; ++i) st(out + i * F::N, res[i]);
+        return 0;
+    });
+    return -1;
+}
 }  // extern "C"

@@ -354,3 +354,36 @@ def field_op(field, op, a, b=None):
     bb = _elems(field, b) if b is not None else a
     _lib.check(_lib.load().plk_field_op(field, ops[op], _ptr(a), _ptr(bb), _ptr(out), a.shape[0]))
     return out
+
+
+# ---- the Plonk quotient numerator (plonk.rs:375-456, gates/) ----
+NUM_WIRES, NUM_ROUTED_WIRES, NUM_CONSTANTS, GRID_WIDTH = 9, 6, 6, 65  # plonk.rs:21-25
+
+
+def evaluate_all_constraints(field, local_constant_values, local_wire_values, right_wire_values, below_wire_values, inner_zeta, inner_a):
+    """gates/mod.rs:46-125 at `count` points: constants (count, 6, 4), wires (count, 9, 4) x 3 -> (count, 8, 4).
+    inner_zeta / inner_a: InnerC::ZETA and InnerC::A (4 limbs, Montgomery) - how InnerC enters the curve gates."""
+    k = np.ascontiguousarray(local_constant_values, dtype=np.uint64).reshape(-1, NUM_CONSTANTS, 4)
+    l, r, b = (np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, NUM_WIRES, 4) for x in (local_wire_values, right_wire_values, below_wire_values))
+    count = k.shape[0]
+    assert l.shape[0] == r.shape[0] == b.shape[0] == count
+    zeta, a = (np.ascontiguousarray(x, dtype=np.uint64).reshape(4) for x in (inner_zeta, inner_a))
+    out = np.empty((count, 8, 4), dtype=np.uint64)
+    _lib.check(_lib.load().plk_plonk_evaluate_all_constraints(field, count, _ptr(k), _ptr(l), _ptr(r), _ptr(b), _ptr(zeta), _ptr(a), _ptr(out)))
+    return out
+
+
+def vanishing_points(field, degree, constants_8n, wire_values_8n, s_sigma_values_8n, plonk_z_points_8n, k_is, alpha, beta, gamma, inner_zeta, inner_a):
+    """The 8n-point loop of Prover::vanishing_poly (plonk.rs:392-453); Polynomial::from_evaluations of the result
+    (ifft_with_precomputation_power_of_2) is the vanishing polynomial.  Tables: (6, 8n, 4), (9, 8n, 4), (6, 8n, 4), (8n, 4)."""
+    log_degree = log2_strict(degree)
+    n8 = 8 * degree
+    c = np.ascontiguousarray(constants_8n, dtype=np.uint64).reshape(NUM_CONSTANTS, n8, 4)
+    w = np.ascontiguousarray(wire_values_8n, dtype=np.uint64).reshape(NUM_WIRES, n8, 4)
+    s = np.ascontiguousarray(s_sigma_values_8n, dtype=np.uint64).reshape(NUM_ROUTED_WIRES, n8, 4)
+    z = np.ascontiguousarray(plonk_z_points_8n, dtype=np.uint64).reshape(n8, 4)
+    ks = np.ascontiguousarray(k_is, dtype=np.uint64).reshape(NUM_ROUTED_WIRES, 4)
+    sc = [np.ascontiguousarray(x, dtype=np.uint64).reshape(4) for x in (alpha, beta, gamma, inner_zeta, inner_a)]
+    out = np.empty((n8, 4), dtype=np.uint64)
+    _lib.check(_lib.load().plk_plonk_vanishing_points(field, log_degree, _ptr(c), _ptr(w), _ptr(s), _ptr(z), _ptr(ks), *[_ptr(x) for x in sc], _ptr(out)))
+    return out

@@ -194,6 +194,7 @@ int plk_init(int device) {
 }
 
 void plk_shutdown(void) {
+    (void)plonk_clear_cache_impl();
     (void)poly_clear_cache_impl();
     (void)ntt_clear_cache_impl();
     scratch_clear();
@@ -208,8 +209,11 @@ int plk_curve_scalar_field(int curve) { return curve_scalar_field(curve); }
 // ---- NTT ----
 int plk_ntt_precompute(int field, unsigned log_n) { return ntt_precompute_impl(field, log_n); }
 int plk_ntt_clear_cache(void) {
+    (void)plonk_clear_cache_impl();
     (void)poly_clear_cache_impl();
-    return ntt_clear_cache_impl();
+    const int rc = ntt_clear_cache_impl();
+    scratch_clear();  // "memory pressure": the idle scratch buffers go as well
+    return rc;
 }
 
 int plk_ntt_dev(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, void* stream) {
@@ -331,6 +335,58 @@ int plk_poly_mul(int field, const uint64_t* a, size_t la, const uint64_t* b, siz
     if (got && !out) return set_error(PLK_ERR_INVALID_ARG, "null output");
     if (got) PLK_HIP_TRY(hipMemcpy(out, dout.p, got * 32, hipMemcpyDeviceToHost));
     *out_len = got;
+    return PLK_OK;
+}
+
+// ---- the Plonk quotient numerator ----
+int plk_plonk_vanishing_points_dev(int field, unsigned log_degree, const void* d_constants_8n, const void* d_wires_8n, const void* d_s_sigma_8n,
+                                   const void* d_plonk_z_8n, const uint64_t* k_is, const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma,
+                                   const uint64_t* inner_zeta, const uint64_t* inner_a, void* d_out, void* stream) {
+    return plonk_vanishing_points_dev_impl(field, log_degree, d_constants_8n, d_wires_8n, d_s_sigma_8n, d_plonk_z_8n, k_is, alpha, beta, gamma, inner_zeta,
+                                           inner_a, d_out, as_stream(stream));
+}
+int plk_plonk_vanishing_points(int field, unsigned log_degree, const uint64_t* constants_8n, const uint64_t* wires_8n, const uint64_t* s_sigma_8n,
+                               const uint64_t* plonk_z_8n, const uint64_t* k_is, const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma,
+                               const uint64_t* inner_zeta, const uint64_t* inner_a, uint64_t* out) {
+    if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d is not a circuit scalar field", field);
+    if (log_degree + 3 > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_degree %u too large", log_degree);
+    if (!constants_8n || !wires_8n || !s_sigma_8n || !plonk_z_8n || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    const size_t row = ((size_t)8 << log_degree) * 32;
+    DevBuf dc, dw, ds, dz, dout;
+    PLK_TRY(dc.alloc(6 * row));
+    PLK_TRY(dw.alloc(9 * row));
+    PLK_TRY(ds.alloc(6 * row));
+    PLK_TRY(dz.alloc(row));
+    PLK_TRY(dout.alloc(row));
+    PLK_HIP_TRY(hipMemcpy(dc.p, constants_8n, 6 * row, hipMemcpyHostToDevice));
+    PLK_HIP_TRY(hipMemcpy(dw.p, wires_8n, 9 * row, hipMemcpyHostToDevice));
+    PLK_HIP_TRY(hipMemcpy(ds.p, s_sigma_8n, 6 * row, hipMemcpyHostToDevice));
+    PLK_HIP_TRY(hipMemcpy(dz.p, plonk_z_8n, row, hipMemcpyHostToDevice));
+    PLK_TRY(plonk_vanishing_points_dev_impl(field, log_degree, dc.p, dw.p, ds.p, dz.p, k_is, alpha, beta, gamma, inner_zeta, inner_a, dout.p, nullptr));
+    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
+    PLK_HIP_TRY(hipMemcpy(out, dout.p, row, hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+int plk_plonk_evaluate_all_constraints(int field, size_t count, const uint64_t* constants, const uint64_t* local_wires, const uint64_t* right_wires,
+                                       const uint64_t* below_wires, const uint64_t* inner_zeta, const uint64_t* inner_a, uint64_t* out) {
+    if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d is not a circuit scalar field", field);
+    if (count == 0) return PLK_OK;
+    if (!constants || !local_wires || !right_wires || !below_wires || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    DevBuf dc, dl, dr, db, dout;
+    PLK_TRY(dc.alloc(count * 6 * 32));
+    PLK_TRY(dl.alloc(count * 9 * 32));
+    PLK_TRY(dr.alloc(count * 9 * 32));
+    PLK_TRY(db.alloc(count * 9 * 32));
+    PLK_TRY(dout.alloc(count * 8 * 32));
+    PLK_HIP_TRY(hipMemcpy(dc.p, constants, count * 6 * 32, hipMemcpyHostToDevice));
+    PLK_HIP_TRY(hipMemcpy(dl.p, local_wires, count * 9 * 32, hipMemcpyHostToDevice));
+    PLK_HIP_TRY(hipMemcpy(dr.p, right_wires, count * 9 * 32, hipMemcpyHostToDevice));
+    PLK_HIP_TRY(hipMemcpy(db.p, below_wires, count * 9 * 32, hipMemcpyHostToDevice));
+    PLK_TRY(plonk_all_constraints_dev_impl(field, count, dc.p, dl.p, dr.p, db.p, inner_zeta, inner_a, dout.p, nullptr));
+    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
+    PLK_HIP_TRY(hipMemcpy(out, dout.p, count * 8 * 32, hipMemcpyDeviceToHost));
     return PLK_OK;
 }
 

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <memory>
 #include <string>
 
 #include "../../include/plonky_hip.h"
@@ -84,7 +85,15 @@ int ntt_dev_hooked_impl(int field, unsigned log_n, int inverse, unsigned batch, 
                         hipStream_t stream);
 // device pointer to the power table of the (cached) plan: pw[b] = w^(2^b), b < log_t, w the primitive 2^log_t-th root
 // (log_t = max(log_n, 10)), R-form
-int ntt_plan_pow_table(int field, unsigned log_n, const void** pw, int* log_t);
+// *hold (when given) shares ownership of the plan: keep it until the kernels reading pw have been enqueued AND the stream has
+// been synchronised or the hold is released after them (a concurrent plk_ntt_clear_cache frees the table otherwise)
+int ntt_plan_pow_table(int field, unsigned log_n, const void** pw, int* log_t, std::shared_ptr<const void>* hold = nullptr);
+int plonk_clear_cache_impl();
+int plonk_vanishing_points_dev_impl(int field, unsigned log_degree, const void* d_constants, const void* d_wires, const void* d_s_sigma, const void* d_z,
+                                    const uint64_t* k_is, const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma, const uint64_t* inner_zeta,
+                                    const uint64_t* inner_a, void* d_out, hipStream_t stream);
+int plonk_all_constraints_dev_impl(int field, size_t count, const void* d_constants, const void* d_local, const void* d_right, const void* d_below,
+                                   const uint64_t* inner_zeta, const uint64_t* inner_a, void* d_out, hipStream_t stream);
 
 int field_limbs(int field);
 int curve_limbs(int curve);

@@ -303,7 +303,7 @@ PLK_DI Fe<P> tile_emit(const NttPassArgs& a, const NttHooks& hk, Fz<P> v, const 
 
 // One tile per workgroup; any tile shape (transforms shorter than a tile included).
 template <class P, bool HOOKS>
-__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* __restrict__ in, uint4* __restrict__ out,
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* in, uint4* out,
                                                           const uint4* __restrict__ inner_tw, const uint4* __restrict__ outer_tw,
                                                           const uint4* __restrict__ scale_ptr, NttPassArgs a, NttHooks hk) {
     static_assert(P::NL == 8, "NTT kernels are written for the 256-bit fields");
@@ -632,10 +632,11 @@ int ntt_dev_hooked_impl(int field, unsigned log_n, int inverse, unsigned batch, 
     return ntt_dispatch(field, log_n, inverse, batch, d_in, d_out, &hooks, stream);
 }
 
-int ntt_plan_pow_table(int field, unsigned log_n, const void** pw, int* log_t) {
+int ntt_plan_pow_table(int field, unsigned log_n, const void** pw, int* log_t, std::shared_ptr<const void>* hold) {
     std::shared_ptr<NttPlan> pl;
     PLK_TRY(get_plan(field, log_n, pl));
-    *pw = pl->pw;  // owned by the plan cache (alive until plk_ntt_clear_cache / plk_shutdown)
+    *pw = pl->pw;  // owned by the plan: alive while the cache or *hold references it
+    if (hold) *hold = pl;
     *log_t = (int)log_n > INNER_LOG ? (int)log_n : INNER_LOG;
     return PLK_OK;
 }

@@ -193,7 +193,8 @@ static int divide_by_z_h_t(const void* d_coeffs, size_t len, uint64_t n, void* d
     const size_t ord = size / g2;
     const void* pw = nullptr;
     int log_t = 0;
-    PLK_TRY(ntt_plan_pow_table(P::FIELD_ID, (unsigned)log_size, &pw, &log_t));
+    std::shared_ptr<const void> plan_hold;  // the plan outlives the launches below (hipFree waits for kernels in flight)
+    PLK_TRY(ntt_plan_pow_table(P::FIELD_ID, (unsigned)log_size, &pw, &log_t, &plan_hold));
     std::shared_ptr<ZhTable> zh;
     void* zh_scratch = nullptr;
     const void* inv_tab = nullptr;

@@ -125,3 +125,22 @@ def msm_execute_dev(pre, scalars, out_xy=None, out_zero=None):
     _lib.check(_lib.load().plk_msm_execute_dev(pre._ctx, batch, ctypes.c_void_p(scalars.data_ptr()), n, ctypes.c_void_p(out_xy.data_ptr()),
                                                ctypes.c_void_p(out_zero.data_ptr()), _stream()))
     return out_xy, out_zero
+
+
+def vanishing_points_dev(field, log_degree, constants_8n, wire_values_8n, s_sigma_values_8n, plonk_z_points_8n, k_is, alpha, beta, gamma,
+                         inner_zeta, inner_a, out=None):
+    """Prover::vanishing_poly's 8n-point loop (plonk.rs:392-453) on device-resident tables: int64 CUDA tensors (6, 8n, 4),
+    (9, 8n, 4), (6, 8n, 4), (8n, 4); the scalars are host arrays (4 limbs each; k_is (6, 4))."""
+    n8 = 8 << log_degree
+    for t, rows in ((constants_8n, 6), (wire_values_8n, 9), (s_sigma_values_8n, 6), (plonk_z_points_8n, 1)):
+        assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.numel() == rows * n8 * 4
+    if out is None:
+        out = torch.empty((n8, 4), dtype=torch.int64, device=constants_8n.device)
+    ks = np.ascontiguousarray(k_is, dtype=np.uint64).reshape(6, 4)
+    sc = [np.ascontiguousarray(x, dtype=np.uint64).reshape(4) for x in (alpha, beta, gamma, inner_zeta, inner_a)]
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    _lib.check(_lib.load().plk_plonk_vanishing_points_dev(field, log_degree, ctypes.c_void_p(constants_8n.data_ptr()),
+                                                          ctypes.c_void_p(wire_values_8n.data_ptr()), ctypes.c_void_p(s_sigma_values_8n.data_ptr()),
+                                                          ctypes.c_void_p(plonk_z_points_8n.data_ptr()), p(ks), *[p(x) for x in sc],
+                                                          ctypes.c_void_p(out.data_ptr()), _stream()))
+    return out

@@ -41,6 +41,9 @@ SYMBOLS = [
     ("plk_poly_divide_by_z_h_dev", _i, [_i, _vp, _sz, _sz, _vp, _sz, _vp, _vp]),
     ("plk_poly_mul", _i, [_i, _vp, _sz, _vp, _sz, _vp, _sz, _vp]),
     ("plk_poly_mul_dev", _i, [_i, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp]),
+    ("plk_plonk_vanishing_points_dev", _i, [_i, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("plk_plonk_vanishing_points", _i, [_i, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("plk_plonk_evaluate_all_constraints", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("plk_msm_precompute", _i, [_i, _sz, _vp, _vp, _u, _vp]),
     ("plk_msm_precompute_dev", _i, [_i, _sz, _vp, _vp, _u, _vp, _vp]),
     ("plk_msm_precompute_ex", _i, [_i, _sz, _vp, _vp, _u, _u, _vp]),
