@@ -201,6 +201,19 @@ int plk_curve_fold_pairs(int curve, size_t m, const uint64_t* lo_xy, const uint8
 int plk_curve_fold_pairs_dev(int curve, size_t m, const void* d_lo_xy, const void* d_lo_zero, const void* d_hi_xy, const void* d_hi_zero,
                              const uint64_t* scalar_lo, const uint64_t* scalar_hi, void* d_out_xy, void* d_out_zero, void* stream);
 
+/* ---- batch inversion  (src/field/field.rs:223-278, src/curve/curve.rs:216-232) ------------------------ */
+/* Field::batch_multiplicative_inverse (field.rs:251-278, Montgomery's trick): out[i] = 1 / x[i].  A zero element has no
+ * inverse: the reference panics ("No inverse", field.rs:266) and this returns PLK_ERR_INVALID_ARG (out is then unspecified). */
+int plk_field_batch_inverse(int field, const uint64_t* x, uint64_t* out, size_t count);
+/* Field::batch_multiplicative_inverse_opt (field.rs:223-249): zero elements give None: is_none[i] = 1 and out[i] = 0. */
+int plk_field_batch_inverse_opt(int field, const uint64_t* x, uint64_t* out, uint8_t* is_none, size_t count);
+/* Device form of the _opt variant (d_is_none may be NULL: zeros then just come back as 0).  d_x == d_out allowed.  Asynchronous. */
+int plk_field_batch_inverse_dev(int field, const void* d_x, void* d_out, void* d_is_none, size_t count, void* stream);
+/* ProjectivePoint::batch_to_affine (curve.rs:216-232): count homogeneous projective points (X, Y, Z: 3L limbs each, x = X / Z,
+ * y = Y / Z; `zero` flags, count bytes or NULL) -> affine (2L limbs each) + zero flags, AffinePoint::ZERO = (0, 0, true). */
+int plk_curve_batch_to_affine(int curve, size_t count, const uint64_t* proj_xyz, const uint8_t* proj_zero, uint64_t* out_xy, uint8_t* out_zero);
+int plk_curve_batch_to_affine_dev(int curve, size_t count, const void* d_proj_xyz, const void* d_proj_zero, void* d_out_xy, void* d_out_zero, void* stream);
+
 /* ---- self-test ------------------------------------------------------------------------------ */
 /* Runs the quad-cooperative point arithmetic of the MSM reduction tail (ecz_coop.cuh) against the one-lane
  * arithmetic on the n affine points pts_xy (n * 2L limbs, Montgomery), `quads` quads cycling through 8 cases

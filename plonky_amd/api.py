@@ -387,3 +387,35 @@ def vanishing_points(field, degree, constants_8n, wire_values_8n, s_sigma_values
     out = np.empty((n8, 4), dtype=np.uint64)
     _lib.check(_lib.load().plk_plonk_vanishing_points(field, log_degree, _ptr(c), _ptr(w), _ptr(s), _ptr(z), _ptr(ks), *[_ptr(x) for x in sc], _ptr(out)))
     return out
+
+
+# ---- batch inversion (field.rs:223-278, curve.rs:216-232) ----
+def batch_multiplicative_inverse(field, x):
+    """Field::batch_multiplicative_inverse (field.rs:251-278): panics ("No inverse") on a zero element -> AssertionError here."""
+    a = _elems(field, x)
+    out = np.empty_like(a)
+    rc = _lib.load().plk_field_batch_inverse(field, _ptr(a), _ptr(out), a.shape[0])
+    assert rc != _lib.PLK_ERR_INVALID_ARG, "No inverse"
+    _lib.check(rc)
+    return out
+
+
+def batch_multiplicative_inverse_opt(field, x):
+    """Field::batch_multiplicative_inverse_opt (field.rs:223-249): (inverses, is_none) - zero elements have no inverse."""
+    a = _elems(field, x)
+    out = np.empty_like(a)
+    none = np.zeros(a.shape[0], dtype=np.uint8)
+    _lib.check(_lib.load().plk_field_batch_inverse_opt(field, _ptr(a), _ptr(out), _ptr(none), a.shape[0]))
+    return out, none
+
+
+def batch_to_affine(curve, proj_xyz, zero=None):
+    """ProjectivePoint::batch_to_affine (curve.rs:216-232): (n, 3, L) homogeneous projective limbs (+ zero flags) -> ((n, 2, L), zero flags)."""
+    L = _CURVE_LIMBS[curve]
+    p = np.ascontiguousarray(proj_xyz, dtype=np.uint64).reshape(-1, 3, L)
+    n = p.shape[0]
+    z = np.ascontiguousarray(zero, dtype=np.uint8) if zero is not None else None
+    out = np.empty((n, 2, L), dtype=np.uint64)
+    oz = np.zeros(n, dtype=np.uint8)
+    _lib.check(_lib.load().plk_curve_batch_to_affine(curve, n, _ptr(p), _ptr(z) if z is not None else None, _ptr(out), _ptr(oz)))
+    return out, oz

@@ -564,6 +564,62 @@ int plk_curve_fold_pairs(int curve, size_t m, const uint64_t* lo_xy, const uint8
     return PLK_OK;
 }
 
+// ---- batch inversion ----
+int plk_field_batch_inverse_dev(int field, const void* d_x, void* d_out, void* d_is_none, size_t count, void* stream) {
+    if (field_limbs(field) < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
+    return field_batch_inverse_dev_impl(field, d_x, d_out, d_is_none, nullptr, count, as_stream(stream));
+}
+static int batch_inverse_host(int field, const uint64_t* x, uint64_t* out, uint8_t* is_none, size_t count, bool strict) {
+    const int L = field_limbs(field);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
+    if (count == 0) return PLK_OK;
+    if (!x || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    DevBuf dx, dz, dc;
+    PLK_TRY(dx.alloc(count * L * 8));
+    PLK_TRY(dz.alloc(count));
+    PLK_TRY(dc.alloc(4));
+    PLK_HIP_TRY(hipMemcpy(dx.p, x, count * L * 8, hipMemcpyHostToDevice));
+    PLK_HIP_TRY(hipMemset(dc.p, 0, 4));
+    PLK_TRY(field_batch_inverse_dev_impl(field, dx.p, dx.p, dz.p, (unsigned*)dc.p, count, nullptr));
+    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
+    unsigned zeros = 0;
+    PLK_HIP_TRY(hipMemcpy(&zeros, dc.p, 4, hipMemcpyDeviceToHost));
+    if (strict && zeros) return set_error(PLK_ERR_INVALID_ARG, "No inverse: %u of the %zu elements are zero (field.rs:266)", zeros, count);
+    PLK_HIP_TRY(hipMemcpy(out, dx.p, count * L * 8, hipMemcpyDeviceToHost));
+    if (is_none) PLK_HIP_TRY(hipMemcpy(is_none, dz.p, count, hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+int plk_field_batch_inverse(int field, const uint64_t* x, uint64_t* out, size_t count) { return batch_inverse_host(field, x, out, nullptr, count, true); }
+int plk_field_batch_inverse_opt(int field, const uint64_t* x, uint64_t* out, uint8_t* is_none, size_t count) {
+    if (count && !is_none) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    return batch_inverse_host(field, x, out, is_none, count, false);
+}
+int plk_curve_batch_to_affine_dev(int curve, size_t count, const void* d_proj_xyz, const void* d_proj_zero, void* d_out_xy, void* d_out_zero, void* stream) {
+    return curve_batch_to_affine_dev_impl(curve, count, d_proj_xyz, d_proj_zero, d_out_xy, d_out_zero, as_stream(stream));
+}
+int plk_curve_batch_to_affine(int curve, size_t count, const uint64_t* proj_xyz, const uint8_t* proj_zero, uint64_t* out_xy, uint8_t* out_zero) {
+    const int L = curve_limbs(curve);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (count == 0) return PLK_OK;
+    if (!proj_xyz || !out_xy || !out_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    DevBuf dp, dz, dxy, doz;
+    PLK_TRY(dp.alloc(count * 3 * L * 8));
+    PLK_TRY(dxy.alloc(count * 2 * L * 8));
+    PLK_TRY(doz.alloc(count));
+    PLK_HIP_TRY(hipMemcpy(dp.p, proj_xyz, count * 3 * L * 8, hipMemcpyHostToDevice));
+    if (proj_zero) {
+        PLK_TRY(dz.alloc(count));
+        PLK_HIP_TRY(hipMemcpy(dz.p, proj_zero, count, hipMemcpyHostToDevice));
+    }
+    PLK_TRY(curve_batch_to_affine_dev_impl(curve, count, dp.p, proj_zero ? dz.p : nullptr, dxy.p, doz.p, nullptr));
+    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
+    PLK_HIP_TRY(hipMemcpy(out_xy, dxy.p, count * 2 * L * 8, hipMemcpyDeviceToHost));
+    PLK_HIP_TRY(hipMemcpy(out_zero, doz.p, count, hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+
 // ---- self-test ----
 int plk_selftest_quad(int curve, const uint64_t* pts_xy, size_t n, unsigned quads, unsigned* mismatches) {
     const int L = curve_limbs(curve);

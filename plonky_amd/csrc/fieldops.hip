@@ -43,6 +43,139 @@ template <class P> static int field_op_t(int op, const uint64_t* a, const uint64
     return PLK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Field::batch_multiplicative_inverse / _opt (field.rs:223-278) and ProjectivePoint::batch_to_affine (curve.rs:216-232)
+// ---------------------------------------------------------------------------------------------
+// Montgomery's trick, one chain of BATCH_PER_LANE elements per lane: prefix products forward, ONE division-step inversion,
+// back substitution - 3 multiplications per element plus 1/8 of an inversion (an inversion is ~36 multiplications).
+// Sharing one inversion across a wave would not be cheaper: a wave pays for an instruction whether one lane or all 64
+// execute it, so 64 private inversions cost the SIMD exactly what one shared inversion would, without the two
+// cross-lane product scans (12 more multiplications per lane).  Elements of a lane are strided by the grid so that every load
+// and store of a wave is contiguous.  Zero elements (no inverse: `None` in _opt) are replaced by 1 in the chain, come back
+// as 0 and are flagged.
+constexpr int BATCH_PER_LANE = 8;
+template <class P>
+__global__ void __launch_bounds__(128) k_batch_inverse(const uint4* __restrict__ x, uint4* __restrict__ out, uint8_t* __restrict__ is_zero,
+                                                       unsigned* __restrict__ zero_count, size_t count) {
+    constexpr int W = P::NL / 4;
+    const size_t lanes = (size_t)gridDim.x * blockDim.x;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fe<P> v[BATCH_PER_LANE], pre[BATCH_PER_LANE];
+    bool zf[BATCH_PER_LANE];
+    Fe<P> run = fe_one<P>();
+    unsigned zeros = 0;
+#pragma unroll
+    for (int k = 0; k < BATCH_PER_LANE; ++k) {
+        const size_t i = t + (size_t)k * lanes;
+        v[k] = i < count ? fe_load<P>(x + i * W) : fe_one<P>();
+        zf[k] = fe_is_zero<P>(v[k]);
+        if (zf[k]) {
+            v[k] = fe_one<P>();
+            ++zeros;
+        }
+        pre[k] = run;
+        run = fe_mul<P>(run, v[k]);
+    }
+    Fe<P> inv = fe_inv_safegcd<P>(run);
+#pragma unroll
+    for (int k = BATCH_PER_LANE - 1; k >= 0; --k) {
+        const size_t i = t + (size_t)k * lanes;
+        const Fe<P> r = fe_mul<P>(inv, pre[k]);
+        inv = fe_mul<P>(inv, v[k]);
+        if (i < count) {
+            fe_store<P>(out + i * W, zf[k] ? fe_zero<P>() : r);
+            if (is_zero) is_zero[i] = zf[k] ? 1 : 0;
+        }
+    }
+    if (zeros && zero_count) atomicAdd(zero_count, zeros);
+}
+
+// homogeneous projective (X : Y : Z) + zero flag -> affine (x, y) = (X / Z, Y / Z) + zero flag, the reference's own
+// ProjectivePoint / AffinePoint (curve.rs:74-78,176-181): z_inv from batch_multiplicative_inverse_opt (curve.rs:219)
+template <class P>
+__global__ void __launch_bounds__(128) k_batch_to_affine(const uint4* __restrict__ xyz, const uint8_t* __restrict__ pzero, uint4* __restrict__ out_xy,
+                                                         uint8_t* __restrict__ out_zero, size_t count) {
+    constexpr int W = P::NL / 4;
+    const size_t lanes = (size_t)gridDim.x * blockDim.x;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fe<P> z[BATCH_PER_LANE], pre[BATCH_PER_LANE];
+    bool ident[BATCH_PER_LANE];
+    Fe<P> run = fe_one<P>();
+#pragma unroll
+    for (int k = 0; k < BATCH_PER_LANE; ++k) {
+        const size_t i = t + (size_t)k * lanes;
+        ident[k] = true;
+        z[k] = fe_one<P>();
+        if (i < count) {
+            z[k] = fe_load<P>(xyz + (i * 3 + 2) * W);
+            // `zero` is the reference's flag (curve.rs:222-224); a non-flagged point with Z = 0 would make the reference panic on unwrap()
+            ident[k] = (pzero && pzero[i]) || fe_is_zero<P>(z[k]);
+            if (ident[k]) z[k] = fe_one<P>();
+        }
+        pre[k] = run;
+        run = fe_mul<P>(run, z[k]);
+    }
+    Fe<P> inv = fe_inv_safegcd<P>(run);
+#pragma unroll
+    for (int k = BATCH_PER_LANE - 1; k >= 0; --k) {
+        const size_t i = t + (size_t)k * lanes;
+        const Fe<P> zi = fe_mul<P>(inv, pre[k]);
+        inv = fe_mul<P>(inv, z[k]);
+        if (i < count) {
+            Fe<P> ax = fe_zero<P>(), ay = fe_zero<P>();  // AffinePoint::ZERO = (0, 0, zero = true), curve.rs:81-85
+            if (!ident[k]) {
+                ax = fe_mul<P>(fe_load<P>(xyz + (i * 3) * W), zi);
+                ay = fe_mul<P>(fe_load<P>(xyz + (i * 3 + 1) * W), zi);
+            }
+            fe_store<P>(out_xy + (i * 2) * W, ax);
+            fe_store<P>(out_xy + (i * 2 + 1) * W, ay);
+            out_zero[i] = ident[k] ? 1 : 0;
+        }
+    }
+}
+
+static unsigned batch_blocks(size_t count) {
+    const size_t lanes = (count + BATCH_PER_LANE - 1) / BATCH_PER_LANE;
+    return (unsigned)((lanes + 127) / 128);
+}
+
+int field_batch_inverse_dev_impl(int field, const void* d_x, void* d_out, void* d_is_zero, unsigned* d_zero_count, size_t count, hipStream_t stream) {
+    if (count == 0) return PLK_OK;
+    if (!d_x || !d_out) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
+    PLK_TRY(ensure_device());
+    const unsigned blocks = batch_blocks(count);
+    switch (field) {
+#define CASE(ID, P) \
+    case ID: k_batch_inverse<P><<<blocks, 128, 0, stream>>>((const uint4*)d_x, (uint4*)d_out, (uint8_t*)d_is_zero, d_zero_count, count); break;
+        CASE(PLK_FIELD_TWEEDLEDEE_BASE, TweedledeeBaseParams)
+        CASE(PLK_FIELD_TWEEDLEDUM_BASE, TweedledumBaseParams)
+        CASE(PLK_FIELD_BLS12_377_SCALAR, Bls12377ScalarParams)
+        CASE(PLK_FIELD_BLS12_377_BASE, Bls12377BaseParams)
+#undef CASE
+        default: return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
+    }
+    PLK_HIP_TRY(hipGetLastError());
+    return PLK_OK;
+}
+
+int curve_batch_to_affine_dev_impl(int curve, size_t count, const void* d_xyz, const void* d_zero, void* d_out_xy, void* d_out_zero, hipStream_t stream) {
+    if (count == 0) return PLK_OK;
+    if (!d_xyz || !d_out_xy || !d_out_zero) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
+    PLK_TRY(ensure_device());
+    const unsigned blocks = batch_blocks(count);
+    switch (curve) {
+#define CASE(ID, P) \
+    case ID: k_batch_to_affine<P><<<blocks, 128, 0, stream>>>((const uint4*)d_xyz, (const uint8_t*)d_zero, (uint4*)d_out_xy, (uint8_t*)d_out_zero, count); break;
+        CASE(PLK_CURVE_TWEEDLEDEE, TweedledeeBaseParams)
+        CASE(PLK_CURVE_TWEEDLEDUM, TweedledumBaseParams)
+        CASE(PLK_CURVE_BLS12_377, Bls12377BaseParams)
+#undef CASE
+        default: return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    }
+    PLK_HIP_TRY(hipGetLastError());
+    return PLK_OK;
+}
+
 int field_op_impl(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count) {
     if (op < 0 || op > 9) return set_error(PLK_ERR_INVALID_ARG, "bad field op %d", op);
     if (!a || !out || (op <= 2 && !b)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");

@@ -483,6 +483,18 @@ template <class FP> PLK_DI XyzzZ<FP> xyzzz_load_raw(const uint4* src) {
 // 24 per lane) almost every bucket leaves the kernel whole, and k_msm_assemble only finds the head pieces of the first lane
 // of a block and of lanes that lie entirely inside one bucket (head_live[lane] = 1).
 constexpr int ACC_THREADS = 128;
+// the bucket of sorted position pos, known to lie after bucket b: usually b + 1; a search when empty buckets follow (sparse
+// scalar vectors - Z = 1, zero-padded quotient chunks - leave most buckets empty: a linear walk would cost a load per bucket)
+PLK_DI uint32_t next_bucket(const uint32_t* __restrict__ off, uint32_t b, uint32_t buckets, uint32_t pos) {
+    uint32_t lo = b + 1;
+    if (off[lo + 1] > pos) return lo;
+    uint32_t hi = buckets;  // off[lo] <= pos < off[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
+}
 template <class C>
 PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ off,
                                 uint4* __restrict__ p_start, uint4* __restrict__ p_head, uint8_t* __restrict__ head_live, uint32_t buckets, uint32_t chunk,
@@ -528,21 +540,15 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
                 }
                 head = false;
                 acc = xyzzz_identity<FP>();
-                do {
-                    ++b;
-                    next = off[b + 1];
-                } while (next <= k);
+                b = next_bucket(off, b, buckets, k);
+                next = off[b + 1];
             }
             const uint32_t cur = ent;
             const Fe<FP> cx = x, cy = y;
             const bool cident = ident;
             if (k + 1 < end) {
                 // the next entry may belong to a later bucket (another window in table-free mode): its bucket is known here
-                uint32_t nb = b;
-                if (k + 1 == next) {
-                    nb = b + 1;
-                    while (off[nb + 1] <= k + 1) ++nb;
-                }
+                const uint32_t nb = k + 1 == next ? next_bucket(off, b, buckets, k + 1) : b;
                 const uint32_t nsub = (nb >> wshift) * n_sub;
                 ent = sorted[k + 1];
                 ident = affine_load<FP>(tab + (size_t)((ent >> 1) - nsub) * 2 * W, x, y);

@@ -61,6 +61,11 @@ SYMBOLS = [
     ("plk_msm_precompute_table_dev", _i, [_i, _sz, _vp, _vp, _u, _vp, _vp, _vp]),
     ("plk_curve_fold_pairs", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("plk_curve_fold_pairs_dev", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("plk_field_batch_inverse", _i, [_i, _vp, _vp, _sz]),
+    ("plk_field_batch_inverse_opt", _i, [_i, _vp, _vp, _vp, _sz]),
+    ("plk_field_batch_inverse_dev", _i, [_i, _vp, _vp, _vp, _sz, _vp]),
+    ("plk_curve_batch_to_affine", _i, [_i, _sz, _vp, _vp, _vp, _vp]),
+    ("plk_curve_batch_to_affine_dev", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("plk_selftest_quad", _i, [_i, _vp, _sz, _u, _vp]),
     ("plk_ntt_set_profiling", _i, [_i]),
     ("plk_ntt_get_timings", _i, [_vp, _vp]),

@@ -547,3 +547,67 @@ def test_msm_batch_larger_than_one_group(table_free):
             assert np.array_equal(out[t], exp), t
         one, z1 = pa.msm_execute_parallel(pre, vecs[t])
         assert z1 == ez and (ez or np.array_equal(one, exp)), t
+
+
+# ---------------- batch inversion (field.rs:223-278, curve.rs:216-232) ----------------
+@pytest.mark.parametrize("f", [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.BLS12_377_BASE], ids=lambda f: f.name)
+def test_batch_multiplicative_inverse(f):
+    """bls12_377_base.rs:336-361 (inverses of 1..24 through the batch path) + seeded inputs of awkward lengths vs the oracle's
+    Montgomery-trick restatement; a zero element is `No inverse` (field.rs:266) / None in the _opt variant."""
+    from plonky_amd import api
+    small = ints_to_array([f.to_mont(v) for v in range(1, 25)], f.n_limbs)
+    got = api.batch_multiplicative_inverse(f.field_id, small)
+    assert [f.from_mont(limbs_to_int(r)) for r in got] == [pow(v, -1, f.p) for v in range(1, 25)]
+    for n in (1, 7, 8, 9, 1000, 4097):
+        x = ol.rand_field(f.field_id, 0xBA7C + n, n)
+        assert np.array_equal(api.batch_multiplicative_inverse(f.field_id, x), ol.batch_inverse(f.field_id, x)), n
+    x = ol.rand_field(f.field_id, 5, 100)
+    x[17] = 0
+    x[99] = 0
+    with pytest.raises(AssertionError):
+        api.batch_multiplicative_inverse(f.field_id, x)
+    inv, none = api.batch_multiplicative_inverse_opt(f.field_id, x)
+    assert list(np.nonzero(none)[0]) == [17, 99] and not inv[17].any() and not inv[99].any()
+    keep = np.ones(100, dtype=bool)
+    keep[[17, 99]] = False
+    assert np.array_equal(inv[keep], ol.batch_inverse(f.field_id, x[keep]))
+    assert api.batch_multiplicative_inverse(f.field_id, x[:0]).shape[0] == 0
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_batch_to_affine(c):
+    """curve.rs:216-232: random projective representatives (X, Y, Z) = (x z, y z, z) of known affine points, identity flags."""
+    from plonky_amd import api
+    G = (c.gx, c.gy)
+    p = c.base.p
+    pts, proj, zero = [], [], []
+    for i in range(37):
+        P = br.ec_mul(c, 1000 + 17 * i, G)
+        z = (0x1234567 * (i + 1) + 99) % p
+        pts.append(P)
+        proj.append([P[0] * z % p, P[1] * z % p, z])
+        zero.append(1 if i % 11 == 5 else 0)
+    arr = np.array([[c.base.mont_limbs(v) for v in row] for row in proj], dtype=np.uint64)
+    out, oz = api.batch_to_affine(c.curve_id, arr, zero)
+    for i in range(37):
+        if zero[i]:
+            assert oz[i] == 1 and not out[i].any()
+        else:
+            assert oz[i] == 0 and tuple(from_mont_arr(c.base, out[i])) == pts[i]
+
+
+def test_msm_sparse_scalars_many_buckets():
+    """Scalar vectors that are almost all zero (Z = 1, zero-padded quotient chunks) against a large window: most buckets are
+    empty and the entries of a lane are far apart in the bucket order."""
+    c = br.TWEEDLEDEE
+    n = 4096
+    G = (c.gx, c.gy)
+    D = br.ec_mul(c, 31337, G)
+    bases = ol.gen_bases(0, n, _bases(c, [G])[0], _bases(c, [D])[0])
+    vals = [0] * n
+    vals[0], vals[5], vals[n - 1] = 1, c.scalar.p - 2, 0x123456789ABCDEF0123456789
+    scalars = mont_arr(c.scalar, vals)
+    expected, ez = ol.MsmPrecomputation(0, bases, 8, threads=8).execute(scalars, parallel=True, threads=8)
+    for win in (16, 20):
+        got, gz = pa.msm_execute_parallel(pa.msm_precompute(0, bases, 11, device_window=win), scalars)
+        assert gz == ez and np.array_equal(got, expected), win

@@ -1,8 +1,10 @@
 """The hot-path calls of one Plonk proof (src/plonk.rs:85-200) strung together on the device, data resident in HBM
 between them: 9 wire iNTTs (values_to_polynomials), 9 LDEs to 8n (polynomials_to_values_padded), 9 blinded commitments
-(commit_polynomials), Z: one iNTT + one commitment, the quotient t = vanishing / Z_H (divide_by_z_h) and its 7 chunk
-commitments.  Constraint evaluation (vanishing_poly, permutation_polynomial) is not part of this repository: the numerator
-is a synthetic multiple of Z_H of the right degree.  Usage (GPU box): python tools/prover_pipeline_probe.py [log_n]"""
+(commit_polynomials), Z: one iNTT + LDE + commitment, the vanishing polynomial (vanishing_poly: the 8n-point constraint
+evaluation + one 8n iNTT), the quotient t = vanishing / Z_H (divide_by_z_h) and its 7 chunk commitments.
+The witness is an honest one (ArithmeticGate / ConstantGate rows with random selector constants, identity wiring, hence Z = 1), so
+the numerator is a REAL vanishing polynomial and the division by Z_H is checked to be exact (q * Z_H == vanishing).
+Witness generation, the transcript and the IPA are not part of this probe.  Usage (GPU box): python tools/prover_pipeline_probe.py [log_n]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -21,18 +23,38 @@ g0 = np.stack([synth.mont(0, G[0]), synth.mont(0, G[1])]); dd = np.stack([synth.
 gens = dev.gen_bases_dev(CURVE, n + 1, g0, dd)            # pedersen_g (n) followed by pedersen_h
 t0 = time.perf_counter(); pre = dev.msm_precompute_dev(CURVE, gens); torch.cuda.synchronize()
 print("setup: msm_precompute of %d generators %.1f ms (once per circuit)" % (n + 1, (time.perf_counter() - t0) * 1e3))
-wires = dev.to_device(synth.rand_field(F, 1, 9 * n)).reshape(9, n, 4)
+
+# ---- an honest witness: ArithmeticGate rows (arithmetic.rs:32-46): w3 = c0 w0 w1 + c1 w2, selector constants 1001 c0 c1 ----
+ONE, ZERO = synth.mont(F, 1), synth.mont(F, 0)
+w = synth.rand_field(F, 1, 9 * n).reshape(9, n, 4)
+c0, c1 = synth.rand_field(F, 7, n), synth.rand_field(F, 8, n)
+w[3] = api.field_op(F, "add", api.field_op(F, "mul", api.field_op(F, "mul", c0, w[0]), w[1]), api.field_op(F, "mul", c1, w[2]))
+consts = np.stack([np.tile(ONE, (n, 1)), np.tile(ZERO, (n, 1)), np.tile(ZERO, (n, 1)), np.tile(ONE, (n, 1)), c0, c1])
+# odd rows: ConstantGate (constant.rs:30-39), selector constants 10110 c, w0 = c -- so that the selector polynomials are not constant
+consts[2, 1::2], consts[3, 1::2], consts[4, 1::2] = ONE, ONE, ZERO
+w[0, 1::2] = c1[1::2]
+k_is = synth.rand_field(F, 9, 6)                                                   # get_subgroup_shift(0..5): inputs
+alpha, beta, gamma = synth.rand_field(F, 10, 3)
+ZETA = np.array([7605997034305223424, 3132214451552427455, 3308921103222877309, 2709928666517121162], dtype=np.uint64)  # tweedledum_curve.rs:37-44
+# circuit-constant 8n tables (circuit_builder.rs:1135-1160): constants, S_sigma_j = k_j X (identity wiring)
+t0 = time.perf_counter()
+const_coeffs = dev.ntt_dev(F, dev.to_device(consts), inverse=True)
+consts_8n = dev.ntt_padded_dev(F, const_coeffs, log_n + 3)
+sig = np.zeros((6, 2, 4), dtype=np.uint64); sig[:, 1] = k_is
+sigma_8n = dev.ntt_padded_dev(F, dev.to_device(sig), log_n + 3)
+torch.cuda.synchronize()
+print("setup: constants_8n / s_sigma_values_8n %.1f ms (once per circuit)" % ((time.perf_counter() - t0) * 1e3))
+wires = dev.to_device(w)
 blind = dev.to_device(synth.rand_field(F, 2, 9 + 1 + 7)).reshape(-1, 1, 4)
-zvals = dev.to_device(synth.rand_field(F, 3, n))
-q0 = synth.rand_field(F, 4, 7 * n)
-zpad = np.zeros((n, 4), dtype=np.uint64)
-numer = dev.to_device(api.field_op(F, "sub", np.concatenate([zpad, q0]), np.concatenate([q0, zpad])))   # q0 * (X^n - 1)
+zvals = dev.to_device(np.tile(ONE, (n, 1)))                                         # identity wiring: Z = 1
 t_out = torch.empty((8 * n, 4), dtype=torch.int64, device="cuda")
 ev8 = torch.empty((9, 8 * n, 4), dtype=torch.int64, device="cuda")
+pts = torch.empty((8 * n, 4), dtype=torch.int64, device="cuda")
+t7 = torch.zeros((7 * n, 4), dtype=torch.int64, device="cuda")
 
 
 def run():
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(9)]
     marks[0].record()
     polys = dev.ntt_dev(F, wires, inverse=True)                                     # values_to_polynomials
     marks[1].record()
@@ -41,22 +63,33 @@ def run():
     c_wires = dev.msm_execute_dev(pre, torch.cat([polys, blind[:9]], dim=1).contiguous())   # commit_polynomials (+ [r] H)
     marks[3].record()
     zpoly = dev.ntt_dev(F, zvals, inverse=True)
+    z_8n = dev.ntt_padded_dev(F, zpoly, log_n + 3)                                  # plonk.rs:388-391
     c_z = dev.msm_execute_dev(pre, torch.cat([zpoly, blind[9]], dim=0).contiguous())
     marks[4].record()
-    t = dev.divide_by_z_h_dev(F, numer, n, out=t_out)                               # quotient
+    dev.vanishing_points_dev(F, log_n, consts_8n, ev8, sigma_8n, z_8n, k_is, alpha, beta, gamma, ZETA, ZERO, out=pts)   # plonk.rs:392-453
     marks[5].record()
-    chunks = t[: 7 * n].reshape(7, n, 4)                                            # pad to 7n, split
-    c_t = dev.msm_execute_dev(pre, torch.cat([chunks, blind[10:17]], dim=1).contiguous())
+    vanishing = dev.ntt_dev(F, pts, inverse=True)                                   # Polynomial::from_evaluations, plonk.rs:455
+    t = dev.divide_by_z_h_dev(F, vanishing, n, out=t_out)                           # quotient, plonk.rs:178-181
     marks[6].record()
+    t7.zero_()
+    t7[: min(t.shape[0], 7 * n)] = t[: 7 * n]                                      # plonk.rs:182: pad to 7n, split
+    chunks = t7.reshape(7, n, 4)
+    c_t = dev.msm_execute_dev(pre, torch.cat([chunks, blind[10:17]], dim=1).contiguous())
+    marks[7].record()
     torch.cuda.synchronize()
-    names = ["9 wire iNTT (n)", "9 LDE n -> 8n", "9 wire commitments", "Z: iNTT + commitment", "divide_by_z_h (8n domain)", "7 quotient-chunk commitments"]
-    ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(6)]
-    return names, ms, t
+    names = ["9 wire iNTT (n)", "9 LDE n -> 8n", "9 wire commitments", "Z: iNTT + LDE + commitment", "vanishing points (8n, 10 gates)",
+             "iNTT (8n) + divide_by_z_h", "7 quotient-chunk commitments"]
+    ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(7)]
+    return names, ms, t, vanishing
 
 
 run()
-names, ms, t = run()
-ok = bool(np.array_equal(dev.to_host(t[: 7 * n]), q0))
-for nm, v in zip(names, ms):
-    print("  %-32s %8.3f ms" % (nm, v))
-print("hot-path device time per proof at n = 2^%d: %.2f ms   (quotient check: %s)" % (log_n, sum(ms), ok))
+names, ms, t, vanishing = run()
+q = dev.to_host(t7)
+v = dev.to_host(vanishing)
+zpad = np.zeros((n, 4), dtype=np.uint64)
+back = api.field_op(F, "sub", np.concatenate([zpad, q]), np.concatenate([q, zpad]))   # q * (X^n - 1)
+ok = bool(v.any() and not dev.to_host(t)[7 * n:].any() and np.array_equal(back, v))
+for nm, tv in zip(names, ms):
+    print("  %-34s %8.3f ms" % (nm, tv))
+print("hot-path device time per proof at n = 2^%d: %.2f ms   (real numerator; q * Z_H == vanishing polynomial, deg q < 7n: %s)" % (log_n, sum(ms), ok))
