@@ -214,6 +214,19 @@ int plk_field_batch_inverse_dev(int field, const void* d_x, void* d_out, void* d
 int plk_curve_batch_to_affine(int curve, size_t count, const uint64_t* proj_xyz, const uint8_t* proj_zero, uint64_t* out_xy, uint8_t* out_zero);
 int plk_curve_batch_to_affine_dev(int curve, size_t count, const void* d_proj_xyz, const void* d_proj_zero, void* d_out_xy, void* d_out_zero, void* stream);
 
+/* ---- canonical byte encodings  (src/serialization.rs:17-72) ----------------------------------------- */
+/* ToBytes / FromBytes for field elements (serialization.rs:17-31): BYTES = 8 * limbs little-endian bytes of the CANONICAL
+ * value (field.rs:67-102).  plk_field_from_bytes returns PLK_ERR_INVALID_ARG ("Out of range", field.rs:100) when a record
+ * is not below the modulus.  Host pointers; the conversion runs on the device. */
+int plk_field_to_bytes(int field, const uint64_t* x, size_t count, uint8_t* out_bytes);
+int plk_field_from_bytes(int field, const uint8_t* bytes, size_t count, uint64_t* out);
+/* ToBytes / FromBytes for AffinePoint (serialization.rs:33-72): 1 + BYTES per point: mask = zero | (y odd) << 1, then x.
+ * Decompression recovers y = sqrt(x^3 + B) (Field::square_root, field.rs:440-472) with the parity of the mask.  status
+ * (count bytes, may be NULL): 0 ok, 1 "Out of range", 2 "Invalid x coordinate"; any non-zero status also makes the call
+ * return PLK_ERR_INVALID_ARG (the reference returns Err for the point). */
+int plk_curve_point_to_bytes(int curve, const uint64_t* xy, const uint8_t* zero, size_t count, uint8_t* out_bytes);
+int plk_curve_point_from_bytes(int curve, const uint8_t* bytes, size_t count, uint64_t* out_xy, uint8_t* out_zero, uint8_t* status);
+
 /* ---- self-test ------------------------------------------------------------------------------ */
 /* Runs the quad-cooperative point arithmetic of the MSM reduction tail (ecz_coop.cuh) against the one-lane
  * arithmetic on the n affine points pts_xy (n * 2L limbs, Montgomery), `quads` quads cycling through 8 cases

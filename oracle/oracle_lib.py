@@ -21,7 +21,7 @@ CURVE_SCALAR_BITS = {0: 255, 1: 255, 2: 253}
 
 
 def build(force=False):
-    srcs = [os.path.join(_DIR, "plk_oracle.cpp"), os.path.join(_DIR, "plonk_gates.inc")]
+    srcs = [os.path.join(_DIR, x) for x in ("plk_oracle.cpp", "plonk_gates.inc", "serialization.inc")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", _DIR, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return _SO
@@ -73,6 +73,11 @@ def lib():
         L.orc_eval_l_1.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_mds.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
         L.orc_vanishing_points.argtypes = [ctypes.c_int, ctypes.c_size_t] + [ctypes.c_void_p] * 11 + [ctypes.c_int]
+        L.orc_field_to_bytes.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.orc_field_from_bytes.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.orc_field_sqrt.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_point_to_bytes.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L.orc_point_from_bytes.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -342,3 +347,53 @@ def vanishing_points(field, degree, constants, wires, s_sigma, z, k_is, alpha, b
     out = np.zeros((8 * degree, 4), dtype=np.uint64)
     assert lib().orc_vanishing_points(field, degree, *[_p(x) for x in arrs], _p(out), threads) == 0
     return out
+
+
+# ---- canonical byte encodings (serialization.inc) ----
+def field_to_bytes(field, x):
+    x = _u64(x)
+    L = lib().orc_field_limbs(field)
+    n = x.size // L
+    out = np.zeros(n * L * 8, dtype=np.uint8)
+    assert lib().orc_field_to_bytes(field, _p(x), n, _p(out)) == 0
+    return out.reshape(n, L * 8)
+
+
+def field_from_bytes(field, b):
+    """returns (elements, number of `Out of range` records)"""
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    L = lib().orc_field_limbs(field)
+    n = b.size // (L * 8)
+    out = np.zeros((n, L), dtype=np.uint64)
+    bad = lib().orc_field_from_bytes(field, _p(b), n, _p(out))
+    assert bad >= 0
+    return out, bad
+
+
+def field_sqrt(field, x):
+    x = _u64(x)
+    out = np.zeros_like(x)
+    rc = lib().orc_field_sqrt(field, _p(x), _p(out))
+    assert rc >= 0
+    return out if rc else None
+
+
+def point_to_bytes(curve, xy, zero=None):
+    xy = _u64(xy)
+    L = xy.shape[-1]
+    n = xy.size // (2 * L)
+    z = np.ascontiguousarray(zero, dtype=np.uint8) if zero is not None else np.zeros(n, dtype=np.uint8)
+    out = np.zeros(n * (1 + L * 8), dtype=np.uint8)
+    assert lib().orc_point_to_bytes(curve, _p(xy), _p(z), n, _p(out)) == 0
+    return out.reshape(n, 1 + L * 8)
+
+
+def point_from_bytes(curve, b, limbs):
+    """returns (xy (n, 2, L), zero flags, status: 0 ok / 1 Out of range / 2 Invalid x coordinate)"""
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    n = b.size // (1 + limbs * 8)
+    xy = np.zeros((n, 2, limbs), dtype=np.uint64)
+    zero = np.zeros(n, dtype=np.uint8)
+    status = np.zeros(n, dtype=np.uint8)
+    assert lib().orc_point_from_bytes(curve, _p(b), n, _p(xy), _p(zero), _p(status)) == 0
+    return xy, zero, status

@@ -1003,6 +1003,7 @@ struct Bls12377 : CurveT<Bls12377BaseP, Bls12377ScalarP> {
 };
 
 #include "plonk_gates.inc"
+#include "serialization.inc"
 
 // =============================================================================================
 // C interface for ctypes (tests / cpu_baseline only)
@@ -1430,6 +1431,52 @@ int orc_vanishing_points(int field, size_t degree, const u64* constants, const u
         const std::vector<F> res = plonk::vanishing_points<F>(degree, cv.data(), wv.data(), sv.data(), zv.data(), kv.data(), ld<F>(alpha), ld<F>(beta),
                                                               ld<F>(gamma), ld<F>(zeta), ld<F>(a), threads);
         for (size_t i = 0; i < n8; ++i) st(out + i * F::N, res[i]);
+        return 0;
+    });
+    return -1;
+}
+
+// ---- canonical byte encodings (serialization.inc) ----
+int orc_field_to_bytes(int field, const u64* x, size_t n, uint8_t* out) {
+    FIELD_DISPATCH(field, { for (size_t i = 0; i < n; ++i) ser::to_canonical_u8_vec<F>(ld<F>(x + i * F::N), out + i * F::N * 8); return 0; });
+    return -1;
+}
+// returns the number of records that were "Out of range" (their output is left zero)
+int orc_field_from_bytes(int field, const uint8_t* in, size_t n, u64* out) {
+    FIELD_DISPATCH(field, {
+        int bad = 0;
+        for (size_t i = 0; i < n; ++i) {
+            F v = F::zero();
+            if (!ser::from_canonical_u8_vec<F>(in + i * F::N * 8, v)) { ++bad; v = F::zero(); }
+            st(out + i * F::N, v);
+        }
+        return bad;
+    });
+    return -1;
+}
+int orc_field_sqrt(int field, const u64* x, u64* out) {  // 1: root written, 0: not a square
+    FIELD_DISPATCH(field, { F r; if (!ser::square_root(ld<F>(x), r)) return 0; st(out, r); return 1; });
+    return -1;
+}
+static u64 curve_b_small(int curve) { return curve == 0 ? 5 : curve == 1 ? 7 : 1; }  // tweedledee_curve.rs:12, tweedledum_curve.rs:12-13, bls12_377_curve.rs:15
+int orc_point_to_bytes(int curve, const u64* xy, const uint8_t* zero, size_t n, uint8_t* out) {
+    CURVE_DISPATCH(curve, {
+        const size_t rec = 1 + C::Base::N * 8;
+        for (size_t i = 0; i < n; ++i) ser::write_point<C>(ld_aff<C>(xy, zero, i), out + i * rec);
+        return 0;
+    });
+    return -1;
+}
+int orc_point_from_bytes(int curve, const uint8_t* in, size_t n, u64* out_xy, uint8_t* out_zero, uint8_t* status) {
+    CURVE_DISPATCH(curve, {
+        const size_t rec = 1 + C::Base::N * 8;
+        const typename C::Base b = C::Base::from_canonical_u64(curve_b_small(curve));
+        for (size_t i = 0; i < n; ++i) {
+            AffinePoint<C> p = AffinePoint<C>::ZERO();
+            status[i] = (uint8_t)ser::read_point<C>(in + i * rec, b, p);
+            if (status[i]) p = {C::Base::zero(), C::Base::zero(), false};
+            st_aff<C>(out_xy, out_zero, i, p);
+        }
         return 0;
     });
     return -1;

@@ -419,3 +419,51 @@ def batch_to_affine(curve, proj_xyz, zero=None):
     oz = np.zeros(n, dtype=np.uint8)
     _lib.check(_lib.load().plk_curve_batch_to_affine(curve, n, _ptr(p), _ptr(z) if z is not None else None, _ptr(out), _ptr(oz)))
     return out, oz
+
+
+# ---- canonical byte encodings (serialization.rs:17-72) ----
+def field_to_bytes(field, x):
+    """ToBytes for field elements: (n, BYTES) uint8, little-endian canonical value."""
+    a = _elems(field, x)
+    out = np.empty((a.shape[0], a.shape[1] * 8), dtype=np.uint8)
+    _lib.check(_lib.load().plk_field_to_bytes(field, _ptr(a), a.shape[0], _ptr(out)))
+    return out
+
+
+def field_from_bytes(field, b):
+    """FromBytes for field elements; "Out of range" (field.rs:100) raises ValueError."""
+    L = _FIELD_LIMBS[field]
+    bb = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1, L * 8)
+    out = np.empty((bb.shape[0], L), dtype=np.uint64)
+    rc = _lib.load().plk_field_from_bytes(field, _ptr(bb), bb.shape[0], _ptr(out))
+    if rc == _lib.PLK_ERR_INVALID_ARG:
+        raise ValueError(_lib.load().plk_last_error().decode())
+    _lib.check(rc)
+    return out
+
+
+def point_to_bytes(curve, xy, zero=None):
+    """ToBytes for AffinePoint: (n, 1 + BYTES) uint8: mask = zero | (y odd) << 1, then x."""
+    L = _CURVE_LIMBS[curve]
+    p = np.ascontiguousarray(xy, dtype=np.uint64).reshape(-1, 2, L)
+    z = np.ascontiguousarray(zero, dtype=np.uint8) if zero is not None else None
+    out = np.empty((p.shape[0], 1 + L * 8), dtype=np.uint8)
+    _lib.check(_lib.load().plk_curve_point_to_bytes(curve, _ptr(p), _ptr(z) if z is not None else None, p.shape[0], _ptr(out)))
+    return out
+
+
+def point_from_bytes(curve, b, with_status=False):
+    """FromBytes for AffinePoint: ((n, 2, L), zero flags); an undecodable record raises ValueError unless with_status."""
+    L = _CURVE_LIMBS[curve]
+    bb = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1, 1 + L * 8)
+    n = bb.shape[0]
+    out = np.empty((n, 2, L), dtype=np.uint64)
+    oz = np.zeros(n, dtype=np.uint8)
+    st = np.zeros(n, dtype=np.uint8)
+    rc = _lib.load().plk_curve_point_from_bytes(curve, _ptr(bb), n, _ptr(out), _ptr(oz), _ptr(st))
+    if with_status and rc in (_lib.PLK_OK, _lib.PLK_ERR_INVALID_ARG):
+        return out, oz, st
+    if rc == _lib.PLK_ERR_INVALID_ARG:
+        raise ValueError(_lib.load().plk_last_error().decode())
+    _lib.check(rc)
+    return out, oz

@@ -620,6 +620,88 @@ int plk_curve_batch_to_affine(int curve, size_t count, const uint64_t* proj_xyz,
     return PLK_OK;
 }
 
+// ---- canonical byte encodings ----
+int plk_field_to_bytes(int field, const uint64_t* x, size_t count, uint8_t* out_bytes) {
+    const int L = field_limbs(field);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
+    if (count == 0) return PLK_OK;
+    if (!x || !out_bytes) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    DevBuf dx, db;
+    PLK_TRY(dx.alloc(count * L * 8));
+    PLK_TRY(db.alloc(count * L * 8));
+    PLK_HIP_TRY(hipMemcpy(dx.p, x, count * L * 8, hipMemcpyHostToDevice));
+    PLK_TRY(field_bytes_impl(field, 0, dx.p, count, db.p, nullptr, nullptr));
+    PLK_HIP_TRY(hipMemcpy(out_bytes, db.p, count * L * 8, hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+int plk_field_from_bytes(int field, const uint8_t* bytes, size_t count, uint64_t* out) {
+    const int L = field_limbs(field);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
+    if (count == 0) return PLK_OK;
+    if (!bytes || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    DevBuf dx, db, dc;
+    PLK_TRY(dx.alloc(count * L * 8));
+    PLK_TRY(db.alloc(count * L * 8));
+    PLK_TRY(dc.alloc(4));
+    PLK_HIP_TRY(hipMemcpy(db.p, bytes, count * L * 8, hipMemcpyHostToDevice));
+    PLK_HIP_TRY(hipMemset(dc.p, 0, 4));
+    PLK_TRY(field_bytes_impl(field, 1, db.p, count, dx.p, (unsigned*)dc.p, nullptr));
+    unsigned bad = 0;
+    PLK_HIP_TRY(hipMemcpy(&bad, dc.p, 4, hipMemcpyDeviceToHost));
+    PLK_HIP_TRY(hipMemcpy(out, dx.p, count * L * 8, hipMemcpyDeviceToHost));
+    if (bad) return set_error(PLK_ERR_INVALID_ARG, "Out of range: %u of the %zu records are not below the modulus (field.rs:100)", bad, count);
+    return PLK_OK;
+}
+int plk_curve_point_to_bytes(int curve, const uint64_t* xy, const uint8_t* zero, size_t count, uint8_t* out_bytes) {
+    const int L = curve_limbs(curve);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (count == 0) return PLK_OK;
+    if (!xy || !out_bytes) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    const size_t rec = 1 + (size_t)L * 8;
+    DevBuf dp, dz, db;
+    PLK_TRY(dp.alloc(count * 2 * L * 8));
+    PLK_TRY(db.alloc(count * rec));
+    PLK_HIP_TRY(hipMemcpy(dp.p, xy, count * 2 * L * 8, hipMemcpyHostToDevice));
+    if (zero) {
+        PLK_TRY(dz.alloc(count));
+        PLK_HIP_TRY(hipMemcpy(dz.p, zero, count, hipMemcpyHostToDevice));
+    }
+    PLK_TRY(point_bytes_impl(curve, 0, dp.p, zero ? dz.p : nullptr, count, db.p, nullptr, nullptr, nullptr));
+    PLK_HIP_TRY(hipMemcpy(out_bytes, db.p, count * rec, hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+int plk_curve_point_from_bytes(int curve, const uint8_t* bytes, size_t count, uint64_t* out_xy, uint8_t* out_zero, uint8_t* status) {
+    const int L = curve_limbs(curve);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (count == 0) return PLK_OK;
+    if (!bytes || !out_xy || !out_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    const size_t rec = 1 + (size_t)L * 8;
+    DevBuf dp, dz, db, ds;
+    PLK_TRY(dp.alloc(count * 2 * L * 8));
+    PLK_TRY(dz.alloc(count));
+    PLK_TRY(ds.alloc(count));
+    PLK_TRY(db.alloc(count * rec));
+    PLK_HIP_TRY(hipMemcpy(db.p, bytes, count * rec, hipMemcpyHostToDevice));
+    PLK_TRY(point_bytes_impl(curve, 1, db.p, nullptr, count, dp.p, dz.p, ds.p, nullptr));
+    std::vector<uint8_t> st(count);
+    PLK_HIP_TRY(hipMemcpy(st.data(), ds.p, count, hipMemcpyDeviceToHost));
+    PLK_HIP_TRY(hipMemcpy(out_xy, dp.p, count * 2 * L * 8, hipMemcpyDeviceToHost));
+    PLK_HIP_TRY(hipMemcpy(out_zero, dz.p, count, hipMemcpyDeviceToHost));
+    size_t bad = 0, first = 0;
+    for (size_t i = 0; i < count; ++i) {
+        if (status) status[i] = st[i];
+        if (st[i] && !bad++) first = i;
+    }
+    if (bad)
+        return set_error(PLK_ERR_INVALID_ARG, "%zu of the %zu points do not decode (first: record %zu, %s)", bad, count, first,
+                         st[first] == 1 ? "Out of range" : "Invalid x coordinate");
+    return PLK_OK;
+}
+
 // ---- self-test ----
 int plk_selftest_quad(int curve, const uint64_t* pts_xy, size_t n, unsigned quads, unsigned* mismatches) {
     const int L = curve_limbs(curve);

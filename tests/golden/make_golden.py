@@ -69,6 +69,18 @@ def main():
                  numerator=arr([f.to_mont(v) for v in m], 4), quotient=arr([f.to_mont(v) for v in quot + [0] * (size - len(quot))], 4),
                  a=arr([f.to_mont(v) for v in a], 4), b=arr([f.to_mont(v) for v in b], 4),
                  product=arr([f.to_mont(v) for v in prod + [0] * (psize - len(prod))], 4))
+    # byte encodings (serialization.rs:17-72): canonical little-endian field bytes; points as mask byte + x, from big-int maths
+    for c in (br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377):
+        f, L = c.base, c.base.n_limbs
+        G = (c.gx, c.gy)
+        vals = [0, 1, 2, f.p - 1, f.p // 2, 0x0123456789ABCDEF << 64 | 0xFEDCBA9876543210] + [f.from_mont(synth.to_int(r)) for r in synth.rand_field(f.field_id, 0x601D5000 + f.field_id, 6)]
+        fbytes = np.array([list(v.to_bytes(8 * L, "little")) for v in vals], dtype=np.uint8)
+        pts = [G, br.ec_neg(c, G)] + [br.ec_mul(c, k, G) for k in (2, 3, 0xDEADBEEF, c.scalar.p - 5)]
+        zero = [0] * len(pts) + [1]
+        pts.append((0, 0))
+        pbytes = np.array([[(1 if z else 0) | (2 if P[1] & 1 else 0)] + list(P[0].to_bytes(8 * L, "little")) for P, z in zip(pts, zero)], dtype=np.uint8)
+        np.savez(os.path.join(OUT, "bytes_%s.npz" % c.name), curve=c.curve_id, field=f.field_id, elems=arr([f.to_mont(v) for v in vals], L), elem_bytes=fbytes,
+                 points=np.stack([arr([f.to_mont(P[0]), f.to_mont(P[1])], L) for P in pts]), points_zero=np.array(zero, dtype=np.uint8), point_bytes=pbytes)
     print("golden vectors written to", OUT)
 
 

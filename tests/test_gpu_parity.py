@@ -611,3 +611,48 @@ def test_msm_sparse_scalars_many_buckets():
     for win in (16, 20):
         got, gz = pa.msm_execute_parallel(pa.msm_precompute(0, bases, 11, device_window=win), scalars)
         assert gz == ez and np.array_equal(got, expected), win
+
+
+# ---------------- canonical byte encodings (serialization.rs:17-72) ----------------
+def test_bytes_match_golden_and_oracle():
+    import glob, os
+    from plonky_amd import api
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    paths = sorted(glob.glob(os.path.join(gold, "bytes_*.npz")))
+    assert len(paths) == 3
+    for path in paths:
+        g = np.load(path)
+        f, c = int(g["field"]), int(g["curve"])
+        assert np.array_equal(api.field_to_bytes(f, g["elems"]), g["elem_bytes"]), path
+        assert np.array_equal(api.field_from_bytes(f, g["elem_bytes"]), g["elems"]), path
+        assert np.array_equal(api.point_to_bytes(c, g["points"], g["points_zero"]), g["point_bytes"]), path
+        xy, zero = api.point_from_bytes(c, g["point_bytes"])
+        assert np.array_equal(zero, g["points_zero"]) and np.array_equal(xy, g["points"]), path
+    for f in (br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.BLS12_377_BASE):
+        x = ol.rand_field(f.field_id, 0x5E71A2, 333)
+        b = api.field_to_bytes(f.field_id, x)
+        assert np.array_equal(b, ol.field_to_bytes(f.field_id, x)) and np.array_equal(api.field_from_bytes(f.field_id, b), x)
+        raw = np.array([list(v.to_bytes(8 * f.n_limbs, "little")) for v in (5, f.p, f.p - 1)], dtype=np.uint8)
+        with pytest.raises(ValueError, match="Out of range"):
+            api.field_from_bytes(f.field_id, raw)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+def test_point_bytes_round_trip_and_errors(c):
+    """test_curve_serialization! (serialization.rs:177-210) on the device, decompression (Tonelli-Shanks) included."""
+    from plonky_amd import api
+    f, L = c.base, c.base.n_limbs
+    G = (c.gx, c.gy)
+    pts = [br.ec_mul(c, 3 + 977 * k, G) for k in range(40)]
+    xy = np.stack([ints_to_array([f.to_mont(P[0]), f.to_mont(P[1])], L) for P in pts] + [np.zeros((2, L), dtype=np.uint64)])
+    zero = np.array([0] * len(pts) + [1], dtype=np.uint8)
+    b = api.point_to_bytes(c.curve_id, xy, zero)
+    assert np.array_equal(b, ol.point_to_bytes(c.curve_id, xy, zero))
+    back, bz = api.point_from_bytes(c.curve_id, b)
+    assert np.array_equal(bz, zero) and np.array_equal(back, xy)
+    bad_x = next(x for x in range(2, 100) if pow((x ** 3 + c.b) % f.p, (f.p - 1) // 2, f.p) == f.p - 1)
+    rec = np.array([[0] + list(bad_x.to_bytes(8 * L, "little")), [2] + list(f.p.to_bytes(8 * L, "little")), list(b[0])], dtype=np.uint8)
+    with pytest.raises(ValueError):
+        api.point_from_bytes(c.curve_id, rec)
+    _, _, status = api.point_from_bytes(c.curve_id, rec, with_status=True)
+    assert list(status) == [2, 1, 0]
