@@ -227,6 +227,17 @@ int plk_field_from_bytes(int field, const uint8_t* bytes, size_t count, uint64_t
 int plk_curve_point_to_bytes(int curve, const uint64_t* xy, const uint8_t* zero, size_t count, uint8_t* out_bytes);
 int plk_curve_point_from_bytes(int curve, const uint8_t* bytes, size_t count, uint64_t* out_xy, uint8_t* out_zero, uint8_t* status);
 
+/* ---- scalar side of an IPA round  (src/halo.rs:63-118) --------------------------------------------------- */
+/* Field::inner_product (field.rs:213-221): *d_out = sum_i a[i] b[i] (one element, device memory).  Asynchronous on `stream`.
+ * The point side of a round is plk_msm (msm_parallel on fresh generators: L_j, R_j, halo.rs:87-93) and
+ * plk_curve_fold_pairs (G' = [u^-1] G_lo + [u] G_hi, halo.rs:119-123). */
+int plk_field_inner_product_dev(int field, const void* d_a, const void* d_b, size_t count, void* d_out, void* stream);
+/* add_slices(scalar_lo.scale_slice(lo), scalar_hi.scale_slice(hi)) (halo.rs:117-118: halo_a' = u^-1 a_hi + u a_lo,
+ * halo_b' = u^-1 b_lo + u b_hi): d_out[i] = scalar_lo * d_lo[i] + scalar_hi * d_hi[i]; the two scalars are host pointers
+ * (field limbs, Montgomery).  d_out may alias d_lo.  Asynchronous on `stream`. */
+int plk_field_fold_slices_dev(int field, const void* d_lo, const void* d_hi, const uint64_t* scalar_lo, const uint64_t* scalar_hi, size_t count,
+                              void* d_out, void* stream);
+
 /* ---- self-test ------------------------------------------------------------------------------ */
 /* Runs the quad-cooperative point arithmetic of the MSM reduction tail (ecz_coop.cuh) against the one-lane
  * arithmetic on the n affine points pts_xy (n * 2L limbs, Montgomery), `quads` quads cycling through 8 cases

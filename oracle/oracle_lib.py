@@ -397,3 +397,44 @@ def point_from_bytes(curve, b, limbs):
     status = np.zeros(n, dtype=np.uint8)
     assert lib().orc_point_from_bytes(curve, _p(b), n, _p(xy), _p(zero), _p(status)) == 0
     return xy, zero, status
+
+
+# ---- one round of the inner-product argument, composed from the restated primitives (halo.rs:63-124) ----
+def _ip(field, a, b):
+    """Field::inner_product (field.rs:213-221)"""
+    acc = np.zeros(a.shape[1], dtype=np.uint64)
+    prod = field_binop(field, "mul", a, b)
+    for row in prod:
+        acc = field_binop(field, "add", acc.reshape(1, -1), row.reshape(1, -1))[0]
+    return acc
+
+
+def halo_round_lr(curve, scalar_field, halo_a, halo_b, halo_g, pedersen_h, u_prime, l_blinding, r_blinding, threads=4):
+    """L_j = msm_parallel(a_lo, g_hi, 8) + [l_j] H + [<a_lo, b_hi>] U' and R_j likewise (halo.rs:86-93): ((2, 2, L), [zero, zero])."""
+    m = halo_a.shape[0] // 2
+    outs, zeros = [], []
+    for a_half, b_half, g_half, blind in ((halo_a[:m], halo_b[m:], halo_g[m:], l_blinding), (halo_a[m:], halo_b[:m], halo_g[:m], r_blinding)):
+        xy, z = MsmPrecomputation(curve, g_half, 8, threads=threads).execute(a_half, parallel=True, threads=threads)
+        t1, z1 = scalar_mul(curve, blind, pedersen_h)
+        t2, z2 = scalar_mul(curve, _ip(scalar_field, a_half, b_half), u_prime)
+        xy, z = affine_add(curve, xy, z, t1, z1)
+        xy, z = affine_add(curve, xy, z, t2, z2)
+        outs.append(xy)
+        zeros.append(z)
+    return np.stack(outs), zeros
+
+
+def halo_round_fold(curve, scalar_field, halo_a, halo_b, halo_g, u_j, u_j_inv):
+    """halo.rs:117-123: the folded (halo_a, halo_b, halo_g, zero flags)."""
+    m = halo_a.shape[0] // 2
+    scale = lambda s, v: field_binop(scalar_field, "mul", np.tile(_u64(s), (v.shape[0], 1)), v)
+    a2 = field_binop(scalar_field, "add", scale(u_j_inv, halo_a[m:]), scale(u_j, halo_a[:m]))
+    b2 = field_binop(scalar_field, "add", scale(u_j_inv, halo_b[:m]), scale(u_j, halo_b[m:]))
+    g2, gz = [], []
+    for i in range(m):
+        p1, z1 = scalar_mul(curve, u_j_inv, halo_g[i])
+        p2, z2 = scalar_mul(curve, u_j, halo_g[m + i])
+        xy, z = affine_add(curve, p1, z1, p2, z2)
+        g2.append(xy)
+        gz.append(z)
+    return a2, b2, np.stack(g2), np.array(gz, dtype=np.uint8)

@@ -702,6 +702,15 @@ int plk_curve_point_from_bytes(int curve, const uint8_t* bytes, size_t count, ui
     return PLK_OK;
 }
 
+// ---- scalar side of an IPA round ----
+int plk_field_inner_product_dev(int field, const void* d_a, const void* d_b, size_t count, void* d_out, void* stream) {
+    return field_inner_product_dev_impl(field, d_a, d_b, count, d_out, as_stream(stream));
+}
+int plk_field_fold_slices_dev(int field, const void* d_lo, const void* d_hi, const uint64_t* scalar_lo, const uint64_t* scalar_hi, size_t count,
+                              void* d_out, void* stream) {
+    return field_fold_slices_dev_impl(field, d_lo, d_hi, scalar_lo, scalar_hi, count, d_out, as_stream(stream));
+}
+
 // ---- self-test ----
 int plk_selftest_quad(int curve, const uint64_t* pts_xy, size_t n, unsigned quads, unsigned* mismatches) {
     const int L = curve_limbs(curve);

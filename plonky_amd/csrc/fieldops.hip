@@ -176,6 +176,118 @@ int curve_batch_to_affine_dev_impl(int curve, size_t count, const void* d_xyz, c
     return PLK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// scalar side of an IPA round (halo.rs:63-118): Field::inner_product (field.rs:213-221) and the folds
+// halo_a' = u^-1 a_hi + u a_lo, halo_b' = u^-1 b_lo + u b_hi (add_slices of scale_slice, halo.rs:117-118)
+// ---------------------------------------------------------------------------------------------
+// Field addition is exact, commutative and associative: any summation order gives the reference's value.
+template <class P>
+__global__ void __launch_bounds__(256) k_inner_product(const uint4* __restrict__ a, const uint4* __restrict__ b, size_t count, uint4* __restrict__ part) {
+    constexpr int W = P::NL / 4;
+    __shared__ uint4 s_acc[256 * W];
+    Fe<P> acc = fe_zero<P>();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        acc = fe_add<P>(acc, fe_mul<P>(fe_load<P>(a + i * W), fe_load<P>(b + i * W)));
+    fe_store<P>(s_acc + threadIdx.x * W, acc);
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            acc = fe_add<P>(acc, fe_load<P>(s_acc + (threadIdx.x + d) * W));
+            fe_store<P>(s_acc + threadIdx.x * W, acc);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) fe_store<P>(part + blockIdx.x * W, acc);
+}
+template <class P> __global__ void __launch_bounds__(256) k_sum_parts(const uint4* __restrict__ part, unsigned n, uint4* __restrict__ out) {
+    constexpr int W = P::NL / 4;
+    __shared__ uint4 s_acc[256 * W];
+    Fe<P> acc = fe_zero<P>();
+    for (unsigned i = threadIdx.x; i < n; i += 256) acc = fe_add<P>(acc, fe_load<P>(part + i * W));
+    fe_store<P>(s_acc + threadIdx.x * W, acc);
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            acc = fe_add<P>(acc, fe_load<P>(s_acc + (threadIdx.x + d) * W));
+            fe_store<P>(s_acc + threadIdx.x * W, acc);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) fe_store<P>(out, acc);
+}
+struct FoldScalars {
+    uint32_t lo[12], hi[12];
+};
+template <class P>
+__global__ void __launch_bounds__(256) k_fold_slices(const uint4* __restrict__ lo, const uint4* __restrict__ hi, FoldScalars sc, size_t count, uint4* __restrict__ out) {
+    constexpr int W = P::NL / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fe<P> sl, sh;
+#pragma unroll
+    for (int k = 0; k < P::NL; ++k) {
+        sl.v[k] = sc.lo[k];
+        sh.v[k] = sc.hi[k];
+    }
+    fe_store<P>(out + i * W, fe_add<P>(fe_mul<P>(sl, fe_load<P>(lo + i * W)), fe_mul<P>(sh, fe_load<P>(hi + i * W))));
+}
+
+int field_inner_product_dev_impl(int field, const void* d_a, const void* d_b, size_t count, void* d_out, hipStream_t stream) {
+    if (!d_out || (count && (!d_a || !d_b))) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
+    PLK_TRY(ensure_device());
+    const int L = field_limbs(field);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
+    unsigned blocks = (unsigned)((count + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks == 0) blocks = 1;
+    void* part = scratch_acquire((size_t)blocks * L * 8, stream);
+    if (!part) return PLK_ERR_OOM;
+    switch (field) {
+#define CASE(ID, P)                                                                                                   \
+    case ID:                                                                                                          \
+        k_inner_product<P><<<blocks, 256, 0, stream>>>((const uint4*)d_a, (const uint4*)d_b, count, (uint4*)part);   \
+        k_sum_parts<P><<<1, 256, 0, stream>>>((const uint4*)part, blocks, (uint4*)d_out);                            \
+        break;
+        CASE(PLK_FIELD_TWEEDLEDEE_BASE, TweedledeeBaseParams)
+        CASE(PLK_FIELD_TWEEDLEDUM_BASE, TweedledumBaseParams)
+        CASE(PLK_FIELD_BLS12_377_SCALAR, Bls12377ScalarParams)
+        CASE(PLK_FIELD_BLS12_377_BASE, Bls12377BaseParams)
+#undef CASE
+    }
+    hipError_t e = hipGetLastError();
+    scratch_release(part, stream);
+    if (e != hipSuccess) return set_error(PLK_ERR_HIP, "inner product launch failed: %s", hipGetErrorString(e));
+    return PLK_OK;
+}
+
+int field_fold_slices_dev_impl(int field, const void* d_lo, const void* d_hi, const uint64_t* s_lo, const uint64_t* s_hi, size_t count, void* d_out,
+                               hipStream_t stream) {
+    if (count == 0) return PLK_OK;
+    if (!d_lo || !d_hi || !d_out || !s_lo || !s_hi) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    const int L = field_limbs(field);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
+    FoldScalars sc;
+    for (int k = 0; k < L; ++k) {
+        sc.lo[2 * k] = (uint32_t)s_lo[k];
+        sc.lo[2 * k + 1] = (uint32_t)(s_lo[k] >> 32);
+        sc.hi[2 * k] = (uint32_t)s_hi[k];
+        sc.hi[2 * k + 1] = (uint32_t)(s_hi[k] >> 32);
+    }
+    const unsigned blocks = (unsigned)((count + 255) / 256);
+    switch (field) {
+#define CASE(ID, P) \
+    case ID: k_fold_slices<P><<<blocks, 256, 0, stream>>>((const uint4*)d_lo, (const uint4*)d_hi, sc, count, (uint4*)d_out); break;
+        CASE(PLK_FIELD_TWEEDLEDEE_BASE, TweedledeeBaseParams)
+        CASE(PLK_FIELD_TWEEDLEDUM_BASE, TweedledumBaseParams)
+        CASE(PLK_FIELD_BLS12_377_SCALAR, Bls12377ScalarParams)
+        CASE(PLK_FIELD_BLS12_377_BASE, Bls12377BaseParams)
+#undef CASE
+    }
+    PLK_HIP_TRY(hipGetLastError());
+    return PLK_OK;
+}
+
 int field_op_impl(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count) {
     if (op < 0 || op > 9) return set_error(PLK_ERR_INVALID_ARG, "bad field op %d", op);
     if (!a || !out || (op <= 2 && !b)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");

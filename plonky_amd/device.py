@@ -144,3 +144,83 @@ def vanishing_points_dev(field, log_degree, constants_8n, wire_values_8n, s_sigm
                                                           ctypes.c_void_p(plonk_z_points_8n.data_ptr()), p(ks), *[p(x) for x in sc],
                                                           ctypes.c_void_p(out.data_ptr()), _stream()))
     return out
+
+
+# ---- one round of the inner-product argument (halo.rs:63-124) on device-resident vectors ----
+def _limbs(x, n=4):
+    return np.ascontiguousarray(x, dtype=np.uint64).reshape(n)
+
+
+def inner_product_dev(field, a, b):
+    """Field::inner_product (field.rs:213-221) -> (1, 4) int64 CUDA tensor."""
+    assert a.is_cuda and b.is_cuda and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    out = torch.empty((1, a.shape[-1]), dtype=torch.int64, device=a.device)
+    _lib.check(_lib.load().plk_field_inner_product_dev(field, ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), a.shape[0],
+                                                       ctypes.c_void_p(out.data_ptr()), _stream()))
+    return out
+
+
+def fold_slices_dev(field, lo, hi, scalar_lo, scalar_hi):
+    """scalar_lo * lo + scalar_hi * hi (add_slices of scale_slice, halo.rs:117-118)."""
+    assert lo.is_cuda and hi.is_cuda and lo.is_contiguous() and hi.is_contiguous() and lo.shape == hi.shape
+    out = torch.empty_like(lo)
+    sl, sh = _limbs(scalar_lo, lo.shape[-1]), _limbs(scalar_hi, lo.shape[-1])
+    _lib.check(_lib.load().plk_field_fold_slices_dev(field, ctypes.c_void_p(lo.data_ptr()), ctypes.c_void_p(hi.data_ptr()),
+                                                     sl.ctypes.data_as(ctypes.c_void_p), sh.ctypes.data_as(ctypes.c_void_p), lo.shape[0],
+                                                     ctypes.c_void_p(out.data_ptr()), _stream()))
+    return out
+
+
+def fold_generators_dev(curve, g_lo, g_hi, scalar_lo, scalar_hi, lo_zero=None, hi_zero=None):
+    """G' = [scalar_lo] G_lo + [scalar_hi] G_hi pair by pair (halo.rs:119-123) -> ((m, 2, L), (m,) zero flags) on device."""
+    assert g_lo.is_cuda and g_hi.is_cuda and g_lo.is_contiguous() and g_hi.is_contiguous() and g_lo.shape == g_hi.shape
+    m = g_lo.shape[0]
+    out = torch.empty_like(g_lo)
+    oz = torch.empty((m,), dtype=torch.uint8, device=g_lo.device)
+    sl, sh = _limbs(scalar_lo), _limbs(scalar_hi)
+    zp = lambda z: ctypes.c_void_p(z.data_ptr()) if z is not None else None
+    _lib.check(_lib.load().plk_curve_fold_pairs_dev(curve, m, ctypes.c_void_p(g_lo.data_ptr()), zp(lo_zero), ctypes.c_void_p(g_hi.data_ptr()), zp(hi_zero),
+                                                    sl.ctypes.data_as(ctypes.c_void_p), sh.ctypes.data_as(ctypes.c_void_p),
+                                                    ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(oz.data_ptr()), _stream()))
+    return out, oz
+
+
+def halo_round_lr_dev(curve, halo_a, halo_b, halo_g, pedersen_h, u_prime, l_blinding, r_blinding, g_zero=None):
+    """L_j = <a_lo, G_hi> + [l_j] H + [<a_lo, b_hi>] U',  R_j = <a_hi, G_lo> + [r_j] H + [<a_hi, b_lo>] U' (halo.rs:86-93).
+    halo_a / halo_b: (n, 4) scalars, halo_g: (n, 2, L) affine generators (g_zero: (n,) identity flags or None); pedersen_h /
+    u_prime: (2, L) affine host points; the blinding factors are host scalars.  The msm_parallel, the blinding term and the
+    inner-product term are ONE table-free MSM over [G_half..., H, U'] each.  Returns ((2, 2, L), (2,)): L_j then R_j, affine."""
+    from .api import CURVE_SCALAR_FIELD
+    n = halo_a.shape[0]
+    m = n // 2
+    sf = CURVE_SCALAR_FIELD[curve]
+    L = _CURVE_LIMBS[curve]
+    extra = to_device(np.stack([np.ascontiguousarray(pedersen_h, dtype=np.uint64).reshape(2, L), np.ascontiguousarray(u_prime, dtype=np.uint64).reshape(2, L)]))
+    outs, zeros = [], []
+    for a_half, b_half, g_half, gz, blind in ((halo_a[:m], halo_b[m:], halo_g[m:], None if g_zero is None else g_zero[m:], l_blinding),
+                                              (halo_a[m:], halo_b[:m], halo_g[:m], None if g_zero is None else g_zero[:m], r_blinding)):
+        ip = inner_product_dev(sf, a_half.contiguous(), b_half.contiguous())
+        scal = torch.cat([a_half, to_device(_limbs(blind).reshape(1, 4)), ip], dim=0).contiguous()
+        bases = torch.cat([g_half, extra], dim=0).contiguous()
+        zf = None
+        if gz is not None:
+            zf = torch.cat([gz, torch.zeros(2, dtype=torch.uint8, device=gz.device)]).contiguous()
+        pre = msm_precompute_dev(curve, bases, zero=zf, table_free=True)
+        xy, z = msm_execute_dev(pre, scal)
+        torch.cuda.synchronize()
+        pre.free()
+        outs.append(xy[0])
+        zeros.append(z[0])
+    return torch.stack(outs), torch.stack(zeros)
+
+
+def halo_round_fold_dev(curve, halo_a, halo_b, halo_g, u_j, u_j_inv, g_zero=None):
+    """halo_a' = u^-1 a_hi + u a_lo, halo_b' = u^-1 b_lo + u b_hi, G' = [u^-1] G_lo + [u] G_hi (halo.rs:117-123)."""
+    from .api import CURVE_SCALAR_FIELD
+    m = halo_a.shape[0] // 2
+    sf = CURVE_SCALAR_FIELD[curve]
+    a2 = fold_slices_dev(sf, halo_a[m:].contiguous(), halo_a[:m].contiguous(), u_j_inv, u_j)
+    b2 = fold_slices_dev(sf, halo_b[:m].contiguous(), halo_b[m:].contiguous(), u_j_inv, u_j)
+    g2, gz2 = fold_generators_dev(curve, halo_g[:m].contiguous(), halo_g[m:].contiguous(), u_j_inv, u_j,
+                                  None if g_zero is None else g_zero[:m].contiguous(), None if g_zero is None else g_zero[m:].contiguous())
+    return a2, b2, g2, gz2

@@ -70,6 +70,8 @@ SYMBOLS = [
     ("plk_field_from_bytes", _i, [_i, _vp, _sz, _vp]),
     ("plk_curve_point_to_bytes", _i, [_i, _vp, _vp, _sz, _vp]),
     ("plk_curve_point_from_bytes", _i, [_i, _vp, _sz, _vp, _vp, _vp]),
+    ("plk_field_inner_product_dev", _i, [_i, _vp, _vp, _sz, _vp, _vp]),
+    ("plk_field_fold_slices_dev", _i, [_i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     ("plk_selftest_quad", _i, [_i, _vp, _sz, _u, _vp]),
     ("plk_ntt_set_profiling", _i, [_i]),
     ("plk_ntt_get_timings", _i, [_vp, _vp]),
