@@ -75,6 +75,8 @@ void* scratch_acquire(size_t bytes, hipStream_t stream) {
     ScratchEntry* best = nullptr;
     for (auto& e : g_scratch) {
         if (e.in_call || e.device != dev || e.bytes < bytes) continue;
+        // a small request must not take (and keep) a buffer sized for a whole transform: at most 4x the request above 1 MiB
+        if (e.bytes > ((size_t)1 << 20) && e.bytes / 4 > bytes) continue;
         const bool ordered = !e.used || e.stream == stream || hipEventQuery(e.ev) == hipSuccess;
         if (!ordered) continue;
         if (!best || e.bytes < best->bytes) best = &e;
@@ -127,6 +129,111 @@ void scratch_clear() {
         if (e.p) keep.push_back(e);
     g_scratch.swap(keep);
 }
+
+// ---- host-pointer entry points: one lane per calling thread ----
+// The reference calls the hot path from Rayon workers (plonk_util.rs:173-189: nine transforms / commitments at once).  Every
+// host thread that enters through a host-pointer entry point owns a lane: a non-blocking stream, and a pinned staging
+// buffer through which its inputs and outputs cross PCIe with asynchronous copies; device buffers come from the scratch
+// pool.  Nothing goes through the null stream or through hipMalloc / hipFree (both synchronise the whole device), so
+// concurrent callers overlap on the GPU instead of queueing behind each other.
+constexpr size_t PIN_CAP = (size_t)256 << 20;  // larger transfers go straight from / to the caller's pageable memory
+struct HostLane {
+    hipStream_t stream = nullptr;
+    int device = -1;
+    uint8_t* pin = nullptr;
+    size_t pin_bytes = 0, pin_used = 0;
+    ~HostLane() {
+        if (pin) (void)hipHostFree(pin);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+static thread_local HostLane t_lane;
+
+static int lane_get(HostLane*& out) {
+    PLK_TRY(ensure_device());
+    int dev = 0;
+    PLK_HIP_TRY(hipGetDevice(&dev));
+    HostLane& l = t_lane;
+    if (l.stream && l.device != dev) {
+        (void)hipStreamDestroy(l.stream);
+        l.stream = nullptr;
+    }
+    if (!l.stream) {
+        PLK_HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        l.device = dev;
+    }
+    if (l.pin_used) (void)hipStreamSynchronize(l.stream);  // a call that failed half way may have left copies in flight
+    l.pin_used = 0;
+    out = &l;
+    return PLK_OK;
+}
+// a piece of the lane's pinned buffer, valid until the lane is synchronised; nullptr when it does not fit
+static uint8_t* lane_stage(HostLane& l, size_t bytes) {
+    const size_t need = (l.pin_used + bytes + 255) & ~(size_t)255;
+    if (need > PIN_CAP) return nullptr;
+    if (need > l.pin_bytes) {
+        if (l.pin_used) return nullptr;  // pieces handed out earlier in this call are still in flight
+        size_t want = l.pin_bytes ? l.pin_bytes : ((size_t)4 << 20);
+        while (want < need) want *= 2;
+        if (l.pin) (void)hipHostFree(l.pin);
+        l.pin = nullptr;
+        l.pin_bytes = 0;
+        if (hipHostMalloc((void**)&l.pin, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        l.pin_bytes = want;
+    }
+    uint8_t* p = l.pin + l.pin_used;
+    l.pin_used = need;
+    return p;
+}
+static int lane_h2d(HostLane& l, void* d, const void* h, size_t bytes) {
+    if (!bytes) return PLK_OK;
+    if (uint8_t* st = lane_stage(l, bytes)) {
+        memcpy(st, h, bytes);
+        PLK_HIP_TRY(hipMemcpyAsync(d, st, bytes, hipMemcpyHostToDevice, l.stream));
+    } else {
+        PLK_HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, l.stream));  // pageable: the runtime stages it, in stream order
+    }
+    return PLK_OK;
+}
+// device -> caller memory; `flush` pairs (staging piece, destination) are copied out by lane_finish after the synchronisation
+struct LaneOut {
+    uint8_t* st;
+    void* dst;
+    size_t bytes;
+};
+static int lane_d2h(HostLane& l, std::vector<LaneOut>& outs, void* h, const void* d, size_t bytes) {
+    if (!bytes) return PLK_OK;
+    if (uint8_t* st = lane_stage(l, bytes)) {
+        PLK_HIP_TRY(hipMemcpyAsync(st, d, bytes, hipMemcpyDeviceToHost, l.stream));
+        outs.push_back({st, h, bytes});
+    } else {
+        PLK_HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, l.stream));
+    }
+    return PLK_OK;
+}
+static int lane_finish(HostLane& l, std::vector<LaneOut>& outs) {
+    PLK_HIP_TRY(hipStreamSynchronize(l.stream));
+    for (const LaneOut& o : outs) memcpy(o.dst, o.st, o.bytes);
+    outs.clear();
+    l.pin_used = 0;
+    return PLK_OK;
+}
+// device buffer of a lane, from the scratch pool
+struct LaneBuf {
+    void* p = nullptr;
+    hipStream_t s = nullptr;
+    ~LaneBuf() {
+        if (p) scratch_release(p, s);
+    }
+    int alloc(size_t bytes, hipStream_t stream) {
+        s = stream;
+        p = scratch_acquire(bytes ? bytes : 16, stream);
+        return p ? PLK_OK : PLK_ERR_OOM;
+    }
+};
 
 static std::atomic<int> g_device{-1};
 
@@ -225,18 +332,22 @@ int plk_ntt_batch(int field, unsigned log_n, int inverse, unsigned batch, const 
     if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
     if (batch == 0) return PLK_OK;
     if (!in || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    PLK_TRY(ensure_device());
+    HostLane* l = nullptr;
+    PLK_TRY(lane_get(l));
     const size_t bytes = ((size_t)1 << log_n) * 32;
-    DevBuf buf;
-    PLK_TRY(buf.alloc(bytes * batch));
+    LaneBuf buf;
+    PLK_TRY(buf.alloc(bytes * batch, l->stream));
     for (unsigned b = 0; b < batch; ++b) {
         if (!in[b] || !out[b]) return set_error(PLK_ERR_INVALID_ARG, "null pointer in batch slot %u", b);
-        PLK_HIP_TRY(hipMemcpy((uint8_t*)buf.p + b * bytes, in[b], bytes, hipMemcpyHostToDevice));
+        PLK_TRY(lane_h2d(*l, (uint8_t*)buf.p + b * bytes, in[b], bytes));
     }
-    PLK_TRY(ntt_dev_impl(field, log_n, inverse, batch, buf.p, buf.p, nullptr));
-    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
-    for (unsigned b = 0; b < batch; ++b) PLK_HIP_TRY(hipMemcpy(out[b], (uint8_t*)buf.p + b * bytes, bytes, hipMemcpyDeviceToHost));
-    return PLK_OK;
+    PLK_TRY(ntt_dev_impl(field, log_n, inverse, batch, buf.p, buf.p, l->stream));
+    // the inputs' staging pieces are free again once the transform has consumed them: the outputs reuse the same pinned memory
+    std::vector<LaneOut> outs;
+    PLK_HIP_TRY(hipStreamSynchronize(l->stream));
+    l->pin_used = 0;
+    for (unsigned b = 0; b < batch; ++b) PLK_TRY(lane_d2h(*l, outs, out[b], (uint8_t*)buf.p + b * bytes, bytes));
+    return lane_finish(*l, outs);
 }
 
 int plk_ntt(int field, unsigned log_n, int inverse, const uint64_t* in, uint64_t* out) {
@@ -405,15 +516,18 @@ int plk_msm_precompute_ex(int curve, size_t n, const uint64_t* bases_xy, const u
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (n && !bases_xy) return set_error(PLK_ERR_INVALID_ARG, "null bases");
-    PLK_TRY(ensure_device());
-    DevBuf db, dz;
-    PLK_TRY(db.alloc(n * 2 * L * 8));
-    if (n) PLK_HIP_TRY(hipMemcpy(db.p, bases_xy, n * 2 * L * 8, hipMemcpyHostToDevice));
+    HostLane* l = nullptr;
+    PLK_TRY(lane_get(l));
+    LaneBuf db, dz;
+    PLK_TRY(db.alloc(n * 2 * L * 8, l->stream));
+    PLK_TRY(lane_h2d(*l, db.p, bases_xy, n * 2 * L * 8));
     if (base_zero) {
-        PLK_TRY(dz.alloc(n));
-        if (n) PLK_HIP_TRY(hipMemcpy(dz.p, base_zero, n, hipMemcpyHostToDevice));
+        PLK_TRY(dz.alloc(n, l->stream));
+        PLK_TRY(lane_h2d(*l, dz.p, base_zero, n));
     }
-    return msm_precompute_dev_impl(curve, n, db.p, base_zero ? dz.p : nullptr, window_bits, flags, nullptr, out_ctx);
+    const int rc = msm_precompute_dev_impl(curve, n, db.p, base_zero ? dz.p : nullptr, window_bits, flags, l->stream, out_ctx);  // synchronises the stream
+    l->pin_used = 0;
+    return rc;
 }
 int plk_msm_precompute(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, unsigned window_bits, plk_msm_ctx** out_ctx) {
     return plk_msm_precompute_ex(curve, n, bases_xy, base_zero, window_bits, 0, out_ctx);
@@ -438,22 +552,23 @@ int plk_msm_execute_batch(plk_msm_ctx* ctx, unsigned batch, const uint64_t* cons
                          msm_ctx_len(ctx));
     if (batch == 0) return PLK_OK;
     if (!scalars || !out_xy || !out_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    PLK_TRY(ensure_device());
+    HostLane* l = nullptr;
+    PLK_TRY(lane_get(l));
     const size_t L = (size_t)curve_limbs(msm_ctx_curve(ctx));
     const size_t sb = n_scalars * 32;
-    DevBuf ds, dxy, dz;
-    PLK_TRY(ds.alloc(sb * batch));
-    PLK_TRY(dxy.alloc((size_t)batch * 2 * L * 8));
-    PLK_TRY(dz.alloc(batch));
+    LaneBuf ds, dxy, dz;
+    PLK_TRY(ds.alloc(sb * batch, l->stream));
+    PLK_TRY(dxy.alloc((size_t)batch * 2 * L * 8, l->stream));
+    PLK_TRY(dz.alloc(batch, l->stream));
     for (unsigned b = 0; b < batch; ++b) {
         if (n_scalars && !scalars[b]) return set_error(PLK_ERR_INVALID_ARG, "null scalars in batch slot %u", b);
-        if (n_scalars) PLK_HIP_TRY(hipMemcpy((uint8_t*)ds.p + b * sb, scalars[b], sb, hipMemcpyHostToDevice));
+        PLK_TRY(lane_h2d(*l, (uint8_t*)ds.p + b * sb, scalars[b], sb));
     }
-    PLK_TRY(msm_execute_dev_impl(ctx, batch, ds.p, n_scalars, dxy.p, dz.p, nullptr));
-    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
-    PLK_HIP_TRY(hipMemcpy(out_xy, dxy.p, (size_t)batch * 2 * L * 8, hipMemcpyDeviceToHost));
-    PLK_HIP_TRY(hipMemcpy(out_zero, dz.p, batch, hipMemcpyDeviceToHost));
-    return PLK_OK;
+    PLK_TRY(msm_execute_dev_impl(ctx, batch, ds.p, n_scalars, dxy.p, dz.p, l->stream));
+    std::vector<LaneOut> outs;
+    PLK_TRY(lane_d2h(*l, outs, out_xy, dxy.p, (size_t)batch * 2 * L * 8));
+    PLK_TRY(lane_d2h(*l, outs, out_zero, dz.p, batch));
+    return lane_finish(*l, outs);
 }
 
 int plk_msm_execute(plk_msm_ctx* ctx, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xy, uint8_t* out_zero) {

@@ -1167,7 +1167,7 @@ template <class C> static size_t accumulate_slots() {
 }
 
 // One slab per workspace: a single hipMalloc / hipFree instead of a dozen (they dominate a one-shot msm_parallel).
-template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w) {
+template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w, hipStream_t stream) {
     using FP = typename C::FP;
     const size_t packed_bytes = (size_t)4 * FP::NL * 4;
     const size_t raw_bytes = (size_t)raw_u4<FP>() * 16;
@@ -1203,8 +1203,9 @@ template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w) {
         cur += (pt.bytes + 255) & ~(size_t)255;
     }
     // the "last block" counter of k_ord_scan1 and the heavy-list counters start at zero and are left at zero by their users
-    PLK_HIP_TRY(hipMemset(w.meta, 0, (size_t)(1024 + 1025 + 1025 + 8) * 4));
-    PLK_HIP_TRY(hipMemset(w.heavy, 0, 8));
+    // (on the caller's stream: a non-blocking stream is not ordered after the null stream)
+    PLK_HIP_TRY(hipMemsetAsync(w.meta, 0, (size_t)(1024 + 1025 + 1025 + 8) * 4, stream));
+    PLK_HIP_TRY(hipMemsetAsync(w.heavy, 0, 8, stream));
     PLK_HIP_TRY(hipEventCreateWithFlags(&w.ev, hipEventDisableTiming));
     w.ready = true;
     return PLK_OK;
@@ -1241,7 +1242,7 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
     }
     PLK_HIP_TRY(hipMalloc(&ctx->tab, (ctx->table_free ? n : entries) * pt_bytes + 16));
     ctx->ws.resize(1);
-    PLK_TRY(msm_alloc_work<C>(ctx, ctx->ws[0]));
+    PLK_TRY(msm_alloc_work<C>(ctx, ctx->ws[0], stream));
     if (n) {
         k_msm_table<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)ctx->tab, n, ctx->c,
                                                                        ctx->table_free ? 1 : ctx->windows);
@@ -1513,9 +1514,9 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
         ctx->ws.emplace_back();
         int rc;
         switch (ctx->curve) {
-            case PLK_CURVE_TWEEDLEDEE: rc = msm_alloc_work<TweedledeeCurve>(ctx, ctx->ws.back()); break;
-            case PLK_CURVE_TWEEDLEDUM: rc = msm_alloc_work<TweedledumCurve>(ctx, ctx->ws.back()); break;
-            default: rc = msm_alloc_work<Bls12377Curve>(ctx, ctx->ws.back()); break;
+            case PLK_CURVE_TWEEDLEDEE: rc = msm_alloc_work<TweedledeeCurve>(ctx, ctx->ws.back(), stream); break;
+            case PLK_CURVE_TWEEDLEDUM: rc = msm_alloc_work<TweedledumCurve>(ctx, ctx->ws.back(), stream); break;
+            default: rc = msm_alloc_work<Bls12377Curve>(ctx, ctx->ws.back(), stream); break;
         }
         if (rc != PLK_OK) {
             ctx->ws.back().release();

@@ -94,7 +94,21 @@ def build(force=False):
     if force:
         args.append("-B")
     subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    build_host_harness()
     return SO_PATH
+
+
+def build_host_harness():
+    """tests/capi_host: a C++ host program above the C ABI only (what the Rust shim of INTEGRATION.md does), run by the GPU suite."""
+    root = os.path.dirname(os.path.dirname(_CSRC))
+    src, out = os.path.join(root, "tests", "capi_host.cpp"), os.path.join(root, "tests", "capi_host")
+    if not os.path.exists(src):
+        return None
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(SO_PATH)):
+        return out
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", src, "-o", out, "-L" + _CSRC, "-lplonky_hip",
+                           "-Wl,-rpath,$ORIGIN/../plonky_amd/csrc", "-Wl,-rpath,/opt/rocm/lib"])
+    return out
 
 
 _lib = None

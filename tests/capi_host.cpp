@@ -1,0 +1,152 @@
+// tests/capi_host.cpp -- a host program above the C ABI only (no HIP, no Python): what the Rust shim of INTEGRATION.md does.
+//
+// Nine host threads call the hot path at once, exactly as the reference's Rayon workers do (src/plonk_util.rs:173-189: nine
+// wire polynomials are transformed / committed in parallel):
+//   * every thread: fft_with_precomputation_power_of_2 and its inverse on its own vector (round trip, bit exact), one
+//     msm_execute_parallel against the SHARED MsmPrecomputation, one msm_precompute + msm_execute + free of its own;
+//   * the results of the concurrent phase equal those of the same calls made one after the other;
+//   * linearity through the ABI: msm(s0 + s1) = msm(s0) + msm(s1)  (plk_field_op add in the scalar field, plk_curve_sum_affine).
+// Generators are real curve points made through the ABI itself: [2^j] G from plk_msm_precompute_table, spread by
+// plk_curve_fold_pairs.  Exit code 0 and the line "capi_host: OK" on success.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../include/plonky_hip.h"
+
+#define CHECK(expr)                                                                            \
+    do {                                                                                       \
+        int _rc = (expr);                                                                      \
+        if (_rc != PLK_OK) {                                                                   \
+            std::fprintf(stderr, "%s:%d: %s -> %d: %s\n", __FILE__, __LINE__, #expr, _rc, plk_last_error()); \
+            return 1;                                                                          \
+        }                                                                                      \
+    } while (0)
+
+static uint64_t splitmix(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// any 4-limb value below 2^254 is a fully reduced Montgomery representation for the Tweedle fields (p > 2^254)
+static void rand_elems(std::vector<uint64_t>& v, size_t n, uint64_t seed) {
+    v.resize(n * 4);
+    for (size_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 4; ++k) v[4 * i + k] = splitmix(seed);
+        v[4 * i + 3] &= 0x3FFFFFFFFFFFFFFFull;
+    }
+}
+
+int main() {
+    const int CURVE = PLK_CURVE_TWEEDLEDEE, BASE = PLK_FIELD_TWEEDLEDEE_BASE;
+    const int SCALAR = plk_curve_scalar_field(CURVE);
+    const unsigned THREADS = 9, LOG_N = 14;
+    CHECK(plk_init(0));
+    // G = (-1, 2) (tweedledee_curve.rs:14-18) in Montgomery form: from_canonical through the device
+    const uint64_t p_minus_1[4] = {0x842cafd400000000ull, 0x038aa127696286c9ull, 0, 0x4000000000000000ull};  // tweedledee_base.rs:22 minus one
+    uint64_t canon[8] = {p_minus_1[0], p_minus_1[1], p_minus_1[2], p_minus_1[3], 2, 0, 0, 0}, g[8];
+    CHECK(plk_field_op(BASE, 7, canon, nullptr, g, 2));
+    // [2^j] G, j < 255, then 16 spreads [a] T_j + [b] T_(j+1): 16 * 254 distinct valid points
+    const int digits = plk_msm_table_digits(CURVE, 1);
+    std::vector<uint64_t> tab((size_t)digits * 8);
+    std::vector<uint8_t> tab_zero(digits);
+    CHECK(plk_msm_precompute_table(CURVE, 1, g, nullptr, 1, tab.data(), tab_zero.data()));
+    const size_t m = (size_t)digits - 1, n = 16 * m;
+    std::vector<uint64_t> bases(n * 8), ab;
+    std::vector<uint8_t> bz(n);
+    rand_elems(ab, 32, 0xB45E5);
+    for (int r = 0; r < 16; ++r)
+        CHECK(plk_curve_fold_pairs(CURVE, m, tab.data(), nullptr, tab.data() + 8, nullptr, ab.data() + 8 * r, ab.data() + 8 * r + 4, bases.data() + r * m * 8,
+                                   bz.data() + r * m));
+    for (uint8_t z : bz)
+        if (z) {
+            std::fprintf(stderr, "unexpected identity among the generators\n");
+            return 1;
+        }
+    plk_msm_ctx* shared = nullptr;
+    CHECK(plk_msm_precompute(CURVE, n, bases.data(), nullptr, 0, &shared));
+    CHECK(plk_ntt_precompute(BASE, LOG_N));
+
+    struct Job {
+        std::vector<uint64_t> x, y, back, s, own_bases;
+        uint64_t r_shared[8], r_own[8];
+        uint8_t z_shared = 0, z_own = 0;
+        int rc = 0;
+        const char* err = "";
+    };
+    std::vector<Job> jobs(THREADS), seq(THREADS);
+    for (unsigned t = 0; t < THREADS; ++t) {
+        rand_elems(jobs[t].x, (size_t)1 << LOG_N, 1000 + t);
+        rand_elems(jobs[t].s, n, 2000 + t);
+        jobs[t].own_bases.assign(bases.begin() + t * 64 * 8, bases.begin() + (t * 64 + 1024) * 8);
+        seq[t] = jobs[t];
+    }
+    auto work = [&](Job& j) {
+        const size_t nn = (size_t)1 << LOG_N;
+        j.y.resize(nn * 4);
+        j.back.resize(nn * 4);
+        auto fail = [&](int rc) {
+            j.rc = rc;
+            j.err = plk_last_error();
+        };
+        int rc;
+        if ((rc = plk_ntt(BASE, LOG_N, 0, j.x.data(), j.y.data())) != PLK_OK) return fail(rc);
+        if ((rc = plk_ntt(BASE, LOG_N, 1, j.y.data(), j.back.data())) != PLK_OK) return fail(rc);
+        if ((rc = plk_msm_execute(shared, j.s.data(), n, j.r_shared, &j.z_shared)) != PLK_OK) return fail(rc);
+        plk_msm_ctx* own = nullptr;
+        if ((rc = plk_msm_precompute(CURVE, 1024, j.own_bases.data(), nullptr, 0, &own)) != PLK_OK) return fail(rc);
+        rc = plk_msm_execute(own, j.s.data(), 1024, j.r_own, &j.z_own);
+        plk_msm_free(own);
+        if (rc != PLK_OK) return fail(rc);
+    };
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < THREADS; ++t) pool.emplace_back(work, std::ref(jobs[t]));
+        for (auto& th : pool) th.join();
+    }
+    for (unsigned t = 0; t < THREADS; ++t) work(seq[t]);
+    for (unsigned t = 0; t < THREADS; ++t) {
+        const Job &a = jobs[t], &b = seq[t];
+        if (a.rc || b.rc) {
+            std::fprintf(stderr, "thread %u: rc %d / %d: %s %s\n", t, a.rc, b.rc, a.err, b.err);
+            return 1;
+        }
+        if (a.back != a.x || a.y == a.x) {
+            std::fprintf(stderr, "thread %u: NTT round trip failed\n", t);
+            return 1;
+        }
+        if (a.y != b.y || std::memcmp(a.r_shared, b.r_shared, 64) || std::memcmp(a.r_own, b.r_own, 64) || a.z_shared != b.z_shared || a.z_own != b.z_own) {
+            std::fprintf(stderr, "thread %u: concurrent result differs from the sequential one\n", t);
+            return 1;
+        }
+        if (a.z_shared || a.z_own) {
+            std::fprintf(stderr, "thread %u: unexpected identity result\n", t);
+            return 1;
+        }
+    }
+    // linearity: msm(s0 + s1) == msm(s0) + msm(s1)
+    std::vector<uint64_t> s01(n * 4);
+    CHECK(plk_field_op(SCALAR, 0, jobs[0].s.data(), jobs[1].s.data(), s01.data(), n));
+    uint64_t lhs[8], rhs[8], pair[16];
+    uint8_t lz = 0, rz = 0;
+    CHECK(plk_msm_execute(shared, s01.data(), n, lhs, &lz));
+    std::memcpy(pair, jobs[0].r_shared, 64);
+    std::memcpy(pair + 8, jobs[1].r_shared, 64);
+    CHECK(plk_curve_sum_affine(CURVE, 2, pair, nullptr, rhs, &rz));
+    if (lz != rz || std::memcmp(lhs, rhs, 64)) {
+        std::fprintf(stderr, "linearity check failed\n");
+        return 1;
+    }
+    // contract violation -> error code, not a crash (curve_msm.rs:67 assert_eq!)
+    if (plk_msm_execute(shared, s01.data(), n - 1, lhs, &lz) != PLK_ERR_SIZE_MISMATCH) {
+        std::fprintf(stderr, "length mismatch not reported\n");
+        return 1;
+    }
+    plk_msm_free(shared);
+    plk_shutdown();
+    std::printf("capi_host: OK (%u threads, 2^%u-point transforms, %zu-generator MSMs)\n", THREADS, LOG_N, n);
+    return 0;
+}

@@ -656,3 +656,14 @@ def test_point_bytes_round_trip_and_errors(c):
         api.point_from_bytes(c.curve_id, rec)
     _, _, status = api.point_from_bytes(c.curve_id, rec, with_status=True)
     assert list(status) == [2, 1, 0]
+
+
+def test_capi_host_nine_threads():
+    """tests/capi_host.cpp: a C++ program above the C ABI only, nine host threads calling plk_ntt / plk_msm_precompute /
+    plk_msm_execute at once as the reference's Rayon workers do (plonk_util.rs:173-189)."""
+    import os, subprocess
+    from plonky_amd import lib
+    exe = lib.build_host_harness()
+    assert exe and os.path.exists(exe)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "capi_host: OK" in r.stdout, r.stdout + r.stderr
