@@ -14,14 +14,20 @@ def shard_bounds(n, rank, world):
 
 def all_gather_points(xy, zero):
     """xy: (batch, 2, L) int64, zero: (batch,) uint8 - this rank's partial results.
-    Returns (world, batch, 2, L) and (world, batch) on every rank."""
+    Returns (world, batch, 2, L) and (world, batch) on every rank.  ONE collective: the identity flag travels as an extra
+    64-bit word behind the 2L coordinate limbs of its point (the payload is a few hundred bytes: latency, not bandwidth)."""
     world = dist.get_world_size()
-    # output = the ranks' tensors concatenated along dim 0 (the layout both nccl and gloo accept)
-    g_xy = torch.empty((world * xy.shape[0],) + tuple(xy.shape[1:]), dtype=xy.dtype, device=xy.device)
-    g_z = torch.empty((world * zero.shape[0],) + tuple(zero.shape[1:]), dtype=zero.dtype, device=zero.device)
-    dist.all_gather_into_tensor(g_xy, xy.contiguous())
-    dist.all_gather_into_tensor(g_z, zero.contiguous())
-    return g_xy.view((world,) + tuple(xy.shape)), g_z.view((world,) + tuple(zero.shape))
+    batch = xy.shape[0]
+    words = xy.shape[1] * xy.shape[2]
+    packed = torch.empty((batch, words + 1), dtype=torch.int64, device=xy.device)
+    packed[:, :words] = xy.reshape(batch, words)
+    packed[:, words] = zero.to(torch.int64)
+    gathered = torch.empty((world * batch, words + 1), dtype=torch.int64, device=xy.device)
+    dist.all_gather_into_tensor(gathered, packed)
+    gathered = gathered.view(world, batch, words + 1)
+    g_xy = gathered[:, :, :words].reshape((world,) + tuple(xy.shape)).contiguous()
+    g_z = gathered[:, :, words].to(torch.uint8).contiguous()
+    return g_xy, g_z
 
 
 def msm_sharded(execute_local, combine, scalars_local):
@@ -34,3 +40,27 @@ def msm_sharded(execute_local, combine, scalars_local):
     for b in range(xy.shape[0]):
         out.append(combine(g_xy[:, b], g_z[:, b]))
     return out
+
+
+def msm_sharded_hip(pre, scalars_local):
+    """The sharded MSM over the HIP path: `pre` is this rank's device MsmPrecomputation over its base range
+    (plonky_amd.device.msm_precompute_dev), scalars_local the matching slice of every scalar vector ((batch, n_local, 4) int64
+    CUDA tensor).  Per-rank partial results -> one all-gather -> plk_curve_sum_affine per vector.
+    Returns (xy (batch, 2, L) uint64 numpy, zero list) on every rank."""
+    import numpy as np
+    from . import api, device as dev
+
+    def execute_local(sv):
+        xy, z = dev.msm_execute_dev(pre, sv)
+        return xy, z
+
+    def combine(points, zeros):
+        return api.curve_sum_affine(pre.curve, dev.to_host(points), zeros.cpu().numpy())
+
+    res = msm_sharded(execute_local, combine, scalars_local)
+    return np.stack([r[0] for r in res]), [r[1] for r in res]
+
+
+def round_robin(n_items, rank, world):
+    """Independent units (whole transforms: the 9 wire LDEs, the iNTTs of a proof) are dealt out rank by rank - no collective."""
+    return list(range(rank, n_items, world))

@@ -93,3 +93,10 @@ def test_sharded_msm_world_size_2_gloo():
         xy, z = full.execute(scalars[b])
         assert z == 0
         assert res[b] == tuple(c.base.from_mont(v) for v in array_to_ints(xy))
+
+
+def test_round_robin_covers_every_unit_once():
+    for n in (0, 1, 9, 19):
+        for world in (1, 2, 8):
+            got = sorted(i for r in range(world) for i in parallel.round_robin(n, r, world))
+            assert got == list(range(n))
