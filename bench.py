@@ -2,22 +2,23 @@
 """bench.py -- the headline benchmark of BASELINE.json on MI355X.
 
 metric  "MSM Mpairs/sec + NTT Melems/sec, 2^20 Tweedledee, 1/2/4/8 GPU"
-step    one pass of the hot path over one batch of synthetic input:
-          * one forward 2^20-point NTT over TweedledeeBase  (BASELINE configs[1]; fft.rs:103), and
-          * one 2^20-pair MSM on Tweedledee                  (BASELINE configs[2]; curve_msm.rs:102)
-        both with inputs already resident in HBM, tables/precomputation excluded exactly as
+step    one pass of the hot path over one batch of synthetic input (--workload):
+          both    (default) one forward 2^20-point NTT over TweedledeeBase (BASELINE configs[1]; fft.rs:103) and one 2^20-pair
+                  MSM on Tweedledee (configs[2]; curve_msm.rs:102) per GPU.  N > 1: weak scaling - the NTTs are independent
+                  units (no collective); the MSM is a global N * 2^20-pair MSM sharded by contiguous base range: every rank
+                  reduces its own 2^20 pairs, ONE packed all-gather of the N affine partial results and a local point sum.
+          ntt / msm   one component alone.
+          commit9 BASELINE configs[3]: the 9-wire commitment batch of poly_commit.rs:52-66 - nine 2^20 scalar vectors against
+                  the same 2^20 generators.  N > 1: STRONG scaling - the generators are sharded by base range (each rank holds
+                  2^20 / N of them and the matching slice of every vector), one packed all-gather of 9 partial points.
+        --curve bls12_377 --log-n 22 --workload msm  is BASELINE configs[4] (the reference has BLS12-377, not -381).
+        Inputs are resident in HBM before the timed region; tables / precomputation are excluded exactly as
         benches/fft.rs:22-30 and src/bin/msms.rs:25,54-58 exclude them.
-value   whole-job units per second, 1 unit = 1 NTT element or 1 MSM scalar-point pair
-        (2 * 2^20 units per step per GPU); the two components are reported separately in
-        "components" as NTT Melems/s and MSM Mpairs/s - those are the numbers BASELINE.md tracks.
-N > 1   one process per GPU (torch.distributed, backend nccl = RCCL).  NTTs are independent units
-        (no collective).  The MSM is a global N * 2^20-pair MSM sharded by contiguous base range:
-        every rank reduces its own 2^20 pairs, one all-gather of the N affine partial results
-        (65 bytes each) and a local point sum give every rank the result.  Weak scaling.
-
-Use --workload ntt|msm to time one component alone.
+value   whole-job units per second, 1 unit = 1 NTT element or 1 MSM scalar-point pair; the components are reported
+        separately in "components" as NTT Melems/s and MSM Mpairs/s - those are the numbers BASELINE.md tracks.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,68 +28,90 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LOG_N = 20
-NTT_FIELD = 0       # TweedledeeBase
-CURVE = 0           # Tweedledee (scalars in TweedledumBase)
 SEED_NTT = 0xF70020
 SEED_MSM = 0x350020
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+# integer-ALU ceiling of the 256-bit fields: fz_mul at 4 waves / SIMD, measured (profiles/r01_field_op_costs.txt: 188.5 Gop/s)
+VALU_PEAK_GMODMUL = 188.5
+CURVES = {"tweedledee": dict(curve=0, ntt_field=0, scalar_field=1, base_field=0, limbs=4, scalar_bits=255, pair_bytes=96),
+          "bls12_377": dict(curve=2, ntt_field=2, scalar_field=2, base_field=3, limbs=6, scalar_bits=253, pair_bytes=128)}
+STAGES = ["order_count", "order_scatter", "order_buckets", "accumulate", "assemble_lines", "planes", "final"]
 
 
-def cpu_baseline(workload):
-    """The oracle (C++ restatement of the reference algorithm) timed on this host's cores, on a
-    bounded sample (about 10-30 s of CPU work in all): the NTT at the full 2^20 size and the MSM at 2^16 with the
-    reference's w = 11 tables prebuilt, median of 3 runs for every thread count of a small sweep."""
+def kernel_source_hash():
+    """Identifies the kernels a PMC traffic figure was measured on: sha256 over the device sources."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "plonky_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cuh", ".h")):
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(workload, cv):
+    """The oracle (C++ restatement of the reference algorithm, persistent worker pool) timed on this host's cores on a bounded
+    sample: the full 2^20 NTT (T = 1 and the best of a thread sweep, 10 timed runs each after a warm-up run) and the MSM with the
+    reference's w = 11 tables prebuilt: 2^20 pairs at the best thread count (10 runs) and 2^16 pairs at T = 1 (3 runs)."""
     import numpy as np
     from oracle import bigint_ref as br, oracle_lib as ol
     from plonky_amd import synth
     cores = os.cpu_count() or 1
-    sweep = sorted(set(t for t in (1, 8, 32, cores) if t <= cores))
+    sweep = sorted(set(t for t in (8, 32, 64, cores) if t <= cores))
     out = {"kind": "port", "label": "C++ restatement of the reference algorithm (oracle/plk_oracle.cpp), not plonky Rust",
            "host_cores": cores}
+
+    def timed(fn, runs):
+        fn()
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
     used = []
     if workload in ("both", "ntt"):
         ln = 20
-        x = synth.rand_field(NTT_FIELD, SEED_NTT, 1 << ln)
-        pre = ol.FftPrecomputation(NTT_FIELD, 1 << ln)
+        x = synth.rand_field(cv["ntt_field"], SEED_NTT, 1 << ln)
+        pre = ol.FftPrecomputation(cv["ntt_field"], 1 << ln)
         best = None
-        for th in sweep:  # the layer loop forks per layer like Rayon; more threads is not always faster
-            pre.fft_with_precomputation_power_of_2(x, threads=th)
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                pre.fft_with_precomputation_power_of_2(x, threads=th)
-                ts.append(time.perf_counter() - t0)
-            t = sorted(ts)[1]
+        for th in sweep:  # a layer is a fork-join over 2000-pair chunks like the reference's; more threads is not always faster
+            t = timed(lambda: pre.fft_with_precomputation_power_of_2(x, threads=th), 3)
             if best is None or t < best[0]:
                 best = (t, th)
-        out["ntt_melems_per_s"] = (1 << ln) / best[0] / 1e6
+        t_all = timed(lambda: pre.fft_with_precomputation_power_of_2(x, threads=best[1]), 10)
+        t_one = timed(lambda: pre.fft_with_precomputation_power_of_2(x, threads=1), 10)
+        out["ntt_melems_per_s"] = (1 << ln) / t_all / 1e6
         out["ntt_threads"] = best[1]
+        out["ntt_melems_per_s_1_thread"] = (1 << ln) / t_one / 1e6
         used.append(best[1])
-        out["ntt_sample"] = "2^%d TweedledeeBase forward NTT, best of threads %s (= %d), median of 3" % (ln, sweep, best[1])
-    if workload in ("both", "msm"):
-        lm = 16
-        c = br.TWEEDLEDEE
+        out["ntt_sample"] = "2^%d forward NTT, median of 10: T = %d (best of %s) and T = 1" % (ln, best[1], sweep)
+    if workload in ("both", "msm", "commit9"):
+        c = br.CURVES[cv["curve"]]
         G = (c.gx, c.gy)
         D = br.ec_mul(c, 424242, G)
         g0 = np.array([c.base.mont_limbs(G[0]), c.base.mont_limbs(G[1])], dtype=np.uint64)
         dd = np.array([c.base.mont_limbs(D[0]), c.base.mont_limbs(D[1])], dtype=np.uint64)
-        bases = ol.gen_bases(CURVE, 1 << lm, g0, dd)
-        s = synth.rand_field(1, SEED_MSM, 1 << lm)
-        pre = ol.MsmPrecomputation(CURVE, bases, 11, threads=min(cores, 64))  # table build excluded, as src/bin/msms.rs:25
+        lm = 20 if cores >= 32 else 16  # the 2^20 table build and 10 executions need a real host (minutes on 8 cores)
+        th_all = min(cores, 256)
+        bases = ol.gen_bases(cv["curve"], 1 << lm, g0, dd)
+        s = synth.rand_field(cv["scalar_field"], SEED_MSM, 1 << lm)
+        pre = ol.MsmPrecomputation(cv["curve"], bases, 11, threads=th_all)  # table build excluded, as src/bin/msms.rs:25
         best = None
-        for th in sweep:
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                pre.execute(s, parallel=True, threads=th)
-                ts.append(time.perf_counter() - t0)
-            t = sorted(ts)[1]
+        for th in sorted(set(t for t in (32, 64, th_all) if t <= th_all)):
+            t = timed(lambda: pre.execute(s, parallel=True, threads=th), 1)
             if best is None or t < best[0]:
                 best = (t, th)
-        out["msm_mpairs_per_s"] = (1 << lm) / best[0] / 1e6
+        t_all = timed(lambda: pre.execute(s, parallel=True, threads=best[1]), 10)
+        out["msm_mpairs_per_s"] = (1 << lm) / t_all / 1e6
         out["msm_threads"] = best[1]
+        l1 = 16
+        pre1 = pre if lm == l1 else ol.MsmPrecomputation(cv["curve"], bases[: 1 << l1], 11, threads=th_all)
+        t_one = timed(lambda: pre1.execute(s[: 1 << l1], parallel=True, threads=1), 3)
+        out["msm_mpairs_per_s_1_thread"] = (1 << l1) / t_one / 1e6
         used.append(best[1])
-        out["msm_sample"] = "2^%d Tweedledee msm_execute_parallel, w = 11 tables prebuilt, best of threads %s (= %d), median of 3" % (lm, sweep, best[1])
+        out["msm_sample"] = "2^%d-pair msm_execute_parallel, w = 11 tables prebuilt, median of 10 at T = %d; T = 1: 2^%d pairs, median of 3" % (lm, best[1], l1)
     out["cores"] = max(used) if used else 1
     n_units, t_units = 0.0, 0.0
     if "ntt_melems_per_s" in out:
@@ -108,12 +131,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["both", "ntt", "msm"], default="both")
+    ap.add_argument("--workload", choices=["both", "ntt", "msm", "commit9"], default="both")
+    ap.add_argument("--curve", choices=sorted(CURVES), default="tweedledee")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--timed-only", action="store_true", help="run only the warm-up + timed region (for rocprofv3 --pmc passes)")
     args = ap.parse_args()
+    cv = CURVES[args.curve]
+    CURVE, NTT_FIELD = cv["curve"], cv["ntt_field"]
 
     import ctypes
     import numpy as np
@@ -130,15 +156,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from plonky_amd import device as dev, lib, parallel, synth
-    from plonky_amd.selfcheck import closed_form_msm, _mul, _add
+    from plonky_amd import api, device as dev, lib, parallel, synth
+    from plonky_amd.selfcheck import closed_form_msm, _mul
     from plonky_amd.synth import MODULI
     dev.init(local_rank)
     L = lib.load()
 
     n = 1 << args.log_n
+    commit9 = args.workload == "commit9"
     do_ntt = args.workload in ("both", "ntt")
-    do_msm = args.workload in ("both", "msm")
+    do_msm = args.workload in ("both", "msm", "commit9")
+    batch = 9 if commit9 else 1
+    strong = commit9
 
     # ---- synthetic inputs, resident in HBM before the timed region ----
     if do_ntt:
@@ -147,19 +176,26 @@ def main():
         y = torch.empty_like(x)
         lib.check(L.plk_ntt_precompute(NTT_FIELD, args.log_n))
     if do_msm:
-        p = MODULI[0]
-        G = (p - 1, 2)  # tweedledee_curve.rs:14-18
-        d = synth.to_int(synth.rand_field(1, SEED_MSM, 1)[0]) % MODULI[1]
+        from plonky_amd.selfcheck import GENERATORS
+        p = MODULI[cv["base_field"]]
+        G = GENERATORS[CURVE]  # tweedledee_curve.rs:14-18 / bls12_377_curve.rs:16-33
+        d = synth.to_int(synth.rand_field(cv["scalar_field"], SEED_MSM, 1)[0]) % MODULI[cv["scalar_field"]]
         D = _mul(p, d, G)
-        g0 = np.stack([synth.mont(0, G[0]), synth.mont(0, G[1])])
-        dd = np.stack([synth.mont(0, D[0]), synth.mont(0, D[1])])
-        first = rank * n  # this rank's contiguous base range of the global N * n MSM
-        bases = dev.gen_bases_dev(CURVE, n, g0, dd, first=first)
-        s_host = synth.rand_field(1, SEED_MSM + 1 + rank, n)
-        s = dev.to_device(s_host)
+        g0 = np.stack([synth.mont(cv["base_field"], G[0]), synth.mont(cv["base_field"], G[1])])
+        dd = np.stack([synth.mont(cv["base_field"], D[0]), synth.mont(cv["base_field"], D[1])])
+        if strong:
+            lo, hi = parallel.shard_bounds(n, rank, world)       # this rank's slice of the SAME 2^log_n generators
+            first, n_local = lo, hi - lo
+            s_host = np.stack([synth.rand_field(cv["scalar_field"], SEED_MSM + 0x900 + k, n) for k in range(batch)])
+            s = dev.to_device(np.ascontiguousarray(s_host[:, lo:hi]))
+        else:
+            first, n_local = rank * n, n                         # this rank's contiguous range of the global N * n MSM
+            s_host = synth.rand_field(cv["scalar_field"], SEED_MSM + 1 + rank, n)
+            s = dev.to_device(s_host)
+        bases = dev.gen_bases_dev(CURVE, n_local, g0, dd, first=first)
         pre = dev.msm_precompute_dev(CURVE, bases)
-        oxy = torch.empty((1, 2, 4), dtype=torch.int64, device="cuda")
-        oz = torch.empty((1,), dtype=torch.uint8, device="cuda")
+        oxy = torch.empty((batch, 2, cv["limbs"]), dtype=torch.int64, device="cuda")
+        oz = torch.empty((batch,), dtype=torch.uint8, device="cuda")
         g_pair = [None, None]  # the gathered partial points of the base-range shards
 
     def step():
@@ -168,7 +204,7 @@ def main():
         if do_msm:
             dev.msm_execute_dev(pre, s, oxy, oz)
             if world > 1:
-                # the one exchange step of the path: partial results of the base-range shards
+                # the one exchange step of the path: partial results of the base-range shards (one packed all-gather)
                 g_pair[0], g_pair[1] = parallel.all_gather_points(oxy, oz)
 
     def sync():
@@ -200,6 +236,7 @@ def main():
         elapsed = float(t.item())
 
     ntt_kernel_ms = msm_stage_ms = None
+    ntt_launches = 0
     if do_ntt:
         sm, cnt = ctypes.c_double(0), ctypes.c_uint(0)
         L.plk_ntt_get_timings(ctypes.byref(sm), ctypes.byref(cnt))
@@ -211,14 +248,11 @@ def main():
         calls = ctypes.c_uint(0)
         L.plk_msm_get_timings(pre._ctx, arr, ctypes.byref(calls))
         L.plk_msm_set_profiling(pre._ctx, 0)
-        msm_stage_ms = [v / max(1, calls.value) for v in arr]
+        msm_stage_ms = [v / max(1, calls.value) for v in arr]   # per MSM (a profiled batch runs its MSMs one by one)
 
     # ---- component timings (separate short loops, same K) so both headline numbers are reported ----
     comp = {}
-    if args.timed_only:
-        do_ntt_c = do_msm_c = False
-    else:
-        do_ntt_c, do_msm_c = do_ntt, do_msm
+    do_ntt_c, do_msm_c = (False, False) if args.timed_only else (do_ntt, do_msm)
     if do_ntt_c:
         sync()
         t1 = time.perf_counter()
@@ -245,11 +279,10 @@ def main():
         # at the sizes this n implies: divide_by_z_h of a degree < n polynomial by Z_H of n/8, LDE of 9 wires n/8 -> n
         if args.log_n >= 13:
             nq = n // 8
-            from plonky_amd import api as _api
             # m = q0 * (X^nq - 1) for a random q0 of 7 nq coefficients: m[i] = q0[i - nq] - q0[i]
             q0 = synth.rand_field(NTT_FIELD, SEED_NTT + 100 + rank, 7 * nq)
             zpad = np.zeros((nq, 4), dtype=np.uint64)
-            m = dev.to_device(_api.field_op(NTT_FIELD, "sub", np.concatenate([zpad, q0]), np.concatenate([q0, zpad])))
+            m = dev.to_device(api.field_op(NTT_FIELD, "sub", np.concatenate([zpad, q0]), np.concatenate([q0, zpad])))
             q_out = torch.empty((n, 4), dtype=torch.int64, device="cuda")
             dev.divide_by_z_h_dev(NTT_FIELD, m, nq, out=q_out)
             sync()
@@ -280,12 +313,13 @@ def main():
             dev.msm_execute_dev(pre, s, oxy, oz)
         sync()
         tm = (time.perf_counter() - t1) / args.steps
+        pairs = batch * (n if strong else world * n)
         comp["msm_ms"] = tm * 1e3
-        comp["msm_mpairs_per_s"] = world * n / tm / 1e6
-    if do_msm_c:
+        comp["msm_mpairs_per_s"] = pairs / tm / 1e6
+    if do_msm_c and not commit9:
         # commit_polynomials (plonk_util.rs:215-231): the 9 wire polynomials against the same generators, one call
         sb = s.unsqueeze(0).repeat(9, 1, 1).contiguous()
-        oxy9 = torch.empty((9, 2, 4), dtype=torch.int64, device="cuda")
+        oxy9 = torch.empty((9, 2, cv["limbs"]), dtype=torch.int64, device="cuda")
         oz9 = torch.empty((9,), dtype=torch.uint8, device="cuda")
         dev.msm_execute_dev(pre, sb, oxy9, oz9)
         sync()
@@ -297,7 +331,7 @@ def main():
         comp["msm_batch9_ms"] = tb * 1e3
         comp["msm_batch9_mpairs_per_s"] = world * 9 * n / tb / 1e6
         if not args.no_check:
-            comp["_b9_check"] = bool(torch.equal(oxy9, oxy.expand(9, 2, 4)) and int(oz9.sum().item()) == 0)
+            comp["_b9_check"] = bool(torch.equal(oxy9, oxy.expand(9, 2, cv["limbs"])) and int(oz9.sum().item()) == 0)
         del sb
         # msm_parallel (curve_msm.rs:54-61): generators used once -> precompute included, table-free mode
         sync()
@@ -313,8 +347,7 @@ def main():
             comp["_os_check"] = bool(torch.equal(oxy9[:1], oxy) and int(oz9[0].item()) == 0)
     if do_msm:
         comp["msm_window_bits"] = pre.window
-        comp["msm_stage_ms"] = dict(zip(["digits", "partition", "scan_scatter", "accumulate", "bucket_sum", "planes", "final"],
-                                        [round(v, 4) for v in msm_stage_ms]))
+        comp["msm_stage_ms"] = dict(zip(STAGES, [round(v, 4) for v in msm_stage_ms]))
 
     # ---- correctness of what was just timed (not in the timed region) ----
     checks = {}
@@ -325,28 +358,52 @@ def main():
             if "_q_check" in comp:
                 checks["divide_by_z_h_identity"] = comp.pop("_q_check")
         if do_msm:
-            got = dev.to_host(oxy).reshape(2, 4)
-            exp = closed_form_msm(CURVE, s_host, G, D, first=first)
-            gotp = (synth.from_mont(0, got[0]), synth.from_mont(0, got[1]))
-            checks["msm_closed_form_bit_exact"] = bool(int(oz.cpu()[0]) == 0 and gotp == exp)
+            got = dev.to_host(oxy).reshape(batch, 2, cv["limbs"])
+            ok = int(oz.sum().item()) == 0
+            for k in range(batch):
+                sk = s_host[k, first:first + n_local] if strong else s_host
+                exp = closed_form_msm(CURVE, sk, G, D, first=first)   # this rank's partial result
+                gotp = (synth.from_mont(cv["base_field"], got[k][0]), synth.from_mont(cv["base_field"], got[k][1]))
+                ok = ok and gotp == exp
+            checks["msm_closed_form_bit_exact"] = bool(ok)
             if "_b9_check" in comp:
                 checks["msm_batch9_equals_single"] = comp.pop("_b9_check")
             if "_os_check" in comp:
                 checks["msm_one_shot_equals_tabled"] = comp.pop("_os_check")
             if world > 1:
-                tot_xy = torch.empty((1, 2, 4), dtype=torch.int64, device="cuda")
-                tot_z = torch.empty((1,), dtype=torch.uint8, device="cuda")
-                hx, hz = dev.to_host(g_pair[0]).reshape(world, 2, 4), g_pair[1].cpu().numpy().reshape(world)
-                from plonky_amd import api
-                tot, tz = api.curve_sum_affine(CURVE, hx, hz)
-                checks["msm_global_sum_is_point"] = bool(tz == 0)
+                hx = dev.to_host(g_pair[0]).reshape(world, batch, 2, cv["limbs"])
+                hz = g_pair[1].cpu().numpy().reshape(world, batch)
+                ok = True
+                for k in range(batch):
+                    tot, tz = api.curve_sum_affine(CURVE, hx[:, k], hz[:, k])
+                    if strong:  # the global result has a closed form of its own: the whole vector against all 2^log_n generators
+                        exp = closed_form_msm(CURVE, s_host[k], G, D, first=0)
+                        ok = ok and tz == 0 and (synth.from_mont(cv["base_field"], tot[0]), synth.from_mont(cv["base_field"], tot[1])) == exp
+                    else:
+                        ok = ok and tz == 0
+                checks["msm_global_sum_closed_form" if strong else "msm_global_sum_is_point"] = bool(ok)
 
-    units_per_step = (n if do_ntt else 0) + (n if do_msm else 0)
-    value = world * units_per_step * args.steps / elapsed / 1e6
+    units_per_step = (n if do_ntt else 0) + ((batch * n) if do_msm else 0)
+    value = (1 if strong else world) * units_per_step * args.steps / elapsed / 1e6
 
-    # ---- roofline of the dominant kernel ----
-    roofline = None
+    # ---- rooflines: every kernel entry carries the integer-ALU figure (what binds these kernels) and the HBM figure ----
     rooflines = {}
+    src_hash = kernel_source_hash()
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+    except (OSError, ValueError):
+        pass
+
+    def traffic_of(kname):
+        e = pmc.get(kname)
+        # a PMC figure is only valid for the kernels it was measured on, at the size and window it was measured at
+        if not e or pmc.get("kernel_source_sha") != src_hash or e.get("log_n") != args.log_n or pmc.get("curve", "tweedledee") != args.curve:
+            return None, None
+        return e["bytes_per_launch"], e.get("source")
+
+    valu_peak = VALU_PEAK_GMODMUL if args.curve == "tweedledee" else None
     if do_ntt and ntt_launches:
         per_launch_ms = ntt_kernel_ms / ntt_launches
         launches_per_ntt = ntt_launches / args.steps
@@ -354,54 +411,55 @@ def main():
         # one launch of the pass kernel handles all n elements once => 64 B * n / launches_per_ntt per launch
         alg_bytes = 64.0 * n / launches_per_ntt
         ach = alg_bytes / (per_launch_ms * 1e-3) / 1e9
-        rooflines["ntt_pass"] = {"kernel": "k_ntt_pass", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": ach / HBM_PEAK_GBS, "traffic": None, "launch_ms": per_launch_ms,
-                                 "launches_per_transform": launches_per_ntt,
-                                 "modmul_per_s": (n / 2.0 * args.log_n) / (per_launch_ms * launches_per_ntt * 1e-3)}
+        gmm = (n / 2.0 * args.log_n) / (per_launch_ms * launches_per_ntt * 1e-3) / 1e9   # algorithmic: n/2 log n multiplications
+        tr, src = traffic_of("k_ntt_pass")
+        rooflines["ntt_pass"] = {"kernel": "k_ntt_pass", "bound": "valu", "achieved": gmm, "peak": valu_peak, "unit": "G modmul/s",
+                                 "frac": gmm / valu_peak if valu_peak else None, "traffic": tr, "traffic_source": src,
+                                 "hbm": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                         "algorithmic_bytes_per_launch": alg_bytes},
+                                 "launch_ms": per_launch_ms, "launches_per_transform": launches_per_ntt,
+                                 "note": "VALU-bound (DESIGN.md section 4): achieved counts the algorithmic n/2 log n multiplications; the kernel executes more (inter-pass twiddles)"}
     if do_msm:
         acc_ms = msm_stage_ms[3]
-        alg_bytes = 96.0 * n  # 64 B affine base + 32 B scalar per pair
+        alg_bytes = float(cv["pair_bytes"]) * n_local   # affine base + 32 B scalar per pair, one MSM
         ach = alg_bytes / (acc_ms * 1e-3) / 1e9
-        windows = (255 + 1 + pre.window - 1) // pre.window
-        rooflines["msm_accumulate"] = {"kernel": "k_msm_accumulate", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": ach / HBM_PEAK_GBS, "traffic": None, "launch_ms": acc_ms,
-                                       "mixed_adds_per_s": n * windows / (acc_ms * 1e-3),
-                                       "note": "int-ALU bound (~10 modmul per mixed add), HBM fraction is expected to be << 1"}
-    # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE need two
-    # separate passes and cannot be sampled from inside this process): profiles/r01_pmc_traffic.json
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            pmc = json.load(fh)
-        for key, kname in (("ntt_pass", "k_ntt_pass"), ("msm_accumulate", "k_msm_accumulate")):
-            if key in rooflines and kname in pmc and pmc[kname].get("log_n") == args.log_n:
-                rooflines[key]["traffic"] = pmc[kname]["bytes_per_launch"]
-                rooflines[key]["traffic_source"] = pmc[kname]["source"]
-    except (OSError, ValueError):
-        pass
+        windows = (cv["scalar_bits"] + 1 + pre.window - 1) // pre.window
+        adds = n_local * windows
+        gmm = adds * 10.0 / (acc_ms * 1e-3) / 1e9        # a mixed XYZZ addition = 8 M + 2 S
+        tr, src = traffic_of("k_msm_accumulate")
+        rooflines["msm_accumulate"] = {"kernel": "k_msm_accumulate", "bound": "valu", "achieved": gmm, "peak": valu_peak, "unit": "G modmul/s",
+                                       "frac": gmm / valu_peak if valu_peak else None, "traffic": tr, "traffic_source": src,
+                                       "hbm": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                               "algorithmic_bytes_per_launch": alg_bytes},
+                                       "launch_ms": acc_ms, "mixed_adds_per_s": adds / (acc_ms * 1e-3),
+                                       "note": "integer-ALU bound by construction (~2 modmul per algorithmic byte); the HBM fraction is reported because the metric asks for it"}
+    roofline = None
     if rooflines:
-        dom = max(rooflines.values(), key=lambda r: r["launch_ms"] * (r.get("launches_per_transform", 1)))
-        roofline = dom
+        roofline = max(rooflines.values(), key=lambda r: r["launch_ms"] * (r.get("launches_per_transform", 1)))
 
+    wl = {"both": "2^%d %s forward NTT + 2^%d-pair %s MSM per GPU per step" % (args.log_n, "TweedledeeBase" if args.curve == "tweedledee" else "Bls12377Scalar", args.log_n, args.curve),
+          "ntt": "2^%d forward NTT per GPU per step" % args.log_n,
+          "msm": "2^%d-pair %s MSM per GPU per step" % (args.log_n, args.curve),
+          "commit9": "9-wire commitment batch: nine 2^%d-pair %s MSMs against the same generators per step (generators sharded by base range over the GPUs)" % (args.log_n, args.curve)}[args.workload]
     result = {
         "metric": "MSM Mpairs/sec + NTT Melems/sec, 2^20 Tweedledee, 1/2/4/8 GPU",
         "value": value,
         "unit": "M units/s (1 unit = 1 NTT element or 1 MSM scalar-point pair; components below)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": {"both": "2^%d TweedledeeBase forward NTT + 2^%d-pair Tweedledee MSM per GPU per step" % (args.log_n, args.log_n),
-                                "ntt": "2^%d TweedledeeBase forward NTT per GPU per step" % args.log_n,
-                                "msm": "2^%d-pair Tweedledee MSM per GPU per step" % args.log_n}[args.workload],
-                   "log_n": args.log_n, "sharding": "independent NTTs; MSM sharded by base range + all-gather of partial points" if world > 1 else "single GPU",
-                   "seeds": {"ntt": SEED_NTT, "msm": SEED_MSM}},
+        "config": {"workload": wl, "log_n": args.log_n, "curve": args.curve,
+                   "sharding": ("generators sharded by base range + one packed all-gather of partial points" if strong else
+                                "independent NTTs; MSM sharded by base range + one packed all-gather of partial points") if world > 1 else "single GPU",
+                   "seeds": {"ntt": SEED_NTT, "msm": SEED_MSM}, "kernel_source_sha": src_hash},
         "components": comp,
         "checks": checks,
         "roofline": roofline,
         "rooflines": rooflines,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.workload)
+        result["cpu_baseline"] = cpu_baseline(args.workload, cv)
     if rank == 0:
         print(json.dumps(result))
     assert all(checks.values()), "self-check failed: %r" % checks

@@ -409,25 +409,102 @@ template <class P> struct Fp {
 // =============================================================================================
 // A tiny fork-join pool standing in for Rayon's work-stealing pool.
 // =============================================================================================
+// Persistent workers (Rayon keeps its pool alive across calls; forking fresh threads per NTT layer would charge the baseline
+// twenty thread start-ups per transform).  One job at a time (callers are serialised by job_mu); workers take task indices from a
+// shared counter, the calling thread works too.
+class WorkerPool {
+public:
+    static WorkerPool& get() {
+        static WorkerPool p;
+        return p;
+    }
+    void run(size_t n_tasks, int threads, const std::function<void(size_t)>& fn) {
+        std::lock_guard<std::mutex> job_lock(job_mu_);
+        const int helpers = (int)std::min<size_t>((size_t)threads - 1, n_tasks - 1);
+        ensure_workers(helpers);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn;
+            n_tasks_ = n_tasks;
+            next_.store(0);
+            active_ = helpers;
+            wanted_ = helpers;
+            ++generation_;
+        }
+        cv_start_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return active_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    WorkerPool() = default;
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+            ++generation_;
+        }
+        cv_start_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void work() {
+        for (;;) {
+            const size_t i = next_.fetch_add(1);
+            if (i >= n_tasks_) break;
+            (*fn_)(i);
+        }
+    }
+    void ensure_workers(int helpers) {
+        while ((int)workers_.size() < helpers) {
+            const int id = (int)workers_.size();
+            uint64_t born;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                born = generation_;  // jobs published before this worker existed are not its business
+            }
+            workers_.emplace_back([this, id, born] {
+                uint64_t seen = born;
+                for (;;) {
+                    {
+                        std::unique_lock<std::mutex> lk(mu_);
+                        cv_start_.wait(lk, [&] { return generation_ != seen; });
+                        seen = generation_;
+                        if (stop_) return;
+                        if (id >= wanted_) continue;  // this job uses fewer helpers
+                    }
+                    work();
+                    std::lock_guard<std::mutex> lk(mu_);
+                    if (--active_ == 0) cv_done_.notify_one();
+                }
+            });
+        }
+    }
+    std::mutex job_mu_, mu_;
+    std::condition_variable cv_start_, cv_done_;
+    std::vector<std::thread> workers_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t n_tasks_ = 0;
+    std::atomic<size_t> next_{0};
+    int active_ = 0, wanted_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+
+static thread_local bool t_in_parallel_for = false;
 static void parallel_for(size_t n_tasks, int threads, const std::function<void(size_t)>& fn) {
-    if (threads <= 1 || n_tasks <= 1) {
+    if (threads <= 1 || n_tasks <= 1 || t_in_parallel_for) {  // a nested loop runs on the thread that reached it
         for (size_t i = 0; i < n_tasks; ++i) fn(i);
         return;
     }
-    std::atomic<size_t> next{0};
-    auto worker = [&]() {
-        for (;;) {
-            size_t i = next.fetch_add(1);
-            if (i >= n_tasks) break;
-            fn(i);
-        }
+    const std::function<void(size_t)> guarded = [&](size_t i) {
+        const bool was = t_in_parallel_for;
+        t_in_parallel_for = true;
+        fn(i);
+        t_in_parallel_for = was;
     };
-    int t = (int)std::min<size_t>(threads, n_tasks);
-    std::vector<std::thread> pool;
-    pool.reserve(t - 1);
-    for (int i = 0; i < t - 1; ++i) pool.emplace_back(worker);
-    worker();
-    for (auto& th : pool) th.join();
+    WorkerPool::get().run(n_tasks, threads, guarded);
 }
 
 // =============================================================================================

@@ -13,6 +13,13 @@ from .synth import MODULI
 
 CURVE_BASE = {0: 0, 1: 1, 2: 3}
 CURVE_SCALAR = {0: 1, 1: 0, 2: 2}
+# GENERATOR_AFFINE of the curves the harness uses, canonical integers: tweedledee_curve.rs:14-18 (NEG_ONE, TWO) and
+# bls12_377_curve.rs:16-33 (the decimal values of its doc comments)
+GENERATORS = {
+    0: (MODULI[0] - 1, 2),
+    2: (81937999373150964239938255573465948239988671502647976594219695644855304257327692006745978603320413799295628339695,
+        241266749859715473739788878240585681733927191168601896383759122102112907357779751001206799952863815012735208165030),
+}
 
 
 def _add(p, P, Q):
