@@ -234,6 +234,31 @@ template <class P> PLK_DI Fz<P> fz_sqr(const Fz<P>& a) {
     return r;
 }
 
+// ---- reduction without a multiplication ----------------------------------------------------------
+// value < 2^(29 NZ - 2) with lazy limbs  ->  value below 2p congruent to it, without a multiplication: q = an under-estimate
+// of floor(v / p) from the top 30 bits, v - q p by one multiply-subtract per limb.  Replaces the "multiplication by one" that
+// only served to reduce the outputs of the last pass (~220 instructions) by ~70.
+template <class P> PLK_DI Fz<P> fz_reduce_small(Fz<P> v) {
+    constexpr int NZ = FzCfg<P>::NZ;
+    fz_normalize<P>(v);
+    // top = floor(v / 2^(29 (NZ - 1) - 3)): the top limb (< 2^27 for v < 2^(29 NZ - 2)) and the upper 3 bits of the one below
+    const uint32_t top = (v.l[NZ - 1] << 3) | (v.l[NZ - 2] >> 26);
+    constexpr uint32_t p_top = (FzCfg<P>::plimb(NZ - 1) << 3) | (FzCfg<P>::plimb(NZ - 2) >> 26);  // floor(p / 2^(29 (NZ - 1) - 3)), >= 2^23
+    const uint32_t q = top / (p_top + 1u);  // <= floor(v / p), short of it by at most 1 (division by a constant)
+    int64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        acc += (int64_t)v.l[i] - (int64_t)((uint64_t)q * FzCfg<P>::plimb(i));
+        if (i < NZ - 1) {
+            v.l[i] = (uint32_t)acc & FzCfg<P>::M;
+            acc >>= 29;  // arithmetic: a borrow travels as -1
+        } else {
+            v.l[i] = (uint32_t)acc;
+        }
+    }
+    return v;  // in [0, 2p)
+}
+
 // ---- predicates --------------------------------------------------------------------------------
 // value == 0 mod p for a value < 2p with exactly normalised limbs (what fz_mul / fz_sqr return)
 template <class P> PLK_DI bool fz_is_zero_mod_p(const Fz<P>& a) {

@@ -95,8 +95,40 @@ template <class P> __global__ void k_ntt_fill_inner(uint4* tw, const uint4* pw, 
     uint64_t ex = (uint64_t)e << (log_t - INNER_LOG);
     fe_store<P>(tw + e * 2, to_rprime<P>(pow_from_table<P>(pw, inverse ? 32 : 0, ex, log_t)));
 }
-// outer table of a pass: W[k * S + r] = w_{N_t}^(+- r k) (* n^-1 when scale != 0)
-template <class P> __global__ void k_ntt_fill_outer(uint4* tw, const uint4* pw, int log_t, int log_nt, int log_s, int inverse, int scale) {
+// Limb form in global memory: the NZ 29-bit limbs of an element in NZ consecutive words, padded to a multiple of four words
+// (48 B per element for the 256-bit fields), read and written with 16-byte accesses like the reference's own 32-byte
+// elements - but without any re-slicing between 32-bit words and 29-bit limbs.  Used for the data between two passes (values
+// below 2p with exactly normalised limbs, as the exit multiplication leaves them) and for the inter-pass twiddle tables.
+// (A planar layout with 4-byte accesses was measured too: 10 % faster on a batch of 9 transforms, 5 % slower on a single one,
+// whose passes are one round of workgroups and therefore sensitive to the number of memory instructions in flight.)
+template <class P> constexpr int limb_u4() { return (FzCfg<P>::NZ + 3) / 4; }
+template <class P> PLK_DI Fz<P> limbs_load(const uint32_t* __restrict__ base, size_t e) {
+    constexpr int NZ = FzCfg<P>::NZ, U = limb_u4<P>();
+    const uint4* p = reinterpret_cast<const uint4*>(base) + e * U;
+    uint32_t w[4 * U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const uint4 v = p[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    Fz<P> r;
+#pragma unroll
+    for (int l = 0; l < NZ; ++l) r.l[l] = w[l];
+    return r;
+}
+template <class P> PLK_DI void limbs_store(uint32_t* __restrict__ base, size_t e, const Fz<P>& v) {
+    constexpr int NZ = FzCfg<P>::NZ, U = limb_u4<P>();
+    uint4* p = reinterpret_cast<uint4*>(base) + e * U;
+    uint32_t w[4 * U];
+#pragma unroll
+    for (int l = 0; l < 4 * U; ++l) w[l] = l < NZ ? v.l[l] : 0u;
+#pragma unroll
+    for (int i = 0; i < U; ++i) p[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+constexpr size_t limb_bytes(size_t elems, int nz) { return elems * (size_t)((nz + 3) / 4) * 16; }
+
+// outer table of a pass: W[k * S + r] = w_{N_t}^(+- r k) (* n^-1 when scale != 0), R'-form, limb form
+template <class P> __global__ void k_ntt_fill_outer(uint32_t* tw, const uint4* pw, int log_t, int log_nt, int log_s, int inverse, int scale) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ((size_t)1 << log_nt)) return;
     uint64_t r = idx & (((uint64_t)1 << log_s) - 1);
@@ -105,7 +137,7 @@ template <class P> __global__ void k_ntt_fill_outer(uint4* tw, const uint4* pw, 
     ex <<= (log_t - log_nt);
     Fe<P> v = pow_from_table<P>(pw, inverse ? 32 : 0, ex, log_t);
     if (scale) v = fe_mul<P>(v, fe_load<P>(pw + 64 * 2));
-    fe_store<P>(tw + idx * 2, to_rprime<P>(v));
+    limbs_store<P>(tw, idx, fz_from_fe<P>(to_rprime<P>(v)));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -125,25 +157,6 @@ template <class P> PLK_DI void lds_store(uint32_t* base, int stride, int idx, co
 #pragma unroll
     for (int l = 0; l < FzCfg<P>::NZ; ++l) base[l * stride + idx] = v.l[l];
 }
-
-// Timing experiments (tools/ntt_experiments.sh): -DPLK_NTT_EXP=1 replaces the stage multiplications by
-// additions, 2 every multiplication, 3 drops the stage loops, 6 replaces all global loads by synthetic values and
-// drops the stores (7: real loads, no stores; 8: synthetic loads, real stores; 10 / 11: as 7 / 0 but every pass reads the
-// caller's input, i.e. full-entropy data that no launch has written).  Results are wrong by construction;
-// the product build leaves PLK_NTT_EXP undefined.
-#ifndef PLK_NTT_EXP
-#define PLK_NTT_EXP 0
-#endif
-#if PLK_NTT_EXP >= 1 && PLK_NTT_EXP <= 3
-#define STAGE_MUL(P, a, b) fz_add<P>(a, b)
-#else
-#define STAGE_MUL(P, a, b) fz_mul<P>(a, b)
-#endif
-#if PLK_NTT_EXP >= 2 && PLK_NTT_EXP <= 3
-#define OUT_MUL(P, a, b) fz_add<P>(a, b)
-#else
-#define OUT_MUL(P, a, b) fz_mul<P>(a, b)
-#endif
 
 // b^i from a two-level geometric table (R'-form): hi[i >> 10] * lo[i & 1023], < 1.01p
 template <class P> PLK_DI Fz<P> geom_pow(const void* lo, const void* hi, size_t i) {
@@ -214,7 +227,7 @@ PLK_DI size_t tile_tw_index(const NttPassArgs& a, const TileGeom& t, int e) {
 // trips and barriers of a radix-2 sweep, same multiplications).  Ends with a barrier.
 template <class P> PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw, int tid, int log_a, int log_q, int tile_elems) {
     const int Q = 1 << log_q, half_a = (1 << log_a) >> 1;
-    int log_h = PLK_NTT_EXP == 3 ? log_a : 0;
+    int log_h = 0;
     for (; log_h + 1 < log_a; log_h += 2) {
         const int h = 1 << log_h;
         for (int qd = tid; qd < (tile_elems >> 2); qd += NTT_THREADS) {
@@ -226,19 +239,19 @@ template <class P> PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw
             // stage with half-size h: pairs (x0, x1), (x2, x3), twiddle w_{2h}^j for both
             if (log_h > 0) {
                 const Fz<P> wa = lds_load<P>(s_tw, half_a, j << (log_a - 1 - log_h));
-                x1 = STAGE_MUL(P, x1, wa);
-                x3 = STAGE_MUL(P, x3, wa);
+                x1 = fz_mul<P>(x1, wa);
+                x3 = fz_mul<P>(x3, wa);
             }
             Fz<P> y0 = fz_add<P>(x0, x1), y1 = fz_sub<P, 1>(x0, x1);
             Fz<P> y2 = fz_add<P>(x2, x3), y3 = fz_sub<P, 1>(x2, x3);
             // stage with half-size 2h: pairs (y0, y2) with w_{4h}^j and (y1, y3) with w_{4h}^(j+h)
             const Fz<P> wb1 = lds_load<P>(s_tw, half_a, (j + h) << (log_a - 2 - log_h));
-            y3 = STAGE_MUL(P, y3, wb1);
+            y3 = fz_mul<P>(y3, wb1);
             lds_store<P>(s_dat, TILE, i0 + st, fz_add<P>(y1, y3));
             lds_store<P>(s_dat, TILE, i0 + 3 * st, fz_sub<P, 1>(y1, y3));
             if (log_h > 0) {
                 const Fz<P> wb0 = lds_load<P>(s_tw, half_a, j << (log_a - 2 - log_h));
-                y2 = STAGE_MUL(P, y2, wb0);
+                y2 = fz_mul<P>(y2, wb0);
                 lds_store<P>(s_dat, TILE, i0, fz_add<P>(y0, y2));
                 lds_store<P>(s_dat, TILE, i0 + 2 * st, fz_sub<P, 1>(y0, y2));
             } else {
@@ -258,7 +271,7 @@ template <class P> PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw
             const int i0 = (((blk << (log_h + 1)) + j) << log_q) + q, i1 = i0 + (h << log_q);
             const Fz<P> x = lds_load<P>(s_dat, TILE, i0);
             Fz<P> t = lds_load<P>(s_dat, TILE, i1);
-            if (log_h > 0) t = STAGE_MUL(P, t, lds_load<P>(s_tw, half_a, j << (log_a - 1 - log_h)));  // w_{2h}^j, product < 1.2p
+            if (log_h > 0) t = fz_mul<P>(t, lds_load<P>(s_tw, half_a, j << (log_a - 1 - log_h)));  // w_{2h}^j, product < 1.2p
             lds_store<P>(s_dat, TILE, i0, fz_add<P>(x, t));
             lds_store<P>(s_dat, TILE, i1, fz_sub<P, 1>(x, t));  // t < 2p - margin in both cases
         }
@@ -277,35 +290,36 @@ template <class P, bool HOOKS> PLK_DI Fz<P> tile_ingest(const NttPassArgs& a, co
     }
     return x;
 }
-// the multiplication every output gets on its way out (brings the value below 2p): the outer twiddle of a
-// non-last pass (tw), or 1 / n^-1 and the hooks of the last pass
+// what every output gets on its way out: the outer twiddle of a non-last pass (tw), or the factor 1 / n^-1 and the hooks of
+// the last pass.  Returns a value below 2p with exactly normalised limbs.
 template <class P, bool HOOKS>
-PLK_DI Fe<P> tile_emit(const NttPassArgs& a, const NttHooks& hk, Fz<P> v, const Fe<P>& tw, const Fz<P>& scale, size_t g) {
-    if (!a.last) {
-        v = OUT_MUL(P, v, fz_from_fe<P>(tw));
-    } else {
-        Fz<P> mult = scale;  // 1 or n^-1 (R'-form)
-        if constexpr (HOOKS) {
-            // g is the natural output index; every factor is an R'-form value below 2p
-            if (hk.out_tab) {
-                const Fz<P> t = fz_from_fe<P>(fe_load<P>((const uint4*)hk.out_tab + (g & hk.out_mask) * 2));
-                mult = a.scale ? fz_mul<P>(t, scale) : t;
-            }
-            if (hk.out_lo) {
-                const Fz<P> pw = geom_pow<P>(hk.out_lo, hk.out_hi, g);
-                mult = (a.scale || hk.out_tab) ? fz_mul<P>(mult, pw) : pw;
-            }
+PLK_DI Fz<P> tile_emit(const NttPassArgs& a, const NttHooks& hk, Fz<P> v, const Fz<P>& tw, const Fz<P>& scale, size_t g) {
+    if (!a.last) return fz_mul<P>(v, tw);
+    bool have = a.scale != 0;
+    Fz<P> mult = scale;  // n^-1 (R'-form) when a.scale
+    if constexpr (HOOKS) {
+        // g is the natural output index; every factor is an R'-form value below 2p
+        if (hk.out_tab) {
+            const Fz<P> t = fz_from_fe<P>(fe_load<P>((const uint4*)hk.out_tab + (g & hk.out_mask) * 2));
+            mult = have ? fz_mul<P>(t, mult) : t;
+            have = true;
         }
-        v = OUT_MUL(P, v, mult);
+        if (hk.out_lo) {
+            const Fz<P> pw = geom_pow<P>(hk.out_lo, hk.out_hi, g);
+            mult = have ? fz_mul<P>(mult, pw) : pw;
+            have = true;
+        }
     }
-    return fz_to_fe_canonical<P>(v);
+    return have ? fz_mul<P>(v, mult) : fz_reduce_small<P>(v);
 }
 
-// One tile per workgroup; any tile shape (transforms shorter than a tile included).
-template <class P, bool HOOKS>
-__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* in, uint4* out,
-                                                          const uint4* __restrict__ inner_tw, const uint4* __restrict__ outer_tw,
-                                                          const uint4* __restrict__ scale_ptr, NttPassArgs a, NttHooks hk) {
+// One tile per workgroup; any tile shape (transforms shorter than a tile included).  IN_LIMBS / OUT_LIMBS: the pass reads /
+// writes the library's own scratch buffer in limb form (every pass but the first / the last); the caller's buffers are the
+// reference's 32-byte elements.  `in` and `out` may be the same buffer (a tile reads all of its elements before it writes).
+template <class P, bool HOOKS, bool IN_LIMBS, bool OUT_LIMBS>
+__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const void* in, void* out, const uint4* __restrict__ inner_tw,
+                                                          const uint32_t* __restrict__ outer_tw, const uint4* __restrict__ scale_ptr, NttPassArgs a,
+                                                          NttHooks hk) {
     static_assert(P::NL == 8, "NTT kernels are written for the 256-bit fields");
     constexpr int NZ = FzCfg<P>::NZ;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
@@ -318,9 +332,6 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* in, uint4
     uint32_t* s_tw = s_mem + NZ * TILE;
 
     const TileGeom tg = tile_geom(a, blockIdx.x);
-    const uint4* inb = in + tg.b * ((HOOKS && a.first) ? hk.in_stride : n) * 2;
-    uint4* outb = out + tg.b * n * 2;
-
     // stage twiddles (R'-form): w_A^e = inner[e * (1024 / A)], e < A/2
     for (int e = tid; e < half_a; e += NTT_THREADS) {
         const Fe<P> w = fe_load<P>(inner_tw + ((size_t)e << (INNER_LOG - log_a)) * 2);
@@ -328,46 +339,27 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const uint4* in, uint4
     }
     for (int e = tid; e < tile_elems; e += NTT_THREADS) {
         const size_t g = tile_in_index(a, tg, e);
-        Fe<P> v = fe_zero<P>();
-#if PLK_NTT_EXP == 6 || PLK_NTT_EXP == 8
-        for (int l = 0; l < 8; ++l) {  // no memory traffic, full-entropy limbs
-            uint32_t h = ((uint32_t)g * 8u + l + a.log_s) * 0x9e3779b9u;
-            h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-            v.v[l] = h;
+        Fz<P> x;
+        if constexpr (IN_LIMBS) {
+            x = limbs_load<P>((const uint32_t*)in, tg.b * n + g);
+        } else {
+            const uint4* inb = (const uint4*)in + tg.b * ((HOOKS && a.first) ? hk.in_stride : n) * 2;
+            Fe<P> v = fe_zero<P>();
+            if (!HOOKS || !a.first || g < hk.in_len) v = fe_load<P>(inb + g * 2);
+            x = tile_ingest<P, HOOKS>(a, hk, v, g);
         }
-        v.v[7] &= 0x0fffffffu;
-#else
-        if (!HOOKS || !a.first || g < hk.in_len) v = fe_load<P>(inb + g * 2);
-#endif
-        lds_store<P>(s_dat, TILE, tile_in_slot(a, e), tile_ingest<P, HOOKS>(a, hk, v, g));
+        lds_store<P>(s_dat, TILE, tile_in_slot(a, e), x);
     }
     __syncthreads();
     tile_stages<P>(s_dat, s_tw, tid, log_a, log_q, tile_elems);
     const Fz<P> scale = fz_from_fe<P>(fe_load<P>(scale_ptr));
     for (int e = tid; e < tile_elems; e += NTT_THREADS) {
         const size_t g = tile_out_index(a, tg, e);
-        Fe<P> tw = fe_zero<P>();
-#if PLK_NTT_EXP == 6 || PLK_NTT_EXP == 7 || PLK_NTT_EXP == 8 || PLK_NTT_EXP == 10
-#if PLK_NTT_EXP == 7 || PLK_NTT_EXP == 10
-        if (!a.last) tw = fe_load<P>(outer_tw + tile_tw_index(a, tg, e) * 2);
-#else
-        for (int l = 0; l < 8; ++l) {
-            uint32_t h = ((uint32_t)g * 8u + l + 77u) * 0x85ebca6bu;
-            h ^= h >> 15; h *= 0x9e3779b9u; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-            tw.v[l] = h;
-        }
-        tw.v[7] &= 0x0fffffffu;
-#endif
-        const Fe<P> r = tile_emit<P, HOOKS>(a, hk, lds_load<P>(s_dat, TILE, e), tw, scale, g);
-#if PLK_NTT_EXP == 8
-        fe_store<P>(outb + g * 2, r);
-#else
-        if (r.v[0] == 0x12345678u && r.v[5] == 0x9abcdef0u) fe_store<P>(outb + g * 2, r);  // practically never
-#endif
-#else
-        if (!a.last) tw = fe_load<P>(outer_tw + tile_tw_index(a, tg, e) * 2);
-        fe_store<P>(outb + g * 2, tile_emit<P, HOOKS>(a, hk, lds_load<P>(s_dat, TILE, e), tw, scale, g));
-#endif
+        Fz<P> tw = fz_zero<P>();
+        if (!a.last) tw = limbs_load<P>(outer_tw, tile_tw_index(a, tg, e));
+        const Fz<P> r = tile_emit<P, HOOKS>(a, hk, lds_load<P>(s_dat, TILE, e), tw, scale, g);
+        if constexpr (OUT_LIMBS) limbs_store<P>((uint32_t*)out, tg.b * n + g, r);
+        else fe_store<P>((uint4*)out + (tg.b * n + g) * 2, fz_to_fe_canonical<P>(r));
     }
 }
 
@@ -483,10 +475,10 @@ template <class P> static int build_plan_t(NttPlan& pl) {
         for (int t = 0; t + 1 < m; ++t) {
             const int log_s = log_nt - pl.pass_log[t];
             void* tab = nullptr;
-            PLK_HIP_TRY(hipMalloc(&tab, ((size_t)1 << log_nt) * 32));
+            PLK_HIP_TRY(hipMalloc(&tab, limb_bytes((size_t)1 << log_nt, FzCfg<P>::NZ)));
             pl.outer[dir].push_back(tab);
             const size_t cnt = (size_t)1 << log_nt;
-            k_ntt_fill_outer<P><<<(unsigned)((cnt + 255) / 256), 256>>>((uint4*)tab, (const uint4*)pl.pw, log_t, log_nt, log_s, dir,
+            k_ntt_fill_outer<P><<<(unsigned)((cnt + 255) / 256), 256>>>((uint32_t*)tab, (const uint4*)pl.pw, log_t, log_nt, log_s, dir,
                                                                         (dir == 1 && t == 0) ? 1 : 0);
             PLK_HIP_TRY(hipGetLastError());
             log_nt = log_s;
@@ -551,7 +543,7 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
     // buffer and the last pass writes the caller's output.
     void* scratch = nullptr;
     if (m >= 2) {
-        scratch = scratch_acquire(((size_t)batch << log_n) * 32, stream);
+        scratch = scratch_acquire(limb_bytes((size_t)batch << log_n, FzCfg<P>::NZ), stream);
         if (!scratch) return PLK_ERR_OOM;
     }
     int log_nt = log_n;
@@ -584,24 +576,28 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
         const uint4* scale = (const uint4*)pl.pw + (a.scale ? 66 : 65) * 2;
         const bool use_hooks = hooks && (a.first || a.last);
         const NttHooks hk = use_hooks ? *hooks : NttHooks{};
-        if (use_hooks) {
-            k_ntt_pass<P, true><<<(unsigned)tiles, NTT_THREADS, lds_bytes, stream>>>((const uint4*)src, (uint4*)dst, (const uint4*)pl.inner[dir],
-                                                                                   (const uint4*)outer, scale, a, hk);
+        const unsigned tl = (unsigned)tiles;
+        const uint32_t* otw = (const uint32_t*)outer;
+        // the first pass reads the caller's elements, the last one writes them; everything in between is limb form in scratch
+#define PLK_NTT_LAUNCH(H, IL, OL) \
+    k_ntt_pass<P, H, IL, OL><<<tl, NTT_THREADS, lds_bytes, stream>>>(src, dst, (const uint4*)pl.inner[dir], otw, scale, a, hk)
+        if (a.first && a.last) {
+            if (use_hooks) PLK_NTT_LAUNCH(true, false, false); else PLK_NTT_LAUNCH(false, false, false);
+        } else if (a.first) {
+            if (use_hooks) PLK_NTT_LAUNCH(true, false, true); else PLK_NTT_LAUNCH(false, false, true);
+        } else if (a.last) {
+            if (use_hooks) PLK_NTT_LAUNCH(true, true, false); else PLK_NTT_LAUNCH(false, true, false);
         } else {
-            k_ntt_pass<P, false><<<(unsigned)tiles, NTT_THREADS, lds_bytes, stream>>>((const uint4*)src, (uint4*)dst, (const uint4*)pl.inner[dir],
-                                                                                    (const uint4*)outer, scale, a, hk);
+            PLK_NTT_LAUNCH(false, true, true);
         }
+#undef PLK_NTT_LAUNCH
         if (prof) prof_end(stream, pev);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             rc = set_error(PLK_ERR_HIP, "ntt pass launch failed: %s", hipGetErrorString(e));
             break;
         }
-#if PLK_NTT_EXP == 10 || PLK_NTT_EXP == 11
-        src = hooks ? dst : d_in;  // experiment: every pass reads the caller's (random, never modified) input
-#else
         src = dst;
-#endif
         log_nt = a.log_s;
     }
     if (scratch) scratch_release(scratch, stream);

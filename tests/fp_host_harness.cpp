@@ -47,6 +47,12 @@ template <class P> static void run(int op, const uint32_t* a, const uint32_t* b,
                 r = fe_zero<P>();
                 r.v[0] = fz_is_zero_mod_p<P>(m) ? 1u : 0u;
             } break;
+            case 19: {  // x + 13 y through lazy additions (< 14p, like the output of a tile's last stage), reduced without a multiplication
+                Fz<P> v = fz_from_fe<P>(x);
+                const Fz<P> yz = fz_from_fe<P>(y);
+                for (int k = 0; k < 13; ++k) v = fz_add<P>(v, yz);
+                r = fz_to_fe_canonical<P>(fz_reduce_small<P>(v));
+            } break;
             default: r = fe_neg<P>(x); break;
         }
         for (int k = 0; k < P::NL; ++k) out[i * P::NL + k] = r.v[k];

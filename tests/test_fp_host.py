@@ -98,6 +98,7 @@ def test_lazy_29bit_arithmetic_on_host(host_lib, f):
     got_lin = run(host_lib, f, 13, a, b)
     got_chain = run(host_lib, f, 16, a, b)
     got_zero = run(host_lib, f, 17, a, b)
+    got_red = run(host_lib, f, 19, a, b) if n == 4 else None  # fz_reduce_small: the NTT fields
     k = 0
     for i in range(m):
         ai = inputs[i]
@@ -109,6 +110,8 @@ def test_lazy_29bit_arithmetic_on_host(host_lib, f):
             v = (ai + bj) * bj * Rp_inv
             assert got_chain[k] == (u - 2 * v) * (ai - bj) * Rp_inv % p
             assert got_zero[k] == (1 if ai * bj % p == 0 else 0)
+            if got_red is not None:
+                assert got_red[k] == (ai + 13 * bj) % p
             k += 1
     # the value p itself (== 0 mod p) as an operand exercises the second branch of the zero test
     pw = ints_to_array([p] * 3, n)
