@@ -5,6 +5,8 @@ Corrections follow MI355X_MICROARCH.md: the counters are in KiB (x1024); on gfx9
 exactly 1/2 of a wide coalesced 16-byte-per-lane stream - that is the NTT pass kernel's access
 pattern, so its fetch figure is doubled; the MSM accumulation gathers 64-byte points at random
 (4 x 16 B per lane), an uncalibrated pattern, so its raw figure is kept and flagged.
+The output carries the hash of the device sources it was measured on (bench.py's kernel_source_hash): bench.py only reports
+a traffic figure while the kernels are the ones that were measured.
 Usage: python tools/pmc_traffic.py <fetch.db> <write.db> <log_n> <out.json>"""
 import json
 import sqlite3
@@ -29,7 +31,10 @@ def per_kernel(path, counter):
 def main(fetch_db, write_db, log_n, out_path):
     f = per_kernel(fetch_db, "FETCH_SIZE")
     w = per_kernel(write_db, "WRITE_SIZE")
-    res = {}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_hash
+    res = {"kernel_source_sha": kernel_source_hash(), "curve": "tweedledee"}
     for short, fetch_factor, note in (("k_ntt_pass", 2.0, "FETCH_SIZE x2 (wide coalesced stream, gfx950 correction)"),
                                       ("k_msm_accumulate", 1.0, "FETCH_SIZE uncorrected (random 64-byte gathers, uncalibrated pattern)")):
         fk = [k for k in f if short in k]
