@@ -11,7 +11,7 @@
  *    src/util.rs:17, src/field/field.rs:430 -- the shim turns a negative code into a panic);
  *  - all buffers are caller-owned; field elements are the reference's in-memory limbs:
  *    little-endian u64 limbs, MONTGOMERY form, fully reduced (src/field/tweedledee_base.rs:14-18),
- *    4 limbs for TweedledeeBase / TweedledumBase / Bls12377Scalar, 6 for Bls12377Base;
+ *    4 limbs for TweedledeeBase / TweedledumBase / Bls12377Scalar / PallasBase / VestaBase, 6 for Bls12377Base;
  *  - affine points cross the boundary as x limbs followed by y limbs (2*L u64) plus one
  *    "zero" byte per point (AffinePoint.zero, src/curve/curve.rs:74-78); the structs are not
  *    repr(C), so the shim copies fields explicitly;
@@ -46,10 +46,14 @@ extern "C" {
 #define PLK_FIELD_TWEEDLEDUM_BASE 1
 #define PLK_FIELD_BLS12_377_SCALAR 2
 #define PLK_FIELD_BLS12_377_BASE 3 /* curve coordinates only; no NTT entry point needs it */
+#define PLK_FIELD_PALLAS_BASE 4    /* src/field/pallas_base.rs */
+#define PLK_FIELD_VESTA_BASE 5     /* src/field/vesta_base.rs */
 /* curve ids (reference: src/curve/) */
 #define PLK_CURVE_TWEEDLEDEE 0
 #define PLK_CURVE_TWEEDLEDUM 1
 #define PLK_CURVE_BLS12_377 2
+#define PLK_CURVE_PALLAS 3 /* src/curve/pallas_curve.rs: base PallasBase, scalars VestaBase */
+#define PLK_CURVE_VESTA 4  /* src/curve/vesta_curve.rs: base VestaBase, scalars PallasBase */
 
 /* ---- library ---------------------------------------------------------------------------- */
 /* Select the device this process uses (one process per GPU).  Idempotent. */

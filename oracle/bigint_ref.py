@@ -111,7 +111,11 @@ BLS12_377_BASE = FieldSpec(
     258664426012969094010652733694893533536393512754914660539884262666720468348340822774968888139573360124440321458177,
     377, 46, 5)
 
-FIELDS = {f.field_id: f for f in (TWEEDLEDEE_BASE, TWEEDLEDUM_BASE, BLS12_377_SCALAR, BLS12_377_BASE)}
+# pallas_base.rs:21-26 / vesta_base.rs:21-27 ORDER, :117 BITS, :161 TWO_ADICITY, :157 generator FIVE
+PALLAS_BASE = FieldSpec("PallasBase", 4, 4, 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001, 255, 32, 5)
+VESTA_BASE = FieldSpec("VestaBase", 5, 4, 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001, 255, 32, 5)
+
+FIELDS = {f.field_id: f for f in (TWEEDLEDEE_BASE, TWEEDLEDUM_BASE, BLS12_377_SCALAR, BLS12_377_BASE, PALLAS_BASE, VESTA_BASE)}
 
 
 @dataclass(frozen=True)
@@ -138,7 +142,11 @@ BLS12_377 = CurveSpec(
     81937999373150964239938255573465948239988671502647976594219695644855304257327692006745978603320413799295628339695,
     241266749859715473739788878240585681733927191168601896383759122102112907357779751001206799952863815012735208165030)
 
-CURVES = {c.curve_id: c for c in (TWEEDLEDEE, TWEEDLEDUM, BLS12_377)}
+# pallas_curve.rs:7-19, vesta_curve.rs:7-19: A = 0, B = 5, G = (-1, 2)
+PALLAS = CurveSpec("Pallas", 3, PALLAS_BASE, VESTA_BASE, 5, PALLAS_BASE.p - 1, 2)
+VESTA = CurveSpec("Vesta", 4, VESTA_BASE, PALLAS_BASE, 5, VESTA_BASE.p - 1, 2)
+
+CURVES = {c.curve_id: c for c in (TWEEDLEDEE, TWEEDLEDUM, BLS12_377, PALLAS, VESTA)}
 
 
 # ---------------------------------------------------------------------------------------------

@@ -14,10 +14,10 @@ import numpy as np
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_DIR, "liboracle.so")
 
-FIELD_LIMBS = {0: 4, 1: 4, 2: 4, 3: 6}
-CURVE_BASE_FIELD = {0: 0, 1: 1, 2: 3}
-CURVE_SCALAR_FIELD = {0: 1, 1: 0, 2: 2}
-CURVE_SCALAR_BITS = {0: 255, 1: 255, 2: 253}
+FIELD_LIMBS = {0: 4, 1: 4, 2: 4, 3: 6, 4: 4, 5: 4}
+CURVE_BASE_FIELD = {0: 0, 1: 1, 2: 3, 3: 4, 4: 5}
+CURVE_SCALAR_FIELD = {0: 1, 1: 0, 2: 2, 3: 5, 4: 4}
+CURVE_SCALAR_BITS = {0: 255, 1: 255, 2: 253, 3: 255, 4: 255}
 
 
 def build(force=False):

@@ -183,6 +183,36 @@ struct Bls12377BaseP {  // src/field/bls12_377_base.rs:23-46, :169-205
     static constexpr u64 GENERATOR[6] = {9871116327010172167ull, 9167007004823125620ull, 18338974479346628539ull, 5649234265355377548ull, 13442091487463296847ull, 77904398905292312ull};  // FIVE
     static constexpr u64 T[6] = {9586122913090633729ull, 1660523435060625408ull, 2230234197602682880ull, 1883307231910630287ull, 14284016967150029115ull, 121098312706232554ull};
 };
+struct PallasBaseP {  // src/field/pallas_base.rs:20-60, :117-171
+    static constexpr int N = 4;
+    static constexpr int BITS = 255, TWO_ADICITY = 32;
+    static constexpr bool MONTY_SQUARE = true;   // :208-212 overrides square() with monty_square
+    static constexpr bool SHIFT_DOUBLE = false;
+    static constexpr u64 ORDER[4] = {11037532056220336129ull, 2469829653914515739ull, 0ull, 4611686018427387904ull};
+    static constexpr u64 R[4] = {3780891978758094845ull, 11037255111966004397ull, 18446744073709551615ull, 4611686018427387903ull};
+    static constexpr u64 R2[4] = {10122100416058490895ull, 15551789045973377255ull, 8617542898466512152ull, 679271340751763220ull};
+    static constexpr u64 R3[4] = {17403498412575166713ull, 17773050464821424593ull, 16108549121152898092ull, 3090323811697793296ull};
+    static constexpr u64 MU = 11037532056220336127ull;
+    static constexpr u64 TWO[4] = {14970995975005405177ull, 1157936496307941438ull, 18446744073709551615ull, 4611686018427387903ull};
+    static constexpr u64 THREE[4] = {7714355897543163893ull, 9725361954359430096ull, 18446744073709551614ull, 4611686018427387903ull};
+    static constexpr u64 GENERATOR[4] = {11647819816328232941ull, 8413468796752855795ull, 18446744073709551613ull, 4611686018427387903ull};  // FIVE
+    static constexpr u64 T[4] = {11037532056220336129ull, 2469829653914515739ull, 0ull, 4611686014132420608ull};
+};
+struct VestaBaseP {  // src/field/vesta_base.rs:20-60, :117-171
+    static constexpr int N = 4;
+    static constexpr int BITS = 255, TWO_ADICITY = 32;
+    static constexpr bool MONTY_SQUARE = true;   // :208-212 overrides square() with monty_square
+    static constexpr bool SHIFT_DOUBLE = false;
+    static constexpr u64 ORDER[4] = {10108024940646105089ull, 2469829653919213789ull, 0ull, 4611686018427387904ull};
+    static constexpr u64 R[4] = {6569413325480787965ull, 11037255111951910247ull, 18446744073709551615ull, 4611686018427387903ull};
+    static constexpr u64 R2[4] = {18200867980676431887ull, 7474641938123724515ull, 9200329640471491984ull, 679271340771891881ull};
+    static constexpr u64 R3[4] = {39197710403612236ull, 16229805722976916262ull, 9871554806900181859ull, 566775843421393608ull};
+    static constexpr u64 MU = 10108024940646105087ull;
+    static constexpr u64 TWO[4] = {3030801710315470841ull, 1157936496275055089ull, 18446744073709551615ull, 4611686018427387903ull};
+    static constexpr u64 THREE[4] = {17938934168859705333ull, 9725361954307751546ull, 18446744073709551614ull, 4611686018427387903ull};
+    static constexpr u64 GENERATOR[4] = {10861710938529071085ull, 8413468796663592846ull, 18446744073709551613ull, 4611686018427387903ull};  // FIVE
+    static constexpr u64 T[4] = {10108024940646105089ull, 2469829653919213789ull, 0ull, 4611686014132420608ull};
+};
 
 template <class P, int N = P::N> static inline Limbs<N> L(const u64 (&a)[N]) {
     Limbs<N> r;
@@ -1079,6 +1109,16 @@ struct Bls12377 : CurveT<Bls12377BaseP, Bls12377ScalarP> {
     }
 };
 
+// pallas_curve.rs:7-19, vesta_curve.rs:7-19: y^2 = x^3 + 5, generator (-1, 2)
+struct Pallas : CurveT<PallasBaseP, VestaBaseP> {
+    static constexpr unsigned SCALAR_BITS = 255;
+    static AffinePoint<Pallas> generator() { return {-Base::one(), Base::two(), false}; }
+};
+struct Vesta : CurveT<VestaBaseP, PallasBaseP> {
+    static constexpr unsigned SCALAR_BITS = 255;
+    static AffinePoint<Vesta> generator() { return {-Base::one(), Base::two(), false}; }
+};
+
 #include "plonk_gates.inc"
 #include "serialization.inc"
 
@@ -1114,6 +1154,8 @@ template <class C> static void st_aff(u64* xy, uint8_t* zero, size_t i, const Af
         case 1: { typedef Fp<TweedledumBaseP> F; __VA_ARGS__; } break; \
         case 2: { typedef Fp<Bls12377ScalarP> F; __VA_ARGS__; } break; \
         case 3: { typedef Fp<Bls12377BaseP> F; __VA_ARGS__; } break;   \
+        case 4: { typedef Fp<PallasBaseP> F; __VA_ARGS__; } break;     \
+        case 5: { typedef Fp<VestaBaseP> F; __VA_ARGS__; } break;      \
         default: return -1;                         \
     }
 #define CURVE_DISPATCH(curve, ...)                  \
@@ -1121,6 +1163,8 @@ template <class C> static void st_aff(u64* xy, uint8_t* zero, size_t i, const Af
         case 0: { typedef Tweedledee C; __VA_ARGS__; } break; \
         case 1: { typedef Tweedledum C; __VA_ARGS__; } break; \
         case 2: { typedef Bls12377 C; __VA_ARGS__; } break;   \
+        case 3: { typedef Pallas C; __VA_ARGS__; } break;     \
+        case 4: { typedef Vesta C; __VA_ARGS__; } break;      \
         default: return -1;                         \
     }
 
@@ -1196,6 +1240,8 @@ int orc_field_const(int field, int which, u64* out) {
         case 1: return field_const_t<Fp<TweedledumBaseP>, TweedledumBaseP>(which, out);
         case 2: return field_const_t<Fp<Bls12377ScalarP>, Bls12377ScalarP>(which, out);
         case 3: return field_const_t<Fp<Bls12377BaseP>, Bls12377BaseP>(which, out);
+        case 4: return field_const_t<Fp<PallasBaseP>, PallasBaseP>(which, out);
+        case 5: return field_const_t<Fp<VestaBaseP>, VestaBaseP>(which, out);
     }
     return -1;
 }
@@ -1228,6 +1274,8 @@ void* orc_fft_precompute(int field, size_t degree) {
         case 1: h->ptr = new FftHandle<Fp<TweedledumBaseP>>{fft_precompute<Fp<TweedledumBaseP>>(degree)}; break;
         case 2: h->ptr = new FftHandle<Fp<Bls12377ScalarP>>{fft_precompute<Fp<Bls12377ScalarP>>(degree)}; break;
         case 3: h->ptr = new FftHandle<Fp<Bls12377BaseP>>{fft_precompute<Fp<Bls12377BaseP>>(degree)}; break;
+        case 4: h->ptr = new FftHandle<Fp<PallasBaseP>>{fft_precompute<Fp<PallasBaseP>>(degree)}; break;
+        case 5: h->ptr = new FftHandle<Fp<VestaBaseP>>{fft_precompute<Fp<VestaBaseP>>(degree)}; break;
         default: delete h; return nullptr;
     }
     return h;
@@ -1390,7 +1438,7 @@ void* orc_msm_precompute(int curve, size_t n, const u64* bases_xy, const uint8_t
         for (size_t i = 0; i < n; ++i) g[i] = to_projective(ld_aff<C>(bases_xy, zero, i));        \
         h->ptr = new MsmHandle<C>{msm_precompute<C>(g, w, threads)};                              \
     } break;
-        MK(0, Tweedledee) MK(1, Tweedledum) MK(2, Bls12377)
+        MK(0, Tweedledee) MK(1, Tweedledum) MK(2, Bls12377) MK(3, Pallas) MK(4, Vesta)
 #undef MK
         default: delete h; return nullptr;
     }
@@ -1535,7 +1583,7 @@ int orc_field_sqrt(int field, const u64* x, u64* out) {  // 1: root written, 0: 
     FIELD_DISPATCH(field, { F r; if (!ser::square_root(ld<F>(x), r)) return 0; st(out, r); return 1; });
     return -1;
 }
-static u64 curve_b_small(int curve) { return curve == 0 ? 5 : curve == 1 ? 7 : 1; }  // tweedledee_curve.rs:12, tweedledum_curve.rs:12-13, bls12_377_curve.rs:15
+static u64 curve_b_small(int curve) { return curve == 1 ? 7 : curve == 2 ? 1 : 5; }  // + pallas_curve.rs:12, vesta_curve.rs:12 (5)  // tweedledee_curve.rs:12, tweedledum_curve.rs:12-13, bls12_377_curve.rs:15
 int orc_point_to_bytes(int curve, const u64* xy, const uint8_t* zero, size_t n, uint8_t* out) {
     CURVE_DISPATCH(curve, {
         const size_t rec = 1 + C::Base::N * 8;

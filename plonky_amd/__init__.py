@@ -4,7 +4,7 @@ Host-side mirror of the reference's hot-path interface (src/fft.rs, src/curve/cu
 on top of the C ABI in include/plonky_hip.h.  See DESIGN.md.
 """
 from .api import (  # noqa: F401
-    BLS12_377, BLS12_377_BASE, BLS12_377_SCALAR, TWEEDLEDEE, TWEEDLEDEE_BASE, TWEEDLEDUM, TWEEDLEDUM_BASE,
+    BLS12_377, BLS12_377_BASE, BLS12_377_SCALAR, TWEEDLEDEE, TWEEDLEDEE_BASE, TWEEDLEDUM, TWEEDLEDUM_BASE, PALLAS, PALLAS_BASE, VESTA, VESTA_BASE,
     FftPrecomputation, MsmPrecomputation, fft, fft_precompute, fft_with_precomputation,
     fft_with_precomputation_power_of_2, ifft_with_precomputation_power_of_2, msm_execute, msm_execute_batch, msm_execute_parallel,
     msm_parallel, msm_precompute, log2_ceil, log2_strict, polynomial_divide_by_z_h, polynomial_mul,

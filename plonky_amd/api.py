@@ -29,14 +29,14 @@ import numpy as np
 
 from . import lib as _lib
 
-TWEEDLEDEE_BASE, TWEEDLEDUM_BASE, BLS12_377_SCALAR, BLS12_377_BASE = 0, 1, 2, 3
-TWEEDLEDEE, TWEEDLEDUM, BLS12_377 = 0, 1, 2
+TWEEDLEDEE_BASE, TWEEDLEDUM_BASE, BLS12_377_SCALAR, BLS12_377_BASE, PALLAS_BASE, VESTA_BASE = 0, 1, 2, 3, 4, 5
+TWEEDLEDEE, TWEEDLEDUM, BLS12_377, PALLAS, VESTA = 0, 1, 2, 3, 4
 
-_FIELD_LIMBS = {0: 4, 1: 4, 2: 4, 3: 6}
-_CURVE_LIMBS = {0: 4, 1: 4, 2: 6}
-_TWO_ADICITY = {0: 34, 1: 33, 2: 47, 3: 46}
-CURVE_SCALAR_FIELD = {0: 1, 1: 0, 2: 2}
-CURVE_BASE_FIELD = {0: 0, 1: 1, 2: 3}
+_FIELD_LIMBS = {0: 4, 1: 4, 2: 4, 3: 6, 4: 4, 5: 4}
+_CURVE_LIMBS = {0: 4, 1: 4, 2: 6, 3: 4, 4: 4}
+_TWO_ADICITY = {0: 34, 1: 33, 2: 47, 3: 46, 4: 32, 5: 32}
+CURVE_SCALAR_FIELD = {0: 1, 1: 0, 2: 2, 3: 5, 4: 4}
+CURVE_BASE_FIELD = {0: 0, 1: 1, 2: 3, 3: 4, 4: 5}
 
 
 def log2_ceil(n):  # util.rs:2-9

@@ -257,7 +257,9 @@ int field_limbs(int field) {
     switch (field) {
         case PLK_FIELD_TWEEDLEDEE_BASE:
         case PLK_FIELD_TWEEDLEDUM_BASE:
-        case PLK_FIELD_BLS12_377_SCALAR: return 4;
+        case PLK_FIELD_BLS12_377_SCALAR:
+        case PLK_FIELD_PALLAS_BASE:
+        case PLK_FIELD_VESTA_BASE: return 4;
         case PLK_FIELD_BLS12_377_BASE: return 6;
     }
     return PLK_ERR_INVALID_ARG;
@@ -265,7 +267,9 @@ int field_limbs(int field) {
 int curve_limbs(int curve) {
     switch (curve) {
         case PLK_CURVE_TWEEDLEDEE:
-        case PLK_CURVE_TWEEDLEDUM: return 4;
+        case PLK_CURVE_TWEEDLEDUM:
+        case PLK_CURVE_PALLAS:
+        case PLK_CURVE_VESTA: return 4;
         case PLK_CURVE_BLS12_377: return 6;
     }
     return PLK_ERR_INVALID_ARG;
@@ -275,6 +279,8 @@ int curve_scalar_field(int curve) {
         case PLK_CURVE_TWEEDLEDEE: return PLK_FIELD_TWEEDLEDUM_BASE;
         case PLK_CURVE_TWEEDLEDUM: return PLK_FIELD_TWEEDLEDEE_BASE;
         case PLK_CURVE_BLS12_377: return PLK_FIELD_BLS12_377_SCALAR;
+        case PLK_CURVE_PALLAS: return PLK_FIELD_VESTA_BASE;
+        case PLK_CURVE_VESTA: return PLK_FIELD_PALLAS_BASE;
     }
     return PLK_ERR_INVALID_ARG;
 }
@@ -607,7 +613,7 @@ int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint
 
 // ---- the reference's own MsmPrecomputation contents ----
 int plk_msm_table_digits(int curve, unsigned w) {
-    if (curve < 0 || curve > 2 || w == 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d or window 0", curve);
+    if (curve_limbs(curve) < 0 || w == 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d or window 0", curve);
     return msm_table_digits(curve, w);
 }
 int plk_msm_precompute_table_dev(int curve, size_t n, const void* d_bases_xy, const void* d_base_zero, unsigned w, void* d_out_xy, void* d_out_zero,

@@ -34,6 +34,17 @@ struct Bls12377Curve {
     using SP = Bls12377ScalarParams;   // bls12_377_curve.rs:12
 };
 
+struct PallasCurve {
+    static constexpr int CURVE_ID = 3;
+    using FP = PallasBaseParams;       // pallas_curve.rs:8
+    using SP = VestaBaseParams;        // pallas_curve.rs:9
+};
+struct VestaCurve {
+    static constexpr int CURVE_ID = 4;
+    using FP = VestaBaseParams;
+    using SP = PallasBaseParams;
+};
+
 template <class FP> struct Xyzz {
     Fe<FP> x, y, zz, zzz;
 };

@@ -151,6 +151,8 @@ int field_batch_inverse_dev_impl(int field, const void* d_x, void* d_out, void* 
         CASE(PLK_FIELD_TWEEDLEDUM_BASE, TweedledumBaseParams)
         CASE(PLK_FIELD_BLS12_377_SCALAR, Bls12377ScalarParams)
         CASE(PLK_FIELD_BLS12_377_BASE, Bls12377BaseParams)
+        CASE(PLK_FIELD_PALLAS_BASE, PallasBaseParams)
+        CASE(PLK_FIELD_VESTA_BASE, VestaBaseParams)
 #undef CASE
         default: return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
     }
@@ -169,6 +171,8 @@ int curve_batch_to_affine_dev_impl(int curve, size_t count, const void* d_xyz, c
         CASE(PLK_CURVE_TWEEDLEDEE, TweedledeeBaseParams)
         CASE(PLK_CURVE_TWEEDLEDUM, TweedledumBaseParams)
         CASE(PLK_CURVE_BLS12_377, Bls12377BaseParams)
+        CASE(PLK_CURVE_PALLAS, PallasBaseParams)
+        CASE(PLK_CURVE_VESTA, VestaBaseParams)
 #undef CASE
         default: return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     }
@@ -252,6 +256,8 @@ int field_inner_product_dev_impl(int field, const void* d_a, const void* d_b, si
         CASE(PLK_FIELD_TWEEDLEDUM_BASE, TweedledumBaseParams)
         CASE(PLK_FIELD_BLS12_377_SCALAR, Bls12377ScalarParams)
         CASE(PLK_FIELD_BLS12_377_BASE, Bls12377BaseParams)
+        CASE(PLK_FIELD_PALLAS_BASE, PallasBaseParams)
+        CASE(PLK_FIELD_VESTA_BASE, VestaBaseParams)
 #undef CASE
     }
     hipError_t e = hipGetLastError();
@@ -282,6 +288,8 @@ int field_fold_slices_dev_impl(int field, const void* d_lo, const void* d_hi, co
         CASE(PLK_FIELD_TWEEDLEDUM_BASE, TweedledumBaseParams)
         CASE(PLK_FIELD_BLS12_377_SCALAR, Bls12377ScalarParams)
         CASE(PLK_FIELD_BLS12_377_BASE, Bls12377BaseParams)
+        CASE(PLK_FIELD_PALLAS_BASE, PallasBaseParams)
+        CASE(PLK_FIELD_VESTA_BASE, VestaBaseParams)
 #undef CASE
     }
     PLK_HIP_TRY(hipGetLastError());
@@ -297,6 +305,8 @@ int field_op_impl(int field, int op, const uint64_t* a, const uint64_t* b, uint6
         case PLK_FIELD_TWEEDLEDUM_BASE: return field_op_t<TweedledumBaseParams>(op, a, b, out, count);
         case PLK_FIELD_BLS12_377_SCALAR: return field_op_t<Bls12377ScalarParams>(op, a, b, out, count);
         case PLK_FIELD_BLS12_377_BASE: return field_op_t<Bls12377BaseParams>(op, a, b, out, count);
+        case PLK_FIELD_PALLAS_BASE: return field_op_t<PallasBaseParams>(op, a, b, out, count);
+        case PLK_FIELD_VESTA_BASE: return field_op_t<VestaBaseParams>(op, a, b, out, count);
     }
     return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
 }

@@ -204,6 +204,8 @@ int curve_fold_pairs_dev_impl(int curve, size_t m, const void* d_lo, const void*
         case PLK_CURVE_TWEEDLEDEE: return fold_pairs_t<TweedledeeCurve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream);
         case PLK_CURVE_TWEEDLEDUM: return fold_pairs_t<TweedledumCurve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream);
         case PLK_CURVE_BLS12_377: return fold_pairs_t<Bls12377Curve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream);
+        case PLK_CURVE_PALLAS: return fold_pairs_t<PallasCurve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream);
+        case PLK_CURVE_VESTA: return fold_pairs_t<VestaCurve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream);
     }
     return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
 }

@@ -1267,7 +1267,7 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
                             plk_msm_ctx** out_ctx) {
     if (!out_ctx) return set_error(PLK_ERR_INVALID_ARG, "null out_ctx");
     *out_ctx = nullptr;
-    if (curve < 0 || curve > 2) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (curve_limbs(curve) < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (n && !d_bases) return set_error(PLK_ERR_INVALID_ARG, "null bases");
     PLK_TRY(ensure_device());
     const bool table_free = (flags & PLK_MSM_TABLE_FREE) != 0;
@@ -1340,6 +1340,8 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     switch (curve) {
         case PLK_CURVE_TWEEDLEDEE: rc = msm_precompute_t<TweedledeeCurve>(ctx, d_bases, d_zero, stream); break;
         case PLK_CURVE_TWEEDLEDUM: rc = msm_precompute_t<TweedledumCurve>(ctx, d_bases, d_zero, stream); break;
+        case PLK_CURVE_PALLAS: rc = msm_precompute_t<PallasCurve>(ctx, d_bases, d_zero, stream); break;
+        case PLK_CURVE_VESTA: rc = msm_precompute_t<VestaCurve>(ctx, d_bases, d_zero, stream); break;
         default: rc = msm_precompute_t<Bls12377Curve>(ctx, d_bases, d_zero, stream); break;
     }
     if (rc != PLK_OK) {
@@ -1494,6 +1496,8 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
         switch (ctx->curve) {
             case PLK_CURVE_TWEEDLEDEE: return msm_execute_t<TweedledeeCurve>(ctx, w, sc, oxy, oz, st, phases);
             case PLK_CURVE_TWEEDLEDUM: return msm_execute_t<TweedledumCurve>(ctx, w, sc, oxy, oz, st, phases);
+            case PLK_CURVE_PALLAS: return msm_execute_t<PallasCurve>(ctx, w, sc, oxy, oz, st, phases);
+            case PLK_CURVE_VESTA: return msm_execute_t<VestaCurve>(ctx, w, sc, oxy, oz, st, phases);
             default: return msm_execute_t<Bls12377Curve>(ctx, w, sc, oxy, oz, st, phases);
         }
     };
@@ -1516,6 +1520,8 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
         switch (ctx->curve) {
             case PLK_CURVE_TWEEDLEDEE: rc = msm_alloc_work<TweedledeeCurve>(ctx, ctx->ws.back(), stream); break;
             case PLK_CURVE_TWEEDLEDUM: rc = msm_alloc_work<TweedledumCurve>(ctx, ctx->ws.back(), stream); break;
+            case PLK_CURVE_PALLAS: rc = msm_alloc_work<PallasCurve>(ctx, ctx->ws.back(), stream); break;
+            case PLK_CURVE_VESTA: rc = msm_alloc_work<VestaCurve>(ctx, ctx->ws.back(), stream); break;
             default: rc = msm_alloc_work<Bls12377Curve>(ctx, ctx->ws.back(), stream); break;
         }
         if (rc != PLK_OK) {
@@ -1540,6 +1546,8 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
         switch (ctx->curve) {
             case PLK_CURVE_TWEEDLEDEE: rc = msm_reduce_t<TweedledeeCurve>(ctx, tb, stream, nomark); break;
             case PLK_CURVE_TWEEDLEDUM: rc = msm_reduce_t<TweedledumCurve>(ctx, tb, stream, nomark); break;
+            case PLK_CURVE_PALLAS: rc = msm_reduce_t<PallasCurve>(ctx, tb, stream, nomark); break;
+            case PLK_CURVE_VESTA: rc = msm_reduce_t<VestaCurve>(ctx, tb, stream, nomark); break;
             default: rc = msm_reduce_t<Bls12377Curve>(ctx, tb, stream, nomark); break;
         }
         PLK_TRY(rc);
@@ -1601,7 +1609,7 @@ static int msm_reference_table_t(size_t n, const void* d_bases, const void* d_ze
 
 int msm_reference_table_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned w, void* d_out_xy, void* d_out_zero,
                                  hipStream_t stream) {
-    if (curve < 0 || curve > 2) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (curve_limbs(curve) < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (w < 1 || w > 64) return set_error(PLK_ERR_INVALID_ARG, "window size %u outside [1, 64]", w);
     if (n == 0) return PLK_OK;
     if (!d_bases || !d_out_xy || !d_out_zero) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
@@ -1610,6 +1618,8 @@ int msm_reference_table_dev_impl(int curve, size_t n, const void* d_bases, const
     switch (curve) {
         case PLK_CURVE_TWEEDLEDEE: return msm_reference_table_t<TweedledeeCurve>(n, d_bases, d_zero, (int)w, digits, d_out_xy, d_out_zero, stream);
         case PLK_CURVE_TWEEDLEDUM: return msm_reference_table_t<TweedledumCurve>(n, d_bases, d_zero, (int)w, digits, d_out_xy, d_out_zero, stream);
+        case PLK_CURVE_PALLAS: return msm_reference_table_t<PallasCurve>(n, d_bases, d_zero, (int)w, digits, d_out_xy, d_out_zero, stream);
+        case PLK_CURVE_VESTA: return msm_reference_table_t<VestaCurve>(n, d_bases, d_zero, (int)w, digits, d_out_xy, d_out_zero, stream);
         default: return msm_reference_table_t<Bls12377Curve>(n, d_bases, d_zero, (int)w, digits, d_out_xy, d_out_zero, stream);
     }
 }
@@ -1624,6 +1634,8 @@ int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void
         CASE(PLK_CURVE_TWEEDLEDEE, TweedledeeCurve)
         CASE(PLK_CURVE_TWEEDLEDUM, TweedledumCurve)
         CASE(PLK_CURVE_BLS12_377, Bls12377Curve)
+        CASE(PLK_CURVE_PALLAS, PallasCurve)
+        CASE(PLK_CURVE_VESTA, VestaCurve)
 #undef CASE
         default: return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     }
@@ -1643,6 +1655,8 @@ int selftest_quad_dev_impl(int curve, const void* d_pts, uint32_t n, uint32_t qu
         case PLK_CURVE_TWEEDLEDEE: k_selftest_quad<TweedledeeCurve><<<blocks, 256>>>((const uint4*)d_pts, n, d_cnt); break;
         case PLK_CURVE_TWEEDLEDUM: k_selftest_quad<TweedledumCurve><<<blocks, 256>>>((const uint4*)d_pts, n, d_cnt); break;
         case PLK_CURVE_BLS12_377: k_selftest_quad<Bls12377Curve><<<blocks, 256>>>((const uint4*)d_pts, n, d_cnt); break;
+        case PLK_CURVE_PALLAS: k_selftest_quad<PallasCurve><<<blocks, 256>>>((const uint4*)d_pts, n, d_cnt); break;
+        case PLK_CURVE_VESTA: k_selftest_quad<VestaCurve><<<blocks, 256>>>((const uint4*)d_pts, n, d_cnt); break;
         default: scratch_release(d_cnt, nullptr); return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     }
     hipError_t e = hipMemcpy(counts, d_cnt, 32, hipMemcpyDeviceToHost);
@@ -1659,6 +1673,8 @@ int curve_gen_bases_dev_impl(int curve, size_t n, uint64_t first, const void* d_
         CASE(PLK_CURVE_TWEEDLEDEE, TweedledeeCurve)
         CASE(PLK_CURVE_TWEEDLEDUM, TweedledumCurve)
         CASE(PLK_CURVE_BLS12_377, Bls12377Curve)
+        CASE(PLK_CURVE_PALLAS, PallasCurve)
+        CASE(PLK_CURVE_VESTA, VestaCurve)
 #undef CASE
         default: return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     }

@@ -509,6 +509,8 @@ static int get_plan(int field, unsigned log_n, std::shared_ptr<NttPlan>& out) {
         case PLK_FIELD_TWEEDLEDEE_BASE: rc = build_plan_t<TweedledeeBaseParams>(*pl); break;
         case PLK_FIELD_TWEEDLEDUM_BASE: rc = build_plan_t<TweedledumBaseParams>(*pl); break;
         case PLK_FIELD_BLS12_377_SCALAR: rc = build_plan_t<Bls12377ScalarParams>(*pl); break;
+        case PLK_FIELD_PALLAS_BASE: rc = build_plan_t<PallasBaseParams>(*pl); break;
+        case PLK_FIELD_VESTA_BASE: rc = build_plan_t<VestaBaseParams>(*pl); break;
         default: return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
     }
     if (rc != PLK_OK) return rc;
@@ -615,6 +617,8 @@ static int ntt_dispatch(int field, unsigned log_n, int inverse, unsigned batch, 
         case PLK_FIELD_TWEEDLEDEE_BASE: return run_plan_t<TweedledeeBaseParams>(*pl, inverse, batch, d_in, d_out, hooks, stream);
         case PLK_FIELD_TWEEDLEDUM_BASE: return run_plan_t<TweedledumBaseParams>(*pl, inverse, batch, d_in, d_out, hooks, stream);
         case PLK_FIELD_BLS12_377_SCALAR: return run_plan_t<Bls12377ScalarParams>(*pl, inverse, batch, d_in, d_out, hooks, stream);
+        case PLK_FIELD_PALLAS_BASE: return run_plan_t<PallasBaseParams>(*pl, inverse, batch, d_in, d_out, hooks, stream);
+        case PLK_FIELD_VESTA_BASE: return run_plan_t<VestaBaseParams>(*pl, inverse, batch, d_in, d_out, hooks, stream);
     }
     return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
 }

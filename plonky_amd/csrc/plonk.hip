@@ -407,6 +407,8 @@ int plonk_vanishing_points_dev_impl(int field, unsigned log_degree, const void* 
         case PLK_FIELD_TWEEDLEDEE_BASE: return vanishing_points_t<TweedledeeBaseParams>(log_degree, d_constants, d_wires, d_s_sigma, d_z, sc, d_out, stream);
         case PLK_FIELD_TWEEDLEDUM_BASE: return vanishing_points_t<TweedledumBaseParams>(log_degree, d_constants, d_wires, d_s_sigma, d_z, sc, d_out, stream);
         case PLK_FIELD_BLS12_377_SCALAR: return vanishing_points_t<Bls12377ScalarParams>(log_degree, d_constants, d_wires, d_s_sigma, d_z, sc, d_out, stream);
+        case PLK_FIELD_PALLAS_BASE: return vanishing_points_t<PallasBaseParams>(log_degree, d_constants, d_wires, d_s_sigma, d_z, sc, d_out, stream);
+        case PLK_FIELD_VESTA_BASE: return vanishing_points_t<VestaBaseParams>(log_degree, d_constants, d_wires, d_s_sigma, d_z, sc, d_out, stream);
     }
     return set_error(PLK_ERR_INVALID_ARG, "field %d is not a circuit scalar field", field);
 }
@@ -433,6 +435,8 @@ int plonk_all_constraints_dev_impl(int field, size_t count, const void* d_consta
         case PLK_FIELD_TWEEDLEDEE_BASE: return all_constraints_t<TweedledeeBaseParams>(count, d_constants, d_local, d_right, d_below, sc, d_out, stream);
         case PLK_FIELD_TWEEDLEDUM_BASE: return all_constraints_t<TweedledumBaseParams>(count, d_constants, d_local, d_right, d_below, sc, d_out, stream);
         case PLK_FIELD_BLS12_377_SCALAR: return all_constraints_t<Bls12377ScalarParams>(count, d_constants, d_local, d_right, d_below, sc, d_out, stream);
+        case PLK_FIELD_PALLAS_BASE: return all_constraints_t<PallasBaseParams>(count, d_constants, d_local, d_right, d_below, sc, d_out, stream);
+        case PLK_FIELD_VESTA_BASE: return all_constraints_t<VestaBaseParams>(count, d_constants, d_local, d_right, d_below, sc, d_out, stream);
     }
     return set_error(PLK_ERR_INVALID_ARG, "field %d is not a circuit scalar field", field);
 }

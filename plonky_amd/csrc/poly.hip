@@ -255,6 +255,8 @@ int poly_divide_by_z_h_dev_impl(int field, const void* d_coeffs, size_t len, siz
         case PLK_FIELD_TWEEDLEDEE_BASE: return divide_by_z_h_t<TweedledeeBaseParams>(d_coeffs, len, n, d_out, out_cap, out_len, stream);
         case PLK_FIELD_TWEEDLEDUM_BASE: return divide_by_z_h_t<TweedledumBaseParams>(d_coeffs, len, n, d_out, out_cap, out_len, stream);
         case PLK_FIELD_BLS12_377_SCALAR: return divide_by_z_h_t<Bls12377ScalarParams>(d_coeffs, len, n, d_out, out_cap, out_len, stream);
+        case PLK_FIELD_PALLAS_BASE: return divide_by_z_h_t<PallasBaseParams>(d_coeffs, len, n, d_out, out_cap, out_len, stream);
+        case PLK_FIELD_VESTA_BASE: return divide_by_z_h_t<VestaBaseParams>(d_coeffs, len, n, d_out, out_cap, out_len, stream);
     }
     return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
 }
@@ -315,6 +317,8 @@ int poly_mul_dev_impl(int field, const void* d_a, size_t la, const void* d_b, si
         case PLK_FIELD_TWEEDLEDEE_BASE: return poly_mul_t<TweedledeeBaseParams>(d_a, la, d_b, lb, d_out, out_cap, out_len, stream);
         case PLK_FIELD_TWEEDLEDUM_BASE: return poly_mul_t<TweedledumBaseParams>(d_a, la, d_b, lb, d_out, out_cap, out_len, stream);
         case PLK_FIELD_BLS12_377_SCALAR: return poly_mul_t<Bls12377ScalarParams>(d_a, la, d_b, lb, d_out, out_cap, out_len, stream);
+        case PLK_FIELD_PALLAS_BASE: return poly_mul_t<PallasBaseParams>(d_a, la, d_b, lb, d_out, out_cap, out_len, stream);
+        case PLK_FIELD_VESTA_BASE: return poly_mul_t<VestaBaseParams>(d_a, la, d_b, lb, d_out, out_cap, out_len, stream);
     }
     return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
 }

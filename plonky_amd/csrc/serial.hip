@@ -173,6 +173,8 @@ int field_bytes_impl(int field, int from_bytes, const void* d_in, size_t count, 
         CASE(PLK_FIELD_TWEEDLEDUM_BASE, TweedledumBaseParams)
         CASE(PLK_FIELD_BLS12_377_SCALAR, Bls12377ScalarParams)
         CASE(PLK_FIELD_BLS12_377_BASE, Bls12377BaseParams)
+        CASE(PLK_FIELD_PALLAS_BASE, PallasBaseParams)
+        CASE(PLK_FIELD_VESTA_BASE, VestaBaseParams)
 #undef CASE
         default: return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
     }
@@ -181,7 +183,8 @@ int field_bytes_impl(int field, int from_bytes, const void* d_in, size_t count, 
 }
 
 // curve constants B (A = 0): tweedledee_curve.rs:11-12 (5), tweedledum_curve.rs:11-13 (7), bls12_377_curve.rs:14-15 (1)
-static uint32_t curve_b(int curve) { return curve == PLK_CURVE_TWEEDLEDEE ? 5u : curve == PLK_CURVE_TWEEDLEDUM ? 7u : 1u; }
+// pallas_curve.rs:12, vesta_curve.rs:12 (5)
+static uint32_t curve_b(int curve) { return curve == PLK_CURVE_TWEEDLEDUM ? 7u : curve == PLK_CURVE_BLS12_377 ? 1u : 5u; }
 
 int point_bytes_impl(int curve, int from_bytes, const void* d_in, const void* d_zero, size_t count, void* d_out, void* d_out_zero, void* d_status,
                      hipStream_t stream) {
@@ -198,6 +201,8 @@ int point_bytes_impl(int curve, int from_bytes, const void* d_in, const void* d_
         CASE(PLK_CURVE_TWEEDLEDEE, TweedledeeBaseParams)
         CASE(PLK_CURVE_TWEEDLEDUM, TweedledumBaseParams)
         CASE(PLK_CURVE_BLS12_377, Bls12377BaseParams)
+        CASE(PLK_CURVE_PALLAS, PallasBaseParams)
+        CASE(PLK_CURVE_VESTA, VestaBaseParams)
 #undef CASE
         default: return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     }

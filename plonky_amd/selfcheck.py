@@ -11,8 +11,8 @@ import numpy as np
 
 from .synth import MODULI
 
-CURVE_BASE = {0: 0, 1: 1, 2: 3}
-CURVE_SCALAR = {0: 1, 1: 0, 2: 2}
+CURVE_BASE = {0: 0, 1: 1, 2: 3, 3: 4, 4: 5}
+CURVE_SCALAR = {0: 1, 1: 0, 2: 2, 3: 5, 4: 4}
 # GENERATOR_AFFINE of the curves the harness uses, canonical integers: tweedledee_curve.rs:14-18 (NEG_ONE, TWO) and
 # bls12_377_curve.rs:16-33 (the decimal values of its doc comments)
 GENERATORS = {

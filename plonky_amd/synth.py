@@ -14,8 +14,10 @@ MODULI = {
     1: 28948022309329048855892746252171976963322203655955319056773317069363642105857,
     2: 8444461749428370424248824938781546531375899335154063827935233455917409239041,
     3: 258664426012969094010652733694893533536393512754914660539884262666720468348340822774968888139573360124440321458177,
+    4: 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001,  # PallasBase
+    5: 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001,  # VestaBase
 }
-LIMBS = {0: 4, 1: 4, 2: 4, 3: 6}
+LIMBS = {0: 4, 1: 4, 2: 4, 3: 6, 4: 4, 5: 4}
 
 _GAMMA = np.uint64(0x9E3779B97F4A7C15)
 

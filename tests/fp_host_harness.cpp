@@ -64,6 +64,8 @@ extern "C" int fp_host_op(int field, int op, const uint32_t* a, const uint32_t* 
         case 1: run<TweedledumBaseParams>(op, a, b, out, n); return 0;
         case 2: run<Bls12377ScalarParams>(op, a, b, out, n); return 0;
         case 3: run<Bls12377BaseParams>(op, a, b, out, n); return 0;
+        case 4: run<PallasBaseParams>(op, a, b, out, n); return 0;
+        case 5: run<VestaBaseParams>(op, a, b, out, n); return 0;
     }
     return -1;
 }
@@ -133,6 +135,8 @@ extern "C" int ecz_host_tree(int field, size_t n, const uint32_t* xs, const uint
         case 0: ecz_tree<TweedledeeBaseParams>(n, xs, ys, negs, out); return 0;
         case 1: ecz_tree<TweedledumBaseParams>(n, xs, ys, negs, out); return 0;
         case 3: ecz_tree<Bls12377BaseParams>(n, xs, ys, negs, out); return 0;
+        case 4: ecz_tree<PallasBaseParams>(n, xs, ys, negs, out); return 0;
+        case 5: ecz_tree<VestaBaseParams>(n, xs, ys, negs, out); return 0;
     }
     return -1;
 }
@@ -141,6 +145,8 @@ extern "C" int ecz_host_sum(int field, size_t n, const uint32_t* xs, const uint3
         case 0: ecz_sum<TweedledeeBaseParams>(n, xs, ys, negs, out); return 0;
         case 1: ecz_sum<TweedledumBaseParams>(n, xs, ys, negs, out); return 0;
         case 3: ecz_sum<Bls12377BaseParams>(n, xs, ys, negs, out); return 0;
+        case 4: ecz_sum<PallasBaseParams>(n, xs, ys, negs, out); return 0;
+        case 5: ecz_sum<VestaBaseParams>(n, xs, ys, negs, out); return 0;
     }
     return -1;
 }

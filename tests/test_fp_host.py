@@ -15,7 +15,7 @@ from tests.test_oracle_kats import reference_test_inputs
 from tests.util import array_to_ints, ints_to_array
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.BLS12_377_BASE]
+FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.BLS12_377_BASE, br.PALLAS_BASE, br.VESTA_BASE]
 
 
 @pytest.fixture(scope="module")

@@ -17,9 +17,9 @@ from tests.test_oracle_kats import (MSM_KAT_X_MONT, MSM_KAT_Y_MONT, _bls_test_ms
                                     reference_test_inputs)
 from tests.util import ints_to_array, limbs_to_int
 
-FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.BLS12_377_BASE]
-NTT_FIELDS = FIELDS[:3]
-CURVES = [br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377]
+FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.BLS12_377_BASE, br.PALLAS_BASE, br.VESTA_BASE]
+NTT_FIELDS = FIELDS[:3] + FIELDS[4:]
+CURVES = [br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377, br.PALLAS, br.VESTA]
 
 
 # ---------------- field arithmetic: the reference's test_arithmetic! sweep on the device ----------------

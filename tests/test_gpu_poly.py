@@ -15,7 +15,7 @@ from oracle import bigint_ref as br
 from oracle import oracle_lib as ol
 from tests.test_oracle_poly import from_mont_arr, mont_arr, times_z_h
 
-NTT_FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR]
+NTT_FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.PALLAS_BASE, br.VESTA_BASE]
 
 
 def mul_by_z_h_mont(f, a, n):

@@ -10,8 +10,8 @@ from oracle import bigint_ref as br
 from oracle import oracle_lib as ol
 from tests.util import array_to_ints, int_to_limbs, ints_to_array, limbs_to_int
 
-FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.BLS12_377_BASE]
-CURVES = [br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377]
+FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.BLS12_377_BASE, br.PALLAS_BASE, br.VESTA_BASE]
+CURVES = [br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377, br.PALLAS, br.VESTA]
 
 
 def mont_arr(f, vals):
@@ -51,6 +51,32 @@ def test_neg_one_literals():
     # bls12_377_base.rs:193-196
     assert list(ol.field_const(3, "NEG_ONE")) == [9384023879812382873, 14252412606051516495, 9184438906438551565,
                                                   11444845376683159689, 8738795276227363922, 81297770384137296]
+
+
+def test_pallas_vesta_literals():
+    """The reference's literals for the Pasta fields and curves (pallas_base.rs, vesta_base.rs, pallas_curve.rs, vesta_curve.rs)."""
+    # pallas_base.rs:21-60: ORDER, R, R2, R3, MU; :153-155 NEG_ONE
+    assert list(ol.field_const(4, "ORDER")) == [0x992d30ed00000001, 0x224698fc094cf91b, 0x0, 0x4000000000000000]
+    assert list(ol.field_const(4, "R")) == [0x34786d38fffffffd, 0x992c350be41914ad, 0xffffffffffffffff, 0x3fffffffffffffff]
+    assert list(ol.field_const(4, "R2")) == [0x8c78ecb30000000f, 0xd7d30dbd8b0de0e7, 0x7797a99bc3c95d18, 0x96d41af7b9cb714]
+    assert list(ol.field_const(4, "R3")) == [0xf185a5993a9e10f9, 0xf6a68f3b6ac5b1d1, 0xdf8d1014353fd42c, 0x2ae309222d2d9910]
+    assert int(ol.field_const(4, "MU")[0]) == 0x992d30ecffffffff
+    assert list(ol.field_const(4, "NEG_ONE")) == [0x64b4c3b400000004, 0x891a63f02533e46e, 0, 0]
+    # vesta_base.rs:22-27 ORDER
+    assert list(ol.field_const(5, "ORDER")) == [0x8c46eb2100000001, 0x224698fc0994a8dd, 0x0, 0x4000000000000000]
+    # the two curves form a cycle: each one's scalar field is the other's base field, and the group orders match
+    for c in (br.PALLAS, br.VESTA):
+        G = (c.gx, c.gy)
+        assert br.ec_on_curve(c, G) and br.ec_mul(c, c.scalar.p, G) is None
+    # pallas_curve.rs:24-35 / vesta_curve.rs:22-33: ZETA is a primitive cube root of unity of the base field, ZETA_SCALAR of the
+    # scalar field, and the endomorphism (x, y) -> (ZETA x, y) is multiplication by ZETA_SCALAR
+    zp = br.PALLAS_BASE.from_mont(limbs_to_int([0xfbdfd7aa9e65eac8, 0x0cd4d654e50025fb, 0xd59892a33785b99a, 0x2a27fb62585e8789]))
+    zv = br.VESTA_BASE.from_mont(limbs_to_int([0x410e7d207feeeee3, 0x6afdf14fd8fa2279, 0xfd3d8a04eca4d4d7, 0x2de2d60777dba4ef]))
+    assert zp != 1 and pow(zp, 3, br.PALLAS_BASE.p) == 1 and zv != 1 and pow(zv, 3, br.VESTA_BASE.p) == 1
+    G = (br.PALLAS.gx, br.PALLAS.gy)
+    assert br.ec_mul(br.PALLAS, zv, G) == (zp * G[0] % br.PALLAS_BASE.p, G[1])
+    G = (br.VESTA.gx, br.VESTA.gy)
+    assert br.ec_mul(br.VESTA, zp, G) == (zv * G[0] % br.VESTA_BASE.p, G[1])
 
 
 # ---- 2. test_to_digits (curve_msm.rs:186-216) ----

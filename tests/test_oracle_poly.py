@@ -11,7 +11,7 @@ from oracle import bigint_ref as br
 from oracle import oracle_lib as ol
 from tests.util import array_to_ints, ints_to_array
 
-NTT_FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR]
+NTT_FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.PALLAS_BASE, br.VESTA_BASE]
 
 
 def mont_arr(f, vals):

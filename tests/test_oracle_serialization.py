@@ -7,8 +7,8 @@ from oracle import bigint_ref as br
 from oracle import oracle_lib as ol
 from tests.util import array_to_ints, ints_to_array
 
-FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.BLS12_377_BASE]
-CURVES = [br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377]
+FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.BLS12_377_BASE, br.PALLAS_BASE, br.VESTA_BASE]
+CURVES = [br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377, br.PALLAS, br.VESTA]
 
 
 @pytest.mark.parametrize("f", FIELDS, ids=lambda f: f.name)
