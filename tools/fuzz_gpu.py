@@ -1,5 +1,5 @@
 """Randomised parity stress on the GPU (not part of the pytest suites: minutes, not seconds): random sizes, windows,
-identity flags, duplicate / opposite generators, skewed scalars, tables and table-free, all three curves; random
+identity flags, duplicate / opposite generators, skewed scalars, tables and table-free, all five curves; random
 polynomial divisions and products; random NTT sizes and batches.  Everything against the oracle, bit for bit.
 Usage: python tools/fuzz_gpu.py [seconds]"""
 import os, random, sys, time
@@ -12,10 +12,10 @@ from tests.util import ints_to_array
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(int(os.environ.get("FUZZ_SEED", "12345")))
-CURVES = [br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377]
-FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR]
+CURVES = [br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377, br.PALLAS, br.VESTA]
+FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.PALLAS_BASE, br.VESTA_BASE]
 t_end = time.time() + budget
-counts = {"msm": 0, "ntt": 0, "poly": 0, "fold": 0}
+counts = {"msm": 0, "ntt": 0, "poly": 0, "fold": 0, "plonk": 0, "misc": 0}
 
 
 def mont(f, vals):
@@ -23,7 +23,7 @@ def mont(f, vals):
 
 
 while time.time() < t_end:
-    kind = rng.choice(["msm", "msm", "ntt", "poly", "fold"])
+    kind = rng.choice(["msm", "msm", "ntt", "poly", "fold", "plonk", "misc"])
     if kind == "msm":
         c = rng.choice(CURVES)
         n = rng.choice([1, 2, 3, 7, 33, 100, 257, 1000, 3000, 5000])
@@ -51,7 +51,7 @@ while time.time() < t_end:
             sc = mont(c.scalar, [rng.choice([0, 1, r - 1, r - 2, (r - 1) // 2, 1 << 200]) for _ in range(n)])
         exp, ez = ol.MsmPrecomputation(c.curve_id, bases, 8, zero=zero, threads=8).execute(sc, parallel=True, threads=8)
         tf = rng.random() < 0.5
-        win = rng.choice([0, 0, 3, 5, 8, 11] + ([] if tf else [14, 16]))
+        win = rng.choice([0, 0, 3, 5, 8, 11] + ([] if tf else [13, 14, 16, 18, 20]))
         pre = pa.msm_precompute(c.curve_id, bases, 8, zero=zero, device_window=win, table_free=tf)
         got, gz = pa.msm_execute_parallel(pre, sc)
         assert gz == ez and (ez or np.array_equal(got, exp)), ("msm", c.name, n, style, tf, win)
@@ -98,6 +98,28 @@ while time.time() < t_end:
         else:
             b = synth.rand_field(f.field_id, rng.randrange(1 << 30), rng.randrange(1, 3000))
             assert np.array_equal(pa.polynomial_mul(f.field_id, a, b), ol.poly_mul(f.field_id, a, b, threads=8)), ("mul", f.name, la)
+    elif kind == "plonk":
+        # the vanishing points of Prover::vanishing_poly on random tables (every gate contributes to every point)
+        f = rng.choice(FIELDS)
+        degree = rng.choice([1, 2, 4, 16, 64, 256])
+        n8 = 8 * degree
+        seed = rng.randrange(1 << 30)
+        mk = lambda rows, k: ol.rand_field(f.field_id, seed + k, rows * n8).reshape(rows, n8, 4)
+        sc = ol.rand_field(f.field_id, seed + 9, 11)
+        args = (mk(6, 1), mk(9, 2), mk(6, 3), mk(1, 4)[0], sc[:6], sc[6], sc[7], sc[8], sc[9], sc[10])
+        assert np.array_equal(pa.api.vanishing_points(f.field_id, degree, *args), ol.vanishing_points(f.field_id, degree, *args, threads=8)), ("plonk", f.name, degree)
+    elif kind == "misc":
+        # batch inversion with zeros, byte encodings round trip
+        f = rng.choice(FIELDS + [br.BLS12_377_BASE])
+        n = rng.choice([1, 7, 8, 9, 100, 1025])
+        x = ol.rand_field(f.field_id, rng.randrange(1 << 30), n)
+        for _ in range(rng.randrange(0, 3)):
+            x[rng.randrange(n)] = 0
+        inv, none = pa.api.batch_multiplicative_inverse_opt(f.field_id, x)
+        nz = ~x.any(axis=1) == False
+        assert np.array_equal(none.astype(bool), ~nz) and (not nz.any() or np.array_equal(inv[nz], ol.batch_inverse(f.field_id, x[nz]))), ("binv", f.name, n)
+        b = pa.api.field_to_bytes(f.field_id, x)
+        assert np.array_equal(b, ol.field_to_bytes(f.field_id, x)) and np.array_equal(pa.api.field_from_bytes(f.field_id, b), x), ("bytes", f.name, n)
     else:
         c = rng.choice(CURVES)
         m = rng.choice([1, 5, 64])
