@@ -1645,7 +1645,7 @@ int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void
 
 // counts[8]: mismatches per case of k_selftest_quad over `quads` quads on the n points d_pts
 int selftest_quad_dev_impl(int curve, const void* d_pts, uint32_t n, uint32_t quads, uint32_t* counts) {
-    if (!d_pts || !counts || n == 0) return set_error(PLK_ERR_INVALID_ARG, "bad argument");
+    if (!d_pts || !counts || n == 0 || quads == 0) return set_error(PLK_ERR_INVALID_ARG, "bad argument");
     PLK_TRY(ensure_device());
     uint32_t* d_cnt = (uint32_t*)scratch_acquire(32, nullptr);
     if (!d_cnt) return PLK_ERR_OOM;
@@ -1659,7 +1659,8 @@ int selftest_quad_dev_impl(int curve, const void* d_pts, uint32_t n, uint32_t qu
         case PLK_CURVE_VESTA: k_selftest_quad<VestaCurve><<<blocks, 256>>>((const uint4*)d_pts, n, d_cnt); break;
         default: scratch_release(d_cnt, nullptr); return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     }
-    hipError_t e = hipMemcpy(counts, d_cnt, 32, hipMemcpyDeviceToHost);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(counts, d_cnt, 32, hipMemcpyDeviceToHost);
     scratch_release(d_cnt, nullptr);
     if (e != hipSuccess) return set_error(PLK_ERR_HIP, "selftest failed: %s", hipGetErrorString(e));
     return PLK_OK;

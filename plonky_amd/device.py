@@ -51,8 +51,9 @@ def ntt_padded_dev(field, x, log_n, out=None):
     """polynomials_to_values_padded on device-resident coefficients: x (batch, len, 4) or (len, 4) with
     len <= 2^log_n; returns (batch, 2^log_n, 4) evaluations.  The zero padding is never stored."""
     assert x.is_cuda and x.dtype == torch.int64 and x.is_contiguous() and x.shape[-1] == 4
+    import math
     length = x.shape[-2]
-    batch = x.numel() // max(length * 4, 1) if length else 1
+    batch = math.prod(x.shape[:-2])  # independent of the length: (B, 0, 4) is B zero polynomials, every output is written
     n = 1 << log_n
     shape = x.shape[:-2] + (n, 4)
     if out is None:

@@ -667,3 +667,36 @@ def test_capi_host_nine_threads():
     assert exe and os.path.exists(exe)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "capi_host: OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_msm_context_shared_by_two_streams():
+    """One device context, executions enqueued back to back on two different HIP streams (the `_dev` entry points are
+    asynchronous): the workspace of the context is handed from one stream to the other through its event, so the second
+    execution may not start before the first one's last kernel.  Every result must be the single-stream one."""
+    torch = pytest.importorskip("torch")
+    from plonky_amd import device as dev
+    dev.init(0)
+    c = br.TWEEDLEDEE
+    n = 1 << 15
+    G = (c.gx, c.gy)
+    D = br.ec_mul(c, 777, G)
+    bases = dev.gen_bases_dev(0, n, _bases(c, [G])[0], _bases(c, [D])[0])
+    pre = dev.msm_precompute_dev(0, bases)
+    svs = [dev.to_device(synth.rand_field(1, 0x5700 + k, n)) for k in range(6)]
+    want = []
+    for s in svs:
+        xy, z = dev.msm_execute_dev(pre, s)
+        torch.cuda.synchronize()
+        want.append((dev.to_host(xy).copy(), int(z.cpu()[0])))
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(3):
+        for k, s in enumerate(svs):
+            with torch.cuda.stream(s1 if (k + rep) % 2 == 0 else s2):
+                outs.append((k, dev.msm_execute_dev(pre, s)))
+    torch.cuda.synchronize()
+    for k, (xy, z) in outs:
+        assert int(z.cpu()[0]) == want[k][1] and np.array_equal(dev.to_host(xy), want[k][0]), k
+    # zero-length polynomials of a batch: every output row is written (ntt_padded_dev)
+    ev = dev.ntt_padded_dev(0, torch.empty((3, 0, 4), dtype=torch.int64, device="cuda"), 6)
+    assert ev.shape == (3, 64, 4) and not dev.to_host(ev).any()
