@@ -53,6 +53,7 @@ struct NttPassArgs {
     int n_prev;       // number of earlier passes (last pass only)
     int prev_log[MAX_PASSES];  // their log sizes a_1..a_{m-1}
     int scale;        // 1: multiply outputs by *scale_ptr (single-pass inverse)
+    int skip;         // first pass of a zero-padded transform: the first `skip` stages only replicate (see tile_stages)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -211,6 +212,13 @@ PLK_DI int tile_in_slot(const NttPassArgs& a, int e) {
     const int q = e & ((1 << a.log_q) - 1), p = e >> a.log_q;
     return ((int)bitrev((uint32_t)p, a.log_a) << a.log_q) + q;
 }
+// with a.skip > 0 the loop runs over SLOTS: slot row s takes the input whose slot row is s with the low `skip` bits cleared
+// (2^skip slots share one input: the replication the skipped stages would have performed)
+PLK_DI int tile_slot_source(const NttPassArgs& a, int e) {
+    const int q = e & ((1 << a.log_q) - 1), s = e >> a.log_q;
+    const int p = (int)bitrev((uint32_t)(s & ~((1 << a.skip) - 1)), a.log_a);
+    return (p << a.log_q) + q;
+}
 // output index (within the transform) of tile element e = (k, q) on store
 PLK_DI size_t tile_out_index(const NttPassArgs& a, const TileGeom& t, int e) {
     const int q = e & ((1 << a.log_q) - 1), k = e >> a.log_q;
@@ -225,9 +233,12 @@ PLK_DI size_t tile_tw_index(const NttPassArgs& a, const TileGeom& t, int e) {
 
 // the stages of a tile in LDS: h = 1, 2, .., A/2, two at a time (radix-4 in registers: half the LDS round
 // trips and barriers of a radix-2 sweep, same multiplications).  Ends with a barrier.
-template <class P> PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw, int tid, int log_a, int log_q, int tile_elems) {
+// `first_stage` > 0: the tile starts at that stage (zero-padded input: when only the rows p < A / 2^k of a column are non-zero,
+// the bit-reversed placement puts them at every 2^k-th slot and the first k butterfly stages pair every value with a zero:
+// (a, 0) -> (a, a).  They are pure replication, done by the loads; polynomials_to_values_padded has k = 3).
+template <class P> PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw, int tid, int log_a, int log_q, int tile_elems, int first_stage) {
     const int Q = 1 << log_q, half_a = (1 << log_a) >> 1;
-    int log_h = 0;
+    int log_h = first_stage;
     for (; log_h + 1 < log_a; log_h += 2) {
         const int h = 1 << log_h;
         for (int qd = tid; qd < (tile_elems >> 2); qd += NTT_THREADS) {
@@ -338,7 +349,8 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const void* in, void* 
         lds_store<P>(s_tw, half_a, e, fz_from_fe<P>(w));
     }
     for (int e = tid; e < tile_elems; e += NTT_THREADS) {
-        const size_t g = tile_in_index(a, tg, e);
+        const bool by_slot = HOOKS && !IN_LIMBS && a.skip > 0;
+        const size_t g = tile_in_index(a, tg, by_slot ? tile_slot_source(a, e) : e);
         Fz<P> x;
         if constexpr (IN_LIMBS) {
             x = limbs_load<P>((const uint32_t*)in, tg.b * n + g);
@@ -348,10 +360,10 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const void* in, void* 
             if (!HOOKS || !a.first || g < hk.in_len) v = fe_load<P>(inb + g * 2);
             x = tile_ingest<P, HOOKS>(a, hk, v, g);
         }
-        lds_store<P>(s_dat, TILE, tile_in_slot(a, e), x);
+        lds_store<P>(s_dat, TILE, by_slot ? e : tile_in_slot(a, e), x);
     }
     __syncthreads();
-    tile_stages<P>(s_dat, s_tw, tid, log_a, log_q, tile_elems);
+    tile_stages<P>(s_dat, s_tw, tid, log_a, log_q, tile_elems, (HOOKS && !IN_LIMBS) ? a.skip : 0);
     const Fz<P> scale = fz_from_fe<P>(fe_load<P>(scale_ptr));
     for (int e = tid; e < tile_elems; e += NTT_THREADS) {
         const size_t g = tile_out_index(a, tg, e);
@@ -569,6 +581,13 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
             a.log_q = a.log_s;
         }
         a.scale = (inverse && m == 1) ? 1 : 0;
+        a.skip = 0;
+        if (hooks && a.first && hooks->in_len > 0 && !hooks->in_lo) {
+            // zero padding by 2^k: the stored coefficients end before n / 2^k
+            int k = 0;
+            while (k < a.log_a && hooks->in_len <= (((size_t)1 << log_n) >> (k + 1))) ++k;
+            a.skip = k;
+        }
         const size_t tiles = (((size_t)1 << log_n) >> (a.log_a + a.log_q)) * batch;
         const void* outer = a.last ? nullptr : pl.outer[dir][t];
         void* dst = a.last ? d_out : scratch;
