@@ -162,6 +162,37 @@ template <class P, int K> PLK_DI Fz<P> fz_sub(const Fz<P>& a, const Fz<P>& b) {
 }
 template <class P> PLK_DI Fz<P> fz_dbl(const Fz<P>& a) { return fz_add<P>(a, a); }
 
+// ---- add / sub without the carry pass ------------------------------------------------------------
+// A value that goes straight into a multiplication by an exactly normalised operand (a table entry: limbs < 2^29) need not
+// have its carries moved first.  Column bound of fz_mul with one operand's limbs <= La and the other's < 2^29:
+//   NZ La 2^29 (a b) + NZ 2^58 (q p) + 2^36 (carry in)  <  2^64   for  La <= 2.5 * 2^30 + 16  and  NZ <= 10,
+// so a sum / difference of up to that limb size is a legal multiplicand (fz_sqr and a product of two such values are not).
+// fz_sub_nc borrows 2^B from each limb's upper neighbour: needs limbs of b <= 2^B - 1 (B = 29: b exactly normalised), the same
+// value condition as fz_sub, and returns limbs <= limbs(a) + 2^B + 2^29.
+template <class P> struct FzNcBound {
+    static_assert(FzCfg<P>::NZ <= 10, "limb bound of the carry-free forms is derived for NZ <= 10");
+    static constexpr uint32_t MUL_LIMB_MAX = 5u * (1u << 29) + 16u;  // 2.5 * 2^30 + 16
+};
+template <class P> PLK_DI Fz<P> fz_add_nc(const Fz<P>& a, const Fz<P>& b) {
+    Fz<P> r;
+#pragma unroll
+    for (int i = 0; i < FzCfg<P>::NZ; ++i) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+template <class P, int K, int B> PLK_DI Fz<P> fz_sub_nc(const Fz<P>& a, const Fz<P>& b) {
+    constexpr int NZ = FzCfg<P>::NZ;
+    Fz<P> r;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        // limb i of 2^K p, plus the 2^B lent by limb i + 1, minus the one lent to limb i - 1
+        const uint32_t c = FzCfg<P>::kp_limb(K, i) - (i == 0 ? (1u << 30) : i == NZ - 1 ? 0u - 2u : (1u << 30) - 2u);
+        constexpr uint32_t lent = 1u << (B - 29);
+        const uint32_t k = i == 0 ? c + (1u << B) : i == NZ - 1 ? c - lent : c + (1u << B) - lent;
+        r.l[i] = a.l[i] - b.l[i] + k;
+    }
+    return r;
+}
+
 // ---- multiplication --------------------------------------------------------------------------
 // Montgomery product a b / R' mod p (lazy): product scanning, quotient digits folded in as they
 // become known (q_k = -column_k mod 2^29 because p = 1 mod 2^29).

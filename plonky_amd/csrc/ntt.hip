@@ -247,29 +247,40 @@ template <class P> PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw
             const int i0 = (((blk << (log_h + 2)) + j) << log_q) + q, st = h << log_q;
             Fz<P> x0 = lds_load<P>(s_dat, TILE, i0), x1 = lds_load<P>(s_dat, TILE, i0 + st);
             Fz<P> x2 = lds_load<P>(s_dat, TILE, i0 + 2 * st), x3 = lds_load<P>(s_dat, TILE, i0 + 3 * st);
-            // stage with half-size h: pairs (x0, x1), (x2, x3), twiddle w_{2h}^j for both
             if (log_h > 0) {
+                // Carries are moved twice per step instead of eight times (fz_add_nc / fz_sub_nc): LDS holds limbs up to
+                // MUL_LIMB_MAX = 2.5 * 2^30 + 16; x1 and x3 go straight into a multiplication by a table entry; x0 and x2 are
+                // carried (limbs < 2^29 + 8) and every sum below stays within the bound:
+                //   y0, y2 <= 2^29 + 8 + 2^29;   y1, y3 <= 2^29 + 8 + 2^30 (borrow 2^29 + limb of 2p);   outputs <= y + 2^30.
+                // stage with half-size h: pairs (x0, x1), (x2, x3), twiddle w_{2h}^j for both
                 const Fz<P> wa = lds_load<P>(s_tw, half_a, j << (log_a - 1 - log_h));
+                fz_carry<P>(x0);
+                fz_carry<P>(x2);
                 x1 = fz_mul<P>(x1, wa);
                 x3 = fz_mul<P>(x3, wa);
-            }
-            Fz<P> y0 = fz_add<P>(x0, x1), y1 = fz_sub<P, 1>(x0, x1);
-            Fz<P> y2 = fz_add<P>(x2, x3), y3 = fz_sub<P, 1>(x2, x3);
-            // stage with half-size 2h: pairs (y0, y2) with w_{4h}^j and (y1, y3) with w_{4h}^(j+h)
-            const Fz<P> wb1 = lds_load<P>(s_tw, half_a, (j + h) << (log_a - 2 - log_h));
-            y3 = fz_mul<P>(y3, wb1);
-            lds_store<P>(s_dat, TILE, i0 + st, fz_add<P>(y1, y3));
-            lds_store<P>(s_dat, TILE, i0 + 3 * st, fz_sub<P, 1>(y1, y3));
-            if (log_h > 0) {
+                const Fz<P> y0 = fz_add_nc<P>(x0, x1), y1 = fz_sub_nc<P, 1, 29>(x0, x1);
+                Fz<P> y2 = fz_add_nc<P>(x2, x3), y3 = fz_sub_nc<P, 1, 29>(x2, x3);
+                // stage with half-size 2h: pairs (y0, y2) with w_{4h}^j and (y1, y3) with w_{4h}^(j+h)
+                const Fz<P> wb1 = lds_load<P>(s_tw, half_a, (j + h) << (log_a - 2 - log_h));
+                y3 = fz_mul<P>(y3, wb1);
+                lds_store<P>(s_dat, TILE, i0 + st, fz_add_nc<P>(y1, y3));
+                lds_store<P>(s_dat, TILE, i0 + 3 * st, fz_sub_nc<P, 1, 29>(y1, y3));
                 const Fz<P> wb0 = lds_load<P>(s_tw, half_a, j << (log_a - 2 - log_h));
                 y2 = fz_mul<P>(y2, wb0);
-                lds_store<P>(s_dat, TILE, i0, fz_add<P>(y0, y2));
-                lds_store<P>(s_dat, TILE, i0 + 2 * st, fz_sub<P, 1>(y0, y2));
+                lds_store<P>(s_dat, TILE, i0, fz_add_nc<P>(y0, y2));
+                lds_store<P>(s_dat, TILE, i0 + 2 * st, fz_sub_nc<P, 1, 29>(y0, y2));
             } else {
-                // first step of a tile: j = 0, w_4^0 = 1, and y2 = x2 + x3 is below 2.1p (the tile's inputs are
-                // canonical, or hooked products below 1.01p): no multiplication, subtract under 4p
-                lds_store<P>(s_dat, TILE, i0, fz_add<P>(y0, y2));
-                lds_store<P>(s_dat, TILE, i0 + 2 * st, fz_sub<P, 2>(y0, y2));
+                // first step of a tile: the inputs are exactly normalised (canonical, or products below 1.01p), the
+                // twiddles w_2^0 and w_4^0 are 1: one multiplication; y2 = x2 + x3 is below 2.1p with limbs <= 2^30 - 2
+                const Fz<P> y0 = fz_add_nc<P>(x0, x1), y1 = fz_sub_nc<P, 1, 29>(x0, x1);
+                const Fz<P> y2 = fz_add_nc<P>(x2, x3);
+                Fz<P> y3 = fz_sub_nc<P, 1, 29>(x2, x3);
+                const Fz<P> wb1 = lds_load<P>(s_tw, half_a, (j + h) << (log_a - 2 - log_h));
+                y3 = fz_mul<P>(y3, wb1);
+                lds_store<P>(s_dat, TILE, i0 + st, fz_add_nc<P>(y1, y3));           // <= 2^29 + 2^30 + 2^29
+                lds_store<P>(s_dat, TILE, i0 + 3 * st, fz_sub_nc<P, 1, 29>(y1, y3));  // <= 2^29 + 2^30 + 2^30
+                lds_store<P>(s_dat, TILE, i0, fz_add_nc<P>(y0, y2));                  // <= 2^31
+                lds_store<P>(s_dat, TILE, i0 + 2 * st, fz_sub_nc<P, 2, 30>(y0, y2));  // <= 2^30 + 2^30 + 2^29
             }
         }
         __syncthreads();
@@ -280,11 +291,15 @@ template <class P> PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw
             const int q = bf & (Q - 1), pb = bf >> log_q;
             const int j = pb & (h - 1), blk = pb >> log_h;
             const int i0 = (((blk << (log_h + 1)) + j) << log_q) + q, i1 = i0 + (h << log_q);
-            const Fz<P> x = lds_load<P>(s_dat, TILE, i0);
+            Fz<P> x = lds_load<P>(s_dat, TILE, i0);
             Fz<P> t = lds_load<P>(s_dat, TILE, i1);
-            if (log_h > 0) t = fz_mul<P>(t, lds_load<P>(s_tw, half_a, j << (log_a - 1 - log_h)));  // w_{2h}^j, product < 1.2p
-            lds_store<P>(s_dat, TILE, i0, fz_add<P>(x, t));
-            lds_store<P>(s_dat, TILE, i1, fz_sub<P, 1>(x, t));  // t < 2p - margin in both cases
+            if (log_h > 0) {
+                fz_carry<P>(x);
+                t = fz_mul<P>(t, lds_load<P>(s_tw, half_a, j << (log_a - 1 - log_h)));  // w_{2h}^j, product < 1.2p
+            }
+            // log_h == 0: a two-point transform of exactly normalised inputs
+            lds_store<P>(s_dat, TILE, i0, fz_add_nc<P>(x, t));
+            lds_store<P>(s_dat, TILE, i1, fz_sub_nc<P, 1, 29>(x, t));  // t < 2p - margin in both cases
         }
         __syncthreads();
     }

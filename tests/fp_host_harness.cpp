@@ -53,6 +53,37 @@ template <class P> static void run(int op, const uint32_t* a, const uint32_t* b,
                 for (int k = 0; k < 13; ++k) v = fz_add<P>(v, yz);
                 r = fz_to_fe_canonical<P>(fz_reduce_small<P>(v));
             } break;
+            case 20: case 21: case 22: case 23: {
+                // two radix-4 steps of the NTT tile on the carry-free forms (ntt.hip tile_stages): the first-step shape on
+                // (x, y, y, x), then the general shape on its outputs placed largest-first; twiddles are the normalised x / y
+                if constexpr (FzCfg<P>::NZ > 10) { r = fe_zero<P>(); break; } else {
+                const Fz<P> a = fz_from_fe<P>(x), b = fz_from_fe<P>(y);
+                Fz<P> o[4];
+                {
+                    const Fz<P> y0 = fz_add_nc<P>(a, b), y1 = fz_sub_nc<P, 1, 29>(a, b), y2 = fz_add_nc<P>(b, a);
+                    const Fz<P> y3 = fz_mul<P>(fz_sub_nc<P, 1, 29>(b, a), b);
+                    o[1] = fz_add_nc<P>(y1, y3);
+                    o[3] = fz_sub_nc<P, 1, 29>(y1, y3);
+                    o[0] = fz_add_nc<P>(y0, y2);
+                    o[2] = fz_sub_nc<P, 2, 30>(y0, y2);
+                }
+                Fz<P> x0 = o[3], x1 = o[2], x2 = o[1], x3 = o[0], O[4];
+                fz_carry<P>(x0);
+                fz_carry<P>(x2);
+                x1 = fz_mul<P>(x1, b);
+                x3 = fz_mul<P>(x3, b);
+                const Fz<P> y0 = fz_add_nc<P>(x0, x1), y1 = fz_sub_nc<P, 1, 29>(x0, x1);
+                const Fz<P> y2 = fz_mul<P>(fz_add_nc<P>(x2, x3), b), y3 = fz_mul<P>(fz_sub_nc<P, 1, 29>(x2, x3), a);
+                O[1] = fz_add_nc<P>(y1, y3);
+                O[3] = fz_sub_nc<P, 1, 29>(y1, y3);
+                O[0] = fz_add_nc<P>(y0, y2);
+                O[2] = fz_sub_nc<P, 1, 29>(y0, y2);
+                bool ok = true;
+                for (int k = 0; k < 4; ++k)
+                    for (int i = 0; i < FzCfg<P>::NZ; ++i) ok = ok && O[k].l[i] <= FzNcBound<P>::MUL_LIMB_MAX && o[k].l[i] <= FzNcBound<P>::MUL_LIMB_MAX;
+                r = ok ? fz_to_fe_canonical<P>(fz_mul<P>(O[op - 20], fz_one_rprime<P>())) : fe_zero<P>();
+                }
+            } break;
             default: r = fe_neg<P>(x); break;
         }
         for (int k = 0; k < P::NL; ++k) out[i * P::NL + k] = r.v[k];

@@ -99,6 +99,7 @@ def test_lazy_29bit_arithmetic_on_host(host_lib, f):
     got_chain = run(host_lib, f, 16, a, b)
     got_zero = run(host_lib, f, 17, a, b)
     got_red = run(host_lib, f, 19, a, b) if n == 4 else None  # fz_reduce_small: the NTT fields
+    got_nc = [run(host_lib, f, 20 + t, a, b) for t in range(4)] if n == 4 else None  # carry-free radix-4 steps of the NTT tile
     k = 0
     for i in range(m):
         ai = inputs[i]
@@ -112,6 +113,15 @@ def test_lazy_29bit_arithmetic_on_host(host_lib, f):
             assert got_zero[k] == (1 if ai * bj % p == 0 else 0)
             if got_red is not None:
                 assert got_red[k] == (ai + 13 * bj) % p
+            if got_nc is not None:
+                y3 = (bj - ai) * bj * Rp_inv
+                o = [2 * (ai + bj), (ai - bj) + y3, 0, (ai - bj) - y3]
+                x1, x3 = o[2] * bj * Rp_inv, o[0] * bj * Rp_inv
+                z0, z1 = o[3] + x1, o[3] - x1
+                z2, z3 = (o[1] + x3) * bj * Rp_inv, (o[1] - x3) * ai * Rp_inv
+                want = [z0 + z2, z1 + z3, z0 - z2, z1 - z3]
+                for t in range(4):
+                    assert got_nc[t][k] == want[t] % p, (t, hex(ai), hex(bj))
             k += 1
     # the value p itself (== 0 mod p) as an operand exercises the second branch of the zero test
     pw = ints_to_array([p] * 3, n)
