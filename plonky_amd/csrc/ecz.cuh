@@ -72,8 +72,13 @@ template <class FP> PLK_DI void xyzzz_madd(XyzzZ<FP>& acc, const Fz<FP>& x2, con
         }
         return;
     }
-    Fz<FP> x3 = fz_sub<FP, 2>(fz_sub<FP, 1>(rr, ppp), fz_dbl<FP>(q));  // (1.3 + 2) + 4 < 7.3 < 8
-    Fz<FP> t = fz_sub<FP, 3>(q, x3);                                    // < 1.3 + 8 = 9.3
+    // carries are moved only where a later step needs them (fz_add_nc / fz_sub_nc, fz.cuh): rr - ppp and 2q are consumed by
+    // the subtraction that forms x3 (limbs <= 2^29 + 2^30 and <= 2^30 - 2), t only by the product r t (limbs <= 2^31, r carried)
+    Fz<FP> x3 = fz_sub_nc<FP, 2, 30>(fz_sub_nc<FP, 1, 29>(rr, ppp), fz_add_nc<FP>(q, q));  // (1.3 + 2) + 4 < 7.3 < 8
+    fz_carry<FP>(x3);                                                   // limbs <= 3 * 2^30 -> < 2^29 + 8
+    Fz<FP> t;                                                           // < 1.3 + 8 = 9.3
+    if constexpr (FzCfg<FP>::NZ <= 10) t = fz_sub_nc<FP, 3, 30>(q, x3);  // limbs <= 2^31 <= FzNcBound::MUL_LIMB_MAX
+    else t = fz_sub<FP, 3>(q, x3);                                      // 14 limbs: the column sums have no room for it
     acc.y = fz_sub<FP, 1>(fz_mul<FP>(r, t), fz_mul<FP>(acc.y, ppp));    // < (6*9.3/128 + 1) + 2 < 3.5 < 4
     acc.x = x3;
     acc.zz = zz3;

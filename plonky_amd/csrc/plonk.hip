@@ -33,32 +33,101 @@ constexpr int GRID_WIDTH = 65;       // plonk.rs:25
 constexpr int NUM_TERMS = 8;         // the longest gate constraint list (base_4_sum: 1 + 7, rescue_a: 8)
 constexpr int XS_LO_LOG = 10;
 
-// a field element with operators: keeps the gate formulas readable next to the reference's
-template <class P> struct El {
-    Fe<P> v;
-    PLK_DI El operator+(const El& o) const { return El{fe_add<P>(v, o.v)}; }
-    PLK_DI El operator-(const El& o) const { return El{fe_sub<P>(v, o.v)}; }
-    PLK_DI El operator*(const El& o) const { return El{fe_mul<P>(v, o.v)}; }
-    PLK_DI El sq() const { return El{fe_sqr<P>(v)}; }
-    PLK_DI El dbl() const { return El{fe_dbl<P>(v)}; }  // field.rs:181-183 multiplies by TWO: the same value
-    PLK_DI El quad() const { return dbl().dbl(); }       // field.rs:191-193
-    PLK_DI El pow5() const {                             // exp_usize(5), rescue_a.rs:58, rescue_b.rs:44
-        const El x2 = sq();
+// Working form of the kernels: lazily reduced 29-bit limbs in R'-form (fz.cuh) with the value bound carried in the TYPE, in
+// eighths of p: Lz<P, B> holds a value below (B / 8) p with limbs below 2^29 + 8.  The operators pick the multiple of p a
+// subtraction needs, give every result its bound, and refuse at compile time a product whose operand could exceed 15p or a
+// sum that could leave the 261 bits of the representation - so the gate formulas below read like the reference's and cannot
+// overflow silently.  A product of values below a p and b p comes back below (a b / 127.9 + 1) p (p / R' < 2^-7 (1 + 2^-22)).
+constexpr int LZ_MUL_MAX = 120, LZ_VAL_MAX = 1000;
+constexpr int lz_sub_k(int b) {
+    int k = 0;
+    while ((8 << k) - 1 < b) ++k;  // 2^k p must exceed the subtrahend's bound
+    return k;
+}
+constexpr int lz_mul_bound(int a, int b) { return a * b / 1023 + 9; }
+template <class P, int B> struct Lz {
+    static_assert(FzCfg<P>::NZ == 9 && Mod29<P>::limb(8) <= (1u << 22), "bounds are derived for p < 2^254 (1 + 2^-22), R' = 2^261");
+    Fz<P> v;
+    template <int B2> PLK_DI Lz<P, B2> widen() const {
+        static_assert(B2 >= B, "a bound can only be relaxed");
+        return Lz<P, B2>{v};
+    }
+    PLK_DI Lz<P, lz_mul_bound(B, B)> sq() const {
+        static_assert(B <= LZ_MUL_MAX, "operand of a product above 15p");
+        return {fz_sqr<P>(v)};
+    }
+    PLK_DI Lz<P, 2 * B> dbl() const {  // field.rs:181-183 multiplies by TWO: the same value
+        static_assert(2 * B <= LZ_VAL_MAX, "value could leave the representation");
+        return {fz_add<P>(v, v)};
+    }
+    PLK_DI auto quad() const { return dbl().dbl(); }  // field.rs:191-193
+    PLK_DI Lz<P, 16> rs() const {                      // any value of the representation -> below 2p, no multiplication
+        static_assert(B <= 1023, "value could leave the representation");
+        return {fz_reduce_small<P>(v)};
+    }
+    PLK_DI auto pow5() const {  // exp_usize(5), rescue_a.rs:58, rescue_b.rs:44
+        const auto x2 = sq();
         return x2.sq() * *this;
     }
 };
-template <class P> PLK_DI El<P> el_load(const uint4* p, size_t i) { return El<P>{fe_load<P>(p + i * 2)}; }
-template <class P> PLK_DI El<P> el_one() { return El<P>{fe_one<P>()}; }
-template <class P> PLK_DI El<P> el_zero() { return El<P>{fe_zero<P>()}; }
+template <class P, int A, int B> PLK_DI Lz<P, A + B> operator+(const Lz<P, A>& a, const Lz<P, B>& b) {
+    static_assert(A + B <= LZ_VAL_MAX, "value could leave the representation");
+    return {fz_add<P>(a.v, b.v)};
+}
+template <class P, int A, int B> PLK_DI Lz<P, A + (8 << lz_sub_k(B))> operator-(const Lz<P, A>& a, const Lz<P, B>& b) {
+    static_assert(A + (8 << lz_sub_k(B)) <= LZ_VAL_MAX, "value could leave the representation");
+    return {fz_sub<P, lz_sub_k(B)>(a.v, b.v)};
+}
+template <class P, int A, int B> PLK_DI Lz<P, lz_mul_bound(A, B)> operator*(const Lz<P, A>& a, const Lz<P, B>& b) {
+    static_assert(A <= LZ_MUL_MAX && B <= LZ_MUL_MAX, "operand of a product above 15p");
+    return {fz_mul<P>(a.v, b.v)};
+}
+// keeps a running value small: past 30p it is brought back below 2p
+template <class P, int B> PLK_DI auto lz_tame(const Lz<P, B>& a) {
+    if constexpr (B > 240) return a.rs();
+    else return a;
+}
+// The caller's data is in the reference's R-form (x 2^256, canonical).  R' = 2^261 = 32 R: the R'-form of the same element is
+// 32 x, i.e. the words re-sliced into 29-bit limbs five bits lower, then reduced below 2p without a multiplication.
+template <class P> PLK_DI Lz<P, 16> lz_from_rform(const Fe<P>& x) {
+    constexpr int NZ = FzCfg<P>::NZ, S = 29 * NZ - 32 * P::NL;
+    static_assert(S > 0 && S < 29, "R' / R must be a shift by less than a limb");
+    Fz<P> r;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        const int off = 29 * i - S;
+        uint32_t v;
+        if (off < 0) v = x.v[0] << (-off);
+        else {
+            const int w = off >> 5, sh = off & 31;
+            if (sh == 0) v = x.v[w];
+            else if (sh + 29 <= 32 || w + 1 >= P::NL) v = x.v[w] >> sh;
+            else v = (x.v[w] >> sh) | (x.v[w + 1] << (32 - sh));
+        }
+        r.l[i] = v & FzCfg<P>::M;
+    }
+    return {fz_reduce_small<P>(r)};
+}
+template <class P> PLK_DI Lz<P, 16> lz_load(const uint4* p, size_t i) { return lz_from_rform<P>(fe_load<P>(p + i * 2)); }
+// table entries are stored in R'-form, canonical
+template <class P> PLK_DI Lz<P, 8> lz_table(const uint4* p, size_t i) { return {fz_from_fe<P>(fe_load<P>(p + i * 2))}; }
+template <class P> PLK_DI Lz<P, 8> lz_one() { return {fz_one_rprime<P>()}; }
+// back to the reference's form: x R' * R / R' = x R, below 2p, then the unique representative
+template <class P, int B> PLK_DI Fe<P> lz_to_rform(const Lz<P, B>& a) {
+    static_assert(B <= LZ_MUL_MAX, "operand of a product above 15p");
+    return fz_to_fe_canonical<P>(fz_mul<P>(a.v, fz_const_rprime_to_r<P>()));
+}
 
 // circuit-size tables (device, field, log_degree): everything the loop needs that does not depend on the proof
 struct PlonkTables {
-    void* xs_lo = nullptr;  // g^j, j < 1024 (g = primitive 8n-th root, circuit_builder.rs:1122)
-    void* xs_hi = nullptr;  // g^(1024 j)
-    void* l1 = nullptr;     // L_1(g^i), i < 8n  (plonk_util.rs:14-24)
-    void* small = nullptr;  // [0..7]: 1/1 .. 1/7 then unused; MDS entry (r, c) = 1 / (4 + r - c)  (mds.rs:63-77)
+    void* xs_lo = nullptr;    // g^j, j < 1024 (g = primitive 8n-th root, circuit_builder.rs:1122), R-form: feeds the L_1 table
+    void* xs_hi = nullptr;    // g^(1024 j)
+    void* xs_lo_z = nullptr;  // the same two tables in R'-form: the point x of a lane is one product of them
+    void* xs_hi_z = nullptr;
+    void* l1 = nullptr;       // L_1(g^i), i < 8n  (plonk_util.rs:14-24), R'-form
+    void* small = nullptr;    // [0..7]: 1/1 .. 1/7 then unused, R'-form; MDS entry (r, c) = 1 / (4 + r - c)  (mds.rs:63-77)
     ~PlonkTables() {
-        for (void* p : {xs_lo, xs_hi, l1, small})
+        for (void* p : {xs_lo, xs_hi, xs_lo_z, xs_hi_z, l1, small})
             if (p) (void)hipFree(p);
     }
 };
@@ -72,22 +141,26 @@ int plonk_clear_cache_impl() {
 }
 
 template <class P> __global__ void k_plonk_xs(const uint4* __restrict__ pw, int log_t, int log_n8, uint4* __restrict__ lo, uint4* __restrict__ hi,
-                                              uint4* __restrict__ small) {
+                                              uint4* __restrict__ lo_z, uint4* __restrict__ hi_z, uint4* __restrict__ small) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n_lo = (size_t)1 << XS_LO_LOG;
     const size_t n_hi = log_n8 > XS_LO_LOG ? (size_t)1 << (log_n8 - XS_LO_LOG) : 1;
     if (idx < n_lo) {
         const uint64_t e = (idx & (((uint64_t)1 << log_n8) - 1)) << (log_t - log_n8);
-        fe_store<P>(lo + idx * 2, pow_from_table<P>(pw, 0, e, log_t));
+        const Fe<P> v = pow_from_table<P>(pw, 0, e, log_t);
+        fe_store<P>(lo + idx * 2, v);
+        fe_store<P>(lo_z + idx * 2, to_rprime<P>(v));
     } else if (idx < n_lo + n_hi) {
         const uint64_t e = (((idx - n_lo) << XS_LO_LOG) & (((uint64_t)1 << log_n8) - 1)) << (log_t - log_n8);
-        fe_store<P>(hi + (idx - n_lo) * 2, pow_from_table<P>(pw, 0, e, log_t));
+        const Fe<P> v = pow_from_table<P>(pw, 0, e, log_t);
+        fe_store<P>(hi + (idx - n_lo) * 2, v);
+        fe_store<P>(hi_z + (idx - n_lo) * 2, to_rprime<P>(v));
     } else if (idx < n_lo + n_hi + 7) {
         // 1 / v for v = 1 .. 7
         const uint32_t v = (uint32_t)(idx - n_lo - n_hi) + 1;
         Fe<P> c = fe_zero<P>();
         c.v[0] = v;
-        fe_store<P>(small + (v - 1) * 2, fe_inv_safegcd<P>(fe_from_canonical<P>(c)));
+        fe_store<P>(small + (v - 1) * 2, to_rprime<P>(fe_inv_safegcd<P>(fe_from_canonical<P>(c))));
     }
 }
 template <class P> PLK_DI Fe<P> plonk_x(const uint4* lo, const uint4* hi, size_t i) {
@@ -125,7 +198,7 @@ template <class P> __global__ void __launch_bounds__(64) k_plonk_l1(const uint4*
         const Fe<P> xn = plonk_x<P>(lo, hi, ((i & 7) << log_degree));
         Fe<P> r = fe_mul<P>(fe_sub<P>(xn, one), dinv);
         if (i == 0) r = one;
-        fe_store<P>(l1 + i * 2, r);
+        fe_store<P>(l1 + i * 2, to_rprime<P>(r));
     }
 }
 
@@ -149,10 +222,13 @@ template <class P> static int get_plonk_tables(int log_degree, hipStream_t strea
     const size_t n_lo = (size_t)1 << XS_LO_LOG, n_hi = log_n8 > XS_LO_LOG ? (size_t)1 << (log_n8 - XS_LO_LOG) : 1;
     PLK_HIP_TRY(hipMalloc(&t->xs_lo, n_lo * 32));
     PLK_HIP_TRY(hipMalloc(&t->xs_hi, n_hi * 32));
+    PLK_HIP_TRY(hipMalloc(&t->xs_lo_z, n_lo * 32));
+    PLK_HIP_TRY(hipMalloc(&t->xs_hi_z, n_hi * 32));
     PLK_HIP_TRY(hipMalloc(&t->small, 8 * 32));
     PLK_HIP_TRY(hipMalloc(&t->l1, n8 * 32));
     const size_t cnt = n_lo + n_hi + 7;
-    k_plonk_xs<P><<<(unsigned)((cnt + 127) / 128), 128, 0, stream>>>((const uint4*)pw, log_t, log_n8, (uint4*)t->xs_lo, (uint4*)t->xs_hi, (uint4*)t->small);
+    k_plonk_xs<P><<<(unsigned)((cnt + 127) / 128), 128, 0, stream>>>((const uint4*)pw, log_t, log_n8, (uint4*)t->xs_lo, (uint4*)t->xs_hi, (uint4*)t->xs_lo_z,
+                                                                     (uint4*)t->xs_hi_z, (uint4*)t->small);
     const size_t lanes = (n8 + L1_PER_LANE - 1) / L1_PER_LANE;
     k_plonk_l1<P><<<(unsigned)((lanes + 63) / 64), 64, 0, stream>>>((const uint4*)t->xs_lo, (const uint4*)t->xs_hi, log_degree, (uint4*)t->l1);
     PLK_HIP_TRY(hipGetLastError());
@@ -165,120 +241,140 @@ template <class P> static int get_plonk_tables(int log_degree, hipStream_t strea
 // ---------------------------------------------------------------------------------------------
 // evaluate_all_constraints (gates/mod.rs:46-125): the unified constraint set at one point
 // ---------------------------------------------------------------------------------------------
-// k: local constants [6]; l: local wires [9]; r: right wires (only indices 0..3 are read by any gate); b2, b3: below wires 2, 3
-// (only CurveEndoGate reads below, curve_endo.rs:115-117); small: 1/1 .. 1/7.
-template <class P>
-PLK_DI void all_constraints(const El<P> (&k)[NUM_CONSTANTS], const El<P> (&l)[NUM_WIRES], const El<P> (&r)[4], const El<P>& b2, const El<P>& b3,
-                            const El<P>& zeta, const El<P>& a_coeff, const uint4* __restrict__ small, El<P> (&u)[NUM_TERMS]) {
-    using E = El<P>;
-    const E one = el_one<P>();
-#pragma unroll
-    for (int i = 0; i < NUM_TERMS; ++i) u[i] = el_zero<P>();
-    // prefix filters (gates/mod.rs:289-300); the prefix tree of gates/mod.rs:1-16 shares its products
-    E nk[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) nk[i] = one - k[i];
-    const E p10 = k[0] * nk[1];          // 10
-    const E p101 = p10 * k[2];           // 101
-    const E p1010 = p101 * nk[3];        // 1010
-    const E p1011 = p101 * k[3];         // 1011
-    const E p100 = p10 * nk[2];          // 100
-    const E f_curve_add = p1010 * k[4];                 // 10101   curve_add.rs:60
-    const E f_curve_dbl = p1011 * k[4];                 // 10111   curve_dbl.rs:42
-    const E f_curve_endo = k[0] * k[1];                 // 11      curve_endo.rs:96
-    const E f_base4 = p100 * nk[3];                     // 1000    base_4_sum.rs:34
-    const E f_public_input = p1010 * nk[4] * k[5];      // 101001  public_input.rs:26
-    const E f_constant = p1011 * nk[4];                 // 10110   constant.rs:28
-    const E f_arithmetic = p100 * k[3];                 // 1001    arithmetic.rs:30
-    const E f_rescue_a = nk[0] * nk[1];                 // 00      rescue_a.rs:38
-    const E f_rescue_b = nk[0] * k[1];                  // 01      rescue_b.rs:30
-    // (BufferGate, 101010, has no constraints: buffer.rs:26-33)
+// The gates hand their filter and their constraint list to a sink.  Two sinks:
+//  * TermSink: term t of the unified set += filter * constraint t (what evaluate_all_constraints returns, gates/mod.rs:100-124);
+//  * ReducedSink: total += filter * (c_0 + alpha c_1 + alpha^2 c_2 + ..), the gate's share of reduce_with_powers over the unified
+//    terms (plonk_util.rs:27-33; the sum over the gates and the powers of alpha commute) - one running value instead of eight,
+//    and one product by the filter per gate instead of one per constraint.
+// Ten gates, each adds at most once to a term / to the total, every summand a product (below 1.25p): the sums stay below 12.5p.
+template <class P> using Term = Lz<P, 100>;
+// Between two gates: the instruction scheduler must not interleave them (left alone it overlaps all ten gates for
+// instruction-level parallelism and the kernel needs several times the register file).
+PLK_DI void gate_fence() {
+#ifdef __HIPCC__
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+template <int GATE, class P, int B> PLK_DI void add_product(Term<P>& u, const Lz<P, B>& product) {
+    static_assert(GATE >= 0 && GATE < 10, "ten gates");
+    static_assert(B <= 10, "a summand must be a product");
+    u.v = fz_add<P>(u.v, product.v);
+}
+template <class P> struct TermSink {
+    Term<P> (&u)[NUM_TERMS];
+    template <int GATE, int T, class F> PLK_DI void put(const F&) {}
+    template <int GATE, int T, class F, class C0, class... Cs> PLK_DI void put(const F& f, const C0& c0, const Cs&... cs) {
+        add_product<GATE>(u[T], f * c0);
+        put<GATE, T + 1>(f, cs...);
+    }
+    template <int GATE, class F, class... Cs> PLK_DI void gate(const F& f, const Cs&... cs) {
+        gate_fence();
+        put<GATE, 0>(f, cs...);
+        gate_fence();
+    }
+};
+template <class A, class C0> PLK_DI auto lz_horner(const A&, const C0& c0) { return c0; }
+template <class A, class C0, class... Cs> PLK_DI auto lz_horner(const A& alpha, const C0& c0, const Cs&... cs) { return c0 + lz_horner(alpha, cs...) * alpha; }
+template <class P> struct ReducedSink {
+    Lz<P, 16> alpha;
+    Term<P> total;
+    template <int GATE, class F, class... Cs> PLK_DI void gate(const F& f, const Cs&... cs) {
+        gate_fence();
+        add_product<GATE>(total, f * lz_horner(alpha, cs...));
+        gate_fence();
+    }
+};
+// Base4SumGate's running sum, computed = 4 computed + limb over the seven limbs (base_4_sum.rs:44-48)
+template <int I, class P, int B, class D> PLK_DI auto base4_chain(const Lz<P, B>& computed, const D (&l)[NUM_WIRES]) {
+    if constexpr (I == NUM_WIRES - 2) return computed;
+    else return base4_chain<I + 1>(lz_tame(computed.quad() + l[2 + I]), l);
+}
 
-    {  // CurveAddGate, curve_add.rs:62-101
-        const E x1 = l[0], y1 = l[1], x4 = r[0], y4 = r[1], acc_old = l[2], acc_new = l[3], x2 = l[4], y2 = l[5], bit = l[6], inverse = l[7], lambda = l[8];
-        const E computed_lambda = (y1 - y2) * inverse;
-        const E x3 = lambda.sq() - x1 - x2;
-        const E y3 = lambda * (x1 - x4) - y1;
-        const E not_bit = one - bit;
-        const E computed_x4 = bit * x3 + not_bit * x1;
-        const E computed_y4 = bit * y3 + not_bit * y1;
-        u[0] = u[0] + f_curve_add * (computed_lambda - lambda);
-        u[1] = u[1] + f_curve_add * (computed_x4 - x4);
-        u[2] = u[2] + f_curve_add * (computed_y4 - y4);
-        u[3] = u[3] + f_curve_add * (acc_new - (acc_old.dbl() + bit));
-        u[4] = u[4] + f_curve_add * (bit * not_bit);
-        u[5] = u[5] + f_curve_add * (inverse * (x1 - x2) - one);
-    }
-    {  // CurveDblGate, curve_dbl.rs:44-68
-        const E x_old = l[0], y_old = l[1], x_new = l[2], y_new = l[3], inverse = l[4], lambda = l[5];
-        const E xx = x_old.sq();
-        const E numerator = xx.dbl() + xx + a_coeff;  // square().triple() + A
-        const E computed_lambda = numerator * inverse;
-        const E computed_x_new = lambda.sq() - x_old.dbl();
-        const E computed_y_new = lambda * (x_old - x_new) - y_old;
-        u[0] = u[0] + f_curve_dbl * (computed_lambda - lambda);
-        u[1] = u[1] + f_curve_dbl * (computed_x_new - x_new);
-        u[2] = u[2] + f_curve_dbl * (computed_y_new - y_new);
-        u[3] = u[3] + f_curve_dbl * (y_old.dbl() * inverse - one);
-    }
-    {  // CurveEndoGate, curve_endo.rs:98-141
-        const E x1 = l[0], y1 = l[1], x_in = l[4], y_in = l[5], x3 = r[0], y3 = r[1];
-        const E unsigned_old = l[2], unsigned_new = b2, signed_old = l[3], signed_new = b3, bit0 = l[6], bit1 = l[7], inverse = l[8];
-        const E mult = (zeta - one) * bit1 + one;  // x2's factor and signed_limb_multiplier are the same expression
-        const E x2 = mult * x_in;
-        const E sgn = bit0.dbl() - one;
-        const E y2 = sgn * y_in;
-        const E lambda = (y1 - y2) * inverse;
-        const E computed_x3 = lambda.sq() - x1 - x2;
-        const E computed_y3 = lambda * (x1 - x3) - y1;
-        const E signed_limb = sgn * mult;
-        u[0] = u[0] + f_curve_endo * (computed_x3 - x3);
-        u[1] = u[1] + f_curve_endo * (computed_y3 - y3);
-        u[2] = u[2] + f_curve_endo * (unsigned_new - (unsigned_old.quad() + bit1.dbl() + bit0));
-        u[3] = u[3] + f_curve_endo * (signed_new - (signed_old.dbl() + signed_limb));
-        u[4] = u[4] + f_curve_endo * (bit0 * (bit0 - one));
-        u[5] = u[5] + f_curve_endo * (bit1 * (bit1 - one));
-        u[6] = u[6] + f_curve_endo * (inverse * (x1 - x2) - one);
-    }
-    {  // Base4SumGate, base_4_sum.rs:36-63: 7 limbs in wires 2..8
-        E computed = l[0];
-        const E two = one.dbl(), three = two + one;
+// k: local constants [6]; l: local wires [9]; r: right wires (only indices 0..3 are read by any gate); b2, b3: below wires 2, 3
+// (only CurveEndoGate reads below, curve_endo.rs:115-117); small: 1/1 .. 1/7 (R'-form table).
+// Prefix filters (gates/mod.rs:289-300) are formed where they are used, along the prefix tree of gates/mod.rs:1-16 (BufferGate,
+// 101010, has no constraints: buffer.rs:26-33): a filter kept alive for the whole kernel costs nine registers.
+template <class P, class D, class Sink>
+PLK_DI void all_constraints(const D (&k)[NUM_CONSTANTS], const D (&l)[NUM_WIRES], const D (&r)[4], const D& b2, const D& b3, const D& zeta, const D& a_coeff,
+                            const uint4* __restrict__ small, Sink& sink) {
+    const auto one = lz_one<P>();
+    {  // RescueStepAGate 00, rescue_a.rs:38-69, and RescueStepBGate 01, rescue_b.rs:30-58
+        const auto nk0 = one - k[0];
+        Lz<P, 8> mds[7];
 #pragma unroll
-        for (int i = 0; i < NUM_WIRES - 2; ++i) {
-            const E limb = l[2 + i];
-            computed = computed.quad() + limb;
-            const E product = one * limb * (limb - one) * (limb - two) * (limb - three);  // j = 0: limb - 0
-            u[1 + i] = u[1 + i] + f_base4 * product;
+        for (int i = 0; i < 7; ++i) mds[i] = lz_table<P>(small, i);  // mds[v - 1] = 1 / v; entry (r, c) = 1 / (4 + r - c), mds.rs:63-77
+        // row i of the MDS matrix times (v0 .. v3), plus the round constant, against the right gate's wire i
+#define PLK_MDS_ROW(i, v0, v1, v2, v3) (k[2 + i] + (mds[3 + i] * v0 + mds[2 + i] * v1 + mds[1 + i] * v2 + mds[i] * v3) - r[i])
+        sink.template gate<7>(nk0 * (one - k[1]),                                                         //
+                              l[4].pow5() - l[0], PLK_MDS_ROW(0, l[4], l[5], l[6], l[7]),                 //
+                              l[5].pow5() - l[1], PLK_MDS_ROW(1, l[4], l[5], l[6], l[7]),                 //
+                              l[6].pow5() - l[2], PLK_MDS_ROW(2, l[4], l[5], l[6], l[7]),                 //
+                              l[7].pow5() - l[3], PLK_MDS_ROW(3, l[4], l[5], l[6], l[7]));
+        const auto e0 = l[0].pow5(), e1 = l[1].pow5(), e2 = l[2].pow5(), e3 = l[3].pow5();
+        sink.template gate<8>(nk0 * k[1], PLK_MDS_ROW(0, e0, e1, e2, e3), PLK_MDS_ROW(1, e0, e1, e2, e3), PLK_MDS_ROW(2, e0, e1, e2, e3),
+                              PLK_MDS_ROW(3, e0, e1, e2, e3));
+#undef PLK_MDS_ROW
+    }
+    {  // CurveEndoGate 11, curve_endo.rs:96-141
+        const D &x1 = l[0], &y1 = l[1], &x_in = l[4], &y_in = l[5], &x3 = r[0], &y3 = r[1];
+        const D &unsigned_old = l[2], &unsigned_new = b2, &signed_old = l[3], &signed_new = b3, &bit0 = l[6], &bit1 = l[7], &inverse = l[8];
+        const auto mult = (zeta - one) * bit1 + one;  // x2's factor and signed_limb_multiplier are the same expression
+        const auto x2 = mult * x_in;
+        const auto sgn = bit0.dbl() - one;
+        const auto y2 = sgn * y_in;
+        const auto lambda = (y1 - y2) * inverse;
+        const auto computed_x3 = lambda.sq() - x1 - x2;
+        const auto computed_y3 = lambda * (x1 - x3) - y1;
+        const auto signed_limb = sgn * mult;
+        sink.template gate<2>(k[0] * k[1], computed_x3 - x3, computed_y3 - y3, unsigned_new - (unsigned_old.quad() + bit1.dbl() + bit0).rs(),
+                              signed_new - (signed_old.dbl() + signed_limb), bit0 * (bit0 - one), bit1 * (bit1 - one), inverse * (x1 - x2) - one);
+    }
+    const auto p10 = k[0] * (one - k[1]);
+    {
+        const auto p100 = p10 * (one - k[2]);
+        {  // Base4SumGate 1000, base_4_sum.rs:34-63: 7 limbs in wires 2..8
+            const auto two = one.dbl();
+            const auto three = two + one;
+            // (limb - 0) (limb - 1) (limb - 2) (limb - 3), times ONE in the reference
+#define PLK_B4(i) (l[2 + i] * (l[2 + i] - one) * (l[2 + i] - two) * (l[2 + i] - three))
+            sink.template gate<3>(p100 * (one - k[3]), (base4_chain<0>(l[0], l) - l[1]).rs(), PLK_B4(0), PLK_B4(1), PLK_B4(2), PLK_B4(3), PLK_B4(4), PLK_B4(5),
+                                  PLK_B4(6));
+#undef PLK_B4
         }
-        u[0] = u[0] + f_base4 * (computed - l[1]);
+        // ArithmeticGate 1001, arithmetic.rs:30-46
+        sink.template gate<6>(p100 * k[3], k[4] * l[0] * l[1] + k[5] * l[2] - l[3]);
     }
-    // PublicInputGate, public_input.rs:28-37: advice wires 6..8 against the right gate's wires 0..2
-#pragma unroll
-    for (int i = 0; i < NUM_WIRES - NUM_ROUTED_WIRES; ++i) u[i] = u[i] + f_public_input * (l[NUM_ROUTED_WIRES + i] - r[i]);
-    // ConstantGate, constant.rs:30-39
-    u[0] = u[0] + f_constant * (k[5] - l[0]);
-    // ArithmeticGate, arithmetic.rs:32-46
-    u[0] = u[0] + f_arithmetic * (k[4] * l[0] * l[1] + k[5] * l[2] - l[3]);
-    {  // RescueStepAGate, rescue_a.rs:40-69 and RescueStepBGate, rescue_b.rs:32-58
-        E mds[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) mds[i] = el_load<P>(small, i);  // mds[v - 1] = 1 / v; entry (r, c) = 1 / (4 + r - c)
-        E exps[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) exps[i] = l[i].pow5();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u[2 * i] = u[2 * i] + f_rescue_a * (l[4 + i].pow5() - l[i]);
-            E out_a = k[2 + i], out_b = k[2 + i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const E m = mds[4 + i - j - 1];
-                out_a = out_a + m * l[4 + j];
-                out_b = out_b + m * exps[j];
-            }
-            u[2 * i + 1] = u[2 * i + 1] + f_rescue_a * (out_a - r[i]);
-            u[i] = u[i] + f_rescue_b * (out_b - r[i]);
+    const auto p101 = p10 * k[2];
+    {
+        const auto p1010 = p101 * (one - k[3]);
+        {  // CurveAddGate 10101, curve_add.rs:60-101
+            const D &x1 = l[0], &y1 = l[1], &x4 = r[0], &y4 = r[1], &acc_old = l[2], &acc_new = l[3], &x2 = l[4], &y2 = l[5], &bit = l[6], &inverse = l[7],
+                    &lambda = l[8];
+            const auto computed_lambda = (y1 - y2) * inverse;
+            const auto x3 = lambda.sq() - x1 - x2;
+            const auto y3 = lambda * (x1 - x4) - y1;
+            const auto not_bit = one - bit;
+            const auto computed_x4 = bit * x3 + not_bit * x1;
+            const auto computed_y4 = bit * y3 + not_bit * y1;
+            sink.template gate<0>(p1010 * k[4], computed_lambda - lambda, computed_x4 - x4, computed_y4 - y4, acc_new - (acc_old.dbl() + bit), bit * not_bit,
+                                  inverse * (x1 - x2) - one);
         }
+        // PublicInputGate 101001, public_input.rs:26-37: advice wires 6..8 against the right gate's wires 0..2
+        sink.template gate<4>(p1010 * (one - k[4]) * k[5], l[6] - r[0], l[7] - r[1], l[8] - r[2]);
+    }
+    {
+        const auto p1011 = p101 * k[3];
+        {  // CurveDblGate 10111, curve_dbl.rs:42-68
+            const D &x_old = l[0], &y_old = l[1], &x_new = l[2], &y_new = l[3], &inverse = l[4], &lambda = l[5];
+            const auto xx = x_old.sq();
+            const auto numerator = xx.dbl() + xx + a_coeff;  // square().triple() + A
+            const auto computed_lambda = numerator * inverse;
+            const auto computed_x_new = lambda.sq() - x_old.dbl();
+            const auto computed_y_new = lambda * (x_old - x_new) - y_old;
+            sink.template gate<1>(p1011 * k[4], computed_lambda - lambda, computed_x_new - x_new, computed_y_new - y_new, y_old.dbl() * inverse - one);
+        }
+        // ConstantGate 10110, constant.rs:28-39
+        sink.template gate<5>(p1011 * (one - k[4]), k[5] - l[0]);
     }
 }
 
@@ -286,57 +382,70 @@ struct PlonkScalars {
     uint32_t k_is[NUM_ROUTED_WIRES][8];
     uint32_t alpha[8], beta[8], gamma[8], zeta[8], a[8];
 };
-template <class P> PLK_DI El<P> el_words(const uint32_t (&w)[8]) {
-    El<P> r;
+// the scalars of a launch in the working form, converted once per workgroup: [0..5] k_is, 6 alpha, 7 beta, 8 gamma, 9 zeta, 10 a
+constexpr int NUM_SCALARS = NUM_ROUTED_WIRES + 5;
+template <class P> PLK_DI void stage_scalars(const PlonkScalars& sc, uint32_t (*s_sc)[FzCfg<P>::NZ]) {
+    const int t = threadIdx.x;
+    if (t < NUM_SCALARS) {
+        const uint32_t* w = t < NUM_ROUTED_WIRES ? sc.k_is[t] : t == 6 ? sc.alpha : t == 7 ? sc.beta : t == 8 ? sc.gamma : t == 9 ? sc.zeta : sc.a;
+        Fe<P> x;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.v.v[i] = w[i];
+        for (int i = 0; i < 8; ++i) x.v[i] = w[i];
+        const Lz<P, 16> z = lz_from_rform<P>(x);
+#pragma unroll
+        for (int i = 0; i < FzCfg<P>::NZ; ++i) s_sc[t][i] = z.v.l[i];
+    }
+    __syncthreads();
+}
+template <class P> PLK_DI Lz<P, 16> scalar_at(const uint32_t (*s_sc)[FzCfg<P>::NZ], int t) {
+    Lz<P, 16> r;
+#pragma unroll
+    for (int i = 0; i < FzCfg<P>::NZ; ++i) r.v.l[i] = s_sc[t][i];
     return r;
 }
 
 // plonk.rs:392-453, one lane per point of the 8n domain
 template <class P>
 __global__ void __launch_bounds__(128) k_vanishing_points(const uint4* __restrict__ constants, const uint4* __restrict__ wires, const uint4* __restrict__ s_sigma,
-                                                          const uint4* __restrict__ z, const uint4* __restrict__ xs_lo, const uint4* __restrict__ xs_hi,
+                                                          const uint4* __restrict__ z, const uint4* __restrict__ xs_lo_z, const uint4* __restrict__ xs_hi_z,
                                                           const uint4* __restrict__ l1, const uint4* __restrict__ small, PlonkScalars sc, int log_degree,
                                                           uint4* __restrict__ out) {
     static_assert(P::NL == 8, "256-bit scalar fields");
-    using E = El<P>;
+    using D = Lz<P, 16>;
+    __shared__ uint32_t s_sc[NUM_SCALARS][FzCfg<P>::NZ];
+    stage_scalars<P>(sc, s_sc);
     const size_t n8 = (size_t)8 << log_degree;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;
     const size_t i_right = (i + 8) & (n8 - 1), i_below = (i + 8 * GRID_WIDTH) & (n8 - 1);
-    E k[NUM_CONSTANTS], l[NUM_WIRES], r[4];
+    D k[NUM_CONSTANTS], l[NUM_WIRES], r[4];
 #pragma unroll
-    for (int j = 0; j < NUM_CONSTANTS; ++j) k[j] = el_load<P>(constants, (size_t)j * n8 + i);
+    for (int j = 0; j < NUM_CONSTANTS; ++j) k[j] = lz_load<P>(constants, (size_t)j * n8 + i);
 #pragma unroll
-    for (int j = 0; j < NUM_WIRES; ++j) l[j] = el_load<P>(wires, (size_t)j * n8 + i);
+    for (int j = 0; j < NUM_WIRES; ++j) l[j] = lz_load<P>(wires, (size_t)j * n8 + i);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = el_load<P>(wires, (size_t)j * n8 + i_right);
-    const E b2 = el_load<P>(wires, (size_t)2 * n8 + i_below), b3 = el_load<P>(wires, (size_t)3 * n8 + i_below);
-    E u[NUM_TERMS];
-    all_constraints<P>(k, l, r, b2, b3, el_words<P>(sc.zeta), el_words<P>(sc.a), small, u);
-    const E one = el_one<P>();
-    const E x = E{plonk_x<P>(xs_lo, xs_hi, i)};
-    const E z_x = el_load<P>(z, i), z_gz = el_load<P>(z, i_right);
-    const E z_1_term = el_load<P>(l1, i) * (z_x - one);  // plonk.rs:425
-    const E beta = el_words<P>(sc.beta), gamma = el_words<P>(sc.gamma);
-    E f_prime = one, g_prime = one;
+    for (int j = 0; j < 4; ++j) r[j] = lz_load<P>(wires, (size_t)j * n8 + i_right);
+    const D b2 = lz_load<P>(wires, (size_t)2 * n8 + i_below), b3 = lz_load<P>(wires, (size_t)3 * n8 + i_below);
+    const D alpha = scalar_at<P>(s_sc, 6);
+    ReducedSink<P> sink{alpha, Term<P>{fz_zero<P>()}};
+    all_constraints<P, D>(k, l, r, b2, b3, scalar_at<P>(s_sc, 9), scalar_at<P>(s_sc, 10), small, sink);
+    const auto one = lz_one<P>();
+    const auto x = lz_table<P>(xs_lo_z, i & (((size_t)1 << XS_LO_LOG) - 1)) * lz_table<P>(xs_hi_z, i >> XS_LO_LOG);  // hi[0] = 1
+    const D z_x = lz_load<P>(z, i), z_gz = lz_load<P>(z, i_right);
+    const auto z_1_term = lz_table<P>(l1, i) * (z_x - one);  // plonk.rs:425
+    const D beta = scalar_at<P>(s_sc, 7), gamma = scalar_at<P>(s_sc, 8);
+    Lz<P, 9> f_prime = one.template widen<9>(), g_prime = f_prime;
 #pragma unroll
     for (int j = 0; j < NUM_ROUTED_WIRES; ++j) {  // plonk.rs:428-437
-        const E s_id = el_words<P>(sc.k_is[j]) * x;
-        const E s_sig = el_load<P>(s_sigma, (size_t)j * n8 + i);
+        const auto s_id = scalar_at<P>(s_sc, j) * x;
+        const D s_sig = lz_load<P>(s_sigma, (size_t)j * n8 + i);
         f_prime = f_prime * (l[j] + beta * s_id + gamma);
         g_prime = g_prime * (l[j] + beta * s_sig + gamma);
     }
-    const E v_shift_term = f_prime * z_x - g_prime * z_gz;  // plonk.rs:438
+    const auto v_shift_term = f_prime * z_x - g_prime * z_gz;  // plonk.rs:438
     // reduce_with_powers over [z_1_term, v_shift_term, constraint terms] (plonk.rs:440-447, plonk_util.rs:27-33)
-    const E alpha = el_words<P>(sc.alpha);
-    E sum = el_zero<P>();
-#pragma unroll
-    for (int t = NUM_TERMS - 1; t >= 0; --t) sum = sum * alpha + u[t];
-    sum = sum * alpha + v_shift_term;
-    sum = sum * alpha + z_1_term;
-    fe_store<P>(out + i * 2, sum.v);
+    const auto with_shift = sink.total * alpha + v_shift_term;
+    fe_store<P>(out + i * 2, lz_to_rform<P>(with_shift * alpha + z_1_term));
 }
 
 // evaluate_all_constraints at `count` independent points (constants [count][6], local / right / below [count][9], out [count][8])
@@ -344,20 +453,26 @@ template <class P>
 __global__ void __launch_bounds__(128) k_all_constraints(const uint4* __restrict__ constants, const uint4* __restrict__ local, const uint4* __restrict__ right,
                                                          const uint4* __restrict__ below, const uint4* __restrict__ small, PlonkScalars sc, size_t count,
                                                          uint4* __restrict__ out) {
-    using E = El<P>;
+    using D = Lz<P, 16>;
+    __shared__ uint32_t s_sc[NUM_SCALARS][FzCfg<P>::NZ];
+    stage_scalars<P>(sc, s_sc);
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    E k[NUM_CONSTANTS], l[NUM_WIRES], r[4];
+    D k[NUM_CONSTANTS], l[NUM_WIRES], r[4];
 #pragma unroll
-    for (int j = 0; j < NUM_CONSTANTS; ++j) k[j] = el_load<P>(constants, i * NUM_CONSTANTS + j);
+    for (int j = 0; j < NUM_CONSTANTS; ++j) k[j] = lz_load<P>(constants, i * NUM_CONSTANTS + j);
 #pragma unroll
-    for (int j = 0; j < NUM_WIRES; ++j) l[j] = el_load<P>(local, i * NUM_WIRES + j);
+    for (int j = 0; j < NUM_WIRES; ++j) l[j] = lz_load<P>(local, i * NUM_WIRES + j);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = el_load<P>(right, i * NUM_WIRES + j);
-    E u[NUM_TERMS];
-    all_constraints<P>(k, l, r, el_load<P>(below, i * NUM_WIRES + 2), el_load<P>(below, i * NUM_WIRES + 3), el_words<P>(sc.zeta), el_words<P>(sc.a), small, u);
+    for (int j = 0; j < 4; ++j) r[j] = lz_load<P>(right, i * NUM_WIRES + j);
+    Term<P> u[NUM_TERMS];
 #pragma unroll
-    for (int t = 0; t < NUM_TERMS; ++t) fe_store<P>(out + (i * NUM_TERMS + t) * 2, u[t].v);
+    for (int t = 0; t < NUM_TERMS; ++t) u[t] = Term<P>{fz_zero<P>()};
+    TermSink<P> sink{u};
+    all_constraints<P, D>(k, l, r, lz_load<P>(below, i * NUM_WIRES + 2), lz_load<P>(below, i * NUM_WIRES + 3), scalar_at<P>(s_sc, 9), scalar_at<P>(s_sc, 10),
+                          small, sink);
+#pragma unroll
+    for (int t = 0; t < NUM_TERMS; ++t) fe_store<P>(out + (i * NUM_TERMS + t) * 2, lz_to_rform<P>(u[t]));
 }
 
 static void put_words(uint32_t (&dst)[8], const uint64_t* src) {
@@ -374,7 +489,7 @@ static int vanishing_points_t(unsigned log_degree, const void* d_constants, cons
     PLK_TRY(get_plonk_tables<P>((int)log_degree, stream, t));
     const size_t n8 = (size_t)8 << log_degree;
     k_vanishing_points<P><<<(unsigned)((n8 + 127) / 128), 128, 0, stream>>>((const uint4*)d_constants, (const uint4*)d_wires, (const uint4*)d_s_sigma,
-                                                                           (const uint4*)d_z, (const uint4*)t->xs_lo, (const uint4*)t->xs_hi,
+                                                                           (const uint4*)d_z, (const uint4*)t->xs_lo_z, (const uint4*)t->xs_hi_z,
                                                                            (const uint4*)t->l1, (const uint4*)t->small, sc, (int)log_degree, (uint4*)d_out);
     PLK_HIP_TRY(hipGetLastError());
     // the tables stay alive in the cache (plk_ntt_clear_cache / plk_shutdown drop them after a device synchronisation)
