@@ -40,6 +40,7 @@ constexpr int TILE_LOG = PLK_NTT_TILE_LOG;  // elements per workgroup tile
 constexpr int TILE = 1 << TILE_LOG;
 constexpr int NTT_THREADS = TILE / 4;        // one radix-4 group per thread and stage pair
 constexpr int MAX_PASSES = 6;
+constexpr size_t NTT_LDS_MAX = 160 * 1024;  // per workgroup on gfx950
 constexpr int INNER_LOG = TILE_LOG;      // inner twiddle table: w_TILE^e, e < TILE / 2
 
 struct NttPassArgs {
@@ -54,6 +55,7 @@ struct NttPassArgs {
     int prev_log[MAX_PASSES];  // their log sizes a_1..a_{m-1}
     int scale;        // 1: multiply outputs by *scale_ptr (single-pass inverse)
     int skip;         // first pass of a zero-padded transform: the first `skip` stages only replicate (see tile_stages)
+    int tw_global;    // 1: the stage twiddles do not fit in LDS next to the tile: they are read from the inner table (L1 / L2)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -236,8 +238,16 @@ PLK_DI size_t tile_tw_index(const NttPassArgs& a, const TileGeom& t, int e) {
 // `first_stage` > 0: the tile starts at that stage (zero-padded input: when only the rows p < A / 2^k of a column are non-zero,
 // the bit-reversed placement puts them at every 2^k-th slot and the first k butterfly stages pair every value with a zero:
 // (a, 0) -> (a, a).  They are pure replication, done by the loads; polynomials_to_values_padded has k = 3).
-template <class P> PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw, int tid, int log_a, int log_q, int tile_elems, int first_stage) {
+template <class P>
+PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw, int tid, int log_a, int log_q, int tile_elems, int first_stage, const uint4* __restrict__ g_tw,
+                        bool tw_global) {
     const int Q = 1 << log_q, half_a = (1 << log_a) >> 1;
+    // w_A^e, e < A / 2
+    auto stage_tw = [&](int e) -> Fz<P> {
+        if (TILE_LOG >= 12 && tw_global)  // tuning builds only (tools/gpu/ntt_variants.sh): a 1024-element tile always has room
+            return fz_from_fe<P>(fe_load<P>(g_tw + ((size_t)e << (INNER_LOG - log_a)) * 2));
+        return lds_load<P>(s_tw, half_a, e);
+    };
     int log_h = first_stage;
     for (; log_h + 1 < log_a; log_h += 2) {
         const int h = 1 << log_h;
@@ -253,7 +263,7 @@ template <class P> PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw
                 // carried (limbs < 2^29 + 8) and every sum below stays within the bound:
                 //   y0, y2 <= 2^29 + 8 + 2^29;   y1, y3 <= 2^29 + 8 + 2^30 (borrow 2^29 + limb of 2p);   outputs <= y + 2^30.
                 // stage with half-size h: pairs (x0, x1), (x2, x3), twiddle w_{2h}^j for both
-                const Fz<P> wa = lds_load<P>(s_tw, half_a, j << (log_a - 1 - log_h));
+                const Fz<P> wa = stage_tw(j << (log_a - 1 - log_h));
                 fz_carry<P>(x0);
                 fz_carry<P>(x2);
                 x1 = fz_mul<P>(x1, wa);
@@ -261,11 +271,11 @@ template <class P> PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw
                 const Fz<P> y0 = fz_add_nc<P>(x0, x1), y1 = fz_sub_nc<P, 1, 29>(x0, x1);
                 Fz<P> y2 = fz_add_nc<P>(x2, x3), y3 = fz_sub_nc<P, 1, 29>(x2, x3);
                 // stage with half-size 2h: pairs (y0, y2) with w_{4h}^j and (y1, y3) with w_{4h}^(j+h)
-                const Fz<P> wb1 = lds_load<P>(s_tw, half_a, (j + h) << (log_a - 2 - log_h));
+                const Fz<P> wb1 = stage_tw((j + h) << (log_a - 2 - log_h));
                 y3 = fz_mul<P>(y3, wb1);
                 lds_store<P>(s_dat, TILE, i0 + st, fz_add_nc<P>(y1, y3));
                 lds_store<P>(s_dat, TILE, i0 + 3 * st, fz_sub_nc<P, 1, 29>(y1, y3));
-                const Fz<P> wb0 = lds_load<P>(s_tw, half_a, j << (log_a - 2 - log_h));
+                const Fz<P> wb0 = stage_tw(j << (log_a - 2 - log_h));
                 y2 = fz_mul<P>(y2, wb0);
                 lds_store<P>(s_dat, TILE, i0, fz_add_nc<P>(y0, y2));
                 lds_store<P>(s_dat, TILE, i0 + 2 * st, fz_sub_nc<P, 1, 29>(y0, y2));
@@ -275,7 +285,7 @@ template <class P> PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw
                 const Fz<P> y0 = fz_add_nc<P>(x0, x1), y1 = fz_sub_nc<P, 1, 29>(x0, x1);
                 const Fz<P> y2 = fz_add_nc<P>(x2, x3);
                 Fz<P> y3 = fz_sub_nc<P, 1, 29>(x2, x3);
-                const Fz<P> wb1 = lds_load<P>(s_tw, half_a, (j + h) << (log_a - 2 - log_h));
+                const Fz<P> wb1 = stage_tw((j + h) << (log_a - 2 - log_h));
                 y3 = fz_mul<P>(y3, wb1);
                 lds_store<P>(s_dat, TILE, i0 + st, fz_add_nc<P>(y1, y3));           // <= 2^29 + 2^30 + 2^29
                 lds_store<P>(s_dat, TILE, i0 + 3 * st, fz_sub_nc<P, 1, 29>(y1, y3));  // <= 2^29 + 2^30 + 2^30
@@ -295,7 +305,7 @@ template <class P> PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw
             Fz<P> t = lds_load<P>(s_dat, TILE, i1);
             if (log_h > 0) {
                 fz_carry<P>(x);
-                t = fz_mul<P>(t, lds_load<P>(s_tw, half_a, j << (log_a - 1 - log_h)));  // w_{2h}^j, product < 1.2p
+                t = fz_mul<P>(t, stage_tw(j << (log_a - 1 - log_h)));  // w_{2h}^j, product < 1.2p
             }
             // log_h == 0: a two-point transform of exactly normalised inputs
             lds_store<P>(s_dat, TILE, i0, fz_add_nc<P>(x, t));
@@ -359,7 +369,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const void* in, void* 
 
     const TileGeom tg = tile_geom(a, blockIdx.x);
     // stage twiddles (R'-form): w_A^e = inner[e * (1024 / A)], e < A/2
-    for (int e = tid; e < half_a; e += NTT_THREADS) {
+    for (int e = tid; e < ((TILE_LOG >= 12 && a.tw_global) ? 0 : half_a); e += NTT_THREADS) {
         const Fe<P> w = fe_load<P>(inner_tw + ((size_t)e << (INNER_LOG - log_a)) * 2);
         lds_store<P>(s_tw, half_a, e, fz_from_fe<P>(w));
     }
@@ -378,7 +388,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const void* in, void* 
         lds_store<P>(s_dat, TILE, by_slot ? e : tile_in_slot(a, e), x);
     }
     __syncthreads();
-    tile_stages<P>(s_dat, s_tw, tid, log_a, log_q, tile_elems, (HOOKS && !IN_LIMBS) ? a.skip : 0);
+    tile_stages<P>(s_dat, s_tw, tid, log_a, log_q, tile_elems, (HOOKS && !IN_LIMBS) ? a.skip : 0, inner_tw, a.tw_global != 0);
     const Fz<P> scale = fz_from_fe<P>(fe_load<P>(scale_ptr));
     for (int e = tid; e < tile_elems; e += NTT_THREADS) {
         const size_t g = tile_out_index(a, tg, e);
@@ -608,7 +618,12 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
         void* dst = a.last ? d_out : scratch;
         std::pair<hipEvent_t, hipEvent_t> pev;
         const bool prof = prof_begin(stream, pev);
-        const size_t lds_bytes = ((size_t)FzCfg<P>::NZ * TILE + (size_t)FzCfg<P>::NZ * ((size_t)1 << a.log_a) / 2) * 4;
+        size_t lds_bytes = ((size_t)FzCfg<P>::NZ * TILE + (size_t)FzCfg<P>::NZ * ((size_t)1 << a.log_a) / 2) * 4;
+        a.tw_global = 0;
+        if (lds_bytes > NTT_LDS_MAX) {
+            a.tw_global = 1;
+            lds_bytes = (size_t)FzCfg<P>::NZ * TILE * 4;
+        }
         const uint4* scale = (const uint4*)pl.pw + (a.scale ? 66 : 65) * 2;
         const bool use_hooks = hooks && (a.first || a.last);
         const NttHooks hk = use_hooks ? *hooks : NttHooks{};
