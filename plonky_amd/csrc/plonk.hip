@@ -294,11 +294,13 @@ template <int I, class P, int B, class D> PLK_DI auto base4_chain(const Lz<P, B>
 // (only CurveEndoGate reads below, curve_endo.rs:115-117); small: 1/1 .. 1/7 (R'-form table).
 // Prefix filters (gates/mod.rs:289-300) are formed where they are used, along the prefix tree of gates/mod.rs:1-16 (BufferGate,
 // 101010, has no constraints: buffer.rs:26-33): a filter kept alive for the whole kernel costs nine registers.
-template <class P, class D, class Sink>
+// gate groups (a kernel evaluates a subset: the live set of all ten gates is several register files wide)
+constexpr int GATES_RESCUE = 1, GATES_ENDO = 2, GATES_BASE4_ARITH = 4, GATES_ADD_PUBLIC = 8, GATES_DBL_CONST = 16, GATES_ALL = 31;
+template <class P, class D, int MASK, class Sink>
 PLK_DI void all_constraints(const D (&k)[NUM_CONSTANTS], const D (&l)[NUM_WIRES], const D (&r)[4], const D& b2, const D& b3, const D& zeta, const D& a_coeff,
                             const uint4* __restrict__ small, Sink& sink) {
     const auto one = lz_one<P>();
-    {  // RescueStepAGate 00, rescue_a.rs:38-69, and RescueStepBGate 01, rescue_b.rs:30-58
+    if constexpr ((MASK & GATES_RESCUE) != 0) {  // RescueStepAGate 00, rescue_a.rs:38-69, and RescueStepBGate 01, rescue_b.rs:30-58
         const auto nk0 = one - k[0];
         Lz<P, 8> mds[7];
 #pragma unroll
@@ -315,7 +317,7 @@ PLK_DI void all_constraints(const D (&k)[NUM_CONSTANTS], const D (&l)[NUM_WIRES]
                               PLK_MDS_ROW(3, e0, e1, e2, e3));
 #undef PLK_MDS_ROW
     }
-    {  // CurveEndoGate 11, curve_endo.rs:96-141
+    if constexpr ((MASK & GATES_ENDO) != 0) {  // CurveEndoGate 11, curve_endo.rs:96-141
         const D &x1 = l[0], &y1 = l[1], &x_in = l[4], &y_in = l[5], &x3 = r[0], &y3 = r[1];
         const D &unsigned_old = l[2], &unsigned_new = b2, &signed_old = l[3], &signed_new = b3, &bit0 = l[6], &bit1 = l[7], &inverse = l[8];
         const auto mult = (zeta - one) * bit1 + one;  // x2's factor and signed_limb_multiplier are the same expression
@@ -329,8 +331,9 @@ PLK_DI void all_constraints(const D (&k)[NUM_CONSTANTS], const D (&l)[NUM_WIRES]
         sink.template gate<2>(k[0] * k[1], computed_x3 - x3, computed_y3 - y3, unsigned_new - (unsigned_old.quad() + bit1.dbl() + bit0).rs(),
                               signed_new - (signed_old.dbl() + signed_limb), bit0 * (bit0 - one), bit1 * (bit1 - one), inverse * (x1 - x2) - one);
     }
+    if constexpr ((MASK & (GATES_BASE4_ARITH | GATES_ADD_PUBLIC | GATES_DBL_CONST)) == 0) return;
     const auto p10 = k[0] * (one - k[1]);
-    {
+    if constexpr ((MASK & GATES_BASE4_ARITH) != 0) {
         const auto p100 = p10 * (one - k[2]);
         {  // Base4SumGate 1000, base_4_sum.rs:34-63: 7 limbs in wires 2..8
             const auto two = one.dbl();
@@ -344,8 +347,9 @@ PLK_DI void all_constraints(const D (&k)[NUM_CONSTANTS], const D (&l)[NUM_WIRES]
         // ArithmeticGate 1001, arithmetic.rs:30-46
         sink.template gate<6>(p100 * k[3], k[4] * l[0] * l[1] + k[5] * l[2] - l[3]);
     }
+    if constexpr ((MASK & (GATES_ADD_PUBLIC | GATES_DBL_CONST)) == 0) return;
     const auto p101 = p10 * k[2];
-    {
+    if constexpr ((MASK & GATES_ADD_PUBLIC) != 0) {
         const auto p1010 = p101 * (one - k[3]);
         {  // CurveAddGate 10101, curve_add.rs:60-101
             const D &x1 = l[0], &y1 = l[1], &x4 = r[0], &y4 = r[1], &acc_old = l[2], &acc_new = l[3], &x2 = l[4], &y2 = l[5], &bit = l[6], &inverse = l[7],
@@ -362,7 +366,7 @@ PLK_DI void all_constraints(const D (&k)[NUM_CONSTANTS], const D (&l)[NUM_WIRES]
         // PublicInputGate 101001, public_input.rs:26-37: advice wires 6..8 against the right gate's wires 0..2
         sink.template gate<4>(p1010 * (one - k[4]) * k[5], l[6] - r[0], l[7] - r[1], l[8] - r[2]);
     }
-    {
+    if constexpr ((MASK & GATES_DBL_CONST) != 0) {
         const auto p1011 = p101 * k[3];
         {  // CurveDblGate 10111, curve_dbl.rs:42-68
             const D &x_old = l[0], &y_old = l[1], &x_new = l[2], &y_new = l[3], &inverse = l[4], &lambda = l[5];
@@ -404,20 +408,29 @@ template <class P> PLK_DI Lz<P, 16> scalar_at(const uint32_t (*s_sc)[FzCfg<P>::N
     return r;
 }
 
-// plonk.rs:392-453, one lane per point of the 8n domain
-template <class P>
+// plonk.rs:392-453, one lane per point of the 8n domain, in PASSES launches.  The ten gates, the permutation argument and their
+// inputs (21 + 10 elements per point) are several register files wide; evaluated in one piece the kernel spills to scratch
+// and, at one wave per SIMD, waits out every reload.  A launch evaluates a group of gates and hands the running sum on (limb
+// form, 48 B per point, in `part`):
+//   PASS 0: both Rescue gates                       -> part
+//   PASS 1: CurveEndo, Base4Sum, Arithmetic         -> part +=
+//   PASS 2: CurveAdd, PublicInput, CurveDbl, Constant, the permutation argument and L_1, reduce_with_powers -> out
+// The sum over the gates and the powers of alpha commute (ReducedSink), every value is exact: same result as one loop.
+template <class P, int PASS>
 __global__ void __launch_bounds__(128) k_vanishing_points(const uint4* __restrict__ constants, const uint4* __restrict__ wires, const uint4* __restrict__ s_sigma,
                                                           const uint4* __restrict__ z, const uint4* __restrict__ xs_lo_z, const uint4* __restrict__ xs_hi_z,
                                                           const uint4* __restrict__ l1, const uint4* __restrict__ small, PlonkScalars sc, int log_degree,
-                                                          uint4* __restrict__ out) {
+                                                          uint32_t* __restrict__ part, uint4* __restrict__ out) {
     static_assert(P::NL == 8, "256-bit scalar fields");
     using D = Lz<P, 16>;
+    constexpr int MASK = PASS == 0 ? GATES_RESCUE : PASS == 1 ? (GATES_ENDO | GATES_BASE4_ARITH) : (GATES_ADD_PUBLIC | GATES_DBL_CONST);
     __shared__ uint32_t s_sc[NUM_SCALARS][FzCfg<P>::NZ];
     stage_scalars<P>(sc, s_sc);
     const size_t n8 = (size_t)8 << log_degree;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;
     const size_t i_right = (i + 8) & (n8 - 1), i_below = (i + 8 * GRID_WIDTH) & (n8 - 1);
+    // every input is named here; what the gates of this launch do not read is never loaded
     D k[NUM_CONSTANTS], l[NUM_WIRES], r[4];
 #pragma unroll
     for (int j = 0; j < NUM_CONSTANTS; ++j) k[j] = lz_load<P>(constants, (size_t)j * n8 + i);
@@ -428,24 +441,33 @@ __global__ void __launch_bounds__(128) k_vanishing_points(const uint4* __restric
     const D b2 = lz_load<P>(wires, (size_t)2 * n8 + i_below), b3 = lz_load<P>(wires, (size_t)3 * n8 + i_below);
     const D alpha = scalar_at<P>(s_sc, 6);
     ReducedSink<P> sink{alpha, Term<P>{fz_zero<P>()}};
-    all_constraints<P, D>(k, l, r, b2, b3, scalar_at<P>(s_sc, 9), scalar_at<P>(s_sc, 10), small, sink);
-    const auto one = lz_one<P>();
-    const auto x = lz_table<P>(xs_lo_z, i & (((size_t)1 << XS_LO_LOG) - 1)) * lz_table<P>(xs_hi_z, i >> XS_LO_LOG);  // hi[0] = 1
-    const D z_x = lz_load<P>(z, i), z_gz = lz_load<P>(z, i_right);
-    const auto z_1_term = lz_table<P>(l1, i) * (z_x - one);  // plonk.rs:425
-    const D beta = scalar_at<P>(s_sc, 7), gamma = scalar_at<P>(s_sc, 8);
-    Lz<P, 9> f_prime = one.template widen<9>(), g_prime = f_prime;
+    all_constraints<P, D, MASK>(k, l, r, b2, b3, scalar_at<P>(s_sc, 9), scalar_at<P>(s_sc, 10), small, sink);
+    if constexpr (PASS == 0) {
+        limbs_store<P>(part, i, sink.total.v);  // < 2.5p (two gates)
+    } else if constexpr (PASS == 1) {
+        const Lz<P, 20> before{limbs_load<P>(part, i)};
+        limbs_store<P>(part, i, (before + sink.total).v);  // five gates so far: < 6.25p
+    } else {
+        const Lz<P, 50> before{limbs_load<P>(part, i)};
+        const auto total = before + sink.total;  // < 6.25p + 12.5p
+        const auto one = lz_one<P>();
+        const auto x = lz_table<P>(xs_lo_z, i & (((size_t)1 << XS_LO_LOG) - 1)) * lz_table<P>(xs_hi_z, i >> XS_LO_LOG);  // hi[0] = 1
+        const D z_x = lz_load<P>(z, i), z_gz = lz_load<P>(z, i_right);
+        const auto z_1_term = lz_table<P>(l1, i) * (z_x - one);  // plonk.rs:425
+        const D beta = scalar_at<P>(s_sc, 7), gamma = scalar_at<P>(s_sc, 8);
+        Lz<P, 9> f_prime = one.template widen<9>(), g_prime = f_prime;
 #pragma unroll
-    for (int j = 0; j < NUM_ROUTED_WIRES; ++j) {  // plonk.rs:428-437
-        const auto s_id = scalar_at<P>(s_sc, j) * x;
-        const D s_sig = lz_load<P>(s_sigma, (size_t)j * n8 + i);
-        f_prime = f_prime * (l[j] + beta * s_id + gamma);
-        g_prime = g_prime * (l[j] + beta * s_sig + gamma);
+        for (int j = 0; j < NUM_ROUTED_WIRES; ++j) {  // plonk.rs:428-437
+            const auto s_id = scalar_at<P>(s_sc, j) * x;
+            const D s_sig = lz_load<P>(s_sigma, (size_t)j * n8 + i);
+            f_prime = f_prime * (l[j] + beta * s_id + gamma);
+            g_prime = g_prime * (l[j] + beta * s_sig + gamma);
+        }
+        const auto v_shift_term = f_prime * z_x - g_prime * z_gz;  // plonk.rs:438
+        // reduce_with_powers over [z_1_term, v_shift_term, constraint terms] (plonk.rs:440-447, plonk_util.rs:27-33)
+        const auto with_shift = total.rs() * alpha + v_shift_term;
+        fe_store<P>(out + i * 2, lz_to_rform<P>(with_shift * alpha + z_1_term));
     }
-    const auto v_shift_term = f_prime * z_x - g_prime * z_gz;  // plonk.rs:438
-    // reduce_with_powers over [z_1_term, v_shift_term, constraint terms] (plonk.rs:440-447, plonk_util.rs:27-33)
-    const auto with_shift = sink.total * alpha + v_shift_term;
-    fe_store<P>(out + i * 2, lz_to_rform<P>(with_shift * alpha + z_1_term));
 }
 
 // evaluate_all_constraints at `count` independent points (constants [count][6], local / right / below [count][9], out [count][8])
@@ -469,8 +491,8 @@ __global__ void __launch_bounds__(128) k_all_constraints(const uint4* __restrict
 #pragma unroll
     for (int t = 0; t < NUM_TERMS; ++t) u[t] = Term<P>{fz_zero<P>()};
     TermSink<P> sink{u};
-    all_constraints<P, D>(k, l, r, lz_load<P>(below, i * NUM_WIRES + 2), lz_load<P>(below, i * NUM_WIRES + 3), scalar_at<P>(s_sc, 9), scalar_at<P>(s_sc, 10),
-                          small, sink);
+    all_constraints<P, D, GATES_ALL>(k, l, r, lz_load<P>(below, i * NUM_WIRES + 2), lz_load<P>(below, i * NUM_WIRES + 3), scalar_at<P>(s_sc, 9),
+                                     scalar_at<P>(s_sc, 10), small, sink);
 #pragma unroll
     for (int t = 0; t < NUM_TERMS; ++t) fe_store<P>(out + (i * NUM_TERMS + t) * 2, lz_to_rform<P>(u[t]));
 }
@@ -488,10 +510,20 @@ static int vanishing_points_t(unsigned log_degree, const void* d_constants, cons
     std::shared_ptr<PlonkTables> t;
     PLK_TRY(get_plonk_tables<P>((int)log_degree, stream, t));
     const size_t n8 = (size_t)8 << log_degree;
-    k_vanishing_points<P><<<(unsigned)((n8 + 127) / 128), 128, 0, stream>>>((const uint4*)d_constants, (const uint4*)d_wires, (const uint4*)d_s_sigma,
-                                                                           (const uint4*)d_z, (const uint4*)t->xs_lo_z, (const uint4*)t->xs_hi_z,
-                                                                           (const uint4*)t->l1, (const uint4*)t->small, sc, (int)log_degree, (uint4*)d_out);
-    PLK_HIP_TRY(hipGetLastError());
+    void* part = scratch_acquire(limb_bytes(n8, FzCfg<P>::NZ), stream);
+    if (!part) return PLK_ERR_OOM;
+    const unsigned blocks = (unsigned)((n8 + 127) / 128);
+#define PLK_VANISH(PASS)                                                                                                                                  \
+    k_vanishing_points<P, PASS><<<blocks, 128, 0, stream>>>((const uint4*)d_constants, (const uint4*)d_wires, (const uint4*)d_s_sigma, (const uint4*)d_z, \
+                                                            (const uint4*)t->xs_lo_z, (const uint4*)t->xs_hi_z, (const uint4*)t->l1, (const uint4*)t->small, sc, \
+                                                            (int)log_degree, (uint32_t*)part, (uint4*)d_out)
+    PLK_VANISH(0);
+    PLK_VANISH(1);
+    PLK_VANISH(2);
+#undef PLK_VANISH
+    const hipError_t e = hipGetLastError();
+    scratch_release(part, stream);
+    if (e != hipSuccess) return set_error(PLK_ERR_HIP, "vanishing points launch failed: %s", hipGetErrorString(e));
     // the tables stay alive in the cache (plk_ntt_clear_cache / plk_shutdown drop them after a device synchronisation)
     return PLK_OK;
 }
