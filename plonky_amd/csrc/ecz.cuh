@@ -166,6 +166,27 @@ template <class FP> PLK_DI XyzzZ<FP> xyzzz_load_packed(const uint4* src) {
     r.inf = fe_is_zero<FP>(p.zz);
     return r;
 }
+// the same through volatile loads: a point another workgroup of the running kernel has just written (after a device-scope fence)
+template <class FP> PLK_DI XyzzZ<FP> xyzzz_load_packed_volatile(const uint4* src) {
+    constexpr int NW = 4 * FP::NL;
+    const volatile uint32_t* w = reinterpret_cast<const volatile uint32_t*>(src);
+    Xyzz<FP> p;
+#pragma unroll
+    for (int i = 0; i < FP::NL; ++i) {
+        p.x.v[i] = w[i];
+        p.y.v[i] = w[FP::NL + i];
+        p.zz.v[i] = w[2 * FP::NL + i];
+        p.zzz.v[i] = w[3 * FP::NL + i];
+    }
+    (void)NW;
+    XyzzZ<FP> r;
+    r.x = fz_from_fe<FP>(p.x);
+    r.y = fz_from_fe<FP>(p.y);
+    r.zz = fz_from_fe<FP>(p.zz);
+    r.zzz = fz_from_fe<FP>(p.zzz);
+    r.inf = fe_is_zero<FP>(p.zz);
+    return r;
+}
 // back to the reference's form, then ProjectivePoint::to_affine (curve.rs:206-214)
 template <class FP> PLK_DI void emit_affine(const XyzzZ<FP>& acc, uint4* out_xy, uint8_t* out_zero) {
     constexpr int W = FP::NL / 4;

@@ -161,9 +161,33 @@ PLK_DI uint32_t ord_digit(const uint32_t* s_lim, int tid, int j, const OrdCfg& c
     return ((mag - 1u + (uint32_t)j * cfg.window_buckets) << 1) | neg;
 }
 
-// exclusive scan of s_data[0..count) in place (count <= 4 * blockDim.x); s_tmp: blockDim.x words.  Ends with a barrier.
+// exclusive prefix of `v` over the threads of the block (blockDim.x a multiple of 64, <= 1024); *total (optional) = the block sum.
+// Shuffles inside a wave, one LDS word per wave across: two barriers instead of two per doubling step.  s_tmp: >= 16 words,
+// free again when the call returns.
+PLK_DI uint32_t block_excl_prefix(uint32_t v, uint32_t* s_tmp, uint32_t* total = nullptr) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t u = __shfl_up(inc, d);
+        if (lane >= d) inc += u;
+    }
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+    for (int w = 0; w < nw; ++w) {
+        const uint32_t x = s_tmp[w];
+        if (w < wave) base += x;
+        all += x;
+    }
+    if (total) *total = all;
+    __syncthreads();
+    return base + inc - v;
+}
+// exclusive scan of s_data[0..count) in place (count <= 4 * blockDim.x); s_tmp: 16 words.  The caller's writes to s_data must be
+// visible (a barrier before the call); ends with a barrier.
 PLK_DI void block_excl_scan4(uint32_t* s_data, int count, uint32_t* s_tmp) {
-    const int t = threadIdx.x, nth = blockDim.x;
+    const int t = threadIdx.x;
     uint32_t v[4], sum = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -171,15 +195,7 @@ PLK_DI void block_excl_scan4(uint32_t* s_data, int count, uint32_t* s_tmp) {
         v[k] = idx < count ? s_data[idx] : 0u;
         sum += v[k];
     }
-    s_tmp[t] = sum;
-    __syncthreads();
-    for (int d = 1; d < nth; d <<= 1) {
-        const uint32_t u = t >= d ? s_tmp[t - d] : 0u;
-        __syncthreads();
-        s_tmp[t] += u;
-        __syncthreads();
-    }
-    uint32_t run = s_tmp[t] - sum;
+    uint32_t run = block_excl_prefix(sum, s_tmp);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int idx = t * 4 + k;
@@ -238,22 +254,15 @@ __global__ void __launch_bounds__(256) k_ord_scan1(uint32_t* __restrict__ cnt1, 
     const uint32_t lo = min(nt1, threadIdx.x * per), hi = min(nt1, lo + per);
     uint32_t sum = 0;
     for (uint32_t i = lo; i < hi; ++i) sum += row[i];
-    s_sum[threadIdx.x] = sum;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        uint32_t v = (int)threadIdx.x >= d ? s_sum[threadIdx.x - d] : 0;
-        __syncthreads();
-        s_sum[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = s_sum[threadIdx.x] - sum;
+    uint32_t row_total = 0;
+    uint32_t run = block_excl_prefix(sum, s_sum, &row_total);
     for (uint32_t i = lo; i < hi; ++i) {
         uint32_t v = row[i];
         row[i] = run;
         run += v;
     }
     if (threadIdx.x == 255) {
-        bin_total[blockIdx.x] = s_sum[255];
+        bin_total[blockIdx.x] = row_total;
         __threadfence();
         s_last = atomicAdd(done_counter, 1u) == (uint32_t)nbins - 1u;
     }
@@ -289,6 +298,7 @@ __global__ void __launch_bounds__(ORD_THREADS) k_ord_scatter(const uint4* __rest
     __shared__ uint32_t s_cnt[ORD_MAX_BINS], s_base[ORD_MAX_BINS], s_gbase[ORD_MAX_BINS];
     __shared__ uint32_t s_tmp[ORD_THREADS];
     __shared__ uint2 s_ent[ORD_TILE];
+    __shared__ uint16_t s_rank[ORD_TILE];  // [window][scalar of the sub-tile]: spt * windows <= ORD_TILE
     const int tid = threadIdx.x;
     const uint32_t tile = blockIdx.x;
     for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_gbase[k] = bin_base[k] + cnt1[(size_t)k * cfg.nt1 + tile];
@@ -300,37 +310,34 @@ __global__ void __launch_bounds__(ORD_THREADS) k_ord_scatter(const uint4* __rest
         if (live) ord_park_scalar<SP>(scalars, i, s_lim, tid);
         __syncthreads();
         if (live) {
+            // one atomic per entry: its return value is the entry's rank inside its bin, kept for the placement below
             uint32_t carry = 0;
             for (int j = 0; j < cfg.windows; ++j) {
                 const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
-                if (code != CODE_INVALID) atomicAdd(&s_cnt[code >> (cfg.fine_bits + 1)], 1u);
+                if (code != CODE_INVALID) s_rank[j * cfg.spt + tid] = (uint16_t)atomicAdd(&s_cnt[code >> (cfg.fine_bits + 1)], 1u);
             }
         }
         __syncthreads();
         for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_base[k] = s_cnt[k];
         __syncthreads();
         block_excl_scan4(s_base, cfg.nbins, s_tmp);
-        for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_cnt[k] = s_base[k];  // cursors
-        __syncthreads();
         if (live) {
             uint32_t carry = 0;
             for (int j = 0; j < cfg.windows; ++j) {
                 const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
-                if (code != CODE_INVALID) {
-                    const uint32_t sidx = atomicAdd(&s_cnt[code >> (cfg.fine_bits + 1)], 1u);
-                    s_ent[sidx] = make_uint2(code, (uint32_t)((size_t)j * n + i));
-                }
+                if (code != CODE_INVALID)
+                    s_ent[s_base[code >> (cfg.fine_bits + 1)] + s_rank[j * cfg.spt + tid]] = make_uint2(code, (uint32_t)((size_t)j * n + i));
             }
         }
         __syncthreads();
-        const uint32_t total = s_cnt[cfg.nbins - 1];  // every cursor now sits at the end of its bin
+        const uint32_t total = s_base[cfg.nbins - 1] + s_cnt[cfg.nbins - 1];
         for (uint32_t sidx = tid; sidx < total; sidx += ORD_THREADS) {
             const uint2 e = s_ent[sidx];
             const uint32_t bin = e.x >> (cfg.fine_bits + 1);
             tmp[s_gbase[bin] + (sidx - s_base[bin])] = e;
         }
         __syncthreads();
-        for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_gbase[k] += s_cnt[k] - s_base[k];  // this sub-tile's entries of bin k
+        for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_gbase[k] += s_cnt[k];  // this sub-tile's entries of bin k
     }
 }
 
@@ -614,6 +621,7 @@ struct TailSlot {
     uint4* line_part;     // raw: row partials then column partials
     uint4* plane_part;
     uint4* win_pts;
+    uint32_t* final_done;  // windows finished by k_msm_final (the last one adds them up); zero between executions
     uint4* out_xy;
     uint8_t* out_zero;
 };
@@ -856,6 +864,7 @@ __global__ void __launch_bounds__(PLANE_THREADS) k_msm_planes(TailBatch tb, int 
 // One block per window: sum_p 2^p (sum of the parts of plane p), one quad per (plane, part); parts a power of
 // two <= 16, planes <= 32, planes * parts <= 256.  With one window (tables) the block also normalises the result; with several
 // (table-free mode) it doubles its window into place, 2^(c * window), and k_msm_combine adds the windows.
+constexpr int FINAL_FUSE_WINDOWS = 4;  // up to this many tail windows are added by the last block of k_msm_final itself
 constexpr int FINAL_THREADS = 512;  // <= 8 waves, so the compiler may use 256 VGPRs: the point arithmetic must not spill
 template <class C>
 __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int windows, int parts, int planes, int window_bits) {
@@ -888,9 +897,29 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int w
     if (tid < 4) {
         if (planes > 16) acc = xyzzz_add_q<FP>(acc, xyzzz_load_packed<FP>(s_pts + 32 * 4 * W), ql);
         for (int k = 0; k < win * window_bits; ++k) acc = xyzzz_dbl_q<FP>(acc, ql);
-        if (tid == 0) {
-            if (windows > 1) xyzzz_store_packed<FP>(tb.s[slot].win_pts + (size_t)win * 4 * W, acc);
-            else emit_affine<FP>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
+        if (windows == 1) {
+            if (tid == 0) emit_affine<FP>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
+        } else {
+            uint4* win_pts = tb.s[slot].win_pts;
+            if (tid == 0) xyzzz_store_packed<FP>(win_pts + (size_t)win * 4 * W, acc);
+            if (windows <= FINAL_FUSE_WINDOWS) {
+                // few windows (two in the two-level mode): the block that finishes last adds them up - no launch of its own
+                uint32_t seen = 0;
+                if (tid == 0) {
+                    __threadfence();
+                    seen = atomicAdd(tb.s[slot].final_done, 1u);
+                }
+                seen = __shfl(seen, 0, 4);
+                if (seen == (uint32_t)windows - 1u) {
+                    __threadfence();
+                    for (int o = 0; o < windows; ++o)
+                        if (o != win) acc = xyzzz_add_q<FP>(acc, xyzzz_load_packed_volatile<FP>(win_pts + (size_t)o * 4 * W), ql);
+                    if (tid == 0) {
+                        *tb.s[slot].final_done = 0;
+                        emit_affine<FP>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
+                    }
+                }
+            }
         }
     }
 }
@@ -1365,6 +1394,7 @@ static TailSlot tail_slot(const plk_msm_ctx* ctx, const MsmWork& w, void* d_out_
     t.line_part = (uint4*)w.line_part;
     t.plane_part = (uint4*)w.plane_part;
     t.win_pts = (uint4*)w.win_pts;
+    t.final_done = (uint32_t*)w.meta + (1024 + 1025 + 1025 + 1);
     t.out_xy = (uint4*)d_out_xy;
     t.out_zero = (uint8_t*)d_out_zero;
     return t;
@@ -1397,7 +1427,7 @@ static int msm_reduce_t(plk_msm_ctx* ctx, TailBatch tb, hipStream_t stream, Mark
     PLK_HIP_TRY(hipGetLastError());
     mark();
     k_msm_final<C><<<tw * cnt, FINAL_THREADS, 0, stream>>>(tb, tw, ctx->plane_blocks, ctx->planes, ctx->tail_shift);
-    if (tw > 1) k_msm_combine<C><<<cnt, COMBINE_THREADS, 0, stream>>>(tb, tw);
+    if (tw > FINAL_FUSE_WINDOWS) k_msm_combine<C><<<cnt, COMBINE_THREADS, 0, stream>>>(tb, tw);
     PLK_HIP_TRY(hipGetLastError());
     mark();
     return PLK_OK;
