@@ -15,6 +15,7 @@
 // (y = 0, possible on BLS12-377 G1 whose cofactor is even) double to the identity.
 #pragma once
 #include "fp.cuh"
+#include "glv_params.cuh"
 
 namespace plk {
 
@@ -22,27 +23,32 @@ struct TweedledeeCurve {
     static constexpr int CURVE_ID = 0;
     using FP = TweedledeeBaseParams;   // coordinates  (tweedledee_curve.rs:8)
     using SP = TweedledumBaseParams;   // scalars      (tweedledee_curve.rs:9)
+    using Glv = TweedledeeGlv;         // HaloCurve    (tweedledee_curve.rs:21-37)
 };
 struct TweedledumCurve {
     static constexpr int CURVE_ID = 1;
     using FP = TweedledumBaseParams;
     using SP = TweedledeeBaseParams;
+    using Glv = TweedledumGlv;
 };
 struct Bls12377Curve {
     static constexpr int CURVE_ID = 2;
     using FP = Bls12377BaseParams;     // bls12_377_curve.rs:11
     using SP = Bls12377ScalarParams;   // bls12_377_curve.rs:12
+    using Glv = NoGlv;                 // not a HaloCurve in the reference, and G1 has a cofactor: inputs need not lie in the r-subgroup
 };
 
 struct PallasCurve {
     static constexpr int CURVE_ID = 3;
     using FP = PallasBaseParams;       // pallas_curve.rs:8
     using SP = VestaBaseParams;        // pallas_curve.rs:9
+    using Glv = PallasGlv;
 };
 struct VestaCurve {
     static constexpr int CURVE_ID = 4;
     using FP = VestaBaseParams;
     using SP = PallasBaseParams;
+    using Glv = VestaGlv;
 };
 
 template <class FP> struct Xyzz {

@@ -8,11 +8,19 @@
 // doubling its accumulator and adding one of +-P, +-Q, +-(P+Q), +-(P-Q).  P+Q and P-Q are affine and share
 // one inversion (same denominator x_Q - x_P).  ~255 doublings + ~128 mixed additions + 2 inversions per pair.
 // The result is the unique affine point, as everywhere on this boundary.
+//
+// On the four prime-order curves the two scalars are first split along the endomorphism (glv.cuh): a = a1 + a2 lambda,
+// b = b1 + b2 lambda with half-length parts, G' = [a1] P + [a2] phi(P) + [b1] Q + [b2] phi(Q): ~130 doublings and two joint
+// sparse forms, (a1, a2) over (P, phi P) and (b1, b2) over (Q, phi Q), ~130 additions - 30 % fewer field multiplications.
+// phi(P) = (beta x, y) and P + phi(P) = -phi^2(P) = (beta^2 x, -y) cost one multiplication when they are used; only
+// P - phi(P) and Q - phi(Q) are real additions (one shared inversion).
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
 #include "ec.cuh"
 #include "ecz.cuh"
+#include "glv.cuh"
 #include "tables.cuh"
 
 namespace plk {
@@ -22,6 +30,7 @@ constexpr int FOLD_MAX_COLS = 264;
 struct FoldDigits {
     int cols;                       // number of columns, most significant first
     int8_t d[FOLD_MAX_COLS];        // (da + 1) * 3 + (db + 1): 4 = empty column
+    int8_t e[FOLD_MAX_COLS];        // GLV form: d = the pair (a1, a2) over (P, phi P), e = the pair (b1, b2) over (Q, phi Q)
 };
 
 template <class FP> struct AffZ {  // affine point in R'-form, canonical; ident = the identity
@@ -113,6 +122,78 @@ __global__ void __launch_bounds__(128) k_fold_pairs(const uint4* __restrict__ lo
     emit_affine<FP>(acc, out_xy + i * 2 * W, out_zero + i);
 }
 
+// ---- the same fold along the endomorphism -------------------------------------------------------------------------------
+// P - phi(P) for an affine P = (x, y), x != 0 (a prime-order curve has no point with x = 0: those have order 3):
+// slope (-y - y) / (beta x - x); `inv` = 1 / ((beta - 1) x) in R-form
+template <class FP> PLK_DI void diff_with_phi(const Fe<FP>& x, const Fe<FP>& y, const Fe<FP>& beta_x, const Fe<FP>& inv, AffZ<FP>& D) {
+    const Fe<FP> lam = fe_mul<FP>(fe_neg<FP>(fe_dbl<FP>(y)), inv);
+    const Fe<FP> x3 = fe_sub<FP>(fe_sub<FP>(fe_sqr<FP>(lam), x), beta_x);
+    const Fe<FP> y3 = fe_sub<FP>(fe_mul<FP>(lam, fe_sub<FP>(x, x3)), y);
+    D.x = fz_from_fe<FP>(to_rprime<FP>(x3));
+    D.y = fz_from_fe<FP>(to_rprime<FP>(y3));
+    D.ident = false;
+}
+// one digit pair (u0, u1) of the joint sparse form over (T, phi T): the point to add and whether it is negated.
+//   (1, 0) T   (0, 1) phi T = (beta x, y)   (1, 1) T + phi T = (beta^2 x, -y)   (1, -1) T - phi T = D
+template <class FP>
+PLK_DI void glv_fold_add(XyzzZ<FP>& acc, int code, const AffZ<FP>& T, const AffZ<FP>& D, const Fz<FP>& beta, const Fz<FP>& beta2) {
+    if (code == 4 || T.ident) return;  // the digit is uniform over the grid, the identity flag is not: the addition below is masked per lane
+    const int u0 = code / 3 - 1, u1 = code % 3 - 1;
+    bool neg = u0 != 0 ? u0 < 0 : u1 < 0;
+    Fz<FP> tx = T.x, ty = T.y;
+    if (u0 == 0) {
+        tx = fz_mul<FP>(T.x, beta);
+    } else if (u1 != 0 && u0 == u1) {
+        tx = fz_mul<FP>(T.x, beta2);
+        neg = !neg;
+    } else if (u1 != 0) {
+        tx = D.x;
+        ty = D.y;
+    }
+    if (neg) ty = fz_neg_canonical<FP>(ty);
+    xyzzz_madd<FP>(acc, tx, ty);
+}
+template <class C>
+__global__ void __launch_bounds__(128) k_fold_pairs_glv(const uint4* __restrict__ lo, const uint8_t* __restrict__ lo_zero, const uint4* __restrict__ hi,
+                                                        const uint8_t* __restrict__ hi_zero, size_t m, const FoldDigits* __restrict__ dgp,
+                                                        uint4* __restrict__ out_xy, uint8_t* __restrict__ out_zero) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    if constexpr (C::Glv::ENABLED) {
+        const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= m) return;
+        const Fe<FP> px = fe_load<FP>(lo + i * 2 * W), py = fe_load<FP>(lo + i * 2 * W + W);
+        const Fe<FP> qx = fe_load<FP>(hi + i * 2 * W), qy = fe_load<FP>(hi + i * 2 * W + W);
+        Fe<FP> bc;
+#pragma unroll
+        for (int k = 0; k < FP::NL; ++k) bc.v[k] = C::Glv::BETA[k];
+        const Fe<FP> beta_r = fe_from_canonical<FP>(bc);
+        auto rp = [](const Fe<FP>& v) { return fz_from_fe<FP>(to_rprime<FP>(v)); };
+        AffZ<FP> P, Q, DP, DQ;
+        P.x = rp(px); P.y = rp(py); P.ident = lo_zero ? lo_zero[i] != 0 : false;
+        Q.x = rp(qx); Q.y = rp(qy); Q.ident = hi_zero ? hi_zero[i] != 0 : false;
+        DP = P;
+        DQ = Q;
+        {
+            // 1 / ((beta - 1) x_P) and 1 / ((beta - 1) x_Q) from one inversion; an identity operand lends the value 1
+            const Fe<FP> bm1 = fe_sub<FP>(beta_r, fe_one<FP>());
+            const Fe<FP> dp = P.ident ? fe_one<FP>() : fe_mul<FP>(bm1, px), dq = Q.ident ? fe_one<FP>() : fe_mul<FP>(bm1, qx);
+            const Fe<FP> inv = fe_inv_safegcd<FP>(fe_mul<FP>(dp, dq));
+            if (!P.ident) diff_with_phi<FP>(px, py, fe_mul<FP>(beta_r, px), fe_mul<FP>(inv, dq), DP);
+            if (!Q.ident) diff_with_phi<FP>(qx, qy, fe_mul<FP>(beta_r, qx), fe_mul<FP>(inv, dp), DQ);
+        }
+        const Fz<FP> beta = rp(beta_r), beta2 = rp(fe_sqr<FP>(beta_r));
+        XyzzZ<FP> acc = xyzzz_identity<FP>();
+        const int cols = dgp->cols;
+        for (int k = 0; k < cols; ++k) {
+            acc = xyzzz_dbl<FP>(acc);
+            glv_fold_add<FP>(acc, dgp->d[k], P, DP, beta, beta2);
+            glv_fold_add<FP>(acc, dgp->e[k], Q, DQ, beta, beta2);
+        }
+        emit_affine<FP>(acc, out_xy + i * 2 * W, out_zero + i);
+    }
+}
+
 // joint sparse form (Solinas) of two canonical scalars (8 x 32-bit limbs each), least significant column first
 PLK_DI int joint_sparse_form(const uint32_t* a, const uint32_t* b, int8_t* ua, int8_t* ub) {
     // 9 limbs so that the shifts never lose a bit; the carries d0, d1 in {0, 1} are added on the fly
@@ -156,7 +237,7 @@ struct ScalarPair {
     uint32_t a[8], b[8];  // Montgomery form in the scalar field
 };
 // one thread: Montgomery -> canonical (to_canonical_u64_vec), joint sparse form, most significant column first
-template <class C> __global__ void k_fold_digits(ScalarPair sp, FoldDigits* out) {
+template <class C> __global__ void k_fold_digits(ScalarPair sp, FoldDigits* out, int use_glv) {
     using SP = typename C::SP;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Fe<SP> a, b;
@@ -167,9 +248,31 @@ template <class C> __global__ void k_fold_digits(ScalarPair sp, FoldDigits* out)
     a = fe_to_canonical<SP>(a);
     b = fe_to_canonical<SP>(b);
     int8_t ua[FOLD_MAX_COLS], ub[FOLD_MAX_COLS];
-    const int n = joint_sparse_form(a.v, b.v, ua, ub);
-    out->cols = n;
-    for (int k = 0; k < n; ++k) out->d[k] = (int8_t)((ua[n - 1 - k] + 1) * 3 + (ub[n - 1 - k] + 1));
+    if (C::Glv::ENABLED && use_glv) {
+        // two joint sparse forms of half-length parts, signs applied to the digits, aligned at the least significant column
+        int8_t va[FOLD_MAX_COLS], vb[FOLD_MAX_COLS];
+        uint32_t a1[8], a2[8], b1[8], b2[8];
+        if constexpr (C::Glv::ENABLED) {
+            glv_split<typename C::Glv>(a.v, a1, a2);
+            glv_split<typename C::Glv>(b.v, b1, b2);
+        }
+        const int sa1 = (a1[7] >> 31) ? -1 : 1, sa2 = (a2[7] >> 31) ? -1 : 1, sb1 = (b1[7] >> 31) ? -1 : 1, sb2 = (b2[7] >> 31) ? -1 : 1;
+        a1[7] &= 0x7fffffffu; a2[7] &= 0x7fffffffu; b1[7] &= 0x7fffffffu; b2[7] &= 0x7fffffffu;
+        const int na = joint_sparse_form(a1, a2, ua, ub), nb = joint_sparse_form(b1, b2, va, vb);
+        const int n = na > nb ? na : nb;
+        out->cols = n;
+        for (int k = 0; k < n; ++k) {
+            const int col = n - 1 - k;  // most significant first
+            const int u0 = col < na ? ua[col] * sa1 : 0, u1 = col < na ? ub[col] * sa2 : 0;
+            const int v0 = col < nb ? va[col] * sb1 : 0, v1 = col < nb ? vb[col] * sb2 : 0;
+            out->d[k] = (int8_t)((u0 + 1) * 3 + (u1 + 1));
+            out->e[k] = (int8_t)((v0 + 1) * 3 + (v1 + 1));
+        }
+    } else {
+        const int n = joint_sparse_form(a.v, b.v, ua, ub);
+        out->cols = n;
+        for (int k = 0; k < n; ++k) out->d[k] = (int8_t)((ua[n - 1 - k] + 1) * 3 + (ub[n - 1 - k] + 1));
+    }
 }
 
 template <class C>
@@ -186,9 +289,14 @@ static int fold_pairs_t(size_t m, const void* d_lo, const void* d_lo_zero, const
     }
     FoldDigits* d_dg = (FoldDigits*)scratch_acquire(sizeof(FoldDigits), stream);
     if (!d_dg) return PLK_ERR_OOM;
-    k_fold_digits<C><<<1, 64, 0, stream>>>(sp, d_dg);
-    k_fold_pairs<C><<<(unsigned)((m + 127) / 128), 128, 0, stream>>>((const uint4*)d_lo, (const uint8_t*)d_lo_zero, (const uint4*)d_hi,
-                                                                     (const uint8_t*)d_hi_zero, m, d_dg, (uint4*)d_out_xy, (uint8_t*)d_out_zero);
+    const bool use_glv = C::Glv::ENABLED && !getenv("PLK_FOLD_NO_GLV");
+    k_fold_digits<C><<<1, 64, 0, stream>>>(sp, d_dg, use_glv ? 1 : 0);
+    if (use_glv)
+        k_fold_pairs_glv<C><<<(unsigned)((m + 127) / 128), 128, 0, stream>>>((const uint4*)d_lo, (const uint8_t*)d_lo_zero, (const uint4*)d_hi,
+                                                                             (const uint8_t*)d_hi_zero, m, d_dg, (uint4*)d_out_xy, (uint8_t*)d_out_zero);
+    else
+        k_fold_pairs<C><<<(unsigned)((m + 127) / 128), 128, 0, stream>>>((const uint4*)d_lo, (const uint8_t*)d_lo_zero, (const uint4*)d_hi,
+                                                                         (const uint8_t*)d_hi_zero, m, d_dg, (uint4*)d_out_xy, (uint8_t*)d_out_zero);
     hipError_t e = hipGetLastError();
     scratch_release(d_dg, stream);
     if (e != hipSuccess) return set_error(PLK_ERR_HIP, "fold launch failed: %s", hipGetErrorString(e));

@@ -35,6 +35,7 @@
 #include "common.h"
 #include "ec.cuh"
 #include "ecz.cuh"
+#include "glv.cuh"
 #include "ecz_coop.cuh"
 #include "tables.cuh"
 
@@ -52,17 +53,28 @@ constexpr uint32_t CODE_INVALID = 0xFFFFFFFFu;
 // same 32-bit words.  The generators arrive in the reference's R-form.
 // One lane per generator, on the lazy arithmetic of the accumulation kernel (ecz.cuh): c doublings per window,
 // then back to affine with the division-step inversion (about a quarter of a window's work).
+// glv != 0 (table-free mode on the curves with the endomorphism, glv.cuh): tab[n + i] = phi(G_i) = (beta x, y).
 template <class C>
 __global__ void __launch_bounds__(128) k_msm_table(const uint4* __restrict__ bases, const uint8_t* __restrict__ base_zero, uint4* __restrict__ tab,
-                                                   size_t n, int c, int windows) {
+                                                   size_t n, int c, int windows, int glv) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // R-form (the reference's) -> canonical R'-form, the form the table is stored and consumed in
-    Fe<FP> xr = to_rprime<FP>(fe_load<FP>(bases + i * 2 * W)), yr = to_rprime<FP>(fe_load<FP>(bases + i * 2 * W + W));
+    const Fe<FP> x_in = fe_load<FP>(bases + i * 2 * W);
+    Fe<FP> xr = to_rprime<FP>(x_in), yr = to_rprime<FP>(fe_load<FP>(bases + i * 2 * W + W));
     bool ident = base_zero ? base_zero[i] != 0 : false;
     affine_store<FP>(tab + i * 2 * W, xr, yr, ident);
+    if constexpr (C::Glv::ENABLED) {
+        if (glv) {
+            Fe<FP> beta;
+#pragma unroll
+            for (int k = 0; k < FP::NL; ++k) beta.v[k] = C::Glv::BETA[k];
+            const Fe<FP> xphi = to_rprime<FP>(fe_mul<FP>(x_in, fe_from_canonical<FP>(beta)));
+            affine_store<FP>(tab + (n + i) * 2 * W, xphi, yr, ident);
+        }
+    }
     const Fz<FP> one = fz_one_rprime<FP>();
     for (int j = 1; j < windows; ++j) {
         if (!ident) {
@@ -131,16 +143,17 @@ struct OrdCfg {
     uint32_t spt;            // scalars per sub-tile (<= ORD_THREADS, spt * windows <= ORD_TILE)
     uint32_t sub;            // sub-tiles per tile (one block walks them in turn)
     uint32_t nt1;            // tiles
+    int raw_signed;          // 1: the "scalars" are half scalars of a GLV split: canonical magnitude, sign in bit 255 (glv.cuh)
 };
 
-template <class SP> PLK_DI void ord_park_scalar(const uint4* __restrict__ scalars, size_t i, uint32_t* s_lim, int tid) {
+template <class SP> PLK_DI void ord_park_scalar(const uint4* __restrict__ scalars, size_t i, uint32_t* s_lim, int tid, bool raw_signed) {
     static_assert(SP::NL == 8, "scalar fields are 256-bit");
     const uint4 lo = scalars[i * 2], hi = scalars[i * 2 + 1];
     Fe<SP> s;
     s.v[0] = lo.x; s.v[1] = lo.y; s.v[2] = lo.z; s.v[3] = lo.w;
     s.v[4] = hi.x; s.v[5] = hi.y; s.v[6] = hi.z; s.v[7] = hi.w;
-    // Montgomery -> canonical in the SCALAR field (to_canonical_u64_vec, curve_msm.rs:164)
-    s = fe_to_canonical<SP>(s);
+    // Montgomery -> canonical in the SCALAR field (to_canonical_u64_vec, curve_msm.rs:164); half scalars are canonical already
+    if (!raw_signed) s = fe_to_canonical<SP>(s);
 #pragma unroll
     for (int k = 0; k < 8; ++k) s_lim[k * ORD_THREADS + tid] = s.v[k];
 }
@@ -158,7 +171,9 @@ PLK_DI uint32_t ord_digit(const uint32_t* s_lim, int tid, int j, const OrdCfg& c
     const uint32_t mag = neg ? (1u << c) - v : v;
     carry = neg;
     if (mag == 0) return CODE_INVALID;
-    return ((mag - 1u + (uint32_t)j * cfg.window_buckets) << 1) | neg;
+    // a negative half scalar (sign parked in bit 255, far above its windows) flips every digit
+    const uint32_t flip = cfg.raw_signed ? s_lim[7 * ORD_THREADS + tid] >> 31 : 0u;
+    return ((mag - 1u + (uint32_t)j * cfg.window_buckets) << 1) | (neg ^ flip);
 }
 
 // exclusive prefix of `v` over the threads of the block (blockDim.x a multiple of 64, <= 1024); *total (optional) = the block sum.
@@ -214,6 +229,28 @@ PLK_DI void block_excl_scan4(uint32_t* s_data, int count, uint32_t* s_tmp) {
 // scans and scatters its bin by the fine bits, producing the bucket offsets on the way.  Only LDS atomics; counts,
 // not capacities, drive the layout, so any digit distribution works.
 
+// GLV split of the scalars of a table-free MSM (glv.cuh): half[i] = k1_i, half[n + i] = k2_i (magnitude, sign in bit 255);
+// the ordering kernels then see 2n "scalars" of GLV_BITS bits over the points [G_0 .. G_(n-1), phi(G_0) .. phi(G_(n-1))].
+template <class C>
+__global__ void __launch_bounds__(256) k_glv_split(const uint4* __restrict__ scalars, size_t n, uint4* __restrict__ half) {
+    using SP = typename C::SP;
+    if constexpr (C::Glv::ENABLED) {
+        const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= n) return;
+        const uint4 lo = scalars[i * 2], hi = scalars[i * 2 + 1];
+        Fe<SP> s;
+        s.v[0] = lo.x; s.v[1] = lo.y; s.v[2] = lo.z; s.v[3] = lo.w;
+        s.v[4] = hi.x; s.v[5] = hi.y; s.v[6] = hi.z; s.v[7] = hi.w;
+        s = fe_to_canonical<SP>(s);
+        uint32_t k1[8], k2[8];
+        glv_split<typename C::Glv>(s.v, k1, k2);
+        half[i * 2] = make_uint4(k1[0], k1[1], k1[2], k1[3]);
+        half[i * 2 + 1] = make_uint4(k1[4], k1[5], k1[6], k1[7]);
+        half[(n + i) * 2] = make_uint4(k2[0], k2[1], k2[2], k2[3]);
+        half[(n + i) * 2 + 1] = make_uint4(k2[4], k2[5], k2[6], k2[7]);
+    }
+}
+
 // level 1, step 1: cnt1[bin * nt1 + tile].  A tile is `sub` consecutive sub-tiles of spt scalars, walked by one block.
 template <class C>
 __global__ void __launch_bounds__(ORD_THREADS) k_ord_count(const uint4* __restrict__ scalars, size_t n, OrdCfg cfg, uint32_t* __restrict__ cnt1) {
@@ -227,7 +264,7 @@ __global__ void __launch_bounds__(ORD_THREADS) k_ord_count(const uint4* __restri
         const size_t i = ((size_t)tile * cfg.sub + st) * cfg.spt + tid;
         const bool live = (uint32_t)tid < cfg.spt && i < n;
         __syncthreads();
-        if (live) ord_park_scalar<SP>(scalars, i, s_lim, tid);
+        if (live) ord_park_scalar<SP>(scalars, i, s_lim, tid, cfg.raw_signed != 0);
         __syncthreads();
         if (live) {
             uint32_t carry = 0;
@@ -307,7 +344,7 @@ __global__ void __launch_bounds__(ORD_THREADS) k_ord_scatter(const uint4* __rest
         const bool live = (uint32_t)tid < cfg.spt && i < n;
         __syncthreads();  // the previous sub-tile has been written out
         for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_cnt[k] = 0;
-        if (live) ord_park_scalar<SP>(scalars, i, s_lim, tid);
+        if (live) ord_park_scalar<SP>(scalars, i, s_lim, tid, cfg.raw_signed != 0);
         __syncthreads();
         if (live) {
             // one atomic per entry: its return value is the entry's rank inside its bin, kept for the placement below
@@ -1099,13 +1136,15 @@ struct MsmWork {
     void* plane_part = nullptr;
     void* win_pts = nullptr;   // the per-window results
     void* slab = nullptr;      // the one allocation all of the above point into
+    bool pooled = false;       // slab comes from the library's scratch pool (table-free contexts: built and dropped per call)
     bool ready = false;
     // executions on different streams share the workspace: the next user waits for the previous one's last kernel
     hipEvent_t ev = nullptr;
     hipStream_t last_stream = nullptr;
     bool used = false;
     void release() {
-        if (slab) (void)hipFree(slab);
+        if (slab && pooled) plk::scratch_release(slab, last_stream);  // stream-ordered: the next taker waits for our last kernel
+        else if (slab) (void)hipFree(slab);
         if (ev) (void)hipEventDestroy(ev);
         ev = nullptr;
         slab = nullptr;
@@ -1126,6 +1165,8 @@ struct plk_msm_ctx {
     bool table_free = false;  // no window tables: every window has its own buckets and is doubled into place at the end
     uint32_t chunk = 24;   // entries per accumulation lane
     // tail geometry
+    bool glv = false;        // table-free mode on a curve with the endomorphism: 2n points, half-length scalars (glv.cuh)
+    size_t n_eff = 0;        // points the kernels see: 2n with glv, else n
     bool two_level = false;  // tabled mode with many buckets: row / column sums first
     int L = 0, H = 0;        // bucket grid 2^H x 2^L
     int g_log = 0, lpl_log = 0, lpb_log = 0;
@@ -1137,6 +1178,7 @@ struct plk_msm_ctx {
     size_t max_lanes = 0;
     // device memory
     void* tab = nullptr;
+    hipStream_t tab_stream = nullptr;  // table-free: the stream the (pooled) table was built on
     plk::OrdCfg ord{};
     uint32_t heavy_cap = 0;
     std::vector<MsmWork> ws;   // ws[0] at precompute; a batched execution allocates one per MSM of a group (<= TAIL_MAX)
@@ -1148,7 +1190,19 @@ struct plk_msm_ctx {
     std::vector<std::vector<hipEvent_t>> prof_sets;  // each N_STAGES + 1 events, recorded
     std::vector<std::vector<hipEvent_t>> prof_free;
     ~plk_msm_ctx() {
-        if (tab) (void)hipFree(tab);
+        if (tab && table_free) {
+            // pooled: hand it back ordered after the last kernel that read it (several user streams: wait for them here)
+            hipStream_t last = tab_stream;
+            int users = 0;
+            for (MsmWork& w : ws)
+                if (w.used) {
+                    if (users++ && w.last_stream != last) (void)hipStreamSynchronize(last);
+                    last = w.last_stream;
+                }
+            plk::scratch_release(tab, last);
+        } else if (tab) {
+            (void)hipFree(tab);
+        }
         for (MsmWork& w : ws) w.release();
         for (auto* v : {&prof_sets, &prof_free})
             for (auto& set : *v)
@@ -1200,7 +1254,7 @@ template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w, hipSt
     using FP = typename C::FP;
     const size_t packed_bytes = (size_t)4 * FP::NL * 4;
     const size_t raw_bytes = (size_t)raw_u4<FP>() * 16;
-    const size_t entries = ctx->n * ctx->windows;
+    const size_t entries = ctx->n_eff * ctx->windows;
     const int bucket_windows = ctx->tail_windows;
     // packed operands of the plane sums: the buckets themselves, or (two-level tail) the column and row sums
     const size_t tail_slots = ctx->two_level ? (size_t)bucket_windows * ctx->tail_wbuckets : (size_t)ctx->buckets;
@@ -1225,7 +1279,16 @@ template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w, hipSt
     size_t total = 0;
     for (const Part& pt : parts) total += (pt.bytes + 255) & ~(size_t)255;
     ctx->ws_bytes = total + 256;
-    PLK_HIP_TRY(hipMalloc(&w.slab, total + 256));
+    // A table-free context lives for one call (msm_parallel, an IPA round): its memory comes from the scratch pool, because
+    // hipMalloc + hipFree of a few hundred MB cost as much as a tenth of the MSM itself (0.4 ms of 3.8 at 2^20).
+    w.pooled = ctx->table_free;
+    if (w.pooled) {
+        w.slab = scratch_acquire(total + 256, stream);
+        if (!w.slab) return PLK_ERR_OOM;
+        w.last_stream = stream;
+    } else {
+        PLK_HIP_TRY(hipMalloc(&w.slab, total + 256));
+    }
     uint8_t* cur = (uint8_t*)w.slab;
     for (const Part& pt : parts) {
         *pt.p = pt.bytes ? cur : nullptr;
@@ -1245,7 +1308,7 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
     using FP = typename C::FP;
     const size_t n = ctx->n;
     const size_t pt_bytes = (size_t)2 * FP::NL * 4;
-    const size_t entries = n * ctx->windows;
+    const size_t entries = ctx->n_eff * ctx->windows;
     // entries per accumulation lane: whole rounds of the lanes the GPU holds, at most 72 entries each (longer chunks: fewer pieces)
     {
         const size_t slots = accumulate_slots<C>();
@@ -1269,12 +1332,18 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
         const double heads = (double)entries / (double)ctx->buckets / (double)ctx->chunk;
         ctx->lpb_log = heads > 6.0 ? 3 : heads > 2.0 ? 2 : 0;
     }
-    PLK_HIP_TRY(hipMalloc(&ctx->tab, (ctx->table_free ? n : entries) * pt_bytes + 16));
+    if (ctx->table_free) {
+        ctx->tab = scratch_acquire(ctx->n_eff * pt_bytes + 16, stream);
+        if (!ctx->tab) return PLK_ERR_OOM;
+        ctx->tab_stream = stream;
+    } else {
+        PLK_HIP_TRY(hipMalloc(&ctx->tab, entries * pt_bytes + 16));
+    }
     ctx->ws.resize(1);
     PLK_TRY(msm_alloc_work<C>(ctx, ctx->ws[0], stream));
     if (n) {
         k_msm_table<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)ctx->tab, n, ctx->c,
-                                                                       ctx->table_free ? 1 : ctx->windows);
+                                                                       ctx->table_free ? 1 : ctx->windows, ctx->glv ? 1 : 0);
         PLK_HIP_TRY(hipGetLastError());
     }
     PLK_HIP_TRY(hipStreamSynchronize(stream));
@@ -1300,16 +1369,19 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     if (n && !d_bases) return set_error(PLK_ERR_INVALID_ARG, "null bases");
     PLK_TRY(ensure_device());
     const bool table_free = (flags & PLK_MSM_TABLE_FREE) != 0;
-    int c = window_bits ? (int)window_bits : (table_free ? choose_window_table_free(n ? n : 1) : choose_window(n ? n : 1, curve));
+    // table-free mode on the prime-order curves: split every scalar along the endomorphism (glv.cuh) - 2n points, half the windows
+    const bool glv = table_free && n > 0 && curve != PLK_CURVE_BLS12_377 && !getenv("PLK_MSM_NO_GLV");
+    const size_t n_eff = glv ? 2 * n : n;
+    int c = window_bits ? (int)window_bits : (table_free ? choose_window_table_free(n_eff ? n_eff : 1) : choose_window(n ? n : 1, curve));
     if (c < 2 || c > MSM_MAX_WINDOW) return set_error(PLK_ERR_INVALID_ARG, "window_bits %d outside [2, %d]", c, MSM_MAX_WINDOW);
-    const int windows = (scalar_bits(curve) + 1 + c - 1) / c;
+    const int windows = ((glv ? GLV_BITS : scalar_bits(curve)) + 1 + c - 1) / c;
     if (table_free) {
         if (((size_t)windows << (c - 1)) > 65536 || windows > COMBINE_THREADS / 4)
             return set_error(PLK_ERR_INVALID_ARG, "table-free mode: window_bits %d gives %d windows x %d buckets (limits: 65536 slots, %d windows)", c, windows,
                              1 << (c - 1), COMBINE_THREADS / 4);
     }
-    if (n * (size_t)windows >= ((size_t)1 << 31))
-        return set_error(PLK_ERR_INVALID_ARG, "n * windows = %zu entries exceeds 2^31", n * (size_t)windows);
+    if (n_eff * (size_t)windows >= ((size_t)1 << 31))
+        return set_error(PLK_ERR_INVALID_ARG, "n * windows = %zu entries exceeds 2^31", n_eff * (size_t)windows);
     int dev = 0;
     PLK_HIP_TRY(hipGetDevice(&dev));
     auto* ctx = new plk_msm_ctx();
@@ -1317,6 +1389,8 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     ctx->device = dev;
     ctx->curve = curve;
     ctx->n = n;
+    ctx->glv = glv;
+    ctx->n_eff = n_eff;
     ctx->c = c;
     ctx->windows = windows;
     ctx->wbuckets = 1u << (c - 1);
@@ -1335,9 +1409,10 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
         ctx->buckets = (uint32_t)o.nbins << o.fine_bits;
         o.spt = (uint32_t)(ORD_TILE / windows);
         if (o.spt > (uint32_t)ORD_THREADS) o.spt = ORD_THREADS;
-        o.sub = n >= ((size_t)1 << 16) ? 4 : 1;
-        o.nt1 = (uint32_t)((n + (size_t)o.spt * o.sub - 1) / ((size_t)o.spt * o.sub));
+        o.sub = n_eff >= ((size_t)1 << 16) ? 4 : 1;
+        o.nt1 = (uint32_t)((n_eff + (size_t)o.spt * o.sub - 1) / ((size_t)o.spt * o.sub));
         if (o.nt1 == 0) o.nt1 = 1;
+        o.raw_signed = glv ? 1 : 0;
     }
     // tail geometry
     ctx->two_level = !ctx->table_free && c - 1 >= 12;
@@ -1438,7 +1513,7 @@ constexpr int PH_ORDER = 1, PH_ACC = 2, PH_REDUCE = 4, PH_ALL = 7;
 template <class C>
 static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
                          int phases = PH_ALL) {
-    const size_t n = ctx->n;
+    const size_t n = ctx->n_eff;
     const uint32_t buckets = ctx->buckets;
     const OrdCfg& o = ctx->ord;
     uint32_t* off = (uint32_t*)w.off;
@@ -1465,6 +1540,14 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
     };
     mark();
     if (phases & PH_ORDER) {
+        void* halves = nullptr;
+        if (ctx->glv) {
+            // the two half scalars of every scalar (stream-ordered scratch: handed back once the ordering kernels are enqueued)
+            halves = scratch_acquire(n * 32, stream);
+            if (!halves) return PLK_ERR_OOM;
+            k_glv_split<C><<<(unsigned)((ctx->n + 255) / 256), 256, 0, stream>>>((const uint4*)d_scalars, ctx->n, (uint4*)halves);
+            d_scalars = halves;
+        }
         k_ord_count<C><<<o.nt1, ORD_THREADS, 0, stream>>>((const uint4*)d_scalars, n, o, (uint32_t*)w.cnt1);
         k_ord_scan1<<<o.nbins, 256, 0, stream>>>((uint32_t*)w.cnt1, o.nt1, o.nbins, bin_total, bin_base, seg_base, done_counter);
         PLK_HIP_TRY(hipGetLastError());
@@ -1480,6 +1563,7 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
             k_ord_bin_scatter<<<segs + o.nbins, ORD_BIN_THREADS, 0, stream>>>((const uint2*)w.tmp, bin_base, seg_base, o.fine_bits, o.nbins, buckets,
                                                                               (const uint32_t*)w.cnt2, off, (uint32_t*)w.sorted);
         }
+        if (halves) scratch_release(halves, stream);
         PLK_HIP_TRY(hipGetLastError());
         mark();
     } else {
@@ -1628,7 +1712,7 @@ static int msm_reference_table_t(size_t n, const void* d_bases, const void* d_ze
     const size_t pt_bytes = (size_t)2 * FP::NL * 4;
     void* tab = scratch_acquire(n * digits * pt_bytes + 16, stream);
     if (!tab) return PLK_ERR_OOM;
-    k_msm_table<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)tab, n, w, digits);
+    k_msm_table<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)tab, n, w, digits, 0);
     const size_t total = n * (size_t)digits;
     k_msm_table_export<C><<<(unsigned)((total + 255) / 256), 256, 0, stream>>>((const uint4*)tab, n, digits, (uint4*)d_out_xy, (uint8_t*)d_out_zero);
     hipError_t e = hipGetLastError();

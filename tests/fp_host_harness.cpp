@@ -5,6 +5,7 @@
 #include "../plonky_amd/csrc/fp.cuh"
 #include "../plonky_amd/csrc/fz.cuh"
 #include "../plonky_amd/csrc/ecz.cuh"
+#include "../plonky_amd/csrc/glv.cuh"
 using namespace plk;
 
 template <class P> static void run(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
@@ -178,6 +179,25 @@ extern "C" int ecz_host_sum(int field, size_t n, const uint32_t* xs, const uint3
         case 3: ecz_sum<Bls12377BaseParams>(n, xs, ys, negs, out); return 0;
         case 4: ecz_sum<PallasBaseParams>(n, xs, ys, negs, out); return 0;
         case 5: ecz_sum<VestaBaseParams>(n, xs, ys, negs, out); return 0;
+    }
+    return -1;
+}
+
+// GLV split (glv.cuh): canonical scalars in, (magnitude | sign in bit 255) pairs out
+template <class G> static void glv_run(const uint32_t* k, uint32_t* k1, uint32_t* k2, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t a[8], b[8], c[8];
+        for (int t = 0; t < 8; ++t) a[t] = k[8 * i + t];
+        glv_split<G>(a, b, c);
+        for (int t = 0; t < 8; ++t) { k1[8 * i + t] = b[t]; k2[8 * i + t] = c[t]; }
+    }
+}
+extern "C" int glv_host_split(int curve, const uint32_t* k, uint32_t* k1, uint32_t* k2, size_t n) {
+    switch (curve) {
+        case 0: glv_run<TweedledeeGlv>(k, k1, k2, n); return 0;
+        case 1: glv_run<TweedledumGlv>(k, k1, k2, n); return 0;
+        case 3: glv_run<PallasGlv>(k, k1, k2, n); return 0;
+        case 4: glv_run<VestaGlv>(k, k1, k2, n); return 0;
     }
     return -1;
 }

@@ -182,3 +182,46 @@ def test_lazy_xyzz_accumulation_on_host(host_lib, c):
     # trees that hit a + a (doubling) and a + (-a) at inner nodes
     assert run_sum([pts[0], pts[1], pts[0], pts[1]], [0, 0, 0, 0], "ecz_host_tree") == expect([pts[0], pts[1]] * 2, [0] * 4)
     assert run_sum([pts[0], pts[1], pts[0], pts[1]], [0, 0, 1, 1], "ecz_host_tree") is None
+
+
+@pytest.mark.parametrize("c", [br.TWEEDLEDEE, br.TWEEDLEDUM, br.PALLAS, br.VESTA], ids=lambda c: c.name)
+def test_glv_split_on_host(host_lib, c):
+    """glv.cuh: k = k1 + k2 lambda (mod r) with half-length k1, k2, and [k] P = [k1] P + [k2] phi(P), phi((x, y)) = (beta x, y)
+    (curve.rs:140-149 endomorphism; the reference's own test: *_curve.rs test_endomorphism_*)."""
+    import random, re
+    r, p = c.scalar.p, c.base.p
+    txt = open(os.path.join(os.path.dirname(__file__), "..", "plonky_amd", "csrc", "glv_params.cuh")).read()
+    blk = txt[txt.index("struct %sGlv" % c.name):]
+    blk = blk[:blk.index("\n};")]
+
+    def const(name, n):
+        m = re.search(r"%s\[%d\] = \{([^}]*)\}" % (name, n), blk)
+        return sum(int(w.strip().rstrip("u"), 16) << (32 * i) for i, w in enumerate(m.group(1).split(",")))
+
+    beta, lam = const("BETA", 8), const("LAMBDA", 8)
+    assert pow(beta, 3, p) == 1 and beta != 1 and pow(lam, 3, r) == 1 and lam != 1
+    G = (c.gx, c.gy)
+    assert br.ec_mul(c, lam, G) == (beta * G[0] % p, G[1])
+    rng = random.Random(99)
+    ks = [0, 1, 2, r - 1, r - 2, r // 2, r // 2 + 1, lam, r - lam] + [rng.randrange(r) for _ in range(3000)]
+    k = ints_to_array(ks, 4)
+    k1 = np.zeros_like(k)
+    k2 = np.zeros_like(k)
+    host_lib.glv_host_split.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    assert host_lib.glv_host_split(c.curve_id, k.ctypes.data, k1.ctypes.data, k2.ctypes.data, len(ks)) == 0
+
+    def signed(row):
+        v = synth.to_int(row)
+        return -(v & ((1 << 255) - 1)) if v >> 255 else v
+
+    P = br.ec_mul(c, 424242, G)
+    phiP = (beta * P[0] % p, P[1])
+    neg = lambda Q: (Q[0], (-Q[1]) % p)
+    for i, kv in enumerate(ks):
+        a, b = signed(k1[i]), signed(k2[i])
+        assert abs(a) < 1 << 130 and abs(b) < 1 << 130
+        assert (a + b * lam - kv) % r == 0
+        if i < 40:
+            t1 = br.ec_mul(c, abs(a), P if a >= 0 else neg(P)) if a else None
+            t2 = br.ec_mul(c, abs(b), phiP if b >= 0 else neg(phiP)) if b else None
+            assert br.ec_add(c, t1, t2) == (br.ec_mul(c, kv, P) if kv else None)
