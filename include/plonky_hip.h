@@ -151,9 +151,11 @@ int plk_msm_precompute(int curve, size_t n, const uint64_t* bases_xy, const uint
 int plk_msm_precompute_dev(int curve, size_t n, const void* d_bases_xy, const void* d_base_zero, unsigned window_bits, void* stream,
                            plk_msm_ctx** out_ctx);
 /* flags for the _ex forms.  PLK_MSM_TABLE_FREE: do not build the window tables -- every window gets its own
- * buckets and is doubled into place at the end (~250 dependent doublings, ~1 ms).  For generators that are
- * used once or a few times (msm_parallel, curve_msm.rs:54-61; the IPA rounds of halo.rs:87-91 build a
- * fresh MsmPrecomputation per round): the table build costs about 30 executions. */
+ * buckets and is doubled into place at the end.  For generators that are used once or a few times (msm_parallel,
+ * curve_msm.rs:54-61; the IPA rounds of halo.rs:87-91 build a fresh MsmPrecomputation per round): the table build
+ * costs about 15 executions.  window_bits <= 16 in this mode.  On the prime-order curves (HaloCurve, curve.rs:65-69) the
+ * scalars are split along the endomorphism (2n points, half-length scalars: ~120 dependent doublings instead of ~250);
+ * the context's memory comes from the library's scratch pool (plk_ntt_clear_cache returns it to the driver). */
 #define PLK_MSM_TABLE_FREE 1u
 int plk_msm_precompute_ex(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, unsigned window_bits, unsigned flags,
                           plk_msm_ctx** out_ctx);

@@ -42,6 +42,7 @@
 namespace plk {
 
 constexpr int MSM_MAX_PLANE_PARTS = 16;  // blocks per bit-plane in the reduction (planes * parts quads must fit the final block)
+constexpr int MSM_TF_MAX_WINDOW = 16;  // table-free mode: every window has its own 2^(c-1) buckets
 constexpr int MSM_MAX_WINDOW = 21;   // c - 1 <= 10 coarse + 11 fine bits in the partition (ORD_MAX_BINS, ORD_MAX_FINE)
 constexpr uint32_t CODE_INVALID = 0xFFFFFFFFu;
 
@@ -803,22 +804,25 @@ __global__ void __launch_bounds__(128) k_msm_gsum(TailBatch tb, int L, int H, in
     const uint32_t nbg = (1u << (L + H)) >> g_log;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * nbg) return;
+    // table-free mode: blockIdx.z is the window, every window its own 2^H x 2^L grid of buckets and its own partials
+    const uint32_t wbase = blockIdx.z << (L + H);
+    uint4* part = sl.line_part + (size_t)blockIdx.z * 2 * nbg * RU;
     const uint32_t G = 1u << g_log;
     uint32_t b0, bstep;  // first bucket, distance between consecutive buckets of the group
     uint4* dst;
     if (t < nbg) {
         const uint32_t pr = (1u << L) >> g_log;  // groups per row
         const uint32_t hi = t / pr, g = t % pr;
-        b0 = (hi << L) + (g << g_log);
+        b0 = wbase + (hi << L) + (g << g_log);
         bstep = 1;
-        dst = sl.line_part + (size_t)t * RU;
+        dst = part + (size_t)t * RU;
     } else {
         const uint32_t u = t - nbg;
         const uint32_t lo = u & ((1u << L) - 1u), g = u >> L;
         const uint32_t pc = (1u << H) >> g_log;  // groups per column
-        b0 = ((g << g_log) << L) + lo;
+        b0 = wbase + ((g << g_log) << L) + lo;
         bstep = 1u << L;
-        dst = sl.line_part + ((size_t)nbg + (size_t)lo * pc + g) * RU;
+        dst = part + ((size_t)nbg + (size_t)lo * pc + g) * RU;
     }
     // the load of element k + 1 is in flight while element k is added
     XyzzZ<FP> acc = xyzzz_identity<FP>();
@@ -849,21 +853,22 @@ __global__ void __launch_bounds__(256) k_msm_lsum(TailBatch tb, int L, int H, in
     const uint32_t quad = gid >> 2;
     const uint32_t slot = quad >> qpl_log, part = quad & ((1u << qpl_log) - 1u);
     XyzzZ<FP> acc = xyzzz_identity<FP>();
+    const uint4* lines = sl.line_part + (size_t)blockIdx.z * 2 * nbg * RU;  // blockIdx.z: the window (table-free mode)
     if (slot < 2 * wb) {
         const uint32_t win = slot >> H, idx = slot & (wb - 1u);
         const uint4* src = nullptr;
         uint32_t cnt = 0;
         if (win == 0 && idx < (1u << L)) {
             cnt = (1u << H) >> g_log;
-            src = sl.line_part + ((size_t)nbg + (size_t)idx * cnt) * RU;
+            src = lines + ((size_t)nbg + (size_t)idx * cnt) * RU;
         } else if (win == 1 && idx + 1 < wb) {
             cnt = (1u << L) >> g_log;
-            src = sl.line_part + (size_t)(idx + 1) * cnt * RU;
+            src = lines + (size_t)(idx + 1) * cnt * RU;
         }
         for (uint32_t k = part; k < cnt; k += 1u << qpl_log) acc = xyzzz_add_q<FP>(acc, xyzzz_load_raw<FP>(src + (size_t)k * RU), ql);
     }
     acc = wave_sum_q<FP>(acc, 1 << qpl_log, ql);
-    if (slot < 2 * wb && part == 0 && ql == 0) xyzzz_store_packed<FP>(sl.bucket + (size_t)slot * 4 * W, acc);
+    if (slot < 2 * wb && part == 0 && ql == 0) xyzzz_store_packed<FP>(sl.bucket + ((size_t)blockIdx.z * 2 * wb + slot) * 4 * W, acc);
 }
 
 // The planes and the final kernel run on quads (ecz_coop.cuh): four lanes per point, a doubling is 3
@@ -904,7 +909,7 @@ __global__ void __launch_bounds__(PLANE_THREADS) k_msm_planes(TailBatch tb, int 
 constexpr int FINAL_FUSE_WINDOWS = 4;  // up to this many tail windows are added by the last block of k_msm_final itself
 constexpr int FINAL_THREADS = 512;  // <= 8 waves, so the compiler may use 256 VGPRs: the point arithmetic must not spill
 template <class C>
-__global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int windows, int parts, int planes, int window_bits) {
+__global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int windows, int parts, int planes, int window_bits, int pair_shift) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     __shared__ uint4 s_pts[33 * 4 * W];
@@ -933,7 +938,10 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int w
     __syncthreads();
     if (tid < 4) {
         if (planes > 16) acc = xyzzz_add_q<FP>(acc, xyzzz_load_packed<FP>(s_pts + 32 * 4 * W), ql);
-        for (int k = 0; k < win * window_bits; ++k) acc = xyzzz_dbl_q<FP>(acc, ql);
+        // pair_shift < 0: window `win` weighs 2^(win * window_bits).  Two-level tail: the windows come in pairs (column sums,
+        // row sums) of real window win / 2, the row sums shifted by pair_shift = L more
+        const int shift = pair_shift < 0 ? win * window_bits : (win >> 1) * window_bits + (win & 1) * pair_shift;
+        for (int k = 0; k < shift; ++k) acc = xyzzz_dbl_q<FP>(acc, ql);
         if (windows == 1) {
             if (tid == 0) emit_affine<FP>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
         } else {
@@ -1350,14 +1358,22 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
     return PLK_OK;
 }
 
-// table-free window: windows * 2^(c-1) bucket slots, long chunks wanted
-static int choose_window_table_free(size_t n) {
+// table-free window: windows * 2^(c-1) bucket slots, long chunks wanted.  A top window of one or two bits (131 = 13 * 10 + 1)
+// would put every scalar's top digit into a handful of buckets: a neighbouring width is taken instead.
+static int choose_window_table_free(size_t n, int bits) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
     int c = lg - 5;
+    if (c < 3) c = 3;
+    if (c > MSM_TF_MAX_WINDOW) c = MSM_TF_MAX_WINDOW;
+    auto top = [&](int w) { return bits - ((bits + w - 1) / w - 1) * w; };
+    if (top(c) < 3) {
+        if (c + 1 <= MSM_TF_MAX_WINDOW && top(c + 1) >= 3) c = c + 1;
+        else if (c - 1 >= 3 && top(c - 1) >= 3) c = c - 1;
+    }
     if (const char* e = getenv("PLK_MSM_WINDOW_TF")) c = atoi(e);
     if (c < 3) c = 3;
-    if (c > 12) c = 12;
+    if (c > MSM_TF_MAX_WINDOW) c = MSM_TF_MAX_WINDOW;
     return c;
 }
 
@@ -1372,13 +1388,18 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     // table-free mode on the prime-order curves: split every scalar along the endomorphism (glv.cuh) - 2n points, half the windows
     const bool glv = table_free && n > 0 && curve != PLK_CURVE_BLS12_377 && !getenv("PLK_MSM_NO_GLV");
     const size_t n_eff = glv ? 2 * n : n;
-    int c = window_bits ? (int)window_bits : (table_free ? choose_window_table_free(n_eff ? n_eff : 1) : choose_window(n ? n : 1, curve));
+    int c = window_bits ? (int)window_bits : (table_free ? choose_window_table_free(n_eff ? n_eff : 1, (glv ? GLV_BITS : scalar_bits(curve)) + 1) : choose_window(n ? n : 1, curve));
     if (c < 2 || c > MSM_MAX_WINDOW) return set_error(PLK_ERR_INVALID_ARG, "window_bits %d outside [2, %d]", c, MSM_MAX_WINDOW);
     const int windows = ((glv ? GLV_BITS : scalar_bits(curve)) + 1 + c - 1) / c;
+    if (table_free && c > MSM_TF_MAX_WINDOW)
+        return set_error(PLK_ERR_INVALID_ARG, "table-free mode: window_bits %d above %d", c, MSM_TF_MAX_WINDOW);
     if (table_free) {
-        if (((size_t)windows << (c - 1)) > 65536 || windows > COMBINE_THREADS / 4)
-            return set_error(PLK_ERR_INVALID_ARG, "table-free mode: window_bits %d gives %d windows x %d buckets (limits: 65536 slots, %d windows)", c, windows,
-                             1 << (c - 1), COMBINE_THREADS / 4);
+        // bit-plane reduction over the buckets themselves up to 12 bits, the two-level reduction per window above
+        const size_t slot_limit = c - 1 >= 12 ? (size_t)ORD_MAX_BINS << ORD_MAX_FINE : 65536;
+        const int window_limit = c - 1 >= 12 ? COMBINE_THREADS / 8 : COMBINE_THREADS / 4;
+        if (((size_t)windows << (c - 1)) > slot_limit || windows > window_limit)
+            return set_error(PLK_ERR_INVALID_ARG, "table-free mode: window_bits %d gives %d windows x %d buckets (limits: %zu slots, %d windows)", c, windows,
+                             1 << (c - 1), slot_limit, window_limit);
     }
     if (n_eff * (size_t)windows >= ((size_t)1 << 31))
         return set_error(PLK_ERR_INVALID_ARG, "n * windows = %zu entries exceeds 2^31", n_eff * (size_t)windows);
@@ -1415,7 +1436,7 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
         o.raw_signed = glv ? 1 : 0;
     }
     // tail geometry
-    ctx->two_level = !ctx->table_free && c - 1 >= 12;
+    ctx->two_level = c - 1 >= 12;
     if (ctx->two_level) {
         ctx->L = (c - 1) / 2;
         ctx->H = c - 1 - ctx->L;
@@ -1425,9 +1446,9 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
         if (ctx->g_log < 0) ctx->g_log = 0;
         const int longest = ctx->H - ctx->g_log;  // log2 of the partials per column (rows have L - g_log <= that)
         ctx->lpl_log = longest < 4 ? longest : 4;  // quads per line
-        ctx->tail_windows = 2;
+        ctx->tail_windows = ctx->table_free ? 2 * ctx->windows : 2;  // per real window: its column sums, then its row sums
         ctx->tail_wbuckets = 1u << ctx->H;
-        ctx->tail_shift = ctx->L;
+        ctx->tail_shift = c;  // between real windows (table-free mode); the row sums of a window weigh 2^L more (k_msm_final)
         ctx->planes = ctx->H;  // weights up to 2^H - 1 (rows) / 2^L (columns): plane H - 1 is the top one for rows; columns need bit L <= H - 1 or L == H
         if (ctx->L == ctx->H) ctx->planes = ctx->H + 1;  // column weight 2^L = 2^H needs plane H
     } else {
@@ -1486,11 +1507,12 @@ static int msm_reduce_t(plk_msm_ctx* ctx, TailBatch tb, hipStream_t stream, Mark
     k_msm_heavy_final<C><<<dim3(64, cnt), 256, 0, stream>>>(tb, ctx->heavy_cap);
     const unsigned ab = (unsigned)((((size_t)buckets << ctx->lpb_log) + 255) / 256);
     if (ctx->two_level) {
-        const uint32_t nbg = buckets >> ctx->g_log;
+        const uint32_t nbg = (1u << (ctx->L + ctx->H)) >> ctx->g_log;  // groups per window (rows; as many for the columns)
+        const unsigned wins = ctx->table_free ? (unsigned)ctx->windows : 1u;
         k_msm_assemble<C, false><<<dim3(ab, cnt), 256, 0, stream>>>(tb, buckets, ctx->chunk, ctx->lpb_log);
-        k_msm_gsum<C><<<dim3((2 * nbg + 127) / 128, cnt), 128, 0, stream>>>(tb, ctx->L, ctx->H, ctx->g_log);
+        k_msm_gsum<C><<<dim3((2 * nbg + 127) / 128, cnt, wins), 128, 0, stream>>>(tb, ctx->L, ctx->H, ctx->g_log);
         const size_t lanes = ((size_t)2 << ctx->H) << (ctx->lpl_log + 2);
-        k_msm_lsum<C><<<dim3((unsigned)((lanes + 255) / 256), cnt), 256, 0, stream>>>(tb, ctx->L, ctx->H, ctx->g_log, ctx->lpl_log);
+        k_msm_lsum<C><<<dim3((unsigned)((lanes + 255) / 256), cnt, wins), 256, 0, stream>>>(tb, ctx->L, ctx->H, ctx->g_log, ctx->lpl_log);
     } else {
         k_msm_assemble<C, true><<<dim3(ab, cnt), 256, 0, stream>>>(tb, buckets, ctx->chunk, ctx->lpb_log);
     }
@@ -1501,7 +1523,7 @@ static int msm_reduce_t(plk_msm_ctx* ctx, TailBatch tb, hipStream_t stream, Mark
     k_msm_planes<C><<<pg, PLANE_THREADS, 0, stream>>>(tb, tw, ctx->tail_wbuckets);
     PLK_HIP_TRY(hipGetLastError());
     mark();
-    k_msm_final<C><<<tw * cnt, FINAL_THREADS, 0, stream>>>(tb, tw, ctx->plane_blocks, ctx->planes, ctx->tail_shift);
+    k_msm_final<C><<<tw * cnt, FINAL_THREADS, 0, stream>>>(tb, tw, ctx->plane_blocks, ctx->planes, ctx->tail_shift, ctx->two_level ? ctx->L : -1);
     if (tw > FINAL_FUSE_WINDOWS) k_msm_combine<C><<<cnt, COMBINE_THREADS, 0, stream>>>(tb, tw);
     PLK_HIP_TRY(hipGetLastError());
     mark();

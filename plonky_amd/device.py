@@ -208,8 +208,7 @@ def halo_round_lr_dev(curve, halo_a, halo_b, halo_g, pedersen_h, u_prime, l_blin
             zf = torch.cat([gz, torch.zeros(2, dtype=torch.uint8, device=gz.device)]).contiguous()
         pre = msm_precompute_dev(curve, bases, zero=zf, table_free=True)
         xy, z = msm_execute_dev(pre, scal)
-        torch.cuda.synchronize()
-        pre.free()
+        pre.free()  # a table-free context hands its memory back in stream order: no synchronisation
         outs.append(xy[0])
         zeros.append(z[0])
     return torch.stack(outs), torch.stack(zeros)

@@ -204,7 +204,7 @@ def test_error_behaviour_of_the_new_entry_points():
     c = br.TWEEDLEDEE
     g = mont_arr(c.base, [c.gx, c.gy]).reshape(1, 2, 4)
     ctx = ctypes.c_void_p()
-    assert L.plk_msm_precompute_ex(0, 1, p(g), None, 16, 1, ctypes.byref(ctx)) == lib.PLK_ERR_INVALID_ARG
+    assert L.plk_msm_precompute_ex(0, 1, p(g), None, 17, 1, ctypes.byref(ctx)) == lib.PLK_ERR_INVALID_ARG  # table-free: windows <= 16 bits
     assert L.plk_msm_precompute_ex(0, 1, p(g), None, 40, 0, ctypes.byref(ctx)) == lib.PLK_ERR_INVALID_ARG
     # reference-layout table: window 0
     assert L.plk_msm_table_digits(0, 0) == lib.PLK_ERR_INVALID_ARG

@@ -77,6 +77,8 @@ def test_pallas_vesta_literals():
     assert br.ec_mul(br.PALLAS, zv, G) == (zp * G[0] % br.PALLAS_BASE.p, G[1])
     G = (br.VESTA.gx, br.VESTA.gy)
     assert br.ec_mul(br.VESTA, zp, G) == (zv * G[0] % br.VESTA_BASE.p, G[1])
+    _check_glv_params(br.PALLAS, zp, zv)
+    _check_glv_params(br.VESTA, zv, zp)
 
 
 # ---- 2. test_to_digits (curve_msm.rs:186-216) ----
@@ -386,6 +388,23 @@ def test_endomorphism_constants():
         zeta_p = c.base.from_mont(limbs_to_int(zp))
         zeta_q = c.scalar.from_mont(limbs_to_int(zq))
         assert br.ec_mul(c, zeta_q, G) == (zeta_p * G[0] % c.base.p, G[1])
+        _check_glv_params(c, zeta_p, zeta_q)
+
+
+def _check_glv_params(c, zeta_p, zeta_q):
+    """plonky_amd/csrc/glv_params.cuh (derived from the moduli by tools/gen_glv_params.py) holds the reference's endomorphism:
+    (BETA, LAMBDA) is (ZETA, ZETA_SCALAR) or the other primitive pair (ZETA^2, ZETA_SCALAR^2)."""
+    import os, re
+    txt = open(os.path.join(os.path.dirname(__file__), "..", "plonky_amd", "csrc", "glv_params.cuh")).read()
+    blk = txt[txt.index("struct %sGlv" % c.name):]
+    blk = blk[:blk.index("\n};")]
+
+    def const(name):
+        m = re.search(r"%s\[8\] = \{([^}]*)\}" % name, blk)
+        return sum(int(w.strip().rstrip("u"), 16) << (32 * i) for i, w in enumerate(m.group(1).split(",")))
+
+    p, r = c.base.p, c.scalar.p
+    assert (const("BETA"), const("LAMBDA")) in ((zeta_p, zeta_q), (zeta_p * zeta_p % p, zeta_q * zeta_q % r))
 
 
 # ---- seeded generator: C++ and Python agree; MSM oracle (reference algorithm) vs big-int maths ----

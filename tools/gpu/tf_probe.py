@@ -13,7 +13,7 @@ bases = dev.gen_bases_dev(CURVE, n, g0, g0)
 s = dev.to_device(synth.rand_field(SCALAR, 77, n))
 oxy = torch.empty((1, 2, 4), dtype=torch.int64, device="cuda"); oz = torch.empty((1,), dtype=torch.uint8, device="cuda")
 ref = None
-for c in ["", "8", "10", "11", "12"]:
+for c in ["", "12", "13", "14", "15", "16"]:
     if c: os.environ["PLK_MSM_WINDOW_TF"] = c
     ts = np.zeros(3)
     reps = 6
