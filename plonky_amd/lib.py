@@ -90,7 +90,7 @@ class PlonkyHipError(RuntimeError):
 
 def build(force=False):
     """Compile libplonky_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    args = ["make", "-C", _CSRC, "-j4"]
+    args = ["make", "-C", _CSRC, "-j8"]
     if force:
         args.append("-B")
     subprocess.check_call(args, stdout=subprocess.DEVNULL)
