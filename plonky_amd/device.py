@@ -197,21 +197,43 @@ def halo_round_lr_dev(curve, halo_a, halo_b, halo_g, pedersen_h, u_prime, l_blin
     sf = CURVE_SCALAR_FIELD[curve]
     L = _CURVE_LIMBS[curve]
     extra = to_device(np.stack([np.ascontiguousarray(pedersen_h, dtype=np.uint64).reshape(2, L), np.ascontiguousarray(u_prime, dtype=np.uint64).reshape(2, L)]))
+    # L_j and R_j are independent and, below 2^16 points, pure latency (the window-doubling chain of a table-free MSM):
+    # they run on two streams
+    main = torch.cuda.current_stream()
+    side = _side_stream(halo_a.device)
+    side.wait_stream(main)
     outs, zeros = [], []
-    for a_half, b_half, g_half, gz, blind in ((halo_a[:m], halo_b[m:], halo_g[m:], None if g_zero is None else g_zero[m:], l_blinding),
-                                              (halo_a[m:], halo_b[:m], halo_g[:m], None if g_zero is None else g_zero[:m], r_blinding)):
-        ip = inner_product_dev(sf, a_half.contiguous(), b_half.contiguous())
-        scal = torch.cat([a_half, to_device(_limbs(blind).reshape(1, 4)), ip], dim=0).contiguous()
-        bases = torch.cat([g_half, extra], dim=0).contiguous()
-        zf = None
-        if gz is not None:
-            zf = torch.cat([gz, torch.zeros(2, dtype=torch.uint8, device=gz.device)]).contiguous()
-        pre = msm_precompute_dev(curve, bases, zero=zf, table_free=True)
-        xy, z = msm_execute_dev(pre, scal)
-        pre.free()  # a table-free context hands its memory back in stream order: no synchronisation
+    for k, (a_half, b_half, g_half, gz, blind) in enumerate(((halo_a[:m], halo_b[m:], halo_g[m:], None if g_zero is None else g_zero[m:], l_blinding),
+                                                             (halo_a[m:], halo_b[:m], halo_g[:m], None if g_zero is None else g_zero[:m], r_blinding))):
+        st = main if k == 0 else side
+        with torch.cuda.stream(st):
+            ip = inner_product_dev(sf, a_half.contiguous(), b_half.contiguous())
+            scal = torch.cat([a_half, to_device(_limbs(blind).reshape(1, 4)), ip], dim=0).contiguous()
+            bases = torch.cat([g_half, extra], dim=0).contiguous()
+            zf = None
+            if gz is not None:
+                zf = torch.cat([gz, torch.zeros(2, dtype=torch.uint8, device=gz.device)]).contiguous()
+            pre = msm_precompute_dev(curve, bases, zero=zf, table_free=True)
+            xy, z = msm_execute_dev(pre, scal)
+            pre.free()  # a table-free context hands its memory back in stream order: no synchronisation
+            if st is side:
+                for t in (halo_a, halo_b, halo_g, extra, g_zero, xy, z):
+                    if t is not None:
+                        t.record_stream(side)
         outs.append(xy[0])
         zeros.append(z[0])
+    main.wait_stream(side)
     return torch.stack(outs), torch.stack(zeros)
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
 
 
 def halo_round_fold_dev(curve, halo_a, halo_b, halo_g, u_j, u_j_inv, g_zero=None):
