@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 ( timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error|Error|assert" | tail -8 ) > gpurun_out/r2_tfull.log
-bash tools/gpu/run8.sh
+bash tools/gpu/profile_and_fuzz.sh
 python bench.py > gpurun_out/r02_bench.json 2> gpurun_out/r02_bench.err
 python tools/prover_pipeline_probe.py 17 > gpurun_out/r2_probe17.log 2>&1
 python tools/prover_pipeline_probe.py 20 > gpurun_out/r2_probe20.log 2>&1
