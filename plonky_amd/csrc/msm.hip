@@ -25,7 +25,9 @@
 //
 // Table-free mode (generators used once): only the generators themselves are stored; window j gets its own
 // bucket range [j 2^(c-1), (j+1) 2^(c-1)), the same kernels run over all windows at once, every window's
-// plane sum is doubled into place (2^(c j)) by a quad and k_msm_combine adds the windows.
+// sum (plane sums over its buckets up to 12 bits, over its row / column sums above) is doubled into place (2^(c j)) by a
+// quad and k_msm_combine adds the windows.  On the prime-order curves the scalars are split along the endomorphism first
+// (glv.cuh): 2n points [G.., phi(G)..], half-length scalars, half the windows - half of that doubling chain.
 // Batches: every MSM of a group has its own workspace and the group shares one reduction (msm_execute_dev_impl).
 // The reduction kernels run on quads of lanes (ecz_coop.cuh): they are chains of point operations, i.e. latency.
 #include <mutex>
@@ -769,6 +771,7 @@ __global__ void __launch_bounds__(256) k_msm_assemble(TailBatch tb, uint32_t buc
     constexpr int RU = raw_u4<FP>();
     const TailSlot& sl = tb.s[blockIdx.y];
     if (blockIdx.x == 0 && threadIdx.x < 2) sl.heavy[threadIdx.x] = 0;  // the counters of k_msm_heavy_list are free again
+    if (blockIdx.x == 0 && threadIdx.x == 2) *sl.final_done = 0;        // and so is k_msm_final's (left at zero by its last block anyway)
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = gid >> lpb_log, part = gid & ((1u << lpb_log) - 1u);
     XyzzZ<FP> acc = xyzzz_identity<FP>();

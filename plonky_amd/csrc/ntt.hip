@@ -11,10 +11,11 @@
 // every residual index r < S_t, an A_t-point NTT over the stride-S_t column, multiplies by the
 // inter-pass twiddle w_{N_t}^(r k) and stores in place; the last pass works on contiguous
 // blocks and scatters to the digit-reversed final position.  Each workgroup owns a
-// [A_t x Q] tile (1024 elements, 32 KiB of LDS) so that every global access is a run of
-// Q * 32 B (>= 256 B) contiguous bytes; the A_t-point NTTs run as radix-2 stages inside
-// LDS with the stage twiddles staged in LDS (decimation in time on lazily reduced 29-bit limbs,
-// fz.cuh; input placed bit-reversed by the load indexing, output in natural order).
+// [A_t x Q] tile (1024 elements, 36 KiB of LDS as nine limb planes) so that every global access is a run of
+// Q * 32 B (>= 256 B) contiguous bytes; the A_t-point NTTs run inside LDS, two stages per round trip
+// (radix-4 steps in registers), with the stage twiddles staged in LDS (decimation in time on lazily reduced
+// 29-bit limbs whose carries are moved twice per step, fz.cuh; input placed bit-reversed by the load indexing,
+// output in natural order).  Between two passes the data is in limb form (48 B per element) in a scratch buffer.
 // out[j] = sum_k in[k] w^(jk), w = primitive_root_of_unity(log n) (field.rs:429-435): the same
 // function the reference computes, and field elements have a unique representation, so the
 // limbs are bit-identical.  iNTT = the same passes with w^-1 tables and n^-1 folded into the

@@ -7,13 +7,14 @@
 //   the ten gates' evaluate_unfiltered             gates/*.rs            ->  gate by gate below (file:line at each)
 //   eval_l_1                                       plonk_util.rs:14-24   ->  a cached table of L_1 over the 8n domain
 //   mds_matrix                                     mds.rs:56-77          ->  seven inverses 1/1 .. 1/7 (Cauchy entries 1/(4 + r - c))
-//   reduce_with_powers                             plonk_util.rs:27-33   ->  Horner at the end of the kernel
+//   reduce_with_powers                             plonk_util.rs:27-33   ->  per gate (ReducedSink), closed in the last launch
 // The reference evaluates the 8n points with Rayon, one full field inversion per point for L_1(x) and a freshly
 // cloned MDS matrix per gate; here a point is one lane, everything that depends only on the circuit size (the powers
 // of the 8n-th root, L_1 over the domain, the MDS entries) is a cached table, and the inversions behind L_1 are
 // batched eight to a lane when that table is built.  The closing Polynomial::from_evaluations (plonk.rs:455) is the
-// inverse NTT of ntt.hip.  Every value is a fully reduced field element computed by the same field operations as the
-// reference, so the result is bit-identical (field arithmetic is exact and associative; only the grouping differs).
+// inverse NTT of ntt.hip.  The arithmetic runs on lazily reduced limbs whose value bounds are part of the types (Lz below);
+// every operation is exact modulo p and the result is reduced to the unique representative at the end, so it is
+// bit-identical to the reference's (field arithmetic is exact and associative; only the grouping differs).
 // get_subgroup_shift (partition.rs:140-153) draws its k_i from ChaCha8: they are inputs here.
 #include <map>
 #include <memory>
