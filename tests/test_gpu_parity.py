@@ -234,6 +234,12 @@ def test_msm_matches_oracle(c, n, win):
         scalars[2] = mont_arr(c.scalar, [c.scalar.p - 1])[0]
         bases[5] = bases[4]
         scalars[5] = scalars[4]
+        # values around which the endomorphism split of the table-free mode turns: a cube root of unity, r / 2, 2^128
+        lam = pow(5, (c.scalar.p - 1) // 3, c.scalar.p)
+        scalars[6] = mont_arr(c.scalar, [lam])[0]
+        scalars[7] = mont_arr(c.scalar, [c.scalar.p - lam])[0]
+        scalars[8] = mont_arr(c.scalar, [c.scalar.p // 2])[0]
+        scalars[9] = mont_arr(c.scalar, [1 << 128])[0]
     expected, ez = ol.MsmPrecomputation(c.curve_id, bases, 8, threads=8).execute(scalars, parallel=True, threads=8)
     pre = pa.msm_precompute(c.curve_id, bases, 8, device_window=win)
     got, gz = pa.msm_execute_parallel(pre, scalars)
@@ -465,7 +471,8 @@ def test_fold_generators(c):
     r = c.scalar.p
     u = limbs_to_int(synth.rand_field(c.scalar.field_id, 0xF01D, 1)[0]) % r
     u = c.scalar.from_mont(u) or 3
-    cases = [(pow(u, -1, r), u), (0, 1), (1, 0), (r - 1, 1), (1, r - 1), (5, 5), (0, 0)]
+    lam = pow(5, (r - 1) // 3, r)  # a cube root of unity of the scalar field: the value the endomorphism split turns around
+    cases = [(pow(u, -1, r), u), (0, 1), (1, 0), (r - 1, 1), (1, r - 1), (5, 5), (0, 0), (lam, r - lam), (r // 2, r // 2 + 1), (lam * lam % r, 1 << 128)]
     for a, b in cases:
         sa, sb = mont_arr(c.scalar, [a])[0], mont_arr(c.scalar, [b])[0]
         got, gz = pa.fold_generators(c.curve_id, lo, hi, sa, sb, lo_zero=lz, hi_zero=hz)
