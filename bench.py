@@ -11,7 +11,14 @@ step    one pass of the hot path over one batch of synthetic input (--workload):
           commit9 BASELINE configs[3]: the 9-wire commitment batch of poly_commit.rs:52-66 - nine 2^20 scalar vectors against
                   the same 2^20 generators.  N > 1: STRONG scaling - the generators are sharded by base range (each rank holds
                   2^20 / N of them and the matching slice of every vector), one packed all-gather of 9 partial points.
-        --curve bls12_377 --log-n 22 --workload msm  is BASELINE configs[4] (the reference has BLS12-377, not -381).
+        --curve bls12_377 --log-n 22 --workload msm  is BASELINE configs[4] (the reference has BLS12-377, not -381);
+                  with --shard it is the STRONG-scaling form: one fixed 2^log_n MSM, generators sharded by base range.
+        --emulate-rank r/N  runs rank r's shard of a strong-scaling problem (commit9, msm --shard) alone on one GPU: the
+                  per-rank time from which DESIGN.md section 6 predicts the N-GPU curve without an N-GPU node.
+launch  python bench.py --gpus N            spawns its N ranks itself (one process per GPU, torch.multiprocessing), or
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N   (the driver's form:
+        RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  Backend nccl (= RCCL over xGMI); --same-device puts all
+        ranks on GPU 0 over gloo (the world-size-2 test on a one-GPU box).
         Inputs are resident in HBM before the timed region; tables / precomputation are excluded exactly as
         benches/fft.rs:22-30 and src/bin/msms.rs:25,54-58 exclude them.
 value   whole-job units per second, 1 unit = 1 NTT element or 1 MSM scalar-point pair; the components are reported
@@ -31,8 +38,10 @@ LOG_N = 20
 SEED_NTT = 0xF70020
 SEED_MSM = 0x350020
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
-# integer-ALU ceiling of the 256-bit fields: fz_mul at 4 waves / SIMD, measured (profiles/r01_field_op_costs.txt: 188.5 Gop/s)
-VALU_PEAK_GMODMUL = 188.5
+# integer-ALU ceilings are read from profiles/r03_field_op_costs.json (tools/bench_field.hip on this round's arithmetic headers,
+# tagged with the hash of those headers): fz_mul at 4 waves / SIMD per field and the raw v_mad_u64_u32 issue rate
+CEILINGS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_field_op_costs.json")
+MADS_PER_MODMUL = {4: 126, 6: 294}   # v_mad_u64_u32 per fz_mul: 9 limbs 81 + 45, 14 limbs 196 + 98 (fz.cuh)
 CURVES = {"tweedledee": dict(curve=0, ntt_field=0, scalar_field=1, base_field=0, limbs=4, scalar_bits=255, pair_bytes=96),
           "bls12_377": dict(curve=2, ntt_field=2, scalar_field=2, base_field=3, limbs=6, scalar_bits=253, pair_bytes=128)}
 STAGES = ["order_count", "order_scatter", "order_buckets", "accumulate", "assemble_lines", "planes", "final"]
@@ -47,6 +56,27 @@ def kernel_source_hash():
             with open(os.path.join(d, name), "rb") as fh:
                 h.update(name.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
+
+
+def arith_source_hash():
+    """sha256 over the arithmetic headers a measured ceiling belongs to (fp / fp29 / fz / ec / ecz + parameters)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "plonky_amd", "csrc")
+    for name in ("fp.cuh", "fp29.cuh", "fz.cuh", "ec.cuh", "ecz.cuh", "field_params.cuh"):
+        with open(os.path.join(d, name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_ceilings():
+    """{"fz_mul_gops": {"tweedledee": .., "bls12_377": ..}, "mad_u64_u32_glaneops": .., "arith_source_sha": ..} or {}."""
+    try:
+        with open(CEILINGS_FILE) as fh:
+            c = json.load(fh)
+    except (OSError, ValueError):
+        return {}
+    c["stale"] = c.get("arith_source_sha") != arith_source_hash()
+    return c
 
 
 def cpu_baseline(workload, cv):
@@ -126,7 +156,7 @@ def cpu_baseline(workload, cv):
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -134,10 +164,50 @@ def main():
     ap.add_argument("--workload", choices=["both", "ntt", "msm", "commit9"], default="both")
     ap.add_argument("--curve", choices=sorted(CURVES), default="tweedledee")
     ap.add_argument("--log-n", type=int, default=LOG_N)
+    ap.add_argument("--shard", action="store_true", help="--workload msm: strong scaling - ONE 2^log_n MSM, generators sharded by base range")
+    ap.add_argument("--emulate-rank", default=None, metavar="r/N", help="run rank r's shard of the N-rank strong-scaling problem alone on one GPU")
+    ap.add_argument("--same-device", action="store_true", help="all ranks on GPU 0, gloo backend (world-size-2 test on a one-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--timed-only", action="store_true", help="run only the warm-up + timed region (for rocprofv3 --pmc passes)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _spawned_rank(rank, argv, world, port):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    run(parse_args(argv))
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: one process per GPU, rank 0 prints the JSON line."""
+    import torch
+    import torch.multiprocessing as mp
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    need = 1 if args.same_device else args.gpus
+    if have < need:
+        sys.stderr.write("bench.py --gpus %d: needs %d GPU(s), %d visible (there is no CPU path)\n" % (args.gpus, need, have))
+        sys.exit(3)
+    mp.spawn(_spawned_rank, args=(argv, args.gpus, _free_port()), nprocs=args.gpus, join=True)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)
+    return run(args)
+
+
+def run(args):
     cv = CURVES[args.curve]
     CURVE, NTT_FIELD = cv["curve"], cv["ntt_field"]
 
@@ -149,17 +219,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with `python bench.py --gpus N` or torchrun --nproc-per-node N)" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
-    torch.cuda.set_device(local_rank)
+    device_index = 0 if args.same_device else local_rank
+    assert device_index < torch.cuda.device_count(), "rank %d needs GPU %d, %d visible" % (rank, device_index, torch.cuda.device_count())
+    torch.cuda.set_device(device_index)
+    gloo = bool(args.same_device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if gloo:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
 
     from plonky_amd import api, device as dev, lib, parallel, synth
     from plonky_amd.selfcheck import closed_form_msm, _mul
     from plonky_amd.synth import MODULI
-    dev.init(local_rank)
+    dev.init(device_index)
     L = lib.load()
 
     n = 1 << args.log_n
@@ -167,7 +244,13 @@ def main():
     do_ntt = args.workload in ("both", "ntt")
     do_msm = args.workload in ("both", "msm", "commit9")
     batch = 9 if commit9 else 1
-    strong = commit9
+    strong = commit9 or (args.workload == "msm" and args.shard)
+    # the shard this process computes: its own rank, or (emulation) rank r of N on a single GPU
+    shard_rank, shard_world = rank, world
+    if args.emulate_rank:
+        assert world == 1 and strong, "--emulate-rank needs a strong-scaling workload (commit9, msm --shard) and --gpus 1"
+        shard_rank, shard_world = (int(v) for v in args.emulate_rank.split("/"))
+        assert 0 <= shard_rank < shard_world
 
     # ---- synthetic inputs, resident in HBM before the timed region ----
     if do_ntt:
@@ -184,7 +267,7 @@ def main():
         g0 = np.stack([synth.mont(cv["base_field"], G[0]), synth.mont(cv["base_field"], G[1])])
         dd = np.stack([synth.mont(cv["base_field"], D[0]), synth.mont(cv["base_field"], D[1])])
         if strong:
-            lo, hi = parallel.shard_bounds(n, rank, world)       # this rank's slice of the SAME 2^log_n generators
+            lo, hi = parallel.shard_bounds(n, shard_rank, shard_world)       # this rank's slice of the SAME 2^log_n generators
             first, n_local = lo, hi - lo
             s_host = np.stack([synth.rand_field(cv["scalar_field"], SEED_MSM + 0x900 + k, n) for k in range(batch)])
             s = dev.to_device(np.ascontiguousarray(s_host[:, lo:hi]))
@@ -194,18 +277,20 @@ def main():
             s = dev.to_device(s_host)
         bases = dev.gen_bases_dev(CURVE, n_local, g0, dd, first=first)
         pre = dev.msm_precompute_dev(CURVE, bases)
-        oxy = torch.empty((batch, 2, cv["limbs"]), dtype=torch.int64, device="cuda")
-        oz = torch.empty((batch,), dtype=torch.uint8, device="cuda")
-        g_pair = [None, None]  # the gathered partial points of the base-range shards
+        # the exchange step of the sharded MSM, every buffer allocated once: the MSM writes its partial results straight into
+        # the send record of the ONE all-gather; the ranks' partial points are added on the device
+        ex = parallel.PartialExchange(CURVE, batch, "cuda")
+        oxy, oz = ex.out_xy, ex.out_zero
+        exchange = world > 1 or shard_world > 1
 
     def step():
         if do_ntt:
             dev.ntt_dev(NTT_FIELD, x, out=y)
         if do_msm:
             dev.msm_execute_dev(pre, s, oxy, oz)
-            if world > 1:
-                # the one exchange step of the path: partial results of the base-range shards (one packed all-gather)
-                g_pair[0], g_pair[1] = parallel.all_gather_points(oxy, oz)
+            if exchange:
+                ex.gather()
+                ex.combine()
 
     def sync():
         torch.cuda.synchronize()
@@ -231,7 +316,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -315,8 +400,8 @@ def main():
         tm = (time.perf_counter() - t1) / args.steps
         pairs = batch * (n if strong else world * n)
         comp["msm_ms"] = tm * 1e3
-        comp["msm_mpairs_per_s"] = pairs / tm / 1e6
-    if do_msm_c and not commit9:
+        comp["msm_mpairs_per_s"] = (batch * n_local if args.emulate_rank else pairs) / tm / 1e6
+    if do_msm_c and not strong:
         # commit_polynomials (plonk_util.rs:215-231): the 9 wire polynomials against the same generators, one call
         sb = s.unsqueeze(0).repeat(9, 1, 1).contiguous()
         oxy9 = torch.empty((9, 2, cv["limbs"]), dtype=torch.int64, device="cuda")
@@ -358,6 +443,11 @@ def main():
             if "_q_check" in comp:
                 checks["divide_by_z_h_identity"] = comp.pop("_q_check")
         if do_msm:
+            dev.msm_execute_dev(pre, s, oxy, oz)
+            if exchange:
+                ex.gather()
+                gxy, gz = ex.combine()
+            torch.cuda.synchronize()
             got = dev.to_host(oxy).reshape(batch, 2, cv["limbs"])
             ok = int(oz.sum().item()) == 0
             for k in range(batch):
@@ -371,19 +461,21 @@ def main():
             if "_os_check" in comp:
                 checks["msm_one_shot_equals_tabled"] = comp.pop("_os_check")
             if world > 1:
-                hx = dev.to_host(g_pair[0]).reshape(world, batch, 2, cv["limbs"])
-                hz = g_pair[1].cpu().numpy().reshape(world, batch)
+                # the device sum of the gathered partial points, against the host-pointer sum and (strong scaling) the
+                # closed form of the WHOLE problem: the vector against all 2^log_n generators
+                hx, hz = ex.partials()
+                hx, hz = dev.to_host(hx), hz.cpu().numpy()
+                tot_dev, tz_dev = dev.to_host(gxy), gz.cpu().numpy()
                 ok = True
                 for k in range(batch):
                     tot, tz = api.curve_sum_affine(CURVE, hx[:, k], hz[:, k])
-                    if strong:  # the global result has a closed form of its own: the whole vector against all 2^log_n generators
+                    ok = ok and tz == 0 and int(tz_dev[k]) == 0 and np.array_equal(tot, tot_dev[k])
+                    if strong:
                         exp = closed_form_msm(CURVE, s_host[k], G, D, first=0)
-                        ok = ok and tz == 0 and (synth.from_mont(cv["base_field"], tot[0]), synth.from_mont(cv["base_field"], tot[1])) == exp
-                    else:
-                        ok = ok and tz == 0
+                        ok = ok and (synth.from_mont(cv["base_field"], tot[0]), synth.from_mont(cv["base_field"], tot[1])) == exp
                 checks["msm_global_sum_closed_form" if strong else "msm_global_sum_is_point"] = bool(ok)
 
-    units_per_step = (n if do_ntt else 0) + ((batch * n) if do_msm else 0)
+    units_per_step = (n if do_ntt else 0) + ((batch * (n_local if args.emulate_rank else n)) if do_msm else 0)
     value = (1 if strong else world) * units_per_step * args.steps / elapsed / 1e6
 
     # ---- rooflines: every kernel entry carries the integer-ALU figure (what binds these kernels) and the HBM figure ----
@@ -391,7 +483,7 @@ def main():
     src_hash = kernel_source_hash()
     pmc = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as fh:
             pmc = json.load(fh)
     except (OSError, ValueError):
         pass
@@ -403,7 +495,21 @@ def main():
             return None, None
         return e["bytes_per_launch"], e.get("source")
 
-    valu_peak = VALU_PEAK_GMODMUL if args.curve == "tweedledee" else None
+    ceil = load_ceilings()
+    ceil_ok = bool(ceil) and not ceil.get("stale")
+    valu_peak = ceil.get("fz_mul_gops", {}).get(args.curve) if ceil_ok else None        # G modmul/s: this round's fz_mul at 4 waves / SIMD
+    mad_peak = ceil.get("mad_u64_u32_glaneops") if ceil_ok else None                     # G lane-ops/s: raw v_mad_u64_u32 issue rate
+    mads = MADS_PER_MODMUL[cv["limbs"]]
+    ceil_src = ("profiles/r03_field_op_costs.json (arith_source_sha %s)" % ceil.get("arith_source_sha")) if ceil_ok else None
+
+    def valu_entry(kernel, gmm, executed_gmm, launch_ms, extra):
+        e = {"kernel": kernel, "bound": "valu", "achieved": gmm, "peak": valu_peak, "unit": "G modmul/s",
+             "frac": gmm / valu_peak if valu_peak else None, "peak_source": ceil_src,
+             # executed multiplier instructions against the measured raw issue rate: independent of this repo's fz_mul
+             "mad_issue_frac": executed_gmm * mads / mad_peak if mad_peak else None, "launch_ms": launch_ms}
+        e.update(extra)
+        return e
+
     if do_ntt and ntt_launches:
         per_launch_ms = ntt_kernel_ms / ntt_launches
         launches_per_ntt = ntt_launches / args.steps
@@ -411,14 +517,15 @@ def main():
         # one launch of the pass kernel handles all n elements once => 64 B * n / launches_per_ntt per launch
         alg_bytes = 64.0 * n / launches_per_ntt
         ach = alg_bytes / (per_launch_ms * 1e-3) / 1e9
-        gmm = (n / 2.0 * args.log_n) / (per_launch_ms * launches_per_ntt * 1e-3) / 1e9   # algorithmic: n/2 log n multiplications
+        t_ntt = per_launch_ms * launches_per_ntt * 1e-3
+        gmm = (n / 2.0 * args.log_n) / t_ntt / 1e9   # algorithmic: n/2 log n multiplications
+        gmm_exec = (n * 9.75) / t_ntt / 1e9           # executed: 9.75 per element at 2^20
         tr, src = traffic_of("k_ntt_pass")
-        rooflines["ntt_pass"] = {"kernel": "k_ntt_pass", "bound": "valu", "achieved": gmm, "peak": valu_peak, "unit": "G modmul/s",
-                                 "frac": gmm / valu_peak if valu_peak else None, "traffic": tr, "traffic_source": src,
-                                 "hbm": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                         "algorithmic_bytes_per_launch": alg_bytes},
-                                 "launch_ms": per_launch_ms, "launches_per_transform": launches_per_ntt,
-                                 "note": "VALU-bound (DESIGN.md section 4): achieved counts the algorithmic n/2 log n multiplications; the kernel executes more (inter-pass twiddles)"}
+        rooflines["ntt_pass"] = valu_entry("k_ntt_pass", gmm, gmm_exec, per_launch_ms, {
+            "traffic": tr, "traffic_source": src,
+            "hbm": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes},
+            "launches_per_transform": launches_per_ntt,
+            "note": "VALU-bound (DESIGN.md section 4): achieved counts the algorithmic n/2 log n multiplications; the kernel executes more (inter-pass twiddles)"})
     if do_msm:
         acc_ms = msm_stage_ms[3]
         alg_bytes = float(cv["pair_bytes"]) * n_local   # affine base + 32 B scalar per pair, one MSM
@@ -427,19 +534,18 @@ def main():
         adds = n_local * windows
         gmm = adds * 10.0 / (acc_ms * 1e-3) / 1e9        # a mixed XYZZ addition = 8 M + 2 S
         tr, src = traffic_of("k_msm_accumulate")
-        rooflines["msm_accumulate"] = {"kernel": "k_msm_accumulate", "bound": "valu", "achieved": gmm, "peak": valu_peak, "unit": "G modmul/s",
-                                       "frac": gmm / valu_peak if valu_peak else None, "traffic": tr, "traffic_source": src,
-                                       "hbm": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                               "algorithmic_bytes_per_launch": alg_bytes},
-                                       "launch_ms": acc_ms, "mixed_adds_per_s": adds / (acc_ms * 1e-3),
-                                       "note": "integer-ALU bound by construction (~2 modmul per algorithmic byte); the HBM fraction is reported because the metric asks for it"}
+        rooflines["msm_accumulate"] = valu_entry("k_msm_accumulate", gmm, gmm, acc_ms, {
+            "traffic": tr, "traffic_source": src,
+            "hbm": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes},
+            "mixed_adds_per_s": adds / (acc_ms * 1e-3),
+            "note": "integer-ALU bound by construction (~2 modmul per algorithmic byte); the HBM fraction is reported because the metric asks for it"})
     roofline = None
     if rooflines:
         roofline = max(rooflines.values(), key=lambda r: r["launch_ms"] * (r.get("launches_per_transform", 1)))
 
     wl = {"both": "2^%d %s forward NTT + 2^%d-pair %s MSM per GPU per step" % (args.log_n, "TweedledeeBase" if args.curve == "tweedledee" else "Bls12377Scalar", args.log_n, args.curve),
           "ntt": "2^%d forward NTT per GPU per step" % args.log_n,
-          "msm": "2^%d-pair %s MSM per GPU per step" % (args.log_n, args.curve),
+          "msm": ("ONE 2^%d-pair %s MSM per step, generators sharded by base range over the GPUs" if strong else "2^%d-pair %s MSM per GPU per step") % (args.log_n, args.curve),
           "commit9": "9-wire commitment batch: nine 2^%d-pair %s MSMs against the same generators per step (generators sharded by base range over the GPUs)" % (args.log_n, args.curve)}[args.workload]
     result = {
         "metric": "MSM Mpairs/sec + NTT Melems/sec, 2^20 Tweedledee, 1/2/4/8 GPU",
@@ -450,20 +556,29 @@ def main():
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": wl, "log_n": args.log_n, "curve": args.curve,
-                   "sharding": ("generators sharded by base range + one packed all-gather of partial points" if strong else
-                                "independent NTTs; MSM sharded by base range + one packed all-gather of partial points") if world > 1 else "single GPU",
+                   "sharding": ("generators sharded by base range + one packed all-gather of partial points + device point sum" if strong else
+                                "independent NTTs; MSM sharded by base range + one packed all-gather of partial points + device point sum") if world > 1 else "single GPU",
+                   "backend": ("gloo (ranks share GPU 0)" if gloo else "nccl (RCCL)") if world > 1 else None,
                    "seeds": {"ntt": SEED_NTT, "msm": SEED_MSM}, "kernel_source_sha": src_hash},
         "components": comp,
         "checks": checks,
         "roofline": roofline,
         "rooflines": rooflines,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if args.emulate_rank:
+        # one rank of the N-rank problem alone on one GPU: every rank does the same amount of work, the exchange is one
+        # all-gather of batch x (2L + 1) words per rank (latency-bound: ~20-40 us over xGMI), so the N-GPU step time is this
+        # rank's time plus that, and the predicted whole-job rate is the global unit count over it
+        result["emulated_rank"] = {"rank": shard_rank, "of": shard_world, "n_local": n_local,
+                                   "predicted_global_units_per_s_M": batch * n * args.steps / elapsed / 1e6,
+                                   "note": "value / ms_per_step are THIS rank's shard (n_local generators, all %d vectors) incl. the local copy standing in for the all-gather and the point sum" % batch}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.emulate_rank:
         result["cpu_baseline"] = cpu_baseline(args.workload, cv)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     assert all(checks.values()), "self-check failed: %r" % checks
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -186,6 +186,18 @@ int plk_msm(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_z
  * point addition is not an RCCL reduction op).  Host pointers. */
 int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint8_t* pts_zero, uint64_t* out_xy, uint8_t* out_zero);
 
+/* ---- multi-GPU exchange of partial results (no counterpart in the single-process reference) ----------- */
+/* The generators are sharded by contiguous base range, one process per GPU; each rank reduces its slice of every scalar
+ * vector (plk_msm_execute_dev over its own context) and the ranks exchange their partial points with ONE all-gather.  The
+ * exchange record of a rank is plk_msm_partials_bytes(curve, batch) bytes: batch * 2L limbs (exactly what
+ * plk_msm_execute_dev writes at d_out_xy = record), then batch identity flags (d_out_zero = record + batch * 2L * 8),
+ * padded to a multiple of 16 bytes - so the MSM writes straight into the send buffer of the collective. */
+size_t plk_msm_partials_bytes(int curve, unsigned batch);
+/* d_gathered: `world` records back to back (the all-gather output).  d_out_xy / d_out_zero: the `batch` sums of the
+ * ranks' partial points (point addition is not an RCCL reduction op), unique affine form.  Asynchronous on `stream`. */
+int plk_msm_combine_partials_dev(int curve, unsigned world, unsigned batch, const void* d_gathered, void* d_out_xy, void* d_out_zero,
+                                 void* stream);
+
 /* ---- the reference's own table contents  (curve_msm.rs:16-52) ---------------------------------- */
 /* MsmPrecomputation { powers_per_generator, w } is plain, serde-visible data in the reference (embedded in Circuit,
  * plonk.rs:64-69).  A caller that wants that struct filled from the device gets exactly its contents here:

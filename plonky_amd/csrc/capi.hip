@@ -18,6 +18,8 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void* d_zero, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_gen_bases_dev_impl(int curve, size_t n, uint64_t first, const void* d_g0d, void* d_out, hipStream_t stream);
+size_t msm_partials_bytes(int curve, unsigned batch);
+int msm_combine_partials_dev_impl(int curve, unsigned world, unsigned batch, const void* d_gathered, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_fold_pairs_dev_impl(int curve, size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero,
                               const uint64_t* a_mont, const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int msm_table_digits(int curve, unsigned w);
@@ -609,6 +611,12 @@ int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint
     PLK_HIP_TRY(hipMemcpy(out_xy, dxy.p, 2 * L * 8, hipMemcpyDeviceToHost));
     PLK_HIP_TRY(hipMemcpy(out_zero, doz.p, 1, hipMemcpyDeviceToHost));
     return PLK_OK;
+}
+
+// ---- multi-GPU exchange ----
+size_t plk_msm_partials_bytes(int curve, unsigned batch) { return msm_partials_bytes(curve, batch); }
+int plk_msm_combine_partials_dev(int curve, unsigned world, unsigned batch, const void* d_gathered, void* d_out_xy, void* d_out_zero, void* stream) {
+    return msm_combine_partials_dev_impl(curve, world, batch, d_gathered, d_out_xy, d_out_zero, as_stream(stream));
 }
 
 // ---- the reference's own MsmPrecomputation contents ----

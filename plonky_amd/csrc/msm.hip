@@ -1034,6 +1034,33 @@ __global__ void __launch_bounds__(64) k_sum_affine(const uint4* __restrict__ pts
     }
 }
 
+// Multi-GPU exchange: every rank's partial results for `batch` scalar vectors travel as one packed record
+// (plk_msm_partials_bytes: batch affine points, then batch identity flags); block b adds the `world` partial points of vector b.
+template <class C>
+__global__ void __launch_bounds__(64) k_combine_partials(const uint8_t* __restrict__ gathered, size_t rec_bytes, unsigned world, unsigned batch,
+                                                         uint4* __restrict__ out_xy, uint8_t* __restrict__ out_zero) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    extern __shared__ __attribute__((aligned(16))) uint4 s_pts[];
+    const unsigned b = blockIdx.x;
+    Xyzz<FP> acc = xyzz_identity<FP>();
+    for (unsigned r = threadIdx.x; r < world; r += blockDim.x) {
+        const uint8_t* rec = gathered + (size_t)r * rec_bytes;
+        if (rec[(size_t)batch * 2 * W * 16 + b]) continue;
+        const uint4* pt = (const uint4*)(rec + (size_t)b * 2 * W * 16);
+        Fe<FP> x = fe_load<FP>(pt), y = fe_load<FP>(pt + W);
+        xyzz_madd<FP>(acc, x, y);
+    }
+    acc = block_sum<FP>(acc, s_pts);
+    if (threadIdx.x == 0) {
+        Fe<FP> x, y;
+        const bool ident = xyzz_to_affine<FP, true>(acc, x, y);
+        fe_store<FP>(out_xy + (size_t)b * 2 * W, x);
+        fe_store<FP>(out_xy + (size_t)b * 2 * W + W, y);
+        out_zero[b] = ident ? 1 : 0;
+    }
+}
+
 template <class C>
 __global__ void __launch_bounds__(128) k_gen_bases(const uint4* __restrict__ g0d, uint4* __restrict__ out, size_t n, uint64_t first) {
     using FP = typename C::FP;
@@ -1777,6 +1804,34 @@ int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void
         CASE(PLK_CURVE_VESTA, VestaCurve)
 #undef CASE
         default: return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    }
+    PLK_HIP_TRY(hipGetLastError());
+    return PLK_OK;
+}
+
+size_t msm_partials_bytes(int curve, unsigned batch) {
+    const int L = curve_limbs(curve);
+    if (L < 0) return 0;
+    return ((size_t)batch * 2 * L * 8 + batch + 15) & ~(size_t)15;
+}
+int msm_combine_partials_dev_impl(int curve, unsigned world, unsigned batch, const void* d_gathered, void* d_out_xy, void* d_out_zero, hipStream_t stream) {
+    if (curve_limbs(curve) < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (batch == 0) return PLK_OK;
+    if (world == 0 || !d_gathered || !d_out_xy || !d_out_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer or world = 0");
+    PLK_TRY(ensure_device());
+    const size_t rec = msm_partials_bytes(curve, batch);
+    switch (curve) {
+#define CASE(ID, C)                                                                                                                           \
+    case ID:                                                                                                                                  \
+        k_combine_partials<C><<<batch, 64, 64 * 4 * C::FP::NL * 4, stream>>>((const uint8_t*)d_gathered, rec, world, batch, (uint4*)d_out_xy, \
+                                                                             (uint8_t*)d_out_zero);                                           \
+        break;
+        CASE(PLK_CURVE_TWEEDLEDEE, TweedledeeCurve)
+        CASE(PLK_CURVE_TWEEDLEDUM, TweedledumCurve)
+        CASE(PLK_CURVE_BLS12_377, Bls12377Curve)
+        CASE(PLK_CURVE_PALLAS, PallasCurve)
+        CASE(PLK_CURVE_VESTA, VestaCurve)
+#undef CASE
     }
     PLK_HIP_TRY(hipGetLastError());
     return PLK_OK;

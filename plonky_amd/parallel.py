@@ -1,6 +1,9 @@
 """One-process-per-GPU plumbing for the sharded MSM: contiguous base ranges per
-rank, one all-gather of the affine partial results, local point sum.  Independent NTTs need no
-collective.  Backend-agnostic (nccl = RCCL on the GPUs, gloo in the CPU tests)."""
+rank, ONE all-gather of the packed partial results, point sum on the device.  Independent NTTs need no
+collective.  Backend-agnostic: nccl (= RCCL over xGMI) on the GPUs; gloo in the CPU tests and when several
+ranks share one GPU (the payload - a few hundred bytes - is then staged through host memory)."""
+import ctypes
+
 import torch
 import torch.distributed as dist
 
@@ -12,22 +15,92 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def round_robin(n_items, rank, world):
+    """Independent units (whole transforms: the 9 wire LDEs, the iNTTs of a proof) are dealt out rank by rank - no collective."""
+    return list(range(rank, n_items, world))
+
+
+def _backend():
+    return dist.get_backend() if dist.is_initialized() else None
+
+
+class PartialExchange:
+    """The exchange step of the sharded MSM with every buffer allocated once.
+
+    `send` is this rank's record in the layout of plk_msm_partials_bytes (include/plonky_hip.h): batch affine points
+    then batch identity flags.  `out_xy` / `out_zero` are views INTO it, so plk_msm_execute_dev writes its results straight
+    into the send buffer of the collective; gather() is the one all_gather_into_tensor; combine() adds the ranks' partial
+    points on the device (plk_msm_combine_partials_dev).  No packing, no allocation, no host round trip inside a step
+    (except the host staging gloo needs for device tensors)."""
+
+    def __init__(self, curve, batch, device="cuda"):
+        from . import lib as _lib
+        from .api import _CURVE_LIMBS
+        self.curve, self.batch = curve, batch
+        self.L = _CURVE_LIMBS[curve]
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rec = int(_lib.load().plk_msm_partials_bytes(curve, batch))
+        assert self.rec > 0 and self.rec % 16 == 0
+        dev = torch.device(device)
+        self.send = torch.zeros(self.rec, dtype=torch.uint8, device=dev)
+        self.recv = torch.zeros(self.world * self.rec, dtype=torch.uint8, device=dev)
+        pts = batch * 2 * self.L * 8
+        self.out_xy = self.send[:pts].view(torch.int64).view(batch, 2, self.L)
+        self.out_zero = self.send[pts:pts + batch]
+        self.sum_xy = torch.empty((batch, 2, self.L), dtype=torch.int64, device=dev)
+        self.sum_zero = torch.empty((batch,), dtype=torch.uint8, device=dev)
+        self._host = None
+        if dev.type == "cuda" and _backend() == "gloo":
+            self._host = (torch.zeros(self.rec, dtype=torch.uint8).pin_memory(), torch.zeros(self.world * self.rec, dtype=torch.uint8).pin_memory())
+
+    def gather(self):
+        """ONE collective: every rank's record to every rank."""
+        if self.world == 1:
+            self.recv.copy_(self.send)
+        elif self._host is not None:
+            hs, hr = self._host
+            hs.copy_(self.send)  # synchronises the current stream
+            dist.all_gather_into_tensor(hr, hs)
+            self.recv.copy_(hr, non_blocking=True)
+        else:
+            dist.all_gather_into_tensor(self.recv, self.send)
+        return self.recv
+
+    def combine(self):
+        """Sum of the ranks' partial points per scalar vector -> (sum_xy (batch, 2, L), sum_zero (batch,)) on the device."""
+        from . import lib as _lib
+        assert self.recv.is_cuda, "the point sum runs on the GPU (there is no CPU path)"
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(_lib.load().plk_msm_combine_partials_dev(self.curve, self.world, self.batch, ctypes.c_void_p(self.recv.data_ptr()),
+                                                            ctypes.c_void_p(self.sum_xy.data_ptr()), ctypes.c_void_p(self.sum_zero.data_ptr()), st))
+        return self.sum_xy, self.sum_zero
+
+    def partials(self):
+        """Views of the gathered records: (world, batch, 2, L) int64 and (world, batch) uint8."""
+        rows = self.recv.view(self.world, self.rec)
+        pts = self.batch * 2 * self.L * 8
+        xy = rows[:, :pts].contiguous().view(torch.int64).view(self.world, self.batch, 2, self.L)
+        return xy, rows[:, pts:pts + self.batch].contiguous()
+
+
 def all_gather_points(xy, zero):
-    """xy: (batch, 2, L) int64, zero: (batch,) uint8 - this rank's partial results.
-    Returns (world, batch, 2, L) and (world, batch) on every rank.  ONE collective: the identity flag travels as an extra
-    64-bit word behind the 2L coordinate limbs of its point (the payload is a few hundred bytes: latency, not bandwidth)."""
+    """xy: (batch, 2, L) int64, zero: (batch,) uint8 - this rank's partial results (any device).
+    Returns (world, batch, 2, L) and (world, batch) on every rank.  ONE collective: the identity flags travel behind the
+    coordinate limbs in the same record.  Allocating convenience form of PartialExchange (CPU tests, one-off calls)."""
     world = dist.get_world_size()
-    batch = xy.shape[0]
-    words = xy.shape[1] * xy.shape[2]
-    packed = torch.empty((batch, words + 1), dtype=torch.int64, device=xy.device)
-    packed[:, :words] = xy.reshape(batch, words)
-    packed[:, words] = zero.to(torch.int64)
-    gathered = torch.empty((world * batch, words + 1), dtype=torch.int64, device=xy.device)
-    dist.all_gather_into_tensor(gathered, packed)
-    gathered = gathered.view(world, batch, words + 1)
-    g_xy = gathered[:, :, :words].reshape((world,) + tuple(xy.shape)).contiguous()
-    g_z = gathered[:, :, words].to(torch.uint8).contiguous()
-    return g_xy, g_z
+    batch, L = xy.shape[0], xy.shape[2]
+    pts = batch * 2 * L * 8
+    rec = (pts + batch + 15) & ~15
+    send = torch.zeros(rec, dtype=torch.uint8, device=xy.device)
+    send[:pts] = xy.contiguous().view(torch.uint8).reshape(-1)
+    send[pts:pts + batch] = zero
+    staged = xy.is_cuda and _backend() == "gloo"
+    src = send.cpu() if staged else send
+    recv = torch.empty(world * rec, dtype=torch.uint8, device=src.device)
+    dist.all_gather_into_tensor(recv, src)
+    rows = recv.to(xy.device).view(world, rec)
+    g_xy = rows[:, :pts].contiguous().view(torch.int64).view(world, batch, 2, L)
+    return g_xy, rows[:, pts:pts + batch].contiguous()
 
 
 def msm_sharded(execute_local, combine, scalars_local):
@@ -42,25 +115,15 @@ def msm_sharded(execute_local, combine, scalars_local):
     return out
 
 
-def msm_sharded_hip(pre, scalars_local):
+def msm_sharded_hip(pre, scalars_local, exchange=None):
     """The sharded MSM over the HIP path: `pre` is this rank's device MsmPrecomputation over its base range
     (plonky_amd.device.msm_precompute_dev), scalars_local the matching slice of every scalar vector ((batch, n_local, 4) int64
-    CUDA tensor).  Per-rank partial results -> one all-gather -> plk_curve_sum_affine per vector.
+    CUDA tensor).  Per-rank partial results written into the exchange record -> one all-gather -> point sums on the device.
     Returns (xy (batch, 2, L) uint64 numpy, zero list) on every rank."""
-    import numpy as np
-    from . import api, device as dev
-
-    def execute_local(sv):
-        xy, z = dev.msm_execute_dev(pre, sv)
-        return xy, z
-
-    def combine(points, zeros):
-        return api.curve_sum_affine(pre.curve, dev.to_host(points), zeros.cpu().numpy())
-
-    res = msm_sharded(execute_local, combine, scalars_local)
-    return np.stack([r[0] for r in res]), [r[1] for r in res]
-
-
-def round_robin(n_items, rank, world):
-    """Independent units (whole transforms: the 9 wire LDEs, the iNTTs of a proof) are dealt out rank by rank - no collective."""
-    return list(range(rank, n_items, world))
+    from . import device as dev
+    batch = scalars_local.shape[0] if scalars_local.dim() == 3 else 1
+    ex = exchange if exchange is not None else PartialExchange(pre.curve, batch, scalars_local.device)
+    dev.msm_execute_dev(pre, scalars_local, ex.out_xy, ex.out_zero)
+    ex.gather()
+    xy, z = ex.combine()
+    return dev.to_host(xy), [int(v) for v in z.cpu().numpy()]

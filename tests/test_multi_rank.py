@@ -100,3 +100,52 @@ def test_round_robin_covers_every_unit_once():
         for world in (1, 2, 8):
             got = sorted(i for r in range(world) for i in parallel.round_robin(n, r, world))
             assert got == list(range(n))
+
+
+def _exchange_worker(rank, world, port, batch, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ex = parallel.PartialExchange(0, batch, "cpu")  # record layout of plk_msm_partials_bytes; the point sum itself needs the GPU
+    ex.out_xy.copy_(torch.arange(batch * 8, dtype=torch.int64).view(batch, 2, 4) + 1000 * rank)
+    ex.out_zero.copy_(torch.tensor([(rank + k) % 2 for k in range(batch)], dtype=torch.uint8))
+    ex.gather()
+    xy, z = ex.partials()
+    dist.barrier()
+    if rank == 1:
+        out_q.put((ex.rec, xy.numpy(), z.numpy()))
+    dist.destroy_process_group()
+
+
+def test_partial_exchange_record_layout_world_size_2_gloo():
+    """The preallocated exchange of the sharded MSM: the MSM's output pointers are views into the send record, one
+    all-gather, rank-ordered records on every rank (CPU tensors here; -m gpu runs it over the HIP path)."""
+    batch, world = 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    rec, xy, z = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert rec == (batch * 64 + batch + 15) // 16 * 16
+    for r in range(world):
+        assert np.array_equal(xy[r], np.arange(batch * 8).reshape(batch, 2, 4) + 1000 * r)
+        assert list(z[r]) == [(r + k) % 2 for k in range(batch)]
+
+
+def test_bench_without_gpus_fails_loudly():
+    """`python bench.py --gpus 2` as the driver types it: no assert on WORLD_SIZE - it spawns its ranks itself, and on a box
+    without GPUs it exits non-zero naming the missing devices (there is no CPU path)."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        return
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 3 and "needs 2 GPU(s), 0 visible" in out.stderr
