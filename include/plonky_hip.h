@@ -56,9 +56,13 @@ extern "C" {
 #define PLK_CURVE_VESTA 4  /* src/curve/vesta_curve.rs: base VestaBase, scalars PallasBase */
 
 /* ---- library ---------------------------------------------------------------------------- */
-/* Select the device this process uses (one process per GPU).  Idempotent. */
+/* Select the device this process uses (one process per GPU; -1: from the environment variable PLK_DEVICE).  Idempotent. */
 int plk_init(int device);
 void plk_shutdown(void);
+/* Size gate for the binding: problems below 2^plk_min_gpu_log_n() elements / pairs stay on the reference's
+ * own CPU path - the library itself has no CPU path.  Environment PLK_MIN_GPU_LOG_N, default 12.  plk_init(-1) takes the
+ * device from the environment variable PLK_DEVICE (default 0). */
+unsigned plk_min_gpu_log_n(void);
 /* Text of the last error on the calling thread (never NULL). */
 const char* plk_last_error(void);
 /* u64 limbs per element of a field / per coordinate of a curve; negative on bad id. */
@@ -74,6 +78,13 @@ int plk_curve_scalar_field(int curve);
 int plk_ntt_precompute(int field, unsigned log_n);
 /* Drop every cached table (tests / memory pressure). */
 int plk_ntt_clear_cache(void);
+
+/* The CONTENTS of the reference's FftPrecomputation (fft.rs:28-59; serde-visible, embedded in VerificationKey, verifier.rs:23-26):
+ * subgroups_rev[i] = reverse_index_bits(cyclic_subgroup_known_order(primitive_root_of_unity(i), 2^i)) for i = 0 ..= log_n, layer
+ * after layer: 2^(log_n + 1) - 1 elements, layer i starts at element 2^i - 1.  (The reference builds them serially on the CPU -
+ * 2n multiplications - inside CircuitBuilder::build, circuit_builder.rs:1118-1119.) */
+int plk_ntt_precompute_table(int field, unsigned log_n, uint64_t* out);
+int plk_ntt_precompute_table_dev(int field, unsigned log_n, void* d_out, void* stream);
 
 /* fft_with_precomputation_power_of_2 (fft.rs:103-156) when inverse == 0,
  * ifft_with_precomputation_power_of_2 (fft.rs:82-101) when inverse != 0.
@@ -255,6 +266,36 @@ int plk_field_inner_product_dev(int field, const void* d_a, const void* d_b, siz
  * (field limbs, Montgomery).  d_out may alias d_lo.  Asynchronous on `stream`. */
 int plk_field_fold_slices_dev(int field, const void* d_lo, const void* d_hi, const uint64_t* scalar_lo, const uint64_t* scalar_hi, size_t count,
                               void* d_out, void* stream);
+
+/* ---- one inner-product argument, round by round  (src/halo.rs:63-124) ---------------------------------------------- */
+/* The three vectors of the argument - halo_a, halo_b (n scalars, Montgomery form in the curve's SCALAR field) and halo_g (n
+ * affine generators + optional identity flags) - are copied into a context and stay in HBM for the log2(n) rounds; H =
+ * pedersen_h and U' = u_prime (2L limbs each, affine, host pointers) ride along.  Per round the caller (who owns the
+ * transcript and the RNG, halo.rs:83-114) asks for
+ *     L_j = <a_lo, G_hi> + [l_j] H + [<a_lo, b_hi>] U',   R_j = <a_hi, G_lo> + [r_j] H + [<a_hi, b_lo>] U'      (halo.rs:86-93)
+ * with its blinding factors - again with fresh ones if the challenge has no square root (the reference's retry loop) - and
+ * then folds with the challenge:  halo_a = u^-1 a_hi + u a_lo, halo_b = u^-1 b_lo + u b_hi, halo_g_i = [u^-1] g_lo_i + [u] g_hi_i
+ * (halo.rs:117-123).  Nothing is allocated, created or freed per round.  Once 2^freeze_log or fewer generators are left
+ * (0 = the library's default, 14) they are not folded any more: window tables are built once and the remaining rounds run
+ * as tabled MSMs over that frozen set with challenge-expanded scalars (same group elements, see halo.hip).
+ * n must be a power of two (PLK_ERR_NOT_POW2, util.rs:17).  A context is used by one host thread at a time. */
+typedef struct plk_halo_ctx plk_halo_ctx;
+int plk_halo_begin_dev(int curve, size_t n, const void* d_halo_a, const void* d_halo_b, const void* d_halo_g_xy, const void* d_halo_g_zero,
+                       const uint64_t* pedersen_h_xy, const uint64_t* u_prime_xy, unsigned freeze_log, void* stream, plk_halo_ctx** out_ctx);
+/* Same with host vectors (halo_g_zero may be NULL). */
+int plk_halo_begin(int curve, size_t n, const uint64_t* halo_a, const uint64_t* halo_b, const uint64_t* halo_g_xy, const uint8_t* halo_g_zero,
+                   const uint64_t* pedersen_h_xy, const uint64_t* u_prime_xy, unsigned freeze_log, plk_halo_ctx** out_ctx);
+/* L_j then R_j of the current round, unique affine form: lr_xy 2 x 2L limbs, lr_zero 2 bytes (host).  Blinding factors: 4 limbs
+ * each, Montgomery, host.  Waits for the result (the transcript needs it). */
+int plk_halo_round_lr(plk_halo_ctx* ctx, const uint64_t* l_blinding, const uint64_t* r_blinding, uint64_t* lr_xy, uint8_t* lr_zero);
+/* The folds of the round with the challenge u_j and its inverse (4 limbs each, Montgomery, host); halves the length.  Asynchronous. */
+int plk_halo_round_fold(plk_halo_ctx* ctx, const uint64_t* u_j, const uint64_t* u_j_inv);
+size_t plk_halo_len(const plk_halo_ctx* ctx);      /* current length of the three vectors */
+int plk_halo_frozen(const plk_halo_ctx* ctx);      /* 1 once the generators are kept as tables + coefficients */
+/* Current halo_a / halo_b (len scalars each; NULL to skip) and halo_g (len points + flags; both or neither).  While the
+ * generators are frozen halo_g is only defined again at length 1 (the end of the argument, halo.rs:126-127: one MSM). */
+int plk_halo_read(plk_halo_ctx* ctx, uint64_t* halo_a, uint64_t* halo_b, uint64_t* halo_g_xy, uint8_t* halo_g_zero);
+int plk_halo_free(plk_halo_ctx* ctx);
 
 /* ---- self-test ------------------------------------------------------------------------------ */
 /* Runs the quad-cooperative point arithmetic of the MSM reduction tail (ecz_coop.cuh) against the one-lane

@@ -82,6 +82,16 @@ def fft_precompute(field, degree):
     return FftPrecomputation(field, degree_pow)
 
 
+def fft_precompute_table(field, degree):
+    """The CONTENTS of the reference's FftPrecomputation (fft.rs:28-59), built on the device: the list subgroups_rev[i],
+    i = 0 ..= log2_ceil(degree), each a (2^i, 4) array of the bit-reversed powers of primitive_root_of_unity(i)."""
+    degree_pow = log2_ceil(degree)
+    assert degree_pow <= _TWO_ADICITY[field], "n_power <= TWO_ADICITY"  # field.rs:430
+    flat = np.empty(((2 << degree_pow) - 1, 4), dtype=np.uint64)
+    _lib.check(_lib.load().plk_ntt_precompute_table(field, degree_pow, _ptr(flat)))
+    return [flat[(1 << i) - 1: (2 << i) - 1] for i in range(degree_pow + 1)]
+
+
 def _ntt(field, log_n, inverse, x):
     out = np.empty_like(x)
     _lib.check(_lib.load().plk_ntt(field, log_n, 1 if inverse else 0, _ptr(x), _ptr(out)))
@@ -395,7 +405,8 @@ def batch_multiplicative_inverse(field, x):
     a = _elems(field, x)
     out = np.empty_like(a)
     rc = _lib.load().plk_field_batch_inverse(field, _ptr(a), _ptr(out), a.shape[0])
-    assert rc != _lib.PLK_ERR_INVALID_ARG, "No inverse"
+    if rc == _lib.PLK_ERR_INVALID_ARG and _lib.load().plk_last_error().decode("utf-8", "replace").startswith("No inverse"):
+        raise AssertionError("No inverse")  # the reference panics (field.rs:266); explicit, so it survives python -O
     _lib.check(rc)
     return out
 

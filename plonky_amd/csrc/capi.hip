@@ -9,12 +9,22 @@
 #include "common.h"
 
 struct plk_msm_ctx;
+struct plk_halo_ctx;
 
 namespace plk {
 
+int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, const void* d_g, const void* d_gz, const uint64_t* h_xy,
+                        const uint64_t* u_xy, unsigned freeze_log, hipStream_t stream, plk_halo_ctx** out);
+int halo_round_lr_impl(plk_halo_ctx* c, const uint64_t* l_blind, const uint64_t* r_blind, uint64_t* lr_xy, uint8_t* lr_zero);
+int halo_round_fold_impl(plk_halo_ctx* c, const uint64_t* u_j, const uint64_t* u_j_inv);
+size_t halo_len_impl(const plk_halo_ctx* c);
+int halo_frozen_impl(const plk_halo_ctx* c);
+int halo_read_impl(plk_halo_ctx* c, uint64_t* a, uint64_t* b, uint64_t* g_xy, uint8_t* g_zero);
+void halo_delete(plk_halo_ctx* c);
+
 int field_op_impl(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count);
 int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, unsigned flags, hipStream_t stream,
-                            plk_msm_ctx** out_ctx);
+                            plk_msm_ctx** out_ctx, const void* d_extra = nullptr, size_t n_extra = 0);
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void* d_zero, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_gen_bases_dev_impl(int curve, size_t n, uint64_t first, const void* d_g0d, void* d_out, hipStream_t stream);
@@ -298,6 +308,10 @@ int plk_init(int device) {
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
         return set_error(PLK_ERR_NO_DEVICE, "no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device == -1) {
+        const char* e = getenv("PLK_DEVICE");
+        device = e ? atoi(e) : 0;
+    }
     if (device < 0 || device >= count) return set_error(PLK_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, count);
     PLK_HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
@@ -317,6 +331,11 @@ void plk_shutdown(void) {
 }
 
 const char* plk_last_error(void) { return last_error_ref().c_str(); }
+unsigned plk_min_gpu_log_n(void) {
+    const char* e = getenv("PLK_MIN_GPU_LOG_N");
+    const int v = e ? atoi(e) : 12;
+    return v < 0 ? 0u : (unsigned)v;
+}
 int plk_field_limbs(int field) { return field_limbs(field); }
 int plk_curve_limbs(int curve) { return curve_limbs(curve); }
 int plk_curve_scalar_field(int curve) { return curve_scalar_field(curve); }
@@ -329,6 +348,24 @@ int plk_ntt_clear_cache(void) {
     const int rc = ntt_clear_cache_impl();
     scratch_clear();  // "memory pressure": the idle scratch buffers go as well
     return rc;
+}
+
+int plk_ntt_precompute_table_dev(int field, unsigned log_n, void* d_out, void* stream) {
+    return ntt_reference_table_dev_impl(field, log_n, d_out, as_stream(stream));
+}
+int plk_ntt_precompute_table(int field, unsigned log_n, uint64_t* out) {
+    if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
+    if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
+    if (!out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    HostLane* l = nullptr;
+    PLK_TRY(lane_get(l));
+    const size_t bytes = (((size_t)2 << log_n) - 1) * 32;
+    LaneBuf buf;
+    PLK_TRY(buf.alloc(bytes, l->stream));
+    PLK_TRY(ntt_reference_table_dev_impl(field, log_n, buf.p, l->stream));
+    std::vector<LaneOut> outs;
+    PLK_TRY(lane_d2h(*l, outs, out, buf.p, bytes));
+    return lane_finish(*l, outs);
 }
 
 int plk_ntt_dev(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, void* stream) {
@@ -533,7 +570,8 @@ int plk_msm_precompute_ex(int curve, size_t n, const uint64_t* bases_xy, const u
         PLK_TRY(dz.alloc(n, l->stream));
         PLK_TRY(lane_h2d(*l, dz.p, base_zero, n));
     }
-    const int rc = msm_precompute_dev_impl(curve, n, db.p, base_zero ? dz.p : nullptr, window_bits, flags, l->stream, out_ctx);  // synchronises the stream
+    const int rc = msm_precompute_dev_impl(curve, n, db.p, base_zero ? dz.p : nullptr, window_bits, flags, l->stream, out_ctx);  // synchronises the stream on success
+    if (rc != PLK_OK) (void)hipStreamSynchronize(l->stream);  // an early error return leaves the staged copies in flight
     l->pin_used = 0;
     return rc;
 }
@@ -838,6 +876,50 @@ int plk_field_inner_product_dev(int field, const void* d_a, const void* d_b, siz
 int plk_field_fold_slices_dev(int field, const void* d_lo, const void* d_hi, const uint64_t* scalar_lo, const uint64_t* scalar_hi, size_t count,
                               void* d_out, void* stream) {
     return field_fold_slices_dev_impl(field, d_lo, d_hi, scalar_lo, scalar_hi, count, d_out, as_stream(stream));
+}
+
+// ---- one inner-product argument ----
+int plk_halo_begin_dev(int curve, size_t n, const void* d_halo_a, const void* d_halo_b, const void* d_halo_g_xy, const void* d_halo_g_zero,
+                       const uint64_t* pedersen_h_xy, const uint64_t* u_prime_xy, unsigned freeze_log, void* stream, plk_halo_ctx** out_ctx) {
+    return halo_begin_dev_impl(curve, n, d_halo_a, d_halo_b, d_halo_g_xy, d_halo_g_zero, pedersen_h_xy, u_prime_xy, freeze_log, as_stream(stream), out_ctx);
+}
+int plk_halo_begin(int curve, size_t n, const uint64_t* halo_a, const uint64_t* halo_b, const uint64_t* halo_g_xy, const uint8_t* halo_g_zero,
+                   const uint64_t* pedersen_h_xy, const uint64_t* u_prime_xy, unsigned freeze_log, plk_halo_ctx** out_ctx) {
+    const int L = curve_limbs(curve);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (!halo_a || !halo_b || !halo_g_xy) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    HostLane* l = nullptr;
+    PLK_TRY(lane_get(l));
+    LaneBuf da, db, dg, dz;
+    PLK_TRY(da.alloc(n * 32, l->stream));
+    PLK_TRY(db.alloc(n * 32, l->stream));
+    PLK_TRY(dg.alloc(n * 2 * L * 8, l->stream));
+    PLK_TRY(lane_h2d(*l, da.p, halo_a, n * 32));
+    PLK_TRY(lane_h2d(*l, db.p, halo_b, n * 32));
+    PLK_TRY(lane_h2d(*l, dg.p, halo_g_xy, n * 2 * L * 8));
+    if (halo_g_zero) {
+        PLK_TRY(dz.alloc(n, l->stream));
+        PLK_TRY(lane_h2d(*l, dz.p, halo_g_zero, n));
+    }
+    // the context works on the lane's stream from here on (one host thread per context)
+    const int rc = halo_begin_dev_impl(curve, n, da.p, db.p, dg.p, halo_g_zero ? dz.p : nullptr, pedersen_h_xy, u_prime_xy, freeze_log, l->stream, out_ctx);
+    (void)hipStreamSynchronize(l->stream);
+    l->pin_used = 0;
+    return rc;
+}
+int plk_halo_round_lr(plk_halo_ctx* ctx, const uint64_t* l_blinding, const uint64_t* r_blinding, uint64_t* lr_xy, uint8_t* lr_zero) {
+    return halo_round_lr_impl(ctx, l_blinding, r_blinding, lr_xy, lr_zero);
+}
+int plk_halo_round_fold(plk_halo_ctx* ctx, const uint64_t* u_j, const uint64_t* u_j_inv) { return halo_round_fold_impl(ctx, u_j, u_j_inv); }
+size_t plk_halo_len(const plk_halo_ctx* ctx) { return halo_len_impl(ctx); }
+int plk_halo_frozen(const plk_halo_ctx* ctx) { return halo_frozen_impl(ctx); }
+int plk_halo_read(plk_halo_ctx* ctx, uint64_t* halo_a, uint64_t* halo_b, uint64_t* halo_g_xy, uint8_t* halo_g_zero) {
+    return halo_read_impl(ctx, halo_a, halo_b, halo_g_xy, halo_g_zero);
+}
+int plk_halo_free(plk_halo_ctx* ctx) {
+    if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
+    halo_delete(ctx);
+    return PLK_OK;
 }
 
 // ---- self-test ----

@@ -88,6 +88,7 @@ int ntt_dev_hooked_impl(int field, unsigned log_n, int inverse, unsigned batch, 
 // *hold (when given) shares ownership of the plan: keep it until the kernels reading pw have been enqueued AND the stream has
 // been synchronised or the hold is released after them (a concurrent plk_ntt_clear_cache frees the table otherwise)
 int ntt_plan_pow_table(int field, unsigned log_n, const void** pw, int* log_t, std::shared_ptr<const void>* hold = nullptr);
+int ntt_reference_table_dev_impl(int field, unsigned log_n, void* d_out, hipStream_t stream);
 int plonk_clear_cache_impl();
 int field_inner_product_dev_impl(int field, const void* d_a, const void* d_b, size_t count, void* d_out, hipStream_t stream);
 int field_fold_slices_dev_impl(int field, const void* d_lo, const void* d_hi, const uint64_t* s_lo, const uint64_t* s_hi, size_t count, void* d_out,

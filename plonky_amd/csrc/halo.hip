@@ -1,0 +1,385 @@
+// halo.hip -- the rounds of one inner-product argument (src/halo.rs:63-124) behind the C ABI, device resident.
+//
+// The reference keeps halo_a, halo_b (scalars) and halo_g (points) on the host and, per round j = log n .. 1:
+//   L_j = msm_parallel(a_lo, g_hi) + [l_j] H + [<a_lo, b_hi>] U'        halo.rs:86-89
+//   R_j = msm_parallel(a_hi, g_lo) + [r_j] H + [<a_hi, b_lo>] U'        halo.rs:90-93
+//   (transcript -> challenge u_j, host side)                             halo.rs:95-114
+//   halo_a = u^-1 a_hi + u a_lo,  halo_b = u^-1 b_lo + u b_hi            halo.rs:117-118
+//   halo_g_i = msm_parallel([u^-1, u], [g_lo_i, g_hi_i])                 halo.rs:119-123
+// Here the three vectors live in HBM inside a context; a round is plk_halo_round_lr (the two points cross PCIe: the
+// transcript is on the host) and plk_halo_round_fold (two scalars go in as kernel arguments).  No context is created or
+// freed per round, nothing is allocated, the blinding factors and challenges never touch device memory as separate copies.
+//
+// Two regimes:
+//  * long vectors: L_j / R_j are ONE table-free MSM each over [half of G, H, U'] with the scalars [half of a, blinding factor,
+//    inner product] (two persistent table-free contexts rebound to the halved generator set every round, on two streams);
+//    the generators are folded pair by pair (fold.hip).
+//  * short vectors (<= 2^freeze_log generators left): a table-free MSM and the fold are then pure latency (a chain of
+//    ~120-130 doublings of one point per lane, ~2 ms whatever the size), so the generators are FROZEN: window tables are
+//    built once for G^(f) (+ H, U'), the folded generators are never formed again, and every later round uses
+//        G^(k)_i = sum_{j = i mod n_k} s_j G^(f)_j,   s_j = prod over the folds since of (u^-1 if j fell in the low half, else u)
+//    (the identity behind halo_s, plonk_util.rs:311-339): L_j and R_j are the two scalar vectors of ONE batched tabled MSM
+//    over the frozen set with the scalars a_i s_j, and the final generator is one more MSM with the scalars s_j.  Same group
+//    elements as the reference's, so the affine results are bit-identical.
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "common.h"
+#include "fp.cuh"
+#include "field_params.cuh"
+
+struct plk_msm_ctx;
+
+namespace plk {
+
+int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, unsigned flags, hipStream_t stream,
+                            plk_msm_ctx** out_ctx, const void* d_extra = nullptr, size_t n_extra = 0);
+int msm_rebind_dev_impl(plk_msm_ctx* ctx, size_t n, const void* d_bases, const void* d_zero, const void* d_extra, size_t n_extra, hipStream_t stream);
+int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream);
+void msm_ctx_delete(plk_msm_ctx* ctx);
+int curve_fold_pairs_dev_impl(int curve, size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero,
+                              const uint64_t* a_mont, const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream);
+
+constexpr int HALO_PART_BLOCKS = 256;
+struct HaloScalar {
+    uint32_t v[8];
+};
+
+// One pass over the halves of a and b: the partial sums of <a_lo, b_hi> and <a_hi, b_lo> (Field::inner_product,
+// field.rs:213-221; field addition is exact and associative, any order gives the reference's value) and the scalar vectors
+// of the two MSMs.  Not frozen (m0 == 0): sL = a_lo, sR = a_hi (m entries each).  Frozen: entry j < m0 of the frozen
+// generator set belongs to folded generator r = j mod n_k; it takes part in L (over G_hi) when r >= m with a_lo[r - m], in R
+// (over G_lo) when r < m with a_hi[r] - times its coefficient s_j; the other vector gets 0 (a zero scalar has no digits).
+template <class P>
+__global__ void __launch_bounds__(256) k_halo_prepare(const uint4* __restrict__ a, const uint4* __restrict__ b, size_t m, size_t m0,
+                                                      const uint4* __restrict__ coef, uint4* __restrict__ sL, uint4* __restrict__ sR,
+                                                      uint4* __restrict__ part) {
+    constexpr int W = P::NL / 4;
+    __shared__ uint4 s_acc[2 * 256 * W];
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fe<P> accL = fe_zero<P>(), accR = fe_zero<P>();
+    for (size_t i = t0; i < m; i += stride) {
+        const Fe<P> alo = fe_load<P>(a + i * W), ahi = fe_load<P>(a + (m + i) * W);
+        accL = fe_add<P>(accL, fe_mul<P>(alo, fe_load<P>(b + (m + i) * W)));
+        accR = fe_add<P>(accR, fe_mul<P>(ahi, fe_load<P>(b + i * W)));
+        if (m0 == 0) {
+            fe_store<P>(sL + i * W, alo);
+            fe_store<P>(sR + i * W, ahi);
+        }
+    }
+    const size_t mask = 2 * m - 1;
+    for (size_t j = t0; j < m0; j += stride) {
+        const size_t r = j & mask;
+        const Fe<P> v = fe_mul<P>(fe_load<P>(a + (r >= m ? r - m : m + r) * W), fe_load<P>(coef + j * W));
+        fe_store<P>(sL + j * W, r >= m ? v : fe_zero<P>());
+        fe_store<P>(sR + j * W, r >= m ? fe_zero<P>() : v);
+    }
+    fe_store<P>(s_acc + threadIdx.x * W, accL);
+    fe_store<P>(s_acc + (256 + threadIdx.x) * W, accR);
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            accL = fe_add<P>(accL, fe_load<P>(s_acc + (threadIdx.x + d) * W));
+            accR = fe_add<P>(accR, fe_load<P>(s_acc + (256 + threadIdx.x + d) * W));
+            fe_store<P>(s_acc + threadIdx.x * W, accL);
+            fe_store<P>(s_acc + (256 + threadIdx.x) * W, accR);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        fe_store<P>(part + blockIdx.x * W, accL);
+        fe_store<P>(part + (HALO_PART_BLOCKS + blockIdx.x) * W, accR);
+    }
+}
+// the two inner products from their partial sums; the blinding factor and the inner product become the scalars of H and U':
+// s[cnt] = blinding factor, s[cnt + 1] = inner product
+template <class P>
+__global__ void __launch_bounds__(64) k_halo_close(const uint4* __restrict__ part, unsigned blocks, HaloScalar l_blind, HaloScalar r_blind, size_t cnt,
+                                                   uint4* __restrict__ sL, uint4* __restrict__ sR) {
+    constexpr int W = P::NL / 4;
+    __shared__ uint4 s_acc[2 * 64 * W];
+    Fe<P> accL = fe_zero<P>(), accR = fe_zero<P>();
+    for (unsigned i = threadIdx.x; i < blocks; i += 64) {
+        accL = fe_add<P>(accL, fe_load<P>(part + i * W));
+        accR = fe_add<P>(accR, fe_load<P>(part + (HALO_PART_BLOCKS + i) * W));
+    }
+    fe_store<P>(s_acc + threadIdx.x * W, accL);
+    fe_store<P>(s_acc + (64 + threadIdx.x) * W, accR);
+    __syncthreads();
+    for (int d = 32; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            accL = fe_add<P>(accL, fe_load<P>(s_acc + (threadIdx.x + d) * W));
+            accR = fe_add<P>(accR, fe_load<P>(s_acc + (64 + threadIdx.x + d) * W));
+            fe_store<P>(s_acc + threadIdx.x * W, accL);
+            fe_store<P>(s_acc + (64 + threadIdx.x) * W, accR);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        Fe<P> l, r;
+#pragma unroll
+        for (int k = 0; k < P::NL; ++k) {
+            l.v[k] = l_blind.v[k];
+            r.v[k] = r_blind.v[k];
+        }
+        fe_store<P>(sL + cnt * W, l);
+        fe_store<P>(sL + (cnt + 1) * W, accL);
+        fe_store<P>(sR + cnt * W, r);
+        fe_store<P>(sR + (cnt + 1) * W, accR);
+    }
+}
+// halo_a' = u^-1 a_hi + u a_lo, halo_b' = u^-1 b_lo + u b_hi in place (element i of the low half only depends on elements i and
+// m + i); frozen generators: s_j *= u^-1 when j falls in the low half of the current length, else u
+template <class P>
+__global__ void __launch_bounds__(256) k_halo_fold_scalars(uint4* __restrict__ a, uint4* __restrict__ b, size_t m, HaloScalar u_s, HaloScalar uinv_s,
+                                                           uint4* __restrict__ coef, size_t m0) {
+    constexpr int W = P::NL / 4;
+    Fe<P> u, uinv;
+#pragma unroll
+    for (int k = 0; k < P::NL; ++k) {
+        u.v[k] = u_s.v[k];
+        uinv.v[k] = uinv_s.v[k];
+    }
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) {
+        const Fe<P> alo = fe_load<P>(a + i * W), ahi = fe_load<P>(a + (m + i) * W);
+        const Fe<P> blo = fe_load<P>(b + i * W), bhi = fe_load<P>(b + (m + i) * W);
+        fe_store<P>(a + i * W, fe_add<P>(fe_mul<P>(uinv, ahi), fe_mul<P>(u, alo)));
+        fe_store<P>(b + i * W, fe_add<P>(fe_mul<P>(uinv, blo), fe_mul<P>(u, bhi)));
+    }
+    if (i < m0) {
+        const bool low = (i & (2 * m - 1)) < m;
+        fe_store<P>(coef + i * W, fe_mul<P>(fe_load<P>(coef + i * W), low ? uinv : u));
+    }
+}
+template <class P> __global__ void __launch_bounds__(256) k_halo_fill_one(uint4* __restrict__ coef, size_t count) {
+    constexpr int W = P::NL / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) fe_store<P>(coef + i * W, fe_one<P>());
+}
+
+}  // namespace plk
+
+struct plk_halo_ctx {
+    int curve = 0, sfield = 0, L = 4;
+    size_t n0 = 0, n = 0;       // initial / current length of halo_a, halo_b, halo_g
+    unsigned freeze_log = 14;
+    hipStream_t stream = nullptr, side = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    uint8_t* slab = nullptr;    // one allocation: a | b | g | gz | extra | scal | part | out | coef
+    uint8_t *a = nullptr, *b = nullptr, *g = nullptr, *gz = nullptr, *extra = nullptr, *scal = nullptr, *part = nullptr, *out = nullptr, *coef = nullptr;
+    size_t scal_stride = 0;     // bytes between the L and the R scalar vector
+    plk_msm_ctx *mL = nullptr, *mR = nullptr;  // table-free contexts of the long rounds, rebound every round
+    bool frozen = false;
+    size_t m0 = 0;              // frozen generator count
+    plk_msm_ctx* mT = nullptr;  // tables over [G^(f), H, U']
+    uint8_t* pin = nullptr;     // pinned staging for the results that cross PCIe
+    bool lr_done = false;
+    std::mutex mu;
+    ~plk_halo_ctx() {
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (side) (void)hipStreamSynchronize(side);
+        if (mL) plk::msm_ctx_delete(mL);
+        if (mR) plk::msm_ctx_delete(mR);
+        if (mT) plk::msm_ctx_delete(mT);
+        if (slab) (void)hipFree(slab);
+        if (pin) (void)hipHostFree(pin);
+        if (ev_main) (void)hipEventDestroy(ev_main);
+        if (ev_side) (void)hipEventDestroy(ev_side);
+        if (side) (void)hipStreamDestroy(side);
+    }
+};
+
+namespace plk {
+
+static HaloScalar to_halo_scalar(const uint64_t* s) {
+    HaloScalar h;
+    for (int k = 0; k < 4; ++k) {
+        h.v[2 * k] = (uint32_t)s[k];
+        h.v[2 * k + 1] = (uint32_t)(s[k] >> 32);
+    }
+    return h;
+}
+
+#define HALO_FIELD_SWITCH(field, CALL)                                        \
+    switch (field) {                                                          \
+        case PLK_FIELD_TWEEDLEDEE_BASE: { using P = TweedledeeBaseParams; CALL; } break;   \
+        case PLK_FIELD_TWEEDLEDUM_BASE: { using P = TweedledumBaseParams; CALL; } break;   \
+        case PLK_FIELD_BLS12_377_SCALAR: { using P = Bls12377ScalarParams; CALL; } break;  \
+        case PLK_FIELD_PALLAS_BASE: { using P = PallasBaseParams; CALL; } break;           \
+        default: { using P = VestaBaseParams; CALL; } break;                               \
+    }
+
+// builds the tables over the current generators: from here on they are never folded again
+static int halo_freeze(plk_halo_ctx* c) {
+    c->m0 = c->n;
+    PLK_TRY(msm_precompute_dev_impl(c->curve, c->m0 + 2, c->g, c->gz, 0, 0, c->stream, &c->mT, c->extra, 2));
+    const unsigned blocks = (unsigned)((c->m0 + 255) / 256);
+    HALO_FIELD_SWITCH(c->sfield, (k_halo_fill_one<P><<<blocks, 256, 0, c->stream>>>((uint4*)c->coef, c->m0)));
+    PLK_HIP_TRY(hipGetLastError());
+    c->frozen = true;
+    return PLK_OK;
+}
+
+int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, const void* d_g, const void* d_gz, const uint64_t* h_xy,
+                        const uint64_t* u_xy, unsigned freeze_log, hipStream_t stream, plk_halo_ctx** out) {
+    if (!out) return set_error(PLK_ERR_INVALID_ARG, "null out");
+    *out = nullptr;
+    const int L = curve_limbs(curve);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (n == 0 || (n & (n - 1))) return set_error(PLK_ERR_NOT_POW2, "halo vectors of length %zu: not a power of two (util.rs:17)", n);
+    if (!d_a || !d_b || !d_g || !h_xy || !u_xy) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    auto* c = new plk_halo_ctx();
+    std::unique_ptr<plk_halo_ctx> guard(c);
+    c->curve = curve;
+    c->sfield = curve_scalar_field(curve);
+    c->L = L;
+    c->n0 = c->n = n;
+    c->stream = stream;
+    if (const char* e = getenv("PLK_HALO_FREEZE_LOG")) freeze_log = (unsigned)atoi(e);
+    c->freeze_log = freeze_log ? freeze_log : 14u;
+    const size_t pt = (size_t)2 * L * 8;
+    const size_t fz = (size_t)1 << (c->freeze_log > 40 ? 40 : c->freeze_log);
+    const size_t m0_max = n < fz ? n : fz;                 // frozen set: at most min(n, 2^freeze_log) generators
+    const size_t cnt_max = (n / 2 > m0_max ? n / 2 : m0_max) + 2;
+    c->scal_stride = cnt_max * 32;
+    struct Part { uint8_t** p; size_t bytes; } parts[] = {
+        {&c->a, n * 32}, {&c->b, n * 32}, {&c->g, n * pt}, {&c->gz, n}, {&c->extra, 2 * pt}, {&c->scal, 2 * c->scal_stride},
+        {&c->part, (size_t)2 * HALO_PART_BLOCKS * 32}, {&c->out, 2 * pt + 16}, {&c->coef, m0_max * 32},
+    };
+    size_t total = 0;
+    for (auto& p : parts) total += (p.bytes + 255) & ~(size_t)255;
+    PLK_HIP_TRY(hipMalloc((void**)&c->slab, total));
+    uint8_t* cur = c->slab;
+    for (auto& p : parts) {
+        *p.p = cur;
+        cur += (p.bytes + 255) & ~(size_t)255;
+    }
+    PLK_HIP_TRY(hipHostMalloc((void**)&c->pin, 4 * pt + 64 + 2 * 32, hipHostMallocDefault));
+    PLK_HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    PLK_HIP_TRY(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+    PLK_HIP_TRY(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+    PLK_HIP_TRY(hipMemcpyAsync(c->a, d_a, n * 32, hipMemcpyDeviceToDevice, stream));
+    PLK_HIP_TRY(hipMemcpyAsync(c->b, d_b, n * 32, hipMemcpyDeviceToDevice, stream));
+    PLK_HIP_TRY(hipMemcpyAsync(c->g, d_g, n * pt, hipMemcpyDeviceToDevice, stream));
+    if (d_gz) PLK_HIP_TRY(hipMemcpyAsync(c->gz, d_gz, n, hipMemcpyDeviceToDevice, stream));
+    else PLK_HIP_TRY(hipMemsetAsync(c->gz, 0, n, stream));
+    memcpy(c->pin, h_xy, pt);
+    memcpy(c->pin + pt, u_xy, pt);
+    PLK_HIP_TRY(hipMemcpyAsync(c->extra, c->pin, 2 * pt, hipMemcpyHostToDevice, stream));
+    if (n >= 2) {
+        if (n <= fz) {
+            PLK_TRY(halo_freeze(c));
+        } else {
+            // the two table-free contexts of the long rounds, sized for the first (largest) round
+            PLK_TRY(msm_precompute_dev_impl(curve, n / 2 + 2, c->g + (n / 2) * pt, c->gz + n / 2, 0, PLK_MSM_TABLE_FREE, stream, &c->mL, c->extra, 2));
+            PLK_TRY(msm_precompute_dev_impl(curve, n / 2 + 2, c->g, c->gz, 0, PLK_MSM_TABLE_FREE, stream, &c->mR, c->extra, 2));
+        }
+    }
+    PLK_HIP_TRY(hipStreamSynchronize(stream));  // the staging copy of H, U' is consumed
+    *out = guard.release();
+    return PLK_OK;
+}
+
+int halo_round_lr_impl(plk_halo_ctx* c, const uint64_t* l_blind, const uint64_t* r_blind, uint64_t* lr_xy, uint8_t* lr_zero) {
+    if (!c || !l_blind || !r_blind || !lr_xy || !lr_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->n < 2) return set_error(PLK_ERR_INVALID_ARG, "the argument is finished (length %zu)", c->n);
+    const size_t m = c->n / 2, pt = (size_t)2 * c->L * 8;
+    const size_t m0 = c->frozen ? c->m0 : 0, cnt = c->frozen ? c->m0 : m;
+    uint8_t* sL = c->scal;
+    uint8_t* sR = c->scal + (c->frozen ? (cnt + 2) * 32 : c->scal_stride);  // frozen: the two vectors back to back, one batched call
+    const size_t work = m > m0 ? m : m0;
+    unsigned blocks = (unsigned)((work + 255) / 256);
+    if (blocks > HALO_PART_BLOCKS) blocks = HALO_PART_BLOCKS;
+    const HaloScalar lb = to_halo_scalar(l_blind), rb = to_halo_scalar(r_blind);
+    HALO_FIELD_SWITCH(c->sfield, (k_halo_prepare<P><<<blocks, 256, 0, c->stream>>>((const uint4*)c->a, (const uint4*)c->b, m, m0, (const uint4*)c->coef,
+                                                                                     (uint4*)sL, (uint4*)sR, (uint4*)c->part),
+                                  k_halo_close<P><<<1, 64, 0, c->stream>>>((const uint4*)c->part, blocks, lb, rb, cnt, (uint4*)sL, (uint4*)sR)));
+    PLK_HIP_TRY(hipGetLastError());
+    uint8_t* out_xy = c->out;
+    uint8_t* out_z = c->out + 2 * pt;
+    if (c->frozen) {
+        PLK_TRY(msm_execute_dev_impl(c->mT, 2, sL, c->m0 + 2, out_xy, out_z, c->stream));
+    } else {
+        // L on the caller's stream, R on the side stream: below ~2^16 points each is a dependency chain, not throughput
+        PLK_HIP_TRY(hipEventRecord(c->ev_main, c->stream));
+        PLK_HIP_TRY(hipStreamWaitEvent(c->side, c->ev_main, 0));
+        PLK_TRY(msm_rebind_dev_impl(c->mR, m + 2, c->g, c->gz, c->extra, 2, c->side));
+        PLK_TRY(msm_execute_dev_impl(c->mR, 1, sR, m + 2, out_xy + pt, out_z + 1, c->side));
+        PLK_HIP_TRY(hipEventRecord(c->ev_side, c->side));
+        PLK_TRY(msm_rebind_dev_impl(c->mL, m + 2, c->g + m * pt, c->gz + m, c->extra, 2, c->stream));
+        PLK_TRY(msm_execute_dev_impl(c->mL, 1, sL, m + 2, out_xy, out_z, c->stream));
+        PLK_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_side, 0));
+    }
+    PLK_HIP_TRY(hipMemcpyAsync(c->pin, c->out, 2 * pt + 2, hipMemcpyDeviceToHost, c->stream));
+    PLK_HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(lr_xy, c->pin, 2 * pt);
+    lr_zero[0] = c->pin[2 * pt];
+    lr_zero[1] = c->pin[2 * pt + 1];
+    c->lr_done = true;
+    return PLK_OK;
+}
+
+int halo_round_fold_impl(plk_halo_ctx* c, const uint64_t* u_j, const uint64_t* u_j_inv) {
+    if (!c || !u_j || !u_j_inv) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->n < 2) return set_error(PLK_ERR_INVALID_ARG, "the argument is finished (length %zu)", c->n);
+    const size_t m = c->n / 2, pt = (size_t)2 * c->L * 8;
+    const size_t m0 = c->frozen ? c->m0 : 0;
+    const size_t work = m > m0 ? m : m0;
+    HALO_FIELD_SWITCH(c->sfield, (k_halo_fold_scalars<P><<<(unsigned)((work + 255) / 256), 256, 0, c->stream>>>(
+                                     (uint4*)c->a, (uint4*)c->b, m, to_halo_scalar(u_j), to_halo_scalar(u_j_inv), (uint4*)c->coef, m0)));
+    PLK_HIP_TRY(hipGetLastError());
+    if (!c->frozen) {
+        // G'_i = [u^-1] G_lo_i + [u] G_hi_i in place (pair i only touches elements i and m + i)
+        PLK_TRY(curve_fold_pairs_dev_impl(c->curve, m, c->g, c->gz, c->g + m * pt, c->gz + m, u_j_inv, u_j, c->g, c->gz, c->stream));
+    }
+    c->n = m;
+    c->lr_done = false;
+    if (!c->frozen && c->n >= 2 && c->n <= ((size_t)1 << (c->freeze_log > 40 ? 40 : c->freeze_log))) PLK_TRY(halo_freeze(c));
+    return PLK_OK;
+}
+
+size_t halo_len_impl(const plk_halo_ctx* c) { return c ? c->n : 0; }
+int halo_frozen_impl(const plk_halo_ctx* c) { return c && c->frozen ? 1 : 0; }
+
+// current halo_a, halo_b (n scalars each) and - while the generators are still folded explicitly - halo_g (n points + flags);
+// with n == 1 and frozen generators the single generator is the MSM <s, G^(f)>
+int halo_read_impl(plk_halo_ctx* c, uint64_t* a, uint64_t* b, uint64_t* g_xy, uint8_t* g_zero) {
+    if (!c) return set_error(PLK_ERR_INVALID_ARG, "null context");
+    PLK_TRY(ensure_device());
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t pt = (size_t)2 * c->L * 8;
+    if (a) PLK_HIP_TRY(hipMemcpyAsync(a, c->a, c->n * 32, hipMemcpyDeviceToHost, c->stream));
+    if (b) PLK_HIP_TRY(hipMemcpyAsync(b, c->b, c->n * 32, hipMemcpyDeviceToHost, c->stream));
+    if (g_xy || g_zero) {
+        if (!g_xy || !g_zero) return set_error(PLK_ERR_INVALID_ARG, "g_xy and g_zero go together");
+        if (!c->frozen) {
+            PLK_HIP_TRY(hipMemcpyAsync(g_xy, c->g, c->n * pt, hipMemcpyDeviceToHost, c->stream));
+            PLK_HIP_TRY(hipMemcpyAsync(g_zero, c->gz, c->n, hipMemcpyDeviceToHost, c->stream));
+        } else if (c->n == 1) {
+            // halo_g[0] = sum_j s_j G^(f)_j (scalars of H and U': zero)
+            PLK_HIP_TRY(hipMemcpyAsync(c->scal, c->coef, c->m0 * 32, hipMemcpyDeviceToDevice, c->stream));
+            PLK_HIP_TRY(hipMemsetAsync(c->scal + c->m0 * 32, 0, 64, c->stream));
+            PLK_TRY(msm_execute_dev_impl(c->mT, 1, c->scal, c->m0 + 2, c->out, c->out + 2 * pt, c->stream));
+            PLK_HIP_TRY(hipMemcpyAsync(c->pin, c->out, 2 * pt + 2, hipMemcpyDeviceToHost, c->stream));
+            PLK_HIP_TRY(hipStreamSynchronize(c->stream));
+            memcpy(g_xy, c->pin, pt);
+            g_zero[0] = c->pin[2 * pt];
+        } else {
+            return set_error(PLK_ERR_INVALID_ARG, "the generators are frozen (length %zu <= 2^%u): halo_g exists again when the argument is finished", c->n,
+                             c->freeze_log);
+        }
+    }
+    PLK_HIP_TRY(hipStreamSynchronize(c->stream));
+    return PLK_OK;
+}
+
+void halo_delete(plk_halo_ctx* c) { delete c; }
+
+}  // namespace plk

@@ -57,17 +57,20 @@ constexpr uint32_t CODE_INVALID = 0xFFFFFFFFu;
 // One lane per generator, on the lazy arithmetic of the accumulation kernel (ecz.cuh): c doublings per window,
 // then back to affine with the division-step inversion (about a quarter of a window's work).
 // glv != 0 (table-free mode on the curves with the endomorphism, glv.cuh): tab[n + i] = phi(G_i) = (beta x, y).
+// The generators may come in two pieces: n_main points at `bases` (+ optional identity flags) followed by n - n_main points at
+// `extra` (an IPA round appends H and U' to the half of G it multiplies, halo.rs:86-93).
 template <class C>
 __global__ void __launch_bounds__(128) k_msm_table(const uint4* __restrict__ bases, const uint8_t* __restrict__ base_zero, uint4* __restrict__ tab,
-                                                   size_t n, int c, int windows, int glv) {
+                                                   size_t n, int c, int windows, int glv, size_t n_main, const uint4* __restrict__ extra) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // R-form (the reference's) -> canonical R'-form, the form the table is stored and consumed in
-    const Fe<FP> x_in = fe_load<FP>(bases + i * 2 * W);
-    Fe<FP> xr = to_rprime<FP>(x_in), yr = to_rprime<FP>(fe_load<FP>(bases + i * 2 * W + W));
-    bool ident = base_zero ? base_zero[i] != 0 : false;
+    const uint4* src = i < n_main ? bases + i * 2 * W : extra + (i - n_main) * 2 * W;
+    const Fe<FP> x_in = fe_load<FP>(src);
+    Fe<FP> xr = to_rprime<FP>(x_in), yr = to_rprime<FP>(fe_load<FP>(src + W));
+    bool ident = (base_zero && i < n_main) ? base_zero[i] != 0 : false;
     affine_store<FP>(tab + i * 2 * W, xr, yr, ident);
     if constexpr (C::Glv::ENABLED) {
         if (glv) {
@@ -136,6 +139,9 @@ constexpr int ORD_MAX_BINS = 1024;  // coarse bins
 constexpr int ORD_MAX_FINE = 11;    // fine bits: buckets per coarse bin <= 2048
 constexpr int ORD_BIN_THREADS = 512;
 constexpr uint32_t ORD_SEG = 8192;  // entries per level-2 workgroup
+// k_ord_bin_scatter stages a whole segment in LDS (3 fine-bit tables + the staged entries): ~74 KB, above the 64 KB a workgroup
+// gets on gfx90a / gfx942 - this library is built for gfx950 (160 KB of LDS per CU) only, plk_init refuses other devices
+static_assert(3 * (4u << ORD_MAX_FINE) + 4 * ORD_BIN_THREADS + 6 * ORD_SEG <= 160 * 1024, "k_ord_bin_scatter's LDS tile must fit a gfx950 CU");
 
 struct OrdCfg {
     int c;                   // window bits
@@ -1174,6 +1180,7 @@ struct MsmWork {
     void* plane_part = nullptr;
     void* win_pts = nullptr;   // the per-window results
     void* slab = nullptr;      // the one allocation all of the above point into
+    size_t cap[15] = {};       // bytes of each part above, in the order of msm_work_parts (a context that is rebound to fewer points keeps its layout)
     bool pooled = false;       // slab comes from the library's scratch pool (table-free contexts: built and dropped per call)
     bool ready = false;
     // executions on different streams share the workspace: the next user waits for the previous one's last kernel
@@ -1216,6 +1223,7 @@ struct plk_msm_ctx {
     size_t max_lanes = 0;
     // device memory
     void* tab = nullptr;
+    size_t tab_cap = 0;      // bytes allocated for the table
     hipStream_t tab_stream = nullptr;  // table-free: the stream the (pooled) table was built on
     plk::OrdCfg ord{};
     uint32_t heavy_cap = 0;
@@ -1276,19 +1284,25 @@ static int choose_window(size_t n, int curve) {
 
 // accumulation lanes the GPU runs at once (for the chunk size: whole rounds of lanes, no ragged last round)
 template <class C> static size_t accumulate_slots() {
-    static size_t slots = 0;
-    if (slots == 0) {
-        int per_cu = 0, dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
+    static std::mutex mu;
+    static size_t slots[64] = {};  // per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& s = slots[dev & 63];
+    if (s == 0) {
+        int per_cu = 0, cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_accumulate<C>, ACC_THREADS, 0) != hipSuccess || per_cu <= 0) per_cu = 6;
-        slots = (size_t)per_cu * ACC_THREADS * (size_t)cus;
+        s = (size_t)per_cu * ACC_THREADS * (size_t)cus;
     }
-    return slots;
+    return s;
 }
 
 // One slab per workspace: a single hipMalloc / hipFree instead of a dozen (they dominate a one-shot msm_parallel).
-template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w, hipStream_t stream) {
+constexpr int MSM_WORK_PARTS = 15;
+struct WorkPart { void** p; size_t bytes; };
+template <class C> static void msm_work_parts(const plk_msm_ctx* ctx, MsmWork& w, WorkPart* parts) {
     using FP = typename C::FP;
     const size_t packed_bytes = (size_t)4 * FP::NL * 4;
     const size_t raw_bytes = (size_t)raw_u4<FP>() * 16;
@@ -1296,8 +1310,7 @@ template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w, hipSt
     const int bucket_windows = ctx->tail_windows;
     // packed operands of the plane sums: the buckets themselves, or (two-level tail) the column and row sums
     const size_t tail_slots = ctx->two_level ? (size_t)bucket_windows * ctx->tail_wbuckets : (size_t)ctx->buckets;
-    struct Part { void** p; size_t bytes; };
-    const Part parts[] = {
+    const WorkPart src[MSM_WORK_PARTS] = {
         {&w.tmp, entries * 8 + 16},
         {&w.sorted, entries * 4 + 16},
         {&w.cnt1, (size_t)ctx->ord.nbins * ctx->ord.nt1 * 4},
@@ -1314,8 +1327,13 @@ template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w, hipSt
         {&w.plane_part, (size_t)bucket_windows * ctx->planes * ctx->plane_blocks * packed_bytes},
         {&w.win_pts, bucket_windows > 1 ? (size_t)bucket_windows * packed_bytes : 0},
     };
+    for (int k = 0; k < MSM_WORK_PARTS; ++k) parts[k] = src[k];
+}
+template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w, hipStream_t stream) {
+    WorkPart parts[MSM_WORK_PARTS];
+    msm_work_parts<C>(ctx, w, parts);
     size_t total = 0;
-    for (const Part& pt : parts) total += (pt.bytes + 255) & ~(size_t)255;
+    for (const WorkPart& pt : parts) total += (pt.bytes + 255) & ~(size_t)255;
     ctx->ws_bytes = total + 256;
     // A table-free context lives for one call (msm_parallel, an IPA round): its memory comes from the scratch pool, because
     // hipMalloc + hipFree of a few hundred MB cost as much as a tenth of the MSM itself (0.4 ms of 3.8 at 2^20).
@@ -1328,9 +1346,10 @@ template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w, hipSt
         PLK_HIP_TRY(hipMalloc(&w.slab, total + 256));
     }
     uint8_t* cur = (uint8_t*)w.slab;
-    for (const Part& pt : parts) {
-        *pt.p = pt.bytes ? cur : nullptr;
-        cur += (pt.bytes + 255) & ~(size_t)255;
+    for (int k = 0; k < MSM_WORK_PARTS; ++k) {
+        *parts[k].p = parts[k].bytes ? cur : nullptr;
+        w.cap[k] = parts[k].bytes;
+        cur += (parts[k].bytes + 255) & ~(size_t)255;
     }
     // the "last block" counter of k_ord_scan1 and the heavy-list counters start at zero and are left at zero by their users
     // (on the caller's stream: a non-blocking stream is not ordered after the null stream)
@@ -1341,11 +1360,8 @@ template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w, hipSt
     return PLK_OK;
 }
 
-template <class C>
-static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d_zero, hipStream_t stream) {
-    using FP = typename C::FP;
-    const size_t n = ctx->n;
-    const size_t pt_bytes = (size_t)2 * FP::NL * 4;
+// entries per accumulation lane and what follows from it (lanes, heavy-bucket capacity, lanes per bucket in k_msm_assemble)
+template <class C> static void msm_configure_lanes(plk_msm_ctx* ctx) {
     const size_t entries = ctx->n_eff * ctx->windows;
     // entries per accumulation lane: whole rounds of the lanes the GPU holds, at most 72 entries each (longer chunks: fewer pieces)
     {
@@ -1370,21 +1386,59 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
         const double heads = (double)entries / (double)ctx->buckets / (double)ctx->chunk;
         ctx->lpb_log = heads > 6.0 ? 3 : heads > 2.0 ? 2 : 0;
     }
+}
+
+template <class C> static void msm_launch_table(plk_msm_ctx* ctx, const void* d_bases, const void* d_zero, const void* d_extra, size_t n_extra,
+                                                hipStream_t stream) {
+    const size_t n = ctx->n;
+    if (!n) return;
+    k_msm_table<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)ctx->tab, n, ctx->c,
+                                                                   ctx->table_free ? 1 : ctx->windows, ctx->glv ? 1 : 0, n - n_extra, (const uint4*)d_extra);
+}
+
+template <class C>
+static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d_zero, const void* d_extra, size_t n_extra, hipStream_t stream) {
+    using FP = typename C::FP;
+    const size_t pt_bytes = (size_t)2 * FP::NL * 4;
+    const size_t entries = ctx->n_eff * ctx->windows;
+    msm_configure_lanes<C>(ctx);
     if (ctx->table_free) {
-        ctx->tab = scratch_acquire(ctx->n_eff * pt_bytes + 16, stream);
+        ctx->tab_cap = ctx->n_eff * pt_bytes + 16;
+        ctx->tab = scratch_acquire(ctx->tab_cap, stream);
         if (!ctx->tab) return PLK_ERR_OOM;
         ctx->tab_stream = stream;
     } else {
-        PLK_HIP_TRY(hipMalloc(&ctx->tab, entries * pt_bytes + 16));
+        ctx->tab_cap = entries * pt_bytes + 16;
+        PLK_HIP_TRY(hipMalloc(&ctx->tab, ctx->tab_cap));
     }
     ctx->ws.resize(1);
     PLK_TRY(msm_alloc_work<C>(ctx, ctx->ws[0], stream));
-    if (n) {
-        k_msm_table<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)ctx->tab, n, ctx->c,
-                                                                       ctx->table_free ? 1 : ctx->windows, ctx->glv ? 1 : 0);
-        PLK_HIP_TRY(hipGetLastError());
-    }
+    msm_launch_table<C>(ctx, d_bases, d_zero, d_extra, n_extra, stream);
+    PLK_HIP_TRY(hipGetLastError());
     PLK_HIP_TRY(hipStreamSynchronize(stream));
+    return PLK_OK;
+}
+
+// A table-free context re-used for another (smaller or equal) generator set: new geometry, same memory, no allocation, no
+// synchronisation - the rounds of an inner-product argument halve their generators every time (halo.rs:63-124).
+template <class C>
+static int msm_rebind_t(plk_msm_ctx* ctx, const void* d_bases, const void* d_zero, const void* d_extra, size_t n_extra, hipStream_t stream) {
+    using FP = typename C::FP;
+    const size_t pt_bytes = (size_t)2 * FP::NL * 4;
+    msm_configure_lanes<C>(ctx);
+    if (ctx->n_eff * pt_bytes + 16 > ctx->tab_cap) return set_error(PLK_ERR_INVALID_ARG, "rebind: %zu points do not fit the context's table", ctx->n_eff);
+    MsmWork& w = ctx->ws[0];
+    WorkPart parts[MSM_WORK_PARTS];
+    MsmWork probe;  // only its field addresses are used
+    msm_work_parts<C>(ctx, probe, parts);
+    for (int k = 0; k < MSM_WORK_PARTS; ++k)
+        if (parts[k].bytes > w.cap[k])
+            return set_error(PLK_ERR_INVALID_ARG, "rebind: workspace part %d needs %zu bytes, the context holds %zu", k, parts[k].bytes, w.cap[k]);
+    if (w.used && w.last_stream != stream) PLK_HIP_TRY(hipStreamWaitEvent(stream, w.ev, 0));
+    msm_launch_table<C>(ctx, d_bases, d_zero, d_extra, n_extra, stream);
+    PLK_HIP_TRY(hipGetLastError());
+    ctx->tab_stream = stream;
+    w.last_stream = stream;
     return PLK_OK;
 }
 
@@ -1407,14 +1461,8 @@ static int choose_window_table_free(size_t n, int bits) {
     return c;
 }
 
-int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, unsigned flags, hipStream_t stream,
-                            plk_msm_ctx** out_ctx) {
-    if (!out_ctx) return set_error(PLK_ERR_INVALID_ARG, "null out_ctx");
-    *out_ctx = nullptr;
-    if (curve_limbs(curve) < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
-    if (n && !d_bases) return set_error(PLK_ERR_INVALID_ARG, "null bases");
-    PLK_TRY(ensure_device());
-    const bool table_free = (flags & PLK_MSM_TABLE_FREE) != 0;
+// window, ordering configuration and tail geometry of a context over n generators (no device work, no allocation)
+static int msm_configure(plk_msm_ctx* ctx, int curve, size_t n, unsigned window_bits, bool table_free) {
     // table-free mode on the prime-order curves: split every scalar along the endomorphism (glv.cuh) - 2n points, half the windows
     const bool glv = table_free && n > 0 && curve != PLK_CURVE_BLS12_377 && !getenv("PLK_MSM_NO_GLV");
     const size_t n_eff = glv ? 2 * n : n;
@@ -1433,11 +1481,7 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     }
     if (n_eff * (size_t)windows >= ((size_t)1 << 31))
         return set_error(PLK_ERR_INVALID_ARG, "n * windows = %zu entries exceeds 2^31", n_eff * (size_t)windows);
-    int dev = 0;
-    PLK_HIP_TRY(hipGetDevice(&dev));
-    auto* ctx = new plk_msm_ctx();
     ctx->table_free = table_free;
-    ctx->device = dev;
     ctx->curve = curve;
     ctx->n = n;
     ctx->glv = glv;
@@ -1467,6 +1511,7 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     }
     // tail geometry
     ctx->two_level = c - 1 >= 12;
+    ctx->L = ctx->H = ctx->g_log = ctx->lpl_log = 0;
     if (ctx->two_level) {
         ctx->L = (c - 1) / 2;
         ctx->H = c - 1 - ctx->L;
@@ -1491,13 +1536,28 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     while (ctx->plane_blocks < MSM_MAX_PLANE_PARTS && (uint32_t)ctx->plane_blocks * 512u < ctx->tail_wbuckets &&
            ctx->planes * ctx->plane_blocks * 4 <= FINAL_THREADS)  // after doubling: planes * parts / 2 quads in the final block
         ctx->plane_blocks *= 2;
-    int rc;
-    switch (curve) {
-        case PLK_CURVE_TWEEDLEDEE: rc = msm_precompute_t<TweedledeeCurve>(ctx, d_bases, d_zero, stream); break;
-        case PLK_CURVE_TWEEDLEDUM: rc = msm_precompute_t<TweedledumCurve>(ctx, d_bases, d_zero, stream); break;
-        case PLK_CURVE_PALLAS: rc = msm_precompute_t<PallasCurve>(ctx, d_bases, d_zero, stream); break;
-        case PLK_CURVE_VESTA: rc = msm_precompute_t<VestaCurve>(ctx, d_bases, d_zero, stream); break;
-        default: rc = msm_precompute_t<Bls12377Curve>(ctx, d_bases, d_zero, stream); break;
+    return PLK_OK;
+}
+
+int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, unsigned flags, hipStream_t stream,
+                            plk_msm_ctx** out_ctx, const void* d_extra, size_t n_extra) {
+    if (!out_ctx) return set_error(PLK_ERR_INVALID_ARG, "null out_ctx");
+    *out_ctx = nullptr;
+    if (curve_limbs(curve) < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (n > n_extra && !d_bases) return set_error(PLK_ERR_INVALID_ARG, "null bases");
+    if (n_extra > n || (n_extra && !d_extra)) return set_error(PLK_ERR_INVALID_ARG, "bad extra generators");
+    PLK_TRY(ensure_device());
+    int dev = 0;
+    PLK_HIP_TRY(hipGetDevice(&dev));
+    auto* ctx = new plk_msm_ctx();
+    ctx->device = dev;
+    int rc = msm_configure(ctx, curve, n, window_bits, (flags & PLK_MSM_TABLE_FREE) != 0);
+    if (rc == PLK_OK) switch (curve) {
+        case PLK_CURVE_TWEEDLEDEE: rc = msm_precompute_t<TweedledeeCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream); break;
+        case PLK_CURVE_TWEEDLEDUM: rc = msm_precompute_t<TweedledumCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream); break;
+        case PLK_CURVE_PALLAS: rc = msm_precompute_t<PallasCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream); break;
+        case PLK_CURVE_VESTA: rc = msm_precompute_t<VestaCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream); break;
+        default: rc = msm_precompute_t<Bls12377Curve>(ctx, d_bases, d_zero, d_extra, n_extra, stream); break;
     }
     if (rc != PLK_OK) {
         delete ctx;
@@ -1505,6 +1565,23 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     }
     *out_ctx = ctx;
     return PLK_OK;
+}
+
+// see msm_rebind_t.  n counts the extra generators (the last n_extra of the n points come from d_extra).
+int msm_rebind_dev_impl(plk_msm_ctx* ctx, size_t n, const void* d_bases, const void* d_zero, const void* d_extra, size_t n_extra, hipStream_t stream) {
+    if (!ctx || !ctx->table_free || ctx->ws.empty()) return set_error(PLK_ERR_INVALID_ARG, "rebind needs a table-free context");
+    if (n_extra > n || (n > n_extra && !d_bases) || (n_extra && !d_extra)) return set_error(PLK_ERR_INVALID_ARG, "bad generators");
+    PLK_TRY(ensure_device());
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const int curve = ctx->curve;
+    PLK_TRY(msm_configure(ctx, curve, n, 0, true));
+    switch (curve) {
+        case PLK_CURVE_TWEEDLEDEE: return msm_rebind_t<TweedledeeCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream);
+        case PLK_CURVE_TWEEDLEDUM: return msm_rebind_t<TweedledumCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream);
+        case PLK_CURVE_PALLAS: return msm_rebind_t<PallasCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream);
+        case PLK_CURVE_VESTA: return msm_rebind_t<VestaCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream);
+        default: return msm_rebind_t<Bls12377Curve>(ctx, d_bases, d_zero, d_extra, n_extra, stream);
+    }
 }
 
 static TailSlot tail_slot(const plk_msm_ctx* ctx, const MsmWork& w, void* d_out_xy, void* d_out_zero) {
@@ -1600,6 +1677,19 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
             k_glv_split<C><<<(unsigned)((ctx->n + 255) / 256), 256, 0, stream>>>((const uint4*)d_scalars, ctx->n, (uint4*)halves);
             d_scalars = halves;
         }
+        // the pooled buffers of this call go back on every path out of it
+        struct Guard {
+            void*& halves;
+            std::vector<hipEvent_t>& ev;
+            plk_msm_ctx* ctx;
+            hipStream_t stream;
+            bool armed = true;
+            ~Guard() {
+                if (!armed) return;
+                if (halves) scratch_release(halves, stream);
+                if (!ev.empty()) ctx->prof_free.push_back(ev);
+            }
+        } guard{halves, ev, ctx, stream};
         k_ord_count<C><<<o.nt1, ORD_THREADS, 0, stream>>>((const uint4*)d_scalars, n, o, (uint32_t*)w.cnt1);
         k_ord_scan1<<<o.nbins, 256, 0, stream>>>((uint32_t*)w.cnt1, o.nt1, o.nbins, bin_total, bin_base, seg_base, done_counter);
         PLK_HIP_TRY(hipGetLastError());
@@ -1615,8 +1705,9 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
             k_ord_bin_scatter<<<segs + o.nbins, ORD_BIN_THREADS, 0, stream>>>((const uint2*)w.tmp, bin_base, seg_base, o.fine_bits, o.nbins, buckets,
                                                                               (const uint32_t*)w.cnt2, off, (uint32_t*)w.sorted);
         }
-        if (halves) scratch_release(halves, stream);
         PLK_HIP_TRY(hipGetLastError());
+        guard.armed = false;
+        if (halves) scratch_release(halves, stream);
         mark();
     } else {
         stage += 3;
@@ -1764,7 +1855,7 @@ static int msm_reference_table_t(size_t n, const void* d_bases, const void* d_ze
     const size_t pt_bytes = (size_t)2 * FP::NL * 4;
     void* tab = scratch_acquire(n * digits * pt_bytes + 16, stream);
     if (!tab) return PLK_ERR_OOM;
-    k_msm_table<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)tab, n, w, digits, 0);
+    k_msm_table<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)tab, n, w, digits, 0, n, nullptr);
     const size_t total = n * (size_t)digits;
     k_msm_table_export<C><<<(unsigned)((total + 255) / 256), 256, 0, stream>>>((const uint4*)tab, n, digits, (uint4*)d_out_xy, (uint8_t*)d_out_zero);
     hipError_t e = hipGetLastError();

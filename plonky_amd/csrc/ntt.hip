@@ -112,6 +112,18 @@ template <class P> __global__ void k_ntt_fill_outer(uint32_t* tw, const uint4* p
     limbs_store<P>(tw, idx, fz_from_fe<P>(to_rprime<P>(v)));
 }
 
+// The reference's own table (FftPrecomputation::subgroups_rev, fft.rs:28-59), flat: element 2^i - 1 + k is entry k of layer i =
+// g_i^(bitrev_i(k)) with g_i = primitive_root_of_unity(i) = w^(2^(log_t - i)) (field.rs:429-435), R-form as the reference stores it
+PLK_DI uint32_t bitrev_u32(uint32_t x, int bits) { return bits == 0 ? 0u : (__brev(x) >> (32 - bits)); }
+template <class P> __global__ void __launch_bounds__(256) k_ntt_reference_table(uint4* __restrict__ out, const uint4* __restrict__ pw, int log_t, int log_n) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ((size_t)2 << log_n) - 1) return;
+    const int i = 63 - __clzll((unsigned long long)(e + 1));
+    const uint32_t k = (uint32_t)(e + 1 - ((size_t)1 << i));
+    const uint64_t ex = (uint64_t)bitrev_u32(k, i) << (log_t - i);
+    fe_store<P>(out + e * 2, pow_from_table<P>(pw, 0, ex, log_t));
+}
+
 // ---------------------------------------------------------------------------------------------
 // the pass kernel
 // ---------------------------------------------------------------------------------------------
@@ -648,6 +660,30 @@ int ntt_dev_impl(int field, unsigned log_n, int inverse, unsigned batch, const v
 int ntt_dev_hooked_impl(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, const NttHooks& hooks,
                         hipStream_t stream) {
     return ntt_dispatch(field, log_n, inverse, batch, d_in, d_out, &hooks, stream);
+}
+
+int ntt_reference_table_dev_impl(int field, unsigned log_n, void* d_out, hipStream_t stream) {
+    if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
+    if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
+    if (!d_out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    std::shared_ptr<NttPlan> pl;
+    PLK_TRY(get_plan(field, log_n, pl));  // PLK_ERR_TWO_ADICITY beyond the field's 2-adicity (field.rs:430)
+    const int log_t = (int)log_n > INNER_LOG ? (int)log_n : INNER_LOG;
+    const size_t total = ((size_t)2 << log_n) - 1;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    switch (field) {
+#define CASE(ID, P) case ID: k_ntt_reference_table<P><<<blocks, 256, 0, stream>>>((uint4*)d_out, (const uint4*)pl->pw, log_t, (int)log_n); break;
+        CASE(PLK_FIELD_TWEEDLEDEE_BASE, TweedledeeBaseParams)
+        CASE(PLK_FIELD_TWEEDLEDUM_BASE, TweedledumBaseParams)
+        CASE(PLK_FIELD_BLS12_377_SCALAR, Bls12377ScalarParams)
+        CASE(PLK_FIELD_PALLAS_BASE, PallasBaseParams)
+        CASE(PLK_FIELD_VESTA_BASE, VestaBaseParams)
+#undef CASE
+    }
+    PLK_HIP_TRY(hipGetLastError());
+    // the plan (and its power table) must outlive the kernel: the cache may be cleared by another thread
+    PLK_HIP_TRY(hipStreamSynchronize(stream));
+    return PLK_OK;
 }
 
 int ntt_plan_pow_table(int field, unsigned log_n, const void** pw, int* log_t, std::shared_ptr<const void>* hold) {

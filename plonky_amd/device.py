@@ -217,9 +217,11 @@ def halo_round_lr_dev(curve, halo_a, halo_b, halo_g, pedersen_h, u_prime, l_blin
             xy, z = msm_execute_dev(pre, scal)
             pre.free()  # a table-free context hands its memory back in stream order: no synchronisation
             if st is side:
-                for t in (halo_a, halo_b, halo_g, extra, g_zero, xy, z):
+                for t in (halo_a, halo_b, halo_g, extra, g_zero):
                     if t is not None:
                         t.record_stream(side)
+                for t in (xy, z):  # allocated on the side stream, read by torch.stack on the main stream below
+                    t.record_stream(main)
         outs.append(xy[0])
         zeros.append(z[0])
     main.wait_stream(side)
@@ -246,3 +248,68 @@ def halo_round_fold_dev(curve, halo_a, halo_b, halo_g, u_j, u_j_inv, g_zero=None
     g2, gz2 = fold_generators_dev(curve, halo_g[:m].contiguous(), halo_g[m:].contiguous(), u_j_inv, u_j,
                                   None if g_zero is None else g_zero[:m].contiguous(), None if g_zero is None else g_zero[m:].contiguous())
     return a2, b2, g2, gz2
+
+
+class HaloArgument:
+    """One inner-product argument (halo.rs:63-124) behind the C ABI (plk_halo_*): halo_a / halo_b / halo_g are copied into a
+    library context and stay in HBM for the log2(n) rounds; per round the caller - who owns the transcript and the RNG -
+    calls round_lr(l_j, r_j) (possibly again, halo.rs:83-114) and round_fold(u_j, u_j^-1).  halo_a / halo_b: (n, 4) int64
+    CUDA tensors (Montgomery, scalar field); halo_g: (n, 2, L); g_zero: (n,) uint8 or None; pedersen_h / u_prime: (2, L) host."""
+
+    def __init__(self, curve, halo_a, halo_b, halo_g, pedersen_h, u_prime, g_zero=None, freeze_log=0):
+        for t in (halo_a, halo_b, halo_g):
+            assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()
+        n = halo_a.shape[0]
+        assert halo_b.shape[0] == n and halo_g.shape[0] == n
+        self.curve, self.L = curve, _CURVE_LIMBS[curve]
+        h = np.ascontiguousarray(pedersen_h, dtype=np.uint64).reshape(2, self.L)
+        u = np.ascontiguousarray(u_prime, dtype=np.uint64).reshape(2, self.L)
+        ctx = ctypes.c_void_p()
+        zp = ctypes.c_void_p(g_zero.data_ptr()) if g_zero is not None else None
+        _lib.check(_lib.load().plk_halo_begin_dev(curve, n, ctypes.c_void_p(halo_a.data_ptr()), ctypes.c_void_p(halo_b.data_ptr()),
+                                                  ctypes.c_void_p(halo_g.data_ptr()), zp, h.ctypes.data_as(ctypes.c_void_p),
+                                                  u.ctypes.data_as(ctypes.c_void_p), freeze_log, _stream(), ctypes.byref(ctx)))
+        self._ctx = ctx
+
+    def __len__(self):
+        return int(_lib.load().plk_halo_len(self._ctx))
+
+    @property
+    def frozen(self):
+        return bool(_lib.load().plk_halo_frozen(self._ctx))
+
+    def round_lr(self, l_blinding, r_blinding):
+        """(L_j, R_j) as a (2, 2, L) uint64 array + (2,) identity flags, on the host (the transcript's input)."""
+        lr = np.empty((2, 2, self.L), dtype=np.uint64)
+        z = np.zeros(2, dtype=np.uint8)
+        lb, rb = _limbs(l_blinding), _limbs(r_blinding)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(_lib.load().plk_halo_round_lr(self._ctx, p(lb), p(rb), p(lr), p(z)))
+        return lr, z
+
+    def round_fold(self, u_j, u_j_inv):
+        u, ui = _limbs(u_j), _limbs(u_j_inv)
+        _lib.check(_lib.load().plk_halo_round_fold(self._ctx, u.ctypes.data_as(ctypes.c_void_p), ui.ctypes.data_as(ctypes.c_void_p)))
+
+    def read(self, with_g=True):
+        """(halo_a, halo_b[, halo_g, g_zero]) on the host; halo_g of frozen generators exists at length 1 only."""
+        n = len(self)
+        a, b = np.empty((n, 4), dtype=np.uint64), np.empty((n, 4), dtype=np.uint64)
+        p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+        if not with_g:
+            _lib.check(_lib.load().plk_halo_read(self._ctx, p(a), p(b), None, None))
+            return a, b
+        g, gz = np.empty((n, 2, self.L), dtype=np.uint64), np.zeros(n, dtype=np.uint8)
+        _lib.check(_lib.load().plk_halo_read(self._ctx, p(a), p(b), p(g), p(gz)))
+        return a, b, g, gz
+
+    def free(self):
+        if self._ctx:
+            _lib.load().plk_halo_free(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

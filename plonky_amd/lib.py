@@ -26,11 +26,14 @@ SYMBOLS = [
     ("plk_init", _i, [_i]),
     ("plk_shutdown", None, []),
     ("plk_last_error", _cp, []),
+    ("plk_min_gpu_log_n", _u, []),
     ("plk_field_limbs", _i, [_i]),
     ("plk_curve_limbs", _i, [_i]),
     ("plk_curve_scalar_field", _i, [_i]),
     ("plk_ntt_precompute", _i, [_i, _u]),
     ("plk_ntt_clear_cache", _i, []),
+    ("plk_ntt_precompute_table", _i, [_i, _u, _vp]),
+    ("plk_ntt_precompute_table_dev", _i, [_i, _u, _vp, _vp]),
     ("plk_ntt", _i, [_i, _u, _i, _vp, _vp]),
     ("plk_ntt_batch", _i, [_i, _u, _i, _u, _vp, _vp]),
     ("plk_ntt_dev", _i, [_i, _u, _i, _u, _vp, _vp, _vp]),
@@ -74,6 +77,14 @@ SYMBOLS = [
     ("plk_curve_point_from_bytes", _i, [_i, _vp, _sz, _vp, _vp, _vp]),
     ("plk_field_inner_product_dev", _i, [_i, _vp, _vp, _sz, _vp, _vp]),
     ("plk_field_fold_slices_dev", _i, [_i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    ("plk_halo_begin_dev", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp]),
+    ("plk_halo_begin", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp]),
+    ("plk_halo_round_lr", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("plk_halo_round_fold", _i, [_vp, _vp, _vp]),
+    ("plk_halo_len", _sz, [_vp]),
+    ("plk_halo_frozen", _i, [_vp]),
+    ("plk_halo_read", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("plk_halo_free", _i, [_vp]),
     ("plk_selftest_quad", _i, [_i, _vp, _sz, _u, _vp]),
     ("plk_ntt_set_profiling", _i, [_i]),
     ("plk_ntt_get_timings", _i, [_vp, _vp]),

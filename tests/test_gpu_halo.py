@@ -78,3 +78,103 @@ def test_halo_whole_argument_closed_form():
     assert f.from_mont(limbs_to_int(dev.to_host(da)[0])) == sum(x * y for x, y in zip(s_a, a_ints)) % f.p
     exp, ez = ol.MsmPrecomputation(c.curve_id, g, 8, threads=8).execute(mont_arr(f, s_g), parallel=True, threads=8)
     assert ez == 0 and np.array_equal(dev.to_host(dg)[0], exp)
+
+
+# ---- the argument behind the C ABI (plk_halo_*): device-resident vectors, frozen generators for the short rounds ----
+def _run_argument(c, n, freeze_log, seed):
+    """All rounds through plk_halo_*; returns the per-round (L_j, R_j) and the final (a, b, g)."""
+    from plonky_amd import device as dev
+    g, h, up, a, b, _ = _setup(c, n, seed)
+    f = c.scalar
+    rounds = n.bit_length() - 1
+    us = ol.rand_field(f.field_id, seed + 50, max(rounds, 1))
+    blind = ol.rand_field(f.field_id, seed + 60, 2 * max(rounds, 1))
+    arg = dev.HaloArgument(c.curve_id, dev.to_device(a), dev.to_device(b), dev.to_device(g), h, up, freeze_log=freeze_log)
+    lrs, states = [], []
+    for j in range(rounds):
+        lr, z = arg.round_lr(blind[2 * j], blind[2 * j + 1])
+        lr2, z2 = arg.round_lr(blind[2 * j], blind[2 * j + 1])   # the retry of halo.rs:83-114 must not disturb the state
+        assert np.array_equal(lr, lr2) and np.array_equal(z, z2)
+        lrs.append((lr, z))
+        u_inv = ol.field_unop(f.field_id, "inverse", us[j].reshape(1, 4))[0]
+        arg.round_fold(us[j], u_inv)
+        assert len(arg) == n >> (j + 1)
+        states.append(arg.frozen)
+    fa, fb, fg, fgz = arg.read()
+    arg.free()
+    return (g, h, up, a, b, us, blind), lrs, states, (fa, fb, fg, fgz)
+
+
+def _oracle_argument(c, inputs):
+    g, h, up, a, b, us, blind = inputs
+    f = c.scalar
+    n = a.shape[0]
+    lrs = []
+    gz = np.zeros(n, dtype=np.uint8)
+    for j in range(n.bit_length() - 1):
+        exp, ez = ol.halo_round_lr(c.curve_id, f.field_id, a, b, g, h, up, blind[2 * j], blind[2 * j + 1])
+        lrs.append((exp, ez))
+        u_inv = ol.field_unop(f.field_id, "inverse", us[j].reshape(1, 4))[0]
+        a, b, g, gz = ol.halo_round_fold(c.curve_id, f.field_id, a, b, g, us[j], u_inv)
+    return lrs, (a, b, g, gz)
+
+
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("n,freeze_log", [(2, 0), (64, 0), (64, 3), (256, 5), (256, 63), (1, 0)])
+def test_halo_argument_capi_matches_oracle(c, n, freeze_log):
+    """Every round's L_j / R_j and the final (halo_a, halo_b, halo_g) against the oracle's composition of the reference's
+    primitives - with the generators folded explicitly all the way (freeze_log 63: never frozen... until 2 are left), frozen
+    from the start (default 2^14 >= n) and frozen part-way (2^3, 2^5)."""
+    pytest.importorskip("torch")
+    from plonky_amd import device as dev
+    dev.init(0)
+    inputs, lrs, states, (fa, fb, fg, fgz) = _run_argument(c, n, freeze_log if freeze_log != 63 else 1, 4000 + n)
+    exp_lrs, (ea, eb, eg, egz) = _oracle_argument(c, inputs)
+    for j, ((lr, z), (elr, ez)) in enumerate(zip(lrs, exp_lrs)):
+        assert list(z) == list(ez) and np.array_equal(lr, elr), "round %d" % j
+    assert np.array_equal(fa, ea) and np.array_equal(fb, eb)
+    assert np.array_equal(fgz, np.asarray(egz, dtype=np.uint8)) and np.array_equal(fg, eg)
+    if n >= 4 and freeze_log in (3, 5):
+        assert not states[0] and states[-1]   # explicit folds first, frozen generators at the end
+
+
+def test_halo_argument_2p16_closed_form():
+    """A whole 2^16 argument through both regimes (explicit folds down to 2^14, frozen below): the final generator is
+    <s, G> with s_i = prod_j u_j^(+-1) by the bits of i, G_i = G0 + i D: [sum s_i] G0 + [sum i s_i] D on Python integers."""
+    pytest.importorskip("torch")
+    from plonky_amd import device as dev, synth
+    from plonky_amd.selfcheck import _add, _mul
+    dev.init(0)
+    c = br.TWEEDLEDEE
+    f = c.scalar
+    log_n = 16
+    n = 1 << log_n
+    G = (c.gx, c.gy)
+    D = br.ec_mul(c, 0x9E3779B9 + 5, G)
+    pt = lambda P: np.array([c.base.mont_limbs(P[0]), c.base.mont_limbs(P[1])], dtype=np.uint64)
+    g = dev.gen_bases_dev(c.curve_id, n, pt(G), pt(D))
+    a = synth.rand_field(f.field_id, 11, n)
+    b = synth.rand_field(f.field_id, 12, n)
+    us = synth.rand_field(f.field_id, 13, log_n)
+    bl = synth.rand_field(f.field_id, 14, 2)
+    arg = dev.HaloArgument(c.curve_id, dev.to_device(a), dev.to_device(b), g, pt(br.ec_mul(c, 77, G)), pt(br.ec_mul(c, 78, G)))
+    u_ints = [f.from_mont(limbs_to_int(r)) for r in us]
+    for j in range(log_n):
+        lr, z = arg.round_lr(bl[0], bl[1])
+        assert not z.any()
+        arg.round_fold(us[j], np.array(f.mont_limbs(pow(u_ints[j], -1, f.p)), dtype=np.uint64))
+    assert arg.frozen
+    fa, fb, fg, fgz = arg.read()
+    arg.free()
+    # s_i by the bits of i (bit log_n - 1 - j selects hi in round j): vectorised over i with Python integers per bit pattern
+    s = np.ones(1, dtype=object)
+    for j in range(log_n):  # build from the top bit down: s = [s * uinv, s * u] concatenated by halves
+        uj, uinv = u_ints[j], pow(u_ints[j], -1, f.p)
+        s = np.concatenate([s * uinv % f.p, s * uj % f.p]) if j == 0 else np.concatenate([np.concatenate([blk * uinv % f.p, blk * uj % f.p]) for blk in np.split(s, 1 << j)])
+    # after the loop s is ordered with round 0's bit as the most significant: index i = sum bit_j 2^(log_n-1-j)
+    sum_s = int(sum(int(v) for v in s) % f.p)
+    sum_is = int(sum(i * int(v) for i, v in enumerate(s)) % f.p)
+    p = c.base.p
+    exp = _add(p, _mul(p, sum_s, G), _mul(p, sum_is, D))
+    assert int(fgz[0]) == 0 and tuple(from_mont_arr(c.base, fg[0])) == exp
+    a_ints = None  # halo_a's closed form is covered at 2^10 above; here the generator path through both regimes is the point

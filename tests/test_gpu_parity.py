@@ -708,3 +708,28 @@ def test_msm_context_shared_by_two_streams():
     # zero-length polynomials of a batch: every output row is written (ntt_padded_dev)
     ev = dev.ntt_padded_dev(0, torch.empty((3, 0, 4), dtype=torch.int64, device="cuda"), 6)
     assert ev.shape == (3, 64, 4) and not dev.to_host(ev).any()
+
+
+@pytest.mark.parametrize("field", [0, 1, 2, 4, 5])
+@pytest.mark.parametrize("log_n", [0, 1, 5, 12])
+def test_fft_precompute_table_matches_oracle(field, log_n):
+    """plk_ntt_precompute_table: the reference's FftPrecomputation::subgroups_rev (fft.rs:28-59), layer by layer against the
+    oracle's restatement of fft_precompute (orc_fft_table_layer)."""
+    import plonky_amd as pa
+    from plonky_amd import api
+    layers = api.fft_precompute_table(field, 1 << log_n)
+    pre = ol.FftPrecomputation(field, 1 << log_n)
+    assert len(layers) == log_n + 1
+    for i, layer in enumerate(layers):
+        assert np.array_equal(layer, pre.layer(i)), (field, log_n, i)
+
+
+def test_fft_precompute_table_2p20_spot_layers():
+    """At the size of the Plonk prover's tables (fft_precompute(8n) at 2^23 is 2 x 256 MiB; here 2^20): first / last layers."""
+    from plonky_amd import api
+    layers = api.fft_precompute_table(0, 1 << 20)
+    pre = ol.FftPrecomputation(0, 1 << 20)
+    for i in (0, 1, 2, 10, 19, 20):
+        assert np.array_equal(layers[i], pre.layer(i)), i
+    with pytest.raises(AssertionError):
+        api.fft_precompute_table(5, 1 << 33)  # beyond VestaBase's 2-adicity (field.rs:430)

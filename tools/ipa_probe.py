@@ -1,8 +1,7 @@
-"""GPU probe: all log2(n) rounds of the inner-product argument of one opening (halo.rs:63-124) on the device -- per round
-the two L / R terms (one table-free MSM each, blinding and inner-product terms folded in), the two scalar folds and the
-generator fold -- timed as a whole (correctness: tests/test_gpu_halo.py, one round against the oracle and a whole argument
-against the closed form of the folded vectors).
-Usage: python tools/ipa_probe.py [log_n]"""
+"""GPU probe: all log2(n) rounds of the inner-product argument of one opening (halo.rs:63-124) through the C ABI (plk_halo_*:
+device-resident vectors, two persistent table-free contexts for the long rounds, frozen generators + tabled MSMs for the
+short ones) -- timed as a whole and round by round (correctness: tests/test_gpu_halo.py).
+Usage: python tools/ipa_probe.py [log_n] [freeze_log ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,27 +9,50 @@ from plonky_amd import device as dev, synth
 from plonky_amd.selfcheck import GENERATORS, _mul
 from plonky_amd.synth import MODULI
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+freezes = [int(v) for v in sys.argv[2:]] or [0]
 CURVE, BASE, SCAL = 0, 0, 1
 p, r = MODULI[BASE], MODULI[SCAL]
 n = 1 << log_n
 G = GENERATORS[CURVE]
 D = _mul(p, 7, G)
 m = lambda f, v: np.array(synth.mont(f, v), dtype=np.uint64)
+dev.init(0)
 A, B = dev.to_device(synth.rand_field(SCAL, 1, n)), dev.to_device(synth.rand_field(SCAL, 2, n))
 g0 = np.stack([m(BASE, G[0]), m(BASE, G[1])]); dd = np.stack([m(BASE, D[0]), m(BASE, D[1])])
 Gd = dev.gen_bases_dev(CURVE, n, g0, dd)
 H, U = _mul(p, 11, G), _mul(p, 13, G)
 Hm, Um = np.stack([m(BASE, H[0]), m(BASE, H[1])]), np.stack([m(BASE, U[0]), m(BASE, U[1])])
 us = [1 + 17 * j for j in range(log_n)]
-def run():
-    a, b, g, gz = A, B, Gd, None
+ums = [(m(SCAL, u), m(SCAL, pow(u, -1, r))) for u in us]
+bl = [(m(SCAL, 100 + j), m(SCAL, 200 + j)) for j in range(log_n)]
+def run(freeze_log, per_round=None):
+    t0 = time.perf_counter()
+    arg = dev.HaloArgument(CURVE, A, B, Gd, Hm, Um, freeze_log=freeze_log)
+    torch.cuda.synchronize()
+    t_begin = time.perf_counter() - t0
     outs = []
     for j in range(log_n):
-        lr, lrz = dev.halo_round_lr_dev(CURVE, a, b, g, Hm, Um, m(SCAL, 100 + j), m(SCAL, 200 + j), g_zero=gz)
-        a, b, g, gz = dev.halo_round_fold_dev(CURVE, a, b, g, m(SCAL, us[j]), m(SCAL, pow(us[j], -1, r)), g_zero=gz)
-        outs.append(lr)
-    return a, b, g, gz, outs
-run(); torch.cuda.synchronize()
-t0 = time.perf_counter(); a, b, g, gz, outs = run(); torch.cuda.synchronize(); t = time.perf_counter() - t0
-print("IPA at n = 2^%d: %d rounds, %.2f ms in all (%.2f ms per round on average); final vectors of length %d"
-      % (log_n, log_n, t * 1e3, t * 1e3 / log_n, a.shape[0]))
+        t1 = time.perf_counter()
+        outs.append(arg.round_lr(*bl[j]))
+        t2 = time.perf_counter()
+        arg.round_fold(*ums[j])
+        if per_round is not None:
+            torch.cuda.synchronize()
+            per_round.append((len(arg) * 2, (t2 - t1) * 1e3, (time.perf_counter() - t2) * 1e3, arg.frozen))
+    fin = arg.read()
+    t = time.perf_counter() - t0
+    arg.free()
+    return t, t_begin, outs, fin
+ref = None
+for fz in freezes:
+    run(fz)
+    t, tb, outs, fin = run(fz)
+    if ref is None:
+        ref = (outs, fin)
+    same = all(np.array_equal(a[0], b[0]) for a, b in zip(outs, ref[0])) and all(np.array_equal(x, y) for x, y in zip(fin, ref[1]))
+    print("IPA at n = 2^%d, freeze_log %d: %d rounds, %.2f ms in all (begin %.2f ms incl. copies / contexts); same results as the first setting: %s"
+          % (log_n, fz, log_n, t * 1e3, tb * 1e3, same), flush=True)
+pr = []
+run(freezes[0], pr)
+for ln, t_lr, t_fold, frozen in pr:
+    print("  round at length %8d: L/R %.3f ms  fold %.3f ms  %s" % (ln, t_lr, t_fold, "frozen generators" if frozen else ""))
