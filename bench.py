@@ -267,19 +267,23 @@ def run(args):
         g0 = np.stack([synth.mont(cv["base_field"], G[0]), synth.mont(cv["base_field"], G[1])])
         dd = np.stack([synth.mont(cv["base_field"], D[0]), synth.mont(cv["base_field"], D[1])])
         if strong:
-            lo, hi = parallel.shard_bounds(n, shard_rank, shard_world)       # this rank's slice of the SAME 2^log_n generators
-            first, n_local = lo, hi - lo
+            # whole vectors per rank + the remainder sharded by base range (parallel.BatchPlan); one MSM: the sharded case alone
+            plan = parallel.BatchPlan(batch, shard_world, shard_rank, n)
+            first, n_local = plan.first, plan.n_local
             s_host = np.stack([synth.rand_field(cv["scalar_field"], SEED_MSM + 0x900 + k, n) for k in range(batch)])
-            s = dev.to_device(np.ascontiguousarray(s_host[:, lo:hi]))
+            s = dev.to_device(plan.local_scalars(s_host))
+            slots, whole = plan.slots, plan.whole
         else:
             first, n_local = rank * n, n                         # this rank's contiguous range of the global N * n MSM
             s_host = synth.rand_field(cv["scalar_field"], SEED_MSM + 1 + rank, n)
             s = dev.to_device(s_host)
+            slots, whole, plan = 1, 0, None
         bases = dev.gen_bases_dev(CURVE, n_local, g0, dd, first=first)
         pre = dev.msm_precompute_dev(CURVE, bases)
-        # the exchange step of the sharded MSM, every buffer allocated once: the MSM writes its partial results straight into
-        # the send record of the ONE all-gather; the ranks' partial points are added on the device
-        ex = parallel.PartialExchange(CURVE, batch, "cuda")
+        # the exchange step of the sharded MSM, every buffer allocated once: the MSM writes its results straight into the send
+        # record of the ONE all-gather; whole vectors are handed over, sharded ones added up, on the device
+        ex = parallel.PartialExchange(CURVE, batch, "cuda", whole_per_rank=whole, world=shard_world if strong else world,
+                                      rank=shard_rank if strong else rank)
         oxy, oz = ex.out_xy, ex.out_zero
         exchange = world > 1 or shard_world > 1
 
@@ -408,7 +412,7 @@ def run(args):
         tm = (time.perf_counter() - t1) / args.steps
         pairs = batch * (n if strong else world * n)
         comp["msm_ms"] = tm * 1e3
-        comp["msm_mpairs_per_s"] = (batch * n_local if args.emulate_rank else pairs) / tm / 1e6
+        comp["msm_mpairs_per_s"] = (plan.pairs_local() if args.emulate_rank else pairs) / tm / 1e6
     if do_msm_c and not strong:
         # commit_polynomials (plonk_util.rs:215-231): the 9 wire polynomials against the same generators, one call
         sb = s.unsqueeze(0).repeat(9, 1, 1).contiguous()
@@ -438,6 +442,58 @@ def run(args):
         comp["msm_parallel_one_shot_ms"] = (time.perf_counter() - t1) / reps * 1e3
         if not args.no_check:
             comp["_os_check"] = bool(torch.equal(oxy9[:1], oxy) and int(oz9[0].item()) == 0)
+    # ---- the drop-in entry points: HOST pointers, PCIe included - what an unmodified plonk.rs gets (plonk_util.rs:169-231) ----
+    if not args.timed_only and not strong and world == 1 and args.log_n >= 16:
+        PCIE_GBS = 56.0  # measured both ways on this platform (profiles/r03_h2d_probe.txt)
+        vp = ctypes.c_void_p
+        host = {}
+        if do_ntt_c:
+            hin = [np.ascontiguousarray(x_host.copy()) for _ in range(9)]
+            hout = [np.zeros_like(x_host) for _ in range(9)]   # touched: no first-touch page faults inside the timing
+            ins = (vp * 9)(*[a.ctypes.data for a in hin])
+            outs = (vp * 9)(*[a.ctypes.data for a in hout])
+            lib.check(L.plk_ntt_batch(NTT_FIELD, args.log_n, 0, 9, ins, outs))
+            reps = max(2, args.steps // 4)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                lib.check(L.plk_ntt_batch(NTT_FIELD, args.log_n, 0, 9, ins, outs))
+            host["host_ntt9_ms"] = (time.perf_counter() - t1) / reps * 1e3
+            host["host_ntt9_pcie_floor_ms"] = 9 * n * 32 / (PCIE_GBS * 1e9) * 1e3   # one direction; the two directions overlap
+            lib.check(L.plk_ntt(NTT_FIELD, args.log_n, 0, vp(hin[0].ctypes.data), vp(hout[1].ctypes.data)))
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                lib.check(L.plk_ntt(NTT_FIELD, args.log_n, 0, vp(hin[0].ctypes.data), vp(hout[1].ctypes.data)))
+            host["host_ntt_ms"] = (time.perf_counter() - t1) / reps * 1e3
+            if not args.no_check:
+                checks_host_ntt = bool(np.array_equal(hout[0], dev.to_host(y)) and np.array_equal(hout[8], hout[0]) and np.array_equal(hout[1], hout[0]))
+                host["_ntt_ok"] = checks_host_ntt
+            del hin, hout
+        if do_msm_c:
+            hs = [np.ascontiguousarray(s_host.copy()) for _ in range(9)]
+            hxy = np.zeros((9, 2, cv["limbs"]), dtype=np.uint64)
+            hz = np.zeros(9, dtype=np.uint8)
+            ptrs = (vp * 9)(*[a.ctypes.data for a in hs])
+            lib.check(L.plk_msm_execute_batch(pre._ctx, 9, ptrs, n, vp(hxy.ctypes.data), vp(hz.ctypes.data)))
+            reps = max(2, args.steps // 4)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                lib.check(L.plk_msm_execute_batch(pre._ctx, 9, ptrs, n, vp(hxy.ctypes.data), vp(hz.ctypes.data)))
+            host["host_commit9_ms"] = (time.perf_counter() - t1) / reps * 1e3
+            host["host_commit9_pcie_floor_ms"] = 9 * n * 32 / (PCIE_GBS * 1e9) * 1e3
+            if "msm_batch9_ms" in comp:
+                host["host_commit9_vs_max_pcie_device"] = host["host_commit9_ms"] / max(host["host_commit9_pcie_floor_ms"], comp["msm_batch9_ms"])
+            lib.check(L.plk_msm_execute(pre._ctx, vp(hs[0].ctypes.data), n, vp(hxy.ctypes.data), vp(hz.ctypes.data)))
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                lib.check(L.plk_msm_execute(pre._ctx, vp(hs[0].ctypes.data), n, vp(hxy.ctypes.data), vp(hz.ctypes.data)))
+            host["host_msm_ms"] = (time.perf_counter() - t1) / reps * 1e3
+            if not args.no_check:
+                host["_msm_ok"] = bool(np.array_equal(hxy[0].view(np.int64), oxy[0].cpu().numpy()) and not hz.any())
+            del hs
+        if "host_ntt9_ms" in host and "ntt_batch9_ms" in comp:
+            host["host_ntt9_vs_max_pcie_device"] = host["host_ntt9_ms"] / max(host["host_ntt9_pcie_floor_ms"], comp["ntt_batch9_ms"])
+        host["note"] = "host-pointer C ABI calls on pageable numpy buffers, one caller thread; pcie_floor = bytes one way / 56 GB/s"
+        comp["host_pointer"] = host
     if do_msm:
         comp["msm_window_bits"] = pre.window
         comp["msm_stage_ms"] = dict(zip(STAGES, [round(v, 4) for v in msm_stage_ms]))
@@ -450,17 +506,23 @@ def run(args):
             checks["ntt_roundtrip_bit_exact"] = bool(np.array_equal(back, x_host))
             if "_q_check" in comp:
                 checks["divide_by_z_h_identity"] = comp.pop("_q_check")
+            if "_ntt_ok" in comp.get("host_pointer", {}):
+                checks["host_pointer_ntt_equals_device"] = comp["host_pointer"].pop("_ntt_ok")
         if do_msm:
             dev.msm_execute_dev(pre, s, oxy, oz)
             if exchange:
                 ex.gather()
                 gxy, gz = ex.combine()
             torch.cuda.synchronize()
-            got = dev.to_host(oxy).reshape(batch, 2, cv["limbs"])
+            got = dev.to_host(oxy).reshape(slots, 2, cv["limbs"])
             ok = int(oz.sum().item()) == 0
-            for k in range(batch):
-                sk = s_host[k, first:first + n_local] if strong else s_host
-                exp = closed_form_msm(CURVE, sk, G, D, first=first)   # this rank's partial result
+            for k in range(slots):
+                if not strong:
+                    exp = closed_form_msm(CURVE, s_host, G, D, first=first)          # this rank's range of the global MSM
+                elif k < whole:
+                    exp = closed_form_msm(CURVE, s_host[plan.own[k]], G, D, first=0)  # a whole vector of this rank
+                else:
+                    exp = closed_form_msm(CURVE, s_host[plan.rem[k - whole], plan.lo:plan.hi], G, D, first=plan.lo)  # its slice of a sharded one
                 gotp = (synth.from_mont(cv["base_field"], got[k][0]), synth.from_mont(cv["base_field"], got[k][1]))
                 ok = ok and gotp == exp
             checks["msm_closed_form_bit_exact"] = bool(ok)
@@ -468,22 +530,28 @@ def run(args):
                 checks["msm_batch9_equals_single"] = comp.pop("_b9_check")
             if "_os_check" in comp:
                 checks["msm_one_shot_equals_tabled"] = comp.pop("_os_check")
+            if "_msm_ok" in comp.get("host_pointer", {}):
+                checks["host_pointer_msm_equals_device"] = comp["host_pointer"].pop("_msm_ok")
             if world > 1:
-                # the device sum of the gathered partial points, against the host-pointer sum and (strong scaling) the
-                # closed form of the WHOLE problem: the vector against all 2^log_n generators
+                # the device results of the exchange against the host-pointer point sum over the gathered records and (strong
+                # scaling) the closed form of the WHOLE problem: every vector against all 2^log_n generators
                 hx, hz = ex.partials()
                 hx, hz = dev.to_host(hx), hz.cpu().numpy()
                 tot_dev, tz_dev = dev.to_host(gxy), gz.cpu().numpy()
                 ok = True
-                for k in range(batch):
-                    tot, tz = api.curve_sum_affine(CURVE, hx[:, k], hz[:, k])
-                    ok = ok and tz == 0 and int(tz_dev[k]) == 0 and np.array_equal(tot, tot_dev[k])
+                for v in range(batch):
+                    if v < whole * world:
+                        tot, tz = hx[v % world, v // world], int(hz[v % world, v // world])
+                    else:
+                        sl = whole + (v - whole * world)
+                        tot, tz = api.curve_sum_affine(CURVE, hx[:, sl], hz[:, sl])
+                    ok = ok and tz == 0 and int(tz_dev[v]) == 0 and np.array_equal(tot, tot_dev[v])
                     if strong:
-                        exp = closed_form_msm(CURVE, s_host[k], G, D, first=0)
+                        exp = closed_form_msm(CURVE, s_host[v], G, D, first=0)
                         ok = ok and (synth.from_mont(cv["base_field"], tot[0]), synth.from_mont(cv["base_field"], tot[1])) == exp
                 checks["msm_global_sum_closed_form" if strong else "msm_global_sum_is_point"] = bool(ok)
 
-    units_per_step = (n if do_ntt else 0) + ((batch * (n_local if args.emulate_rank else n)) if do_msm else 0)
+    units_per_step = (n if do_ntt else 0) + (((plan.pairs_local() if args.emulate_rank else batch * n)) if do_msm else 0)
     value = (1 if strong else world) * units_per_step * args.steps / elapsed / 1e6
 
     # ---- rooflines: every kernel entry carries the integer-ALU figure (what binds these kernels) and the HBM figure ----
@@ -536,10 +604,11 @@ def run(args):
             "note": "VALU-bound (DESIGN.md section 4): achieved counts the algorithmic n/2 log n multiplications; the kernel executes more (inter-pass twiddles)"})
     if do_msm:
         acc_ms = msm_stage_ms[3]
-        alg_bytes = float(cv["pair_bytes"]) * n_local   # affine base + 32 B scalar per pair, one MSM
+        n_acc = (plan.hi - plan.lo) if (strong and plan.whole == 0) else n_local   # pairs of the MSM the stage times belong to (slot 0)
+        alg_bytes = float(cv["pair_bytes"]) * n_acc   # affine base + 32 B scalar per pair, one MSM
         ach = alg_bytes / (acc_ms * 1e-3) / 1e9
         windows = (cv["scalar_bits"] + 1 + pre.window - 1) // pre.window
-        adds = n_local * windows
+        adds = n_acc * windows
         gmm = adds * 10.0 / (acc_ms * 1e-3) / 1e9        # a mixed XYZZ addition = 8 M + 2 S
         tr, src = traffic_of("k_msm_accumulate")
         rooflines["msm_accumulate"] = valu_entry("k_msm_accumulate", gmm, gmm, acc_ms, {
@@ -564,7 +633,7 @@ def run(args):
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": wl, "log_n": args.log_n, "curve": args.curve,
-                   "sharding": ("generators sharded by base range + one packed all-gather of partial points + device point sum" if strong else
+                   "sharding": ("whole vectors per rank, the remainder sharded by base range; one packed all-gather + device point sum" if strong else
                                 "independent NTTs; MSM sharded by base range + one packed all-gather of partial points + device point sum") if world > 1 else "single GPU",
                    "backend": ("gloo (ranks share GPU 0)" if gloo else "nccl (RCCL)") if world > 1 else None,
                    "seeds": {"ntt": SEED_NTT, "msm": SEED_MSM}, "kernel_source_sha": src_hash},
@@ -577,9 +646,10 @@ def run(args):
         # one rank of the N-rank problem alone on one GPU: every rank does the same amount of work, the exchange is one
         # all-gather of batch x (2L + 1) words per rank (latency-bound: ~20-40 us over xGMI), so the N-GPU step time is this
         # rank's time plus that, and the predicted whole-job rate is the global unit count over it
-        result["emulated_rank"] = {"rank": shard_rank, "of": shard_world, "n_local": n_local,
+        result["emulated_rank"] = {"rank": shard_rank, "of": shard_world, "n_local": n_local, "whole_vectors": plan.whole, "sharded_vectors": plan.sharded,
+                                   "pairs_local": plan.pairs_local(),
                                    "predicted_global_units_per_s_M": batch * n * args.steps / elapsed / 1e6,
-                                   "note": "value / ms_per_step are THIS rank's shard (n_local generators, all %d vectors) incl. the local copy standing in for the all-gather and the point sum" % batch}
+                                   "note": "value / ms_per_step are THIS rank's share (its whole vectors + its base range of the sharded ones) incl. the local copy standing in for the all-gather and the point sum"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.emulate_rank:
         result["cpu_baseline"] = cpu_baseline(args.workload, cv)
     if rank == 0:

@@ -198,16 +198,19 @@ int plk_msm(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_z
 int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint8_t* pts_zero, uint64_t* out_xy, uint8_t* out_zero);
 
 /* ---- multi-GPU exchange of partial results (no counterpart in the single-process reference) ----------- */
-/* The generators are sharded by contiguous base range, one process per GPU; each rank reduces its slice of every scalar
- * vector (plk_msm_execute_dev over its own context) and the ranks exchange their partial points with ONE all-gather.  The
- * exchange record of a rank is plk_msm_partials_bytes(curve, batch) bytes: batch * 2L limbs (exactly what
- * plk_msm_execute_dev writes at d_out_xy = record), then batch identity flags (d_out_zero = record + batch * 2L * 8),
- * padded to a multiple of 16 bytes - so the MSM writes straight into the send buffer of the collective. */
-size_t plk_msm_partials_bytes(int curve, unsigned batch);
-/* d_gathered: `world` records back to back (the all-gather output).  d_out_xy / d_out_zero: the `batch` sums of the
- * ranks' partial points (point addition is not an RCCL reduction op), unique affine form.  Asynchronous on `stream`. */
-int plk_msm_combine_partials_dev(int curve, unsigned world, unsigned batch, const void* d_gathered, void* d_out_xy, void* d_out_zero,
-                                 void* stream);
+/* One process per GPU.  A batch of scalar vectors against the same generators (commit_polynomials, plonk_util.rs:215-231) is
+ * dealt out as WHOLE vectors, `whole_per_rank` = floor(batch / world) to every rank (vector v belongs to rank v mod world, its
+ * slot there is v / world), and the remaining batch mod world vectors are SHARDED by contiguous base range: every rank reduces
+ * its slice of them.  A single MSM (batch 1) is the sharded case alone.  The ranks exchange their results with ONE all-gather.
+ * The record of a rank holds `slots` = whole_per_rank + (batch - whole_per_rank * world) points: slots * 2L limbs (exactly what
+ * plk_msm_execute_dev writes at d_out_xy = record), then slots identity flags (d_out_zero = record + slots * 2L * 8), padded to
+ * a multiple of 16 bytes = plk_msm_partials_bytes(curve, slots) - the MSM writes straight into the collective's send buffer. */
+size_t plk_msm_partials_bytes(int curve, unsigned slots);
+/* d_gathered: `world` records back to back (the all-gather output).  d_out_xy / d_out_zero: the `batch` results in vector
+ * order, unique affine form: a whole vector is copied from its owner's slot, a sharded one is the sum of the ranks' partial
+ * points (point addition is not an RCCL reduction op).  whole_per_rank = 0: every vector is sharded.  Asynchronous on `stream`. */
+int plk_msm_combine_partials_dev(int curve, unsigned world, unsigned batch, unsigned whole_per_rank, const void* d_gathered, void* d_out_xy,
+                                 void* d_out_zero, void* stream);
 
 /* ---- the reference's own table contents  (curve_msm.rs:16-52) ---------------------------------- */
 /* MsmPrecomputation { powers_per_generator, w } is plain, serde-visible data in the reference (embedded in Circuit,

@@ -24,14 +24,19 @@ void halo_delete(plk_halo_ctx* c);
 
 int field_op_impl(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count);
 int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, unsigned flags, hipStream_t stream,
-                            plk_msm_ctx** out_ctx, const void* d_extra = nullptr, size_t n_extra = 0);
-int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream);
+                            plk_msm_ctx** out_ctx, const void* d_extra = nullptr, size_t n_extra = 0, const size_t* also_n = nullptr,
+                            int also_count = 0);
+int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
+                         hipEvent_t* ready = nullptr);
+int msm_reserve_workspaces_impl(plk_msm_ctx* ctx, unsigned count, hipStream_t stream);
 int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void* d_zero, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_gen_bases_dev_impl(int curve, size_t n, uint64_t first, const void* d_g0d, void* d_out, hipStream_t stream);
 size_t msm_partials_bytes(int curve, unsigned batch);
-int msm_combine_partials_dev_impl(int curve, unsigned world, unsigned batch, const void* d_gathered, void* d_out_xy, void* d_out_zero, hipStream_t stream);
+int msm_combine_partials_dev_impl(int curve, unsigned world, unsigned batch, unsigned whole_per_rank, const void* d_gathered, void* d_out_xy, void* d_out_zero,
+                                  hipStream_t stream);
 int curve_fold_pairs_dev_impl(int curve, size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero,
-                              const uint64_t* a_mont, const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream);
+                              const uint64_t* a_mont, const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream,
+                              const void* d_scalars = nullptr, int plus_lo = 0);
 int msm_table_digits(int curve, unsigned w);
 int msm_reference_table_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned w, void* d_out_xy, void* d_out_zero,
                                  hipStream_t stream);
@@ -144,19 +149,42 @@ void scratch_clear() {
 
 // ---- host-pointer entry points: one lane per calling thread ----
 // The reference calls the hot path from Rayon workers (plonk_util.rs:173-189: nine transforms / commitments at once).  Every
-// host thread that enters through a host-pointer entry point owns a lane: a non-blocking stream, and a pinned staging
-// buffer through which its inputs and outputs cross PCIe with asynchronous copies; device buffers come from the scratch
-// pool.  Nothing goes through the null stream or through hipMalloc / hipFree (both synchronise the whole device), so
-// concurrent callers overlap on the GPU instead of queueing behind each other.
-constexpr size_t PIN_CAP = (size_t)256 << 20;  // larger transfers go straight from / to the caller's pageable memory
+// host thread that enters through a host-pointer entry point owns a lane: non-blocking streams of its own, a small pinned
+// staging buffer, device buffers from the scratch pool.  Nothing goes through the null stream or through hipMalloc / hipFree
+// (both synchronise the whole device), so concurrent callers overlap on the GPU instead of queueing behind each other.
+//
+// The caller's buffers are pageable.  Measured on the MI355X box (profiles/r03_h2d_probe.txt): hipMemcpyAsync straight from /
+// to pageable memory runs at the pinned rate (56.5 GB/s both ways) where a staging memcpy + DMA - round 2's path - reaches
+// 21.9 GB/s; it blocks the calling thread, though.  Registered with hipHostRegister (57 GB/s INCLUDING registration and
+// deregistration) the copies are asynchronous, so ONE caller thread keeps several streams busy: the copy of scalar vector
+// k + 1 runs under the reduction of vector k, the upload of transform k + 1 under the download of transform k.  So: large
+// buffers are registered for the duration of the call and copied directly; only small pieces (results, flags) are staged.
+constexpr size_t PIN_CAP = (size_t)4 << 20;        // the staging buffer serves pieces up to this size
+constexpr size_t DIRECT_MIN = (size_t)64 << 10;    // larger pieces are copied straight from / to the caller's memory
+constexpr int LANE_AUX = 2;
 struct HostLane {
     hipStream_t stream = nullptr;
+    hipStream_t aux[LANE_AUX] = {nullptr, nullptr};  // second / third stream of a call that pipelines copies and kernels
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_ready;                 // per-vector "copy done" events of a batched MSM
     int device = -1;
     uint8_t* pin = nullptr;
     size_t pin_bytes = 0, pin_used = 0;
+    void drop_streams() {
+        for (hipEvent_t e : ev_ready) (void)hipEventDestroy(e);
+        ev_ready.clear();
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        ev_fork = nullptr;
+        for (auto& a : aux) {
+            if (a) (void)hipStreamDestroy(a);
+            a = nullptr;
+        }
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
     ~HostLane() {
         if (pin) (void)hipHostFree(pin);
-        if (stream) (void)hipStreamDestroy(stream);
+        drop_streams();
     }
 };
 static thread_local HostLane t_lane;
@@ -166,10 +194,7 @@ static int lane_get(HostLane*& out) {
     int dev = 0;
     PLK_HIP_TRY(hipGetDevice(&dev));
     HostLane& l = t_lane;
-    if (l.stream && l.device != dev) {
-        (void)hipStreamDestroy(l.stream);
-        l.stream = nullptr;
-    }
+    if (l.stream && l.device != dev) l.drop_streams();
     if (!l.stream) {
         PLK_HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         l.device = dev;
@@ -179,13 +204,53 @@ static int lane_get(HostLane*& out) {
     out = &l;
     return PLK_OK;
 }
+// the lane's extra streams, ordered after everything enqueued on the main one so far
+static int lane_fork(HostLane& l) {
+    if (!l.ev_fork) PLK_HIP_TRY(hipEventCreateWithFlags(&l.ev_fork, hipEventDisableTiming));
+    PLK_HIP_TRY(hipEventRecord(l.ev_fork, l.stream));
+    for (auto& a : l.aux) {
+        if (!a) PLK_HIP_TRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        PLK_HIP_TRY(hipStreamWaitEvent(a, l.ev_fork, 0));
+    }
+    return PLK_OK;
+}
+static int lane_join(HostLane& l) {
+    hipError_t first = hipSuccess;
+    for (auto& a : l.aux)
+        if (a) {
+            const hipError_t e = hipStreamSynchronize(a);
+            if (first == hipSuccess) first = e;
+        }
+    const hipError_t e = hipStreamSynchronize(l.stream);
+    if (first == hipSuccess) first = e;
+    l.pin_used = 0;
+    PLK_HIP_TRY(first);
+    return PLK_OK;
+}
+// a caller buffer registered for the duration of a call: copies from / to it are asynchronous.  Registration can fail (the
+// range is registered already, exotic memory): the copies then simply block the calling thread - same result.
+struct HostPin {
+    void* p = nullptr;
+    HostPin() = default;
+    HostPin(const HostPin&) = delete;
+    HostPin& operator=(const HostPin&) = delete;
+    HostPin(HostPin&& o) noexcept : p(o.p) { o.p = nullptr; }
+    void pin(const void* ptr, size_t bytes) {
+        if (!ptr || bytes < ((size_t)1 << 20)) return;
+        if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(ptr);
+        else (void)hipGetLastError();
+    }
+    ~HostPin() {
+        if (p) (void)hipHostUnregister(p);
+    }
+};
 // a piece of the lane's pinned buffer, valid until the lane is synchronised; nullptr when it does not fit
 static uint8_t* lane_stage(HostLane& l, size_t bytes) {
     const size_t need = (l.pin_used + bytes + 255) & ~(size_t)255;
     if (need > PIN_CAP) return nullptr;
     if (need > l.pin_bytes) {
         if (l.pin_used) return nullptr;  // pieces handed out earlier in this call are still in flight
-        size_t want = l.pin_bytes ? l.pin_bytes : ((size_t)4 << 20);
+        size_t want = l.pin_bytes ? l.pin_bytes : ((size_t)256 << 10);
         while (want < need) want *= 2;
         if (l.pin) (void)hipHostFree(l.pin);
         l.pin = nullptr;
@@ -200,13 +265,15 @@ static uint8_t* lane_stage(HostLane& l, size_t bytes) {
     l.pin_used = need;
     return p;
 }
-static int lane_h2d(HostLane& l, void* d, const void* h, size_t bytes) {
+static int lane_h2d(HostLane& l, void* d, const void* h, size_t bytes, hipStream_t st = nullptr) {
     if (!bytes) return PLK_OK;
-    if (uint8_t* st = lane_stage(l, bytes)) {
-        memcpy(st, h, bytes);
-        PLK_HIP_TRY(hipMemcpyAsync(d, st, bytes, hipMemcpyHostToDevice, l.stream));
+    if (!st) st = l.stream;
+    uint8_t* stg = bytes < DIRECT_MIN ? lane_stage(l, bytes) : nullptr;
+    if (stg) {
+        memcpy(stg, h, bytes);
+        PLK_HIP_TRY(hipMemcpyAsync(d, stg, bytes, hipMemcpyHostToDevice, st));
     } else {
-        PLK_HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, l.stream));  // pageable: the runtime stages it, in stream order
+        PLK_HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st));  // pageable or registered: the pinned rate either way
     }
     return PLK_OK;
 }
@@ -216,13 +283,15 @@ struct LaneOut {
     void* dst;
     size_t bytes;
 };
-static int lane_d2h(HostLane& l, std::vector<LaneOut>& outs, void* h, const void* d, size_t bytes) {
+static int lane_d2h(HostLane& l, std::vector<LaneOut>& outs, void* h, const void* d, size_t bytes, hipStream_t st = nullptr) {
     if (!bytes) return PLK_OK;
-    if (uint8_t* st = lane_stage(l, bytes)) {
-        PLK_HIP_TRY(hipMemcpyAsync(st, d, bytes, hipMemcpyDeviceToHost, l.stream));
-        outs.push_back({st, h, bytes});
+    if (!st) st = l.stream;
+    uint8_t* stg = bytes < DIRECT_MIN ? lane_stage(l, bytes) : nullptr;
+    if (stg) {
+        PLK_HIP_TRY(hipMemcpyAsync(stg, d, bytes, hipMemcpyDeviceToHost, st));
+        outs.push_back({stg, h, bytes});
     } else {
-        PLK_HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, l.stream));
+        PLK_HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, st));
     }
     return PLK_OK;
 }
@@ -237,6 +306,9 @@ static int lane_finish(HostLane& l, std::vector<LaneOut>& outs) {
 struct LaneBuf {
     void* p = nullptr;
     hipStream_t s = nullptr;
+    LaneBuf() = default;
+    LaneBuf(const LaneBuf&) = delete;
+    LaneBuf& operator=(const LaneBuf&) = delete;
     ~LaneBuf() {
         if (p) scratch_release(p, s);
     }
@@ -244,6 +316,40 @@ struct LaneBuf {
         s = stream;
         p = scratch_acquire(bytes ? bytes : 16, stream);
         return p ? PLK_OK : PLK_ERR_OOM;
+    }
+};
+// One host-pointer call on the calling thread's lane: device buffers, uploads, downloads, one synchronisation at the end.
+struct LaneCall {
+    HostLane* l = nullptr;
+    std::vector<LaneOut> outs;
+    std::vector<std::unique_ptr<LaneBuf>> bufs;
+    int begin() { return lane_get(l); }
+    hipStream_t stream() const { return l->stream; }
+    int tmp(void*& d, size_t bytes) {
+        bufs.emplace_back(new LaneBuf());
+        PLK_TRY(bufs.back()->alloc(bytes, l->stream));
+        d = bufs.back()->p;
+        return PLK_OK;
+    }
+    int in(void*& d, const void* h, size_t bytes) {
+        PLK_TRY(tmp(d, bytes));
+        return lane_h2d(*l, d, h, bytes);
+    }
+    int out(void* h, const void* d, size_t bytes) { return lane_d2h(*l, outs, h, d, bytes); }
+    int sync() {  // results of the kernels so far are needed on the host before the call goes on
+        PLK_TRY(lane_finish(*l, outs));
+        return PLK_OK;
+    }
+    bool done = false;
+    int finish() {
+        done = true;
+        return lane_finish(*l, outs);
+    }
+    ~LaneCall() {
+        if (l && !done) {  // an early return: nothing may stay in flight over the staging buffer or the caller's memory
+            (void)hipStreamSynchronize(l->stream);
+            l->pin_used = 0;
+        }
     }
 };
 
@@ -377,22 +483,41 @@ int plk_ntt_batch(int field, unsigned log_n, int inverse, unsigned batch, const 
     if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
     if (batch == 0) return PLK_OK;
     if (!in || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    for (unsigned b = 0; b < batch; ++b)
+        if (!in[b] || !out[b]) return set_error(PLK_ERR_INVALID_ARG, "null pointer in batch slot %u", b);
     HostLane* l = nullptr;
     PLK_TRY(lane_get(l));
     const size_t bytes = ((size_t)1 << log_n) * 32;
     LaneBuf buf;
     PLK_TRY(buf.alloc(bytes * batch, l->stream));
-    for (unsigned b = 0; b < batch; ++b) {
-        if (!in[b] || !out[b]) return set_error(PLK_ERR_INVALID_ARG, "null pointer in batch slot %u", b);
-        PLK_TRY(lane_h2d(*l, (uint8_t*)buf.p + b * bytes, in[b], bytes));
+    if (batch == 1 || bytes < ((size_t)1 << 20)) {
+        // one transform, or small ones: upload, one batched launch, download
+        for (unsigned b = 0; b < batch; ++b) PLK_TRY(lane_h2d(*l, (uint8_t*)buf.p + b * bytes, in[b], bytes));
+        int rc = ntt_dev_impl(field, log_n, inverse, batch, buf.p, buf.p, l->stream);
+        std::vector<LaneOut> outs;
+        for (unsigned b = 0; b < batch && rc == PLK_OK; ++b) rc = lane_d2h(*l, outs, out[b], (uint8_t*)buf.p + b * bytes, bytes);
+        const int rf = lane_finish(*l, outs);
+        return rc != PLK_OK ? rc : rf;
     }
-    PLK_TRY(ntt_dev_impl(field, log_n, inverse, batch, buf.p, buf.p, l->stream));
-    // the inputs' staging pieces are free again once the transform has consumed them: the outputs reuse the same pinned memory
-    std::vector<LaneOut> outs;
-    PLK_HIP_TRY(hipStreamSynchronize(l->stream));
-    l->pin_used = 0;
-    for (unsigned b = 0; b < batch; ++b) PLK_TRY(lane_d2h(*l, outs, out[b], (uint8_t*)buf.p + b * bytes, bytes));
-    return lane_finish(*l, outs);
+    // several large transforms (the nine wire polynomials, plonk_util.rs:169-190): PCIe is the long pole (2 x 32 MiB per 2^20
+    // transform against 0.13 ms of kernels), so transform b runs upload -> kernels -> download on stream b mod 3: the upload of
+    // the next transform and the download of the previous one share the link's two directions
+    std::vector<HostPin> pins(2 * (size_t)batch);
+    for (unsigned b = 0; b < batch; ++b) {
+        pins[2 * b].pin(in[b], bytes);
+        if ((const void*)out[b] != (const void*)in[b]) pins[2 * b + 1].pin(out[b], bytes);
+    }
+    int rc = lane_fork(*l);
+    for (unsigned b = 0; b < batch && rc == PLK_OK; ++b) {
+        hipStream_t st = b % 3 == 0 ? l->stream : l->aux[b % 3 - 1];
+        uint8_t* d = (uint8_t*)buf.p + b * bytes;
+        if (hipMemcpyAsync(d, in[b], bytes, hipMemcpyHostToDevice, st) != hipSuccess) rc = set_error(PLK_ERR_HIP, "upload of transform %u failed", b);
+        if (rc == PLK_OK) rc = ntt_dev_impl(field, log_n, inverse, 1, d, d, st);
+        if (rc == PLK_OK && hipMemcpyAsync(out[b], d, bytes, hipMemcpyDeviceToHost, st) != hipSuccess)
+            rc = set_error(PLK_ERR_HIP, "download of transform %u failed", b);
+    }
+    const int rj = lane_join(*l);  // before the registrations and the device buffer go
+    return rc != PLK_OK ? rc : rj;
 }
 
 int plk_ntt(int field, unsigned log_n, int inverse, const uint64_t* in, uint64_t* out) {
@@ -417,20 +542,25 @@ int plk_ntt_padded_batch(int field, unsigned log_n, unsigned batch, const uint64
         if ((n_in[b] && !in[b]) || !out[b]) return set_error(PLK_ERR_INVALID_ARG, "null pointer in batch slot %u", b);
         if (n_in[b] > max_in) max_in = n_in[b];
     }
-    PLK_TRY(ensure_device());
-    DevBuf din, dout;
-    PLK_TRY(din.alloc(max_in * 32 * batch));
-    PLK_TRY(dout.alloc(n * 32 * batch));
+    LaneCall c;
+    PLK_TRY(c.begin());
+    void *din = nullptr, *dout = nullptr;
+    PLK_TRY(c.tmp(din, max_in * 32 * batch));
+    PLK_TRY(c.tmp(dout, n * 32 * batch));
+    std::vector<HostPin> pins(2 * (size_t)batch);
     for (unsigned b = 0; b < batch; ++b) {
-        uint8_t* slot = (uint8_t*)din.p + (size_t)b * max_in * 32;
-        if (n_in[b]) PLK_HIP_TRY(hipMemcpy(slot, in[b], n_in[b] * 32, hipMemcpyHostToDevice));
+        uint8_t* slot = (uint8_t*)din + (size_t)b * max_in * 32;
+        pins[2 * b].pin(in[b], n_in[b] * 32);
+        PLK_TRY(lane_h2d(*c.l, slot, in[b], n_in[b] * 32));
         // shorter polynomials of the batch: F::ZERO is all-zero limbs in Montgomery form too
-        if (n_in[b] < max_in) PLK_HIP_TRY(hipMemset(slot + n_in[b] * 32, 0, (max_in - n_in[b]) * 32));
+        if (n_in[b] < max_in) PLK_HIP_TRY(hipMemsetAsync(slot + n_in[b] * 32, 0, (max_in - n_in[b]) * 32, c.stream()));
     }
-    PLK_TRY(ntt_padded_dev_impl(field, log_n, batch, din.p, max_in, max_in, dout.p, nullptr));
-    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
-    for (unsigned b = 0; b < batch; ++b) PLK_HIP_TRY(hipMemcpy(out[b], (uint8_t*)dout.p + (size_t)b * n * 32, n * 32, hipMemcpyDeviceToHost));
-    return PLK_OK;
+    PLK_TRY(ntt_padded_dev_impl(field, log_n, batch, din, max_in, max_in, dout, c.stream()));
+    for (unsigned b = 0; b < batch; ++b) {
+        pins[2 * b + 1].pin(out[b], n * 32);
+        PLK_TRY(c.out(out[b], (uint8_t*)dout + (size_t)b * n * 32, n * 32));
+    }
+    return c.finish();
 }
 
 int plk_ntt_padded(int field, unsigned log_n, const uint64_t* in, size_t n_in, uint64_t* out) {
@@ -452,20 +582,19 @@ int plk_poly_divide_by_z_h_dev(int field, const void* d_coeffs, size_t len, size
 int plk_poly_divide_by_z_h(int field, const uint64_t* coeffs, size_t len, size_t n, uint64_t* out, size_t out_cap, size_t* out_len) {
     if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
     if (!out_len || (len && !coeffs)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    PLK_TRY(ensure_device());
     const size_t cap = len > pow2_ceil_sz(len) ? len : pow2_ceil_sz(len);
-    DevBuf din, dout;
-    PLK_TRY(din.alloc(len * 32));
-    PLK_TRY(dout.alloc(cap * 32));
-    if (len) PLK_HIP_TRY(hipMemcpy(din.p, coeffs, len * 32, hipMemcpyHostToDevice));
+    LaneCall c;
+    PLK_TRY(c.begin());
+    void *din = nullptr, *dout = nullptr;
+    PLK_TRY(c.in(din, coeffs, len * 32));
+    PLK_TRY(c.tmp(dout, cap * 32));
     size_t got = 0;
-    PLK_TRY(poly_divide_by_z_h_dev_impl(field, din.p, len, n, dout.p, cap, &got, nullptr));
-    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
+    PLK_TRY(poly_divide_by_z_h_dev_impl(field, din, len, n, dout, cap, &got, c.stream()));  // synchronises the stream once (the degree)
     if (got > out_cap) return set_error(PLK_ERR_INVALID_ARG, "output capacity %zu < result length %zu", out_cap, got);
     if (got && !out) return set_error(PLK_ERR_INVALID_ARG, "null output");
-    if (got) PLK_HIP_TRY(hipMemcpy(out, dout.p, got * 32, hipMemcpyDeviceToHost));
+    PLK_TRY(c.out(out, dout, got * 32));
     *out_len = got;
-    return PLK_OK;
+    return c.finish();
 }
 
 int plk_poly_mul_dev(int field, const void* d_a, size_t la, const void* d_b, size_t lb, void* d_out, size_t out_cap, size_t* out_len,
@@ -476,22 +605,20 @@ int plk_poly_mul_dev(int field, const void* d_a, size_t la, const void* d_b, siz
 int plk_poly_mul(int field, const uint64_t* a, size_t la, const uint64_t* b, size_t lb, uint64_t* out, size_t out_cap, size_t* out_len) {
     if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
     if (!out_len || (la && !a) || (lb && !b)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    PLK_TRY(ensure_device());
     const size_t cap = pow2_ceil_sz(la + lb);
-    DevBuf da, db, dout;
-    PLK_TRY(da.alloc(la * 32));
-    PLK_TRY(db.alloc(lb * 32));
-    PLK_TRY(dout.alloc(cap * 32));
-    if (la) PLK_HIP_TRY(hipMemcpy(da.p, a, la * 32, hipMemcpyHostToDevice));
-    if (lb) PLK_HIP_TRY(hipMemcpy(db.p, b, lb * 32, hipMemcpyHostToDevice));
+    LaneCall c;
+    PLK_TRY(c.begin());
+    void *da = nullptr, *db = nullptr, *dout = nullptr;
+    PLK_TRY(c.in(da, a, la * 32));
+    PLK_TRY(c.in(db, b, lb * 32));
+    PLK_TRY(c.tmp(dout, cap * 32));
     size_t got = 0;
-    PLK_TRY(poly_mul_dev_impl(field, da.p, la, db.p, lb, dout.p, cap, &got, nullptr));
-    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
+    PLK_TRY(poly_mul_dev_impl(field, da, la, db, lb, dout, cap, &got, c.stream()));
     if (got > out_cap) return set_error(PLK_ERR_INVALID_ARG, "output capacity %zu < result length %zu", out_cap, got);
     if (got && !out) return set_error(PLK_ERR_INVALID_ARG, "null output");
-    if (got) PLK_HIP_TRY(hipMemcpy(out, dout.p, got * 32, hipMemcpyDeviceToHost));
+    PLK_TRY(c.out(out, dout, got * 32));
     *out_len = got;
-    return PLK_OK;
+    return c.finish();
 }
 
 // ---- the Plonk quotient numerator ----
@@ -507,43 +634,41 @@ int plk_plonk_vanishing_points(int field, unsigned log_degree, const uint64_t* c
     if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d is not a circuit scalar field", field);
     if (log_degree + 3 > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_degree %u too large", log_degree);
     if (!constants_8n || !wires_8n || !s_sigma_8n || !plonk_z_8n || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    PLK_TRY(ensure_device());
     const size_t row = ((size_t)8 << log_degree) * 32;
-    DevBuf dc, dw, ds, dz, dout;
-    PLK_TRY(dc.alloc(6 * row));
-    PLK_TRY(dw.alloc(9 * row));
-    PLK_TRY(ds.alloc(6 * row));
-    PLK_TRY(dz.alloc(row));
-    PLK_TRY(dout.alloc(row));
-    PLK_HIP_TRY(hipMemcpy(dc.p, constants_8n, 6 * row, hipMemcpyHostToDevice));
-    PLK_HIP_TRY(hipMemcpy(dw.p, wires_8n, 9 * row, hipMemcpyHostToDevice));
-    PLK_HIP_TRY(hipMemcpy(ds.p, s_sigma_8n, 6 * row, hipMemcpyHostToDevice));
-    PLK_HIP_TRY(hipMemcpy(dz.p, plonk_z_8n, row, hipMemcpyHostToDevice));
-    PLK_TRY(plonk_vanishing_points_dev_impl(field, log_degree, dc.p, dw.p, ds.p, dz.p, k_is, alpha, beta, gamma, inner_zeta, inner_a, dout.p, nullptr));
-    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
-    PLK_HIP_TRY(hipMemcpy(out, dout.p, row, hipMemcpyDeviceToHost));
-    return PLK_OK;
+    LaneCall c;
+    PLK_TRY(c.begin());
+    HostPin pc, pw, ps, pz, po;
+    pc.pin(constants_8n, 6 * row);
+    pw.pin(wires_8n, 9 * row);
+    ps.pin(s_sigma_8n, 6 * row);
+    pz.pin(plonk_z_8n, row);
+    po.pin(out, row);
+    void *dc = nullptr, *dw = nullptr, *ds = nullptr, *dz = nullptr, *dout = nullptr;
+    PLK_TRY(c.in(dc, constants_8n, 6 * row));
+    PLK_TRY(c.in(dw, wires_8n, 9 * row));
+    PLK_TRY(c.in(ds, s_sigma_8n, 6 * row));
+    PLK_TRY(c.in(dz, plonk_z_8n, row));
+    PLK_TRY(c.tmp(dout, row));
+    PLK_TRY(plonk_vanishing_points_dev_impl(field, log_degree, dc, dw, ds, dz, k_is, alpha, beta, gamma, inner_zeta, inner_a, dout, c.stream()));
+    PLK_TRY(c.out(out, dout, row));
+    return c.finish();
 }
 int plk_plonk_evaluate_all_constraints(int field, size_t count, const uint64_t* constants, const uint64_t* local_wires, const uint64_t* right_wires,
                                        const uint64_t* below_wires, const uint64_t* inner_zeta, const uint64_t* inner_a, uint64_t* out) {
     if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d is not a circuit scalar field", field);
     if (count == 0) return PLK_OK;
     if (!constants || !local_wires || !right_wires || !below_wires || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    PLK_TRY(ensure_device());
-    DevBuf dc, dl, dr, db, dout;
-    PLK_TRY(dc.alloc(count * 6 * 32));
-    PLK_TRY(dl.alloc(count * 9 * 32));
-    PLK_TRY(dr.alloc(count * 9 * 32));
-    PLK_TRY(db.alloc(count * 9 * 32));
-    PLK_TRY(dout.alloc(count * 8 * 32));
-    PLK_HIP_TRY(hipMemcpy(dc.p, constants, count * 6 * 32, hipMemcpyHostToDevice));
-    PLK_HIP_TRY(hipMemcpy(dl.p, local_wires, count * 9 * 32, hipMemcpyHostToDevice));
-    PLK_HIP_TRY(hipMemcpy(dr.p, right_wires, count * 9 * 32, hipMemcpyHostToDevice));
-    PLK_HIP_TRY(hipMemcpy(db.p, below_wires, count * 9 * 32, hipMemcpyHostToDevice));
-    PLK_TRY(plonk_all_constraints_dev_impl(field, count, dc.p, dl.p, dr.p, db.p, inner_zeta, inner_a, dout.p, nullptr));
-    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
-    PLK_HIP_TRY(hipMemcpy(out, dout.p, count * 8 * 32, hipMemcpyDeviceToHost));
-    return PLK_OK;
+    LaneCall c;
+    PLK_TRY(c.begin());
+    void *dc = nullptr, *dl = nullptr, *dr = nullptr, *db = nullptr, *dout = nullptr;
+    PLK_TRY(c.in(dc, constants, count * 6 * 32));
+    PLK_TRY(c.in(dl, local_wires, count * 9 * 32));
+    PLK_TRY(c.in(dr, right_wires, count * 9 * 32));
+    PLK_TRY(c.in(db, below_wires, count * 9 * 32));
+    PLK_TRY(c.tmp(dout, count * 8 * 32));
+    PLK_TRY(plonk_all_constraints_dev_impl(field, count, dc, dl, dr, db, inner_zeta, inner_a, dout, c.stream()));
+    PLK_TRY(c.out(out, dout, count * 8 * 32));
+    return c.finish();
 }
 
 // ---- MSM ----
@@ -598,6 +723,8 @@ int plk_msm_execute_batch(plk_msm_ctx* ctx, unsigned batch, const uint64_t* cons
                          msm_ctx_len(ctx));
     if (batch == 0) return PLK_OK;
     if (!scalars || !out_xy || !out_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    for (unsigned b = 0; b < batch; ++b)
+        if (n_scalars && !scalars[b]) return set_error(PLK_ERR_INVALID_ARG, "null scalars in batch slot %u", b);
     HostLane* l = nullptr;
     PLK_TRY(lane_get(l));
     const size_t L = (size_t)curve_limbs(msm_ctx_curve(ctx));
@@ -606,15 +733,35 @@ int plk_msm_execute_batch(plk_msm_ctx* ctx, unsigned batch, const uint64_t* cons
     PLK_TRY(ds.alloc(sb * batch, l->stream));
     PLK_TRY(dxy.alloc((size_t)batch * 2 * L * 8, l->stream));
     PLK_TRY(dz.alloc(batch, l->stream));
-    for (unsigned b = 0; b < batch; ++b) {
-        if (n_scalars && !scalars[b]) return set_error(PLK_ERR_INVALID_ARG, "null scalars in batch slot %u", b);
-        PLK_TRY(lane_h2d(*l, (uint8_t*)ds.p + b * sb, scalars[b], sb));
-    }
-    PLK_TRY(msm_execute_dev_impl(ctx, batch, ds.p, n_scalars, dxy.p, dz.p, l->stream));
     std::vector<LaneOut> outs;
-    PLK_TRY(lane_d2h(*l, outs, out_xy, dxy.p, (size_t)batch * 2 * L * 8));
-    PLK_TRY(lane_d2h(*l, outs, out_zero, dz.p, batch));
-    return lane_finish(*l, outs);
+    int rc = PLK_OK;
+    if (batch == 1 || sb < ((size_t)1 << 20)) {
+        for (unsigned b = 0; b < batch; ++b) PLK_TRY(lane_h2d(*l, (uint8_t*)ds.p + b * sb, scalars[b], sb));
+        rc = msm_execute_dev_impl(ctx, batch, ds.p, n_scalars, dxy.p, dz.p, l->stream);
+    } else {
+        // the scalar vectors of a batch (commit_polynomials, plonk_util.rs:215-231: nine 32 MiB vectors at 2^20) cross PCIe on a
+        // second stream, vector b + 1 while vector b is being ordered and accumulated: one event per vector
+        std::vector<HostPin> pins(batch);
+        for (unsigned b = 0; b < batch; ++b) pins[b].pin(scalars[b], sb);
+        rc = lane_fork(*l);
+        while (rc == PLK_OK && l->ev_ready.size() < batch) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = set_error(PLK_ERR_HIP, "hipEventCreate failed");
+            else l->ev_ready.push_back(e);
+        }
+        for (unsigned b = 0; b < batch && rc == PLK_OK; ++b) {
+            if (hipMemcpyAsync((uint8_t*)ds.p + b * sb, scalars[b], sb, hipMemcpyHostToDevice, l->aux[0]) != hipSuccess ||
+                hipEventRecord(l->ev_ready[b], l->aux[0]) != hipSuccess)
+                rc = set_error(PLK_ERR_HIP, "upload of scalar vector %u failed", b);
+        }
+        if (rc == PLK_OK) rc = msm_execute_dev_impl(ctx, batch, ds.p, n_scalars, dxy.p, dz.p, l->stream, l->ev_ready.data());
+        const int rj = lane_join(*l);  // before the registrations go
+        if (rc == PLK_OK) rc = rj;
+    }
+    if (rc == PLK_OK) rc = lane_d2h(*l, outs, out_xy, dxy.p, (size_t)batch * 2 * L * 8);
+    if (rc == PLK_OK) rc = lane_d2h(*l, outs, out_zero, dz.p, batch);
+    const int rf = lane_finish(*l, outs);
+    return rc != PLK_OK ? rc : rf;
 }
 
 int plk_msm_execute(plk_msm_ctx* ctx, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xy, uint8_t* out_zero) {
@@ -634,27 +781,24 @@ int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if ((k && !pts_xy) || !out_xy || !out_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    PLK_TRY(ensure_device());
-    DevBuf dp, dz, dxy, doz;
-    PLK_TRY(dp.alloc(k * 2 * L * 8));
-    PLK_TRY(dxy.alloc(2 * L * 8));
-    PLK_TRY(doz.alloc(1));
-    if (k) PLK_HIP_TRY(hipMemcpy(dp.p, pts_xy, k * 2 * L * 8, hipMemcpyHostToDevice));
-    if (pts_zero) {
-        PLK_TRY(dz.alloc(k));
-        if (k) PLK_HIP_TRY(hipMemcpy(dz.p, pts_zero, k, hipMemcpyHostToDevice));
-    }
-    PLK_TRY(curve_sum_affine_dev_impl(curve, k, dp.p, pts_zero ? dz.p : nullptr, dxy.p, doz.p, nullptr));
-    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
-    PLK_HIP_TRY(hipMemcpy(out_xy, dxy.p, 2 * L * 8, hipMemcpyDeviceToHost));
-    PLK_HIP_TRY(hipMemcpy(out_zero, doz.p, 1, hipMemcpyDeviceToHost));
-    return PLK_OK;
+    LaneCall c;
+    PLK_TRY(c.begin());
+    void *dp = nullptr, *dz = nullptr, *dxy = nullptr, *doz = nullptr;
+    PLK_TRY(c.in(dp, pts_xy, k * 2 * L * 8));
+    if (pts_zero) PLK_TRY(c.in(dz, pts_zero, k));
+    PLK_TRY(c.tmp(dxy, 2 * L * 8));
+    PLK_TRY(c.tmp(doz, 1));
+    PLK_TRY(curve_sum_affine_dev_impl(curve, k, dp, pts_zero ? dz : nullptr, dxy, doz, c.stream()));
+    PLK_TRY(c.out(out_xy, dxy, 2 * L * 8));
+    PLK_TRY(c.out(out_zero, doz, 1));
+    return c.finish();
 }
 
 // ---- multi-GPU exchange ----
-size_t plk_msm_partials_bytes(int curve, unsigned batch) { return msm_partials_bytes(curve, batch); }
-int plk_msm_combine_partials_dev(int curve, unsigned world, unsigned batch, const void* d_gathered, void* d_out_xy, void* d_out_zero, void* stream) {
-    return msm_combine_partials_dev_impl(curve, world, batch, d_gathered, d_out_xy, d_out_zero, as_stream(stream));
+size_t plk_msm_partials_bytes(int curve, unsigned slots) { return msm_partials_bytes(curve, slots); }
+int plk_msm_combine_partials_dev(int curve, unsigned world, unsigned batch, unsigned whole_per_rank, const void* d_gathered, void* d_out_xy,
+                                 void* d_out_zero, void* stream) {
+    return msm_combine_partials_dev_impl(curve, world, batch, whole_per_rank, d_gathered, d_out_xy, d_out_zero, as_stream(stream));
 }
 
 // ---- the reference's own MsmPrecomputation contents ----
@@ -671,24 +815,21 @@ int plk_msm_precompute_table(int curve, size_t n, const uint64_t* bases_xy, cons
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (w < 1 || w > 64) return set_error(PLK_ERR_INVALID_ARG, "window size %u outside [1, 64]", w);
     if (n && (!bases_xy || !out_xy || !out_zero)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    PLK_TRY(ensure_device());
+    if (n == 0) return PLK_OK;
     const size_t digits = (size_t)msm_table_digits(curve, w);
-    DevBuf db, dz, dout, doz;
-    PLK_TRY(db.alloc(n * 2 * L * 8));
-    PLK_TRY(dout.alloc(n * digits * 2 * L * 8));
-    PLK_TRY(doz.alloc(n * digits));
-    if (n) PLK_HIP_TRY(hipMemcpy(db.p, bases_xy, n * 2 * L * 8, hipMemcpyHostToDevice));
-    if (base_zero) {
-        PLK_TRY(dz.alloc(n));
-        if (n) PLK_HIP_TRY(hipMemcpy(dz.p, base_zero, n, hipMemcpyHostToDevice));
-    }
-    PLK_TRY(msm_reference_table_dev_impl(curve, n, db.p, base_zero ? dz.p : nullptr, w, dout.p, doz.p, nullptr));
-    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
-    if (n) {
-        PLK_HIP_TRY(hipMemcpy(out_xy, dout.p, n * digits * 2 * L * 8, hipMemcpyDeviceToHost));
-        PLK_HIP_TRY(hipMemcpy(out_zero, doz.p, n * digits, hipMemcpyDeviceToHost));
-    }
-    return PLK_OK;
+    LaneCall c;
+    PLK_TRY(c.begin());
+    HostPin po;
+    po.pin(out_xy, n * digits * 2 * L * 8);
+    void *db = nullptr, *dz = nullptr, *dout = nullptr, *doz = nullptr;
+    PLK_TRY(c.in(db, bases_xy, n * 2 * L * 8));
+    if (base_zero) PLK_TRY(c.in(dz, base_zero, n));
+    PLK_TRY(c.tmp(dout, n * digits * 2 * L * 8));
+    PLK_TRY(c.tmp(doz, n * digits));
+    PLK_TRY(msm_reference_table_dev_impl(curve, n, db, base_zero ? dz : nullptr, w, dout, doz, c.stream()));
+    PLK_TRY(c.out(out_xy, dout, n * digits * 2 * L * 8));
+    PLK_TRY(c.out(out_zero, doz, n * digits));
+    return c.finish();
 }
 
 // ---- IPA generator fold ----
@@ -702,33 +843,22 @@ int plk_curve_fold_pairs(int curve, size_t m, const uint64_t* lo_xy, const uint8
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (m && (!lo_xy || !hi_xy || !out_xy || !out_zero)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    PLK_TRY(ensure_device());
+    if (!scalar_lo || !scalar_hi) return set_error(PLK_ERR_INVALID_ARG, "null scalar");
+    if (m == 0) return PLK_OK;
     const size_t pb = m * 2 * L * 8;
-    DevBuf dlo, dhi, dlz, dhz, dout, doz;
-    PLK_TRY(dlo.alloc(pb));
-    PLK_TRY(dhi.alloc(pb));
-    PLK_TRY(dout.alloc(pb));
-    PLK_TRY(doz.alloc(m));
-    if (m) {
-        PLK_HIP_TRY(hipMemcpy(dlo.p, lo_xy, pb, hipMemcpyHostToDevice));
-        PLK_HIP_TRY(hipMemcpy(dhi.p, hi_xy, pb, hipMemcpyHostToDevice));
-    }
-    if (lo_zero) {
-        PLK_TRY(dlz.alloc(m));
-        if (m) PLK_HIP_TRY(hipMemcpy(dlz.p, lo_zero, m, hipMemcpyHostToDevice));
-    }
-    if (hi_zero) {
-        PLK_TRY(dhz.alloc(m));
-        if (m) PLK_HIP_TRY(hipMemcpy(dhz.p, hi_zero, m, hipMemcpyHostToDevice));
-    }
-    PLK_TRY(curve_fold_pairs_dev_impl(curve, m, dlo.p, lo_zero ? dlz.p : nullptr, dhi.p, hi_zero ? dhz.p : nullptr, scalar_lo, scalar_hi, dout.p, doz.p,
-                                      nullptr));
-    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
-    if (m) {
-        PLK_HIP_TRY(hipMemcpy(out_xy, dout.p, pb, hipMemcpyDeviceToHost));
-        PLK_HIP_TRY(hipMemcpy(out_zero, doz.p, m, hipMemcpyDeviceToHost));
-    }
-    return PLK_OK;
+    LaneCall c;
+    PLK_TRY(c.begin());
+    void *dlo = nullptr, *dhi = nullptr, *dlz = nullptr, *dhz = nullptr, *dout = nullptr, *doz = nullptr;
+    PLK_TRY(c.in(dlo, lo_xy, pb));
+    PLK_TRY(c.in(dhi, hi_xy, pb));
+    if (lo_zero) PLK_TRY(c.in(dlz, lo_zero, m));
+    if (hi_zero) PLK_TRY(c.in(dhz, hi_zero, m));
+    PLK_TRY(c.tmp(dout, pb));
+    PLK_TRY(c.tmp(doz, m));
+    PLK_TRY(curve_fold_pairs_dev_impl(curve, m, dlo, lo_zero ? dlz : nullptr, dhi, hi_zero ? dhz : nullptr, scalar_lo, scalar_hi, dout, doz, c.stream()));
+    PLK_TRY(c.out(out_xy, dout, pb));
+    PLK_TRY(c.out(out_zero, doz, m));
+    return c.finish();
 }
 
 // ---- batch inversion ----
@@ -741,21 +871,24 @@ static int batch_inverse_host(int field, const uint64_t* x, uint64_t* out, uint8
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
     if (count == 0) return PLK_OK;
     if (!x || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    PLK_TRY(ensure_device());
-    DevBuf dx, dz, dc;
-    PLK_TRY(dx.alloc(count * L * 8));
-    PLK_TRY(dz.alloc(count));
-    PLK_TRY(dc.alloc(4));
-    PLK_HIP_TRY(hipMemcpy(dx.p, x, count * L * 8, hipMemcpyHostToDevice));
-    PLK_HIP_TRY(hipMemset(dc.p, 0, 4));
-    PLK_TRY(field_batch_inverse_dev_impl(field, dx.p, dx.p, dz.p, (unsigned*)dc.p, count, nullptr));
-    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
+    LaneCall c;
+    PLK_TRY(c.begin());
+    void *dx = nullptr, *dz = nullptr, *dc = nullptr;
+    PLK_TRY(c.in(dx, x, count * L * 8));
+    PLK_TRY(c.tmp(dz, count));
+    PLK_TRY(c.tmp(dc, 4));
+    PLK_HIP_TRY(hipMemsetAsync(dc, 0, 4, c.stream()));
+    PLK_TRY(field_batch_inverse_dev_impl(field, dx, dx, dz, (unsigned*)dc, count, c.stream()));
     unsigned zeros = 0;
-    PLK_HIP_TRY(hipMemcpy(&zeros, dc.p, 4, hipMemcpyDeviceToHost));
-    if (strict && zeros) return set_error(PLK_ERR_INVALID_ARG, "No inverse: %u of the %zu elements are zero (field.rs:266)", zeros, count);
-    PLK_HIP_TRY(hipMemcpy(out, dx.p, count * L * 8, hipMemcpyDeviceToHost));
-    if (is_none) PLK_HIP_TRY(hipMemcpy(is_none, dz.p, count, hipMemcpyDeviceToHost));
-    return PLK_OK;
+    PLK_TRY(c.out(&zeros, dc, 4));
+    PLK_TRY(c.sync());
+    if (strict && zeros) {
+        c.done = true;
+        return set_error(PLK_ERR_INVALID_ARG, "No inverse: %u of the %zu elements are zero (field.rs:266)", zeros, count);
+    }
+    PLK_TRY(c.out(out, dx, count * L * 8));
+    if (is_none) PLK_TRY(c.out(is_none, dz, count));
+    return c.finish();
 }
 int plk_field_batch_inverse(int field, const uint64_t* x, uint64_t* out, size_t count) { return batch_inverse_host(field, x, out, nullptr, count, true); }
 int plk_field_batch_inverse_opt(int field, const uint64_t* x, uint64_t* out, uint8_t* is_none, size_t count) {
@@ -770,21 +903,17 @@ int plk_curve_batch_to_affine(int curve, size_t count, const uint64_t* proj_xyz,
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (count == 0) return PLK_OK;
     if (!proj_xyz || !out_xy || !out_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    PLK_TRY(ensure_device());
-    DevBuf dp, dz, dxy, doz;
-    PLK_TRY(dp.alloc(count * 3 * L * 8));
-    PLK_TRY(dxy.alloc(count * 2 * L * 8));
-    PLK_TRY(doz.alloc(count));
-    PLK_HIP_TRY(hipMemcpy(dp.p, proj_xyz, count * 3 * L * 8, hipMemcpyHostToDevice));
-    if (proj_zero) {
-        PLK_TRY(dz.alloc(count));
-        PLK_HIP_TRY(hipMemcpy(dz.p, proj_zero, count, hipMemcpyHostToDevice));
-    }
-    PLK_TRY(curve_batch_to_affine_dev_impl(curve, count, dp.p, proj_zero ? dz.p : nullptr, dxy.p, doz.p, nullptr));
-    PLK_HIP_TRY(hipStreamSynchronize(nullptr));
-    PLK_HIP_TRY(hipMemcpy(out_xy, dxy.p, count * 2 * L * 8, hipMemcpyDeviceToHost));
-    PLK_HIP_TRY(hipMemcpy(out_zero, doz.p, count, hipMemcpyDeviceToHost));
-    return PLK_OK;
+    LaneCall c;
+    PLK_TRY(c.begin());
+    void *dp = nullptr, *dz = nullptr, *dxy = nullptr, *doz = nullptr;
+    PLK_TRY(c.in(dp, proj_xyz, count * 3 * L * 8));
+    if (proj_zero) PLK_TRY(c.in(dz, proj_zero, count));
+    PLK_TRY(c.tmp(dxy, count * 2 * L * 8));
+    PLK_TRY(c.tmp(doz, count));
+    PLK_TRY(curve_batch_to_affine_dev_impl(curve, count, dp, proj_zero ? dz : nullptr, dxy, doz, c.stream()));
+    PLK_TRY(c.out(out_xy, dxy, count * 2 * L * 8));
+    PLK_TRY(c.out(out_zero, doz, count));
+    return c.finish();
 }
 
 // ---- canonical byte encodings ----
@@ -793,31 +922,32 @@ int plk_field_to_bytes(int field, const uint64_t* x, size_t count, uint8_t* out_
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
     if (count == 0) return PLK_OK;
     if (!x || !out_bytes) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    PLK_TRY(ensure_device());
-    DevBuf dx, db;
-    PLK_TRY(dx.alloc(count * L * 8));
-    PLK_TRY(db.alloc(count * L * 8));
-    PLK_HIP_TRY(hipMemcpy(dx.p, x, count * L * 8, hipMemcpyHostToDevice));
-    PLK_TRY(field_bytes_impl(field, 0, dx.p, count, db.p, nullptr, nullptr));
-    PLK_HIP_TRY(hipMemcpy(out_bytes, db.p, count * L * 8, hipMemcpyDeviceToHost));
-    return PLK_OK;
+    LaneCall c;
+    PLK_TRY(c.begin());
+    void *dx = nullptr, *db = nullptr;
+    PLK_TRY(c.in(dx, x, count * L * 8));
+    PLK_TRY(c.tmp(db, count * L * 8));
+    PLK_TRY(field_bytes_impl(field, 0, dx, count, db, nullptr, c.stream()));
+    PLK_TRY(c.out(out_bytes, db, count * L * 8));
+    return c.finish();
 }
 int plk_field_from_bytes(int field, const uint8_t* bytes, size_t count, uint64_t* out) {
     const int L = field_limbs(field);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
     if (count == 0) return PLK_OK;
     if (!bytes || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    PLK_TRY(ensure_device());
-    DevBuf dx, db, dc;
-    PLK_TRY(dx.alloc(count * L * 8));
-    PLK_TRY(db.alloc(count * L * 8));
-    PLK_TRY(dc.alloc(4));
-    PLK_HIP_TRY(hipMemcpy(db.p, bytes, count * L * 8, hipMemcpyHostToDevice));
-    PLK_HIP_TRY(hipMemset(dc.p, 0, 4));
-    PLK_TRY(field_bytes_impl(field, 1, db.p, count, dx.p, (unsigned*)dc.p, nullptr));
+    LaneCall c;
+    PLK_TRY(c.begin());
+    void *dx = nullptr, *db = nullptr, *dc = nullptr;
+    PLK_TRY(c.in(db, bytes, count * L * 8));
+    PLK_TRY(c.tmp(dx, count * L * 8));
+    PLK_TRY(c.tmp(dc, 4));
+    PLK_HIP_TRY(hipMemsetAsync(dc, 0, 4, c.stream()));
+    PLK_TRY(field_bytes_impl(field, 1, db, count, dx, (unsigned*)dc, c.stream()));
     unsigned bad = 0;
-    PLK_HIP_TRY(hipMemcpy(&bad, dc.p, 4, hipMemcpyDeviceToHost));
-    PLK_HIP_TRY(hipMemcpy(out, dx.p, count * L * 8, hipMemcpyDeviceToHost));
+    PLK_TRY(c.out(&bad, dc, 4));
+    PLK_TRY(c.out(out, dx, count * L * 8));
+    PLK_TRY(c.finish());
     if (bad) return set_error(PLK_ERR_INVALID_ARG, "Out of range: %u of the %zu records are not below the modulus (field.rs:100)", bad, count);
     return PLK_OK;
 }
@@ -826,38 +956,36 @@ int plk_curve_point_to_bytes(int curve, const uint64_t* xy, const uint8_t* zero,
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (count == 0) return PLK_OK;
     if (!xy || !out_bytes) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    PLK_TRY(ensure_device());
     const size_t rec = 1 + (size_t)L * 8;
-    DevBuf dp, dz, db;
-    PLK_TRY(dp.alloc(count * 2 * L * 8));
-    PLK_TRY(db.alloc(count * rec));
-    PLK_HIP_TRY(hipMemcpy(dp.p, xy, count * 2 * L * 8, hipMemcpyHostToDevice));
-    if (zero) {
-        PLK_TRY(dz.alloc(count));
-        PLK_HIP_TRY(hipMemcpy(dz.p, zero, count, hipMemcpyHostToDevice));
-    }
-    PLK_TRY(point_bytes_impl(curve, 0, dp.p, zero ? dz.p : nullptr, count, db.p, nullptr, nullptr, nullptr));
-    PLK_HIP_TRY(hipMemcpy(out_bytes, db.p, count * rec, hipMemcpyDeviceToHost));
-    return PLK_OK;
+    LaneCall c;
+    PLK_TRY(c.begin());
+    void *dp = nullptr, *dz = nullptr, *db = nullptr;
+    PLK_TRY(c.in(dp, xy, count * 2 * L * 8));
+    if (zero) PLK_TRY(c.in(dz, zero, count));
+    PLK_TRY(c.tmp(db, count * rec));
+    PLK_TRY(point_bytes_impl(curve, 0, dp, zero ? dz : nullptr, count, db, nullptr, nullptr, c.stream()));
+    PLK_TRY(c.out(out_bytes, db, count * rec));
+    return c.finish();
 }
 int plk_curve_point_from_bytes(int curve, const uint8_t* bytes, size_t count, uint64_t* out_xy, uint8_t* out_zero, uint8_t* status) {
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (count == 0) return PLK_OK;
     if (!bytes || !out_xy || !out_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    PLK_TRY(ensure_device());
     const size_t rec = 1 + (size_t)L * 8;
-    DevBuf dp, dz, db, ds;
-    PLK_TRY(dp.alloc(count * 2 * L * 8));
-    PLK_TRY(dz.alloc(count));
-    PLK_TRY(ds.alloc(count));
-    PLK_TRY(db.alloc(count * rec));
-    PLK_HIP_TRY(hipMemcpy(db.p, bytes, count * rec, hipMemcpyHostToDevice));
-    PLK_TRY(point_bytes_impl(curve, 1, db.p, nullptr, count, dp.p, dz.p, ds.p, nullptr));
+    LaneCall c;
+    PLK_TRY(c.begin());
+    void *dp = nullptr, *dz = nullptr, *ds = nullptr, *db = nullptr;
+    PLK_TRY(c.in(db, bytes, count * rec));
+    PLK_TRY(c.tmp(dp, count * 2 * L * 8));
+    PLK_TRY(c.tmp(dz, count));
+    PLK_TRY(c.tmp(ds, count));
+    PLK_TRY(point_bytes_impl(curve, 1, db, nullptr, count, dp, dz, ds, c.stream()));
     std::vector<uint8_t> st(count);
-    PLK_HIP_TRY(hipMemcpy(st.data(), ds.p, count, hipMemcpyDeviceToHost));
-    PLK_HIP_TRY(hipMemcpy(out_xy, dp.p, count * 2 * L * 8, hipMemcpyDeviceToHost));
-    PLK_HIP_TRY(hipMemcpy(out_zero, dz.p, count, hipMemcpyDeviceToHost));
+    PLK_TRY(c.out(st.data(), ds, count));
+    PLK_TRY(c.out(out_xy, dp, count * 2 * L * 8));
+    PLK_TRY(c.out(out_zero, dz, count));
+    PLK_TRY(c.finish());
     size_t bad = 0, first = 0;
     for (size_t i = 0; i < count; ++i) {
         if (status) status[i] = st[i];

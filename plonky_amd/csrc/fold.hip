@@ -28,6 +28,7 @@ namespace plk {
 constexpr int FOLD_MAX_COLS = 264;
 
 struct FoldDigits {
+    int plus_lo;                    // 1: out_i = lo_i + [b] hi_i (lo is added once at the end, the scalar a is not used)
     int cols;                       // number of columns, most significant first
     int8_t d[FOLD_MAX_COLS];        // (da + 1) * 3 + (db + 1): 4 = empty column
     int8_t e[FOLD_MAX_COLS];        // GLV form: d = the pair (a1, a2) over (P, phi P), e = the pair (b1, b2) over (Q, phi Q)
@@ -119,6 +120,7 @@ __global__ void __launch_bounds__(128) k_fold_pairs(const uint4* __restrict__ lo
         if (neg) ty = fz_neg_canonical<FP>(ty);
         xyzzz_madd<FP>(acc, tx, ty);
     }
+    if (dgp->plus_lo && !P.ident) xyzzz_madd<FP>(acc, P.x, P.y);
     emit_affine<FP>(acc, out_xy + i * 2 * W, out_zero + i);
 }
 
@@ -190,6 +192,7 @@ __global__ void __launch_bounds__(128) k_fold_pairs_glv(const uint4* __restrict_
             glv_fold_add<FP>(acc, dgp->d[k], P, DP, beta, beta2);
             glv_fold_add<FP>(acc, dgp->e[k], Q, DQ, beta, beta2);
         }
+        if (dgp->plus_lo && !P.ident) xyzzz_madd<FP>(acc, P.x, P.y);
         emit_affine<FP>(acc, out_xy + i * 2 * W, out_zero + i);
     }
 }
@@ -237,16 +240,19 @@ struct ScalarPair {
     uint32_t a[8], b[8];  // Montgomery form in the scalar field
 };
 // one thread: Montgomery -> canonical (to_canonical_u64_vec), joint sparse form, most significant column first
-template <class C> __global__ void k_fold_digits(ScalarPair sp, FoldDigits* out, int use_glv) {
+// d_sc (optional): the two scalars in device memory (2 x 8 words, Montgomery) instead of `sp` - an inner-product argument keeps
+// its running scale and the squared challenge there (halo.hip).  plus_lo: the scalar a is replaced by "add lo once at the end".
+template <class C> __global__ void k_fold_digits(ScalarPair sp, const uint32_t* __restrict__ d_sc, FoldDigits* out, int use_glv, int plus_lo) {
     using SP = typename C::SP;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Fe<SP> a, b;
     for (int i = 0; i < 8; ++i) {
-        a.v[i] = sp.a[i];
-        b.v[i] = sp.b[i];
+        a.v[i] = d_sc ? d_sc[i] : sp.a[i];
+        b.v[i] = d_sc ? d_sc[8 + i] : sp.b[i];
     }
-    a = fe_to_canonical<SP>(a);
+    a = plus_lo ? fe_zero<SP>() : fe_to_canonical<SP>(a);
     b = fe_to_canonical<SP>(b);
+    out->plus_lo = plus_lo;
     int8_t ua[FOLD_MAX_COLS], ub[FOLD_MAX_COLS];
     if (C::Glv::ENABLED && use_glv) {
         // two joint sparse forms of half-length parts, signs applied to the digits, aligned at the least significant column
@@ -277,11 +283,11 @@ template <class C> __global__ void k_fold_digits(ScalarPair sp, FoldDigits* out,
 
 template <class C>
 static int fold_pairs_t(size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero, const uint64_t* a_mont,
-                        const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream) {
+                        const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream, const void* d_scalars, int plus_lo) {
     static_assert(C::SP::NL == 8, "scalar fields are 256-bit");
     if (m == 0) return PLK_OK;
-    ScalarPair sp;
-    for (int i = 0; i < 4; ++i) {
+    ScalarPair sp{};
+    for (int i = 0; i < 4 && !d_scalars; ++i) {
         sp.a[2 * i] = (uint32_t)a_mont[i];
         sp.a[2 * i + 1] = (uint32_t)(a_mont[i] >> 32);
         sp.b[2 * i] = (uint32_t)b_mont[i];
@@ -290,7 +296,7 @@ static int fold_pairs_t(size_t m, const void* d_lo, const void* d_lo_zero, const
     FoldDigits* d_dg = (FoldDigits*)scratch_acquire(sizeof(FoldDigits), stream);
     if (!d_dg) return PLK_ERR_OOM;
     const bool use_glv = C::Glv::ENABLED && !getenv("PLK_FOLD_NO_GLV");
-    k_fold_digits<C><<<1, 64, 0, stream>>>(sp, d_dg, use_glv ? 1 : 0);
+    k_fold_digits<C><<<1, 64, 0, stream>>>(sp, (const uint32_t*)d_scalars, d_dg, use_glv ? 1 : 0, plus_lo);
     if (use_glv)
         k_fold_pairs_glv<C><<<(unsigned)((m + 127) / 128), 128, 0, stream>>>((const uint4*)d_lo, (const uint8_t*)d_lo_zero, (const uint4*)d_hi,
                                                                              (const uint8_t*)d_hi_zero, m, d_dg, (uint4*)d_out_xy, (uint8_t*)d_out_zero);
@@ -303,17 +309,20 @@ static int fold_pairs_t(size_t m, const void* d_lo, const void* d_lo_zero, const
     return PLK_OK;
 }
 
+// d_scalars (optional): the two scalars as 2 x 32 bytes of device memory (then a_mont / b_mont are not read).  plus_lo:
+// out_i = lo_i + [b] hi_i.
 int curve_fold_pairs_dev_impl(int curve, size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero,
-                              const uint64_t* a_mont, const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream) {
-    if (!a_mont || !b_mont) return set_error(PLK_ERR_INVALID_ARG, "null scalar");
+                              const uint64_t* a_mont, const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream, const void* d_scalars,
+                              int plus_lo) {
+    if (!d_scalars && (!a_mont || !b_mont)) return set_error(PLK_ERR_INVALID_ARG, "null scalar");
     if (m && (!d_lo || !d_hi || !d_out_xy || !d_out_zero)) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
     PLK_TRY(ensure_device());
     switch (curve) {
-        case PLK_CURVE_TWEEDLEDEE: return fold_pairs_t<TweedledeeCurve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream);
-        case PLK_CURVE_TWEEDLEDUM: return fold_pairs_t<TweedledumCurve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream);
-        case PLK_CURVE_BLS12_377: return fold_pairs_t<Bls12377Curve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream);
-        case PLK_CURVE_PALLAS: return fold_pairs_t<PallasCurve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream);
-        case PLK_CURVE_VESTA: return fold_pairs_t<VestaCurve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream);
+        case PLK_CURVE_TWEEDLEDEE: return fold_pairs_t<TweedledeeCurve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream, d_scalars, plus_lo);
+        case PLK_CURVE_TWEEDLEDUM: return fold_pairs_t<TweedledumCurve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream, d_scalars, plus_lo);
+        case PLK_CURVE_BLS12_377: return fold_pairs_t<Bls12377Curve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream, d_scalars, plus_lo);
+        case PLK_CURVE_PALLAS: return fold_pairs_t<PallasCurve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream, d_scalars, plus_lo);
+        case PLK_CURVE_VESTA: return fold_pairs_t<VestaCurve>(m, d_lo, d_lo_zero, d_hi, d_hi_zero, a_mont, b_mont, d_out_xy, d_out_zero, stream, d_scalars, plus_lo);
     }
     return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
 }

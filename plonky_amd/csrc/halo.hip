@@ -13,7 +13,10 @@
 // Two regimes:
 //  * long vectors: L_j / R_j are ONE table-free MSM each over [half of G, H, U'] with the scalars [half of a, blinding factor,
 //    inner product] (two persistent table-free contexts rebound to the halved generator set every round, on two streams);
-//    the generators are folded pair by pair (fold.hip).
+//    the generators are folded pair by pair (fold.hip) - SCALED: the context keeps G~ and a scalar c with G^(k) = [c] G~^(k),
+//    so that a fold is G~'_i = G~_lo_i + [u^2] G~_hi_i, c' = c u^-1 (one half-length joint sparse form and one addition per pair
+//    instead of two joint sparse forms: ~26 % fewer field multiplications); c goes into the scalars of the MSMs
+//    (<a_lo, G_hi> = <c a_lo, G~_hi>), into the coefficients when the generators are frozen, and onto the points when they are read.
 //  * short vectors (<= 2^freeze_log generators left): a table-free MSM and the fold are then pure latency (a chain of
 //    ~120-130 doublings of one point per lane, ~2 ms whatever the size), so the generators are FROZEN: window tables are
 //    built once for G^(f) (+ H, U'), the folded generators are never formed again, and every later round uses
@@ -34,12 +37,16 @@ struct plk_msm_ctx;
 namespace plk {
 
 int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, unsigned flags, hipStream_t stream,
-                            plk_msm_ctx** out_ctx, const void* d_extra = nullptr, size_t n_extra = 0);
+                            plk_msm_ctx** out_ctx, const void* d_extra = nullptr, size_t n_extra = 0, const size_t* also_n = nullptr,
+                            int also_count = 0);
 int msm_rebind_dev_impl(plk_msm_ctx* ctx, size_t n, const void* d_bases, const void* d_zero, const void* d_extra, size_t n_extra, hipStream_t stream);
-int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream);
+int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
+                         hipEvent_t* ready = nullptr);
+int msm_reserve_workspaces_impl(plk_msm_ctx* ctx, unsigned count, hipStream_t stream);
 void msm_ctx_delete(plk_msm_ctx* ctx);
 int curve_fold_pairs_dev_impl(int curve, size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero,
-                              const uint64_t* a_mont, const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream);
+                              const uint64_t* a_mont, const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream,
+                              const void* d_scalars = nullptr, int plus_lo = 0);
 
 constexpr int HALO_PART_BLOCKS = 256;
 struct HaloScalar {
@@ -51,21 +58,23 @@ struct HaloScalar {
 // of the two MSMs.  Not frozen (m0 == 0): sL = a_lo, sR = a_hi (m entries each).  Frozen: entry j < m0 of the frozen
 // generator set belongs to folded generator r = j mod n_k; it takes part in L (over G_hi) when r >= m with a_lo[r - m], in R
 // (over G_lo) when r < m with a_hi[r] - times its coefficient s_j; the other vector gets 0 (a zero scalar has no digits).
+// `scale`: the running scale c of the explicitly folded generators (one element, device memory): their MSM scalars are c a.
 template <class P>
 __global__ void __launch_bounds__(256) k_halo_prepare(const uint4* __restrict__ a, const uint4* __restrict__ b, size_t m, size_t m0,
-                                                      const uint4* __restrict__ coef, uint4* __restrict__ sL, uint4* __restrict__ sR,
-                                                      uint4* __restrict__ part) {
+                                                      const uint4* __restrict__ coef, const uint4* __restrict__ scale, uint4* __restrict__ sL,
+                                                      uint4* __restrict__ sR, uint4* __restrict__ part) {
     constexpr int W = P::NL / 4;
     __shared__ uint4 s_acc[2 * 256 * W];
     const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Fe<P> accL = fe_zero<P>(), accR = fe_zero<P>();
+    const Fe<P> c = fe_load<P>(scale);
     for (size_t i = t0; i < m; i += stride) {
         const Fe<P> alo = fe_load<P>(a + i * W), ahi = fe_load<P>(a + (m + i) * W);
         accL = fe_add<P>(accL, fe_mul<P>(alo, fe_load<P>(b + (m + i) * W)));
         accR = fe_add<P>(accR, fe_mul<P>(ahi, fe_load<P>(b + i * W)));
         if (m0 == 0) {
-            fe_store<P>(sL + i * W, alo);
-            fe_store<P>(sR + i * W, ahi);
+            fe_store<P>(sL + i * W, fe_mul<P>(c, alo));
+            fe_store<P>(sR + i * W, fe_mul<P>(c, ahi));
         }
     }
     const size_t mask = 2 * m - 1;
@@ -131,9 +140,10 @@ __global__ void __launch_bounds__(64) k_halo_close(const uint4* __restrict__ par
 }
 // halo_a' = u^-1 a_hi + u a_lo, halo_b' = u^-1 b_lo + u b_hi in place (element i of the low half only depends on elements i and
 // m + i); frozen generators: s_j *= u^-1 when j falls in the low half of the current length, else u
+// dsc (explicit folds only, else null): [0] unused, [1] = u^2 (the scalar of the scaled generator fold), [2] = c *= u^-1
 template <class P>
 __global__ void __launch_bounds__(256) k_halo_fold_scalars(uint4* __restrict__ a, uint4* __restrict__ b, size_t m, HaloScalar u_s, HaloScalar uinv_s,
-                                                           uint4* __restrict__ coef, size_t m0) {
+                                                           uint4* __restrict__ coef, size_t m0, uint4* __restrict__ dsc) {
     constexpr int W = P::NL / 4;
     Fe<P> u, uinv;
 #pragma unroll
@@ -142,6 +152,10 @@ __global__ void __launch_bounds__(256) k_halo_fold_scalars(uint4* __restrict__ a
         uinv.v[k] = uinv_s.v[k];
     }
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dsc && i == 0) {
+        fe_store<P>(dsc + 1 * W, fe_sqr<P>(u));
+        fe_store<P>(dsc + 2 * W, fe_mul<P>(fe_load<P>(dsc + 2 * W), uinv));
+    }
     if (i < m) {
         const Fe<P> alo = fe_load<P>(a + i * W), ahi = fe_load<P>(a + (m + i) * W);
         const Fe<P> blo = fe_load<P>(b + i * W), bhi = fe_load<P>(b + (m + i) * W);
@@ -153,10 +167,11 @@ __global__ void __launch_bounds__(256) k_halo_fold_scalars(uint4* __restrict__ a
         fe_store<P>(coef + i * W, fe_mul<P>(fe_load<P>(coef + i * W), low ? uinv : u));
     }
 }
-template <class P> __global__ void __launch_bounds__(256) k_halo_fill_one(uint4* __restrict__ coef, size_t count) {
+// coef[i] = *src (the running scale when the generators are frozen), or 1 when src is null
+template <class P> __global__ void __launch_bounds__(256) k_halo_fill(uint4* __restrict__ coef, size_t count, const uint4* __restrict__ src) {
     constexpr int W = P::NL / 4;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) fe_store<P>(coef + i * W, fe_one<P>());
+    if (i < count) fe_store<P>(coef + i * W, src ? fe_load<P>(src) : fe_one<P>());
 }
 
 }  // namespace plk
@@ -167,8 +182,9 @@ struct plk_halo_ctx {
     unsigned freeze_log = 14;
     hipStream_t stream = nullptr, side = nullptr;
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
-    uint8_t* slab = nullptr;    // one allocation: a | b | g | gz | extra | scal | part | out | coef
+    uint8_t* slab = nullptr;    // one allocation: a | b | g | gz | extra | scal | part | out | coef | dsc
     uint8_t *a = nullptr, *b = nullptr, *g = nullptr, *gz = nullptr, *extra = nullptr, *scal = nullptr, *part = nullptr, *out = nullptr, *coef = nullptr;
+    uint8_t* dsc = nullptr;     // 4 scalars: [0] unused (the fold's first scalar), [1] u^2, [2] the running scale c, [3] zero
     size_t scal_stride = 0;     // bytes between the L and the R scalar vector
     plk_msm_ctx *mL = nullptr, *mR = nullptr;  // table-free contexts of the long rounds, rebound every round
     bool frozen = false;
@@ -215,8 +231,9 @@ static HaloScalar to_halo_scalar(const uint64_t* s) {
 static int halo_freeze(plk_halo_ctx* c) {
     c->m0 = c->n;
     PLK_TRY(msm_precompute_dev_impl(c->curve, c->m0 + 2, c->g, c->gz, 0, 0, c->stream, &c->mT, c->extra, 2));
+    PLK_TRY(msm_reserve_workspaces_impl(c->mT, 2, c->stream));  // L_j and R_j are one batched call
     const unsigned blocks = (unsigned)((c->m0 + 255) / 256);
-    HALO_FIELD_SWITCH(c->sfield, (k_halo_fill_one<P><<<blocks, 256, 0, c->stream>>>((uint4*)c->coef, c->m0)));
+    HALO_FIELD_SWITCH(c->sfield, (k_halo_fill<P><<<blocks, 256, 0, c->stream>>>((uint4*)c->coef, c->m0, (const uint4*)(c->dsc + 2 * 32))));
     PLK_HIP_TRY(hipGetLastError());
     c->frozen = true;
     return PLK_OK;
@@ -247,7 +264,7 @@ int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, c
     c->scal_stride = cnt_max * 32;
     struct Part { uint8_t** p; size_t bytes; } parts[] = {
         {&c->a, n * 32}, {&c->b, n * 32}, {&c->g, n * pt}, {&c->gz, n}, {&c->extra, 2 * pt}, {&c->scal, 2 * c->scal_stride},
-        {&c->part, (size_t)2 * HALO_PART_BLOCKS * 32}, {&c->out, 2 * pt + 16}, {&c->coef, m0_max * 32},
+        {&c->part, (size_t)2 * HALO_PART_BLOCKS * 32}, {&c->out, 2 * pt + 16}, {&c->coef, m0_max * 32}, {&c->dsc, 4 * 32},
     };
     size_t total = 0;
     for (auto& p : parts) total += (p.bytes + 255) & ~(size_t)255;
@@ -269,13 +286,19 @@ int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, c
     memcpy(c->pin, h_xy, pt);
     memcpy(c->pin + pt, u_xy, pt);
     PLK_HIP_TRY(hipMemcpyAsync(c->extra, c->pin, 2 * pt, hipMemcpyHostToDevice, stream));
+    PLK_HIP_TRY(hipMemsetAsync(c->dsc, 0, 4 * 32, stream));
+    HALO_FIELD_SWITCH(c->sfield, (k_halo_fill<P><<<1, 256, 0, stream>>>((uint4*)(c->dsc + 2 * 32), 1, nullptr)));  // c = 1
+    PLK_HIP_TRY(hipGetLastError());
     if (n >= 2) {
         if (n <= fz) {
             PLK_TRY(halo_freeze(c));
         } else {
-            // the two table-free contexts of the long rounds, sized for the first (largest) round
-            PLK_TRY(msm_precompute_dev_impl(curve, n / 2 + 2, c->g + (n / 2) * pt, c->gz + n / 2, 0, PLK_MSM_TABLE_FREE, stream, &c->mL, c->extra, 2));
-            PLK_TRY(msm_precompute_dev_impl(curve, n / 2 + 2, c->g, c->gz, 0, PLK_MSM_TABLE_FREE, stream, &c->mR, c->extra, 2));
+            // the two table-free contexts of the long rounds, sized for every round they will be rebound to
+            size_t also[64];
+            int cnt = 0;
+            for (size_t len = n / 2; len > fz; len /= 2) also[cnt++] = len / 2 + 2;
+            PLK_TRY(msm_precompute_dev_impl(curve, n / 2 + 2, c->g + (n / 2) * pt, c->gz + n / 2, 0, PLK_MSM_TABLE_FREE, stream, &c->mL, c->extra, 2, also, cnt));
+            PLK_TRY(msm_precompute_dev_impl(curve, n / 2 + 2, c->g, c->gz, 0, PLK_MSM_TABLE_FREE, stream, &c->mR, c->extra, 2, also, cnt));
         }
     }
     PLK_HIP_TRY(hipStreamSynchronize(stream));  // the staging copy of H, U' is consumed
@@ -297,7 +320,7 @@ int halo_round_lr_impl(plk_halo_ctx* c, const uint64_t* l_blind, const uint64_t*
     if (blocks > HALO_PART_BLOCKS) blocks = HALO_PART_BLOCKS;
     const HaloScalar lb = to_halo_scalar(l_blind), rb = to_halo_scalar(r_blind);
     HALO_FIELD_SWITCH(c->sfield, (k_halo_prepare<P><<<blocks, 256, 0, c->stream>>>((const uint4*)c->a, (const uint4*)c->b, m, m0, (const uint4*)c->coef,
-                                                                                     (uint4*)sL, (uint4*)sR, (uint4*)c->part),
+                                                                                     (const uint4*)(c->dsc + 2 * 32), (uint4*)sL, (uint4*)sR, (uint4*)c->part),
                                   k_halo_close<P><<<1, 64, 0, c->stream>>>((const uint4*)c->part, blocks, lb, rb, cnt, (uint4*)sL, (uint4*)sR)));
     PLK_HIP_TRY(hipGetLastError());
     uint8_t* out_xy = c->out;
@@ -333,11 +356,13 @@ int halo_round_fold_impl(plk_halo_ctx* c, const uint64_t* u_j, const uint64_t* u
     const size_t m0 = c->frozen ? c->m0 : 0;
     const size_t work = m > m0 ? m : m0;
     HALO_FIELD_SWITCH(c->sfield, (k_halo_fold_scalars<P><<<(unsigned)((work + 255) / 256), 256, 0, c->stream>>>(
-                                     (uint4*)c->a, (uint4*)c->b, m, to_halo_scalar(u_j), to_halo_scalar(u_j_inv), (uint4*)c->coef, m0)));
+                                     (uint4*)c->a, (uint4*)c->b, m, to_halo_scalar(u_j), to_halo_scalar(u_j_inv), (uint4*)c->coef, m0,
+                                     (uint4*)(c->frozen ? nullptr : c->dsc))));
     PLK_HIP_TRY(hipGetLastError());
     if (!c->frozen) {
-        // G'_i = [u^-1] G_lo_i + [u] G_hi_i in place (pair i only touches elements i and m + i)
-        PLK_TRY(curve_fold_pairs_dev_impl(c->curve, m, c->g, c->gz, c->g + m * pt, c->gz + m, u_j_inv, u_j, c->g, c->gz, c->stream));
+        // G'_i = [u^-1] G_lo_i + [u] G_hi_i = [u^-1] (G_lo_i + [u^2] G_hi_i): the scaled fold G~'_i = G~_lo_i + [u^2] G~_hi_i in place
+        // (pair i only touches elements i and m + i); u^2 and the new scale c u^-1 were just written to dsc
+        PLK_TRY(curve_fold_pairs_dev_impl(c->curve, m, c->g, c->gz, c->g + m * pt, c->gz + m, nullptr, nullptr, c->g, c->gz, c->stream, c->dsc, 1));
     }
     c->n = m;
     c->lr_done = false;
@@ -360,8 +385,20 @@ int halo_read_impl(plk_halo_ctx* c, uint64_t* a, uint64_t* b, uint64_t* g_xy, ui
     if (g_xy || g_zero) {
         if (!g_xy || !g_zero) return set_error(PLK_ERR_INVALID_ARG, "g_xy and g_zero go together");
         if (!c->frozen) {
-            PLK_HIP_TRY(hipMemcpyAsync(g_xy, c->g, c->n * pt, hipMemcpyDeviceToHost, c->stream));
-            PLK_HIP_TRY(hipMemcpyAsync(g_zero, c->gz, c->n, hipMemcpyDeviceToHost, c->stream));
+            // halo_g_i = [c] G~_i: the pairwise kernel with the scalars (c, 0) over (G~_i, G~_i)
+            uint8_t* tmp = (uint8_t*)scratch_acquire(c->n * (pt + 1), c->stream);
+            if (!tmp) return PLK_ERR_OOM;
+            const int rc = curve_fold_pairs_dev_impl(c->curve, c->n, c->g, c->gz, c->g, c->gz, nullptr, nullptr, tmp, tmp + c->n * pt, c->stream, c->dsc + 2 * 32, 0);
+            hipError_t e1 = hipSuccess, e2 = hipSuccess;
+            if (rc == PLK_OK) {
+                e1 = hipMemcpyAsync(g_xy, tmp, c->n * pt, hipMemcpyDeviceToHost, c->stream);
+                e2 = hipMemcpyAsync(g_zero, tmp + c->n * pt, c->n, hipMemcpyDeviceToHost, c->stream);
+            }
+            (void)hipStreamSynchronize(c->stream);
+            scratch_release(tmp, c->stream);
+            PLK_TRY(rc);
+            PLK_HIP_TRY(e1);
+            PLK_HIP_TRY(e2);
         } else if (c->n == 1) {
             // halo_g[0] = sum_j s_j G^(f)_j (scalars of H and U': zero)
             PLK_HIP_TRY(hipMemcpyAsync(c->scal, c->coef, c->m0 * 32, hipMemcpyDeviceToDevice, c->stream));

@@ -1040,20 +1040,24 @@ __global__ void __launch_bounds__(64) k_sum_affine(const uint4* __restrict__ pts
     }
 }
 
-// Multi-GPU exchange: every rank's partial results for `batch` scalar vectors travel as one packed record
-// (plk_msm_partials_bytes: batch affine points, then batch identity flags); block b adds the `world` partial points of vector b.
+// Multi-GPU exchange (plonky_hip.h): every rank's results travel as one packed record of `slots` points then
+// `slots` identity flags.  Block v produces vector v: a whole vector (v < whole * world) is rank v % world's slot v / world,
+// a sharded one is the sum over the ranks of slot whole + (v - whole * world).
 template <class C>
-__global__ void __launch_bounds__(64) k_combine_partials(const uint8_t* __restrict__ gathered, size_t rec_bytes, unsigned world, unsigned batch,
-                                                         uint4* __restrict__ out_xy, uint8_t* __restrict__ out_zero) {
+__global__ void __launch_bounds__(64) k_combine_partials(const uint8_t* __restrict__ gathered, size_t rec_bytes, unsigned world, unsigned slots,
+                                                         unsigned whole, uint4* __restrict__ out_xy, uint8_t* __restrict__ out_zero) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     extern __shared__ __attribute__((aligned(16))) uint4 s_pts[];
-    const unsigned b = blockIdx.x;
+    const unsigned v = blockIdx.x;
+    const bool is_whole = v < whole * world;
+    const unsigned slot = is_whole ? v / world : whole + (v - whole * world);
+    const unsigned r0 = is_whole ? v % world : 0, r1 = is_whole ? r0 + 1 : world;
     Xyzz<FP> acc = xyzz_identity<FP>();
-    for (unsigned r = threadIdx.x; r < world; r += blockDim.x) {
+    for (unsigned r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
         const uint8_t* rec = gathered + (size_t)r * rec_bytes;
-        if (rec[(size_t)batch * 2 * W * 16 + b]) continue;
-        const uint4* pt = (const uint4*)(rec + (size_t)b * 2 * W * 16);
+        if (rec[(size_t)slots * 2 * W * 16 + slot]) continue;
+        const uint4* pt = (const uint4*)(rec + (size_t)slot * 2 * W * 16);
         Fe<FP> x = fe_load<FP>(pt), y = fe_load<FP>(pt + W);
         xyzz_madd<FP>(acc, x, y);
     }
@@ -1061,9 +1065,9 @@ __global__ void __launch_bounds__(64) k_combine_partials(const uint8_t* __restri
     if (threadIdx.x == 0) {
         Fe<FP> x, y;
         const bool ident = xyzz_to_affine<FP, true>(acc, x, y);
-        fe_store<FP>(out_xy + (size_t)b * 2 * W, x);
-        fe_store<FP>(out_xy + (size_t)b * 2 * W + W, y);
-        out_zero[b] = ident ? 1 : 0;
+        fe_store<FP>(out_xy + (size_t)v * 2 * W, x);
+        fe_store<FP>(out_xy + (size_t)v * 2 * W + W, y);
+        out_zero[v] = ident ? 1 : 0;
     }
 }
 
@@ -1333,7 +1337,10 @@ template <class C> static int msm_alloc_work(plk_msm_ctx* ctx, MsmWork& w, hipSt
     WorkPart parts[MSM_WORK_PARTS];
     msm_work_parts<C>(ctx, w, parts);
     size_t total = 0;
-    for (const WorkPart& pt : parts) total += (pt.bytes + 255) & ~(size_t)255;
+    for (int k = 0; k < MSM_WORK_PARTS; ++k) {
+        if (parts[k].bytes < w.cap[k]) parts[k].bytes = w.cap[k];  // reserved for the other generator counts of a rebound context
+        total += (parts[k].bytes + 255) & ~(size_t)255;
+    }
     ctx->ws_bytes = total + 256;
     // A table-free context lives for one call (msm_parallel, an IPA round): its memory comes from the scratch pool, because
     // hipMalloc + hipFree of a few hundred MB cost as much as a tenth of the MSM itself (0.4 ms of 3.8 at 2^20).
@@ -1396,14 +1403,36 @@ template <class C> static void msm_launch_table(plk_msm_ctx* ctx, const void* d_
                                                                    ctx->table_free ? 1 : ctx->windows, ctx->glv ? 1 : 0, n - n_extra, (const uint4*)d_extra);
 }
 
+static int msm_configure(plk_msm_ctx* ctx, int curve, size_t n, unsigned window_bits, bool table_free);
 template <class C>
-static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d_zero, const void* d_extra, size_t n_extra, hipStream_t stream) {
+static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d_zero, const void* d_extra, size_t n_extra, hipStream_t stream,
+                            const size_t* also_n, int also_count) {
     using FP = typename C::FP;
     const size_t pt_bytes = (size_t)2 * FP::NL * 4;
+    ctx->ws.resize(1);
+    size_t tab_min = 0;
+    if (also_count > 0) {
+        // the context will be rebound to these generator counts (msm_rebind_dev_impl): every part of the workspace is
+        // sized for the largest need over all of them - the parts are not monotonic in n (the window, hence the bucket and
+        // tile counts, changes with it)
+        const size_t n_own = ctx->n;
+        MsmWork probe;
+        WorkPart parts[MSM_WORK_PARTS];
+        for (int a = 0; a < also_count; ++a) {
+            if (msm_configure(ctx, ctx->curve, also_n[a], 0, ctx->table_free) != PLK_OK) continue;
+            msm_configure_lanes<C>(ctx);
+            msm_work_parts<C>(ctx, probe, parts);
+            for (int k = 0; k < MSM_WORK_PARTS; ++k)
+                if (parts[k].bytes > ctx->ws[0].cap[k]) ctx->ws[0].cap[k] = parts[k].bytes;
+            if (ctx->n_eff * pt_bytes + 16 > tab_min) tab_min = ctx->n_eff * pt_bytes + 16;
+        }
+        PLK_TRY(msm_configure(ctx, ctx->curve, n_own, 0, ctx->table_free));
+    }
     const size_t entries = ctx->n_eff * ctx->windows;
     msm_configure_lanes<C>(ctx);
     if (ctx->table_free) {
         ctx->tab_cap = ctx->n_eff * pt_bytes + 16;
+        if (ctx->tab_cap < tab_min) ctx->tab_cap = tab_min;
         ctx->tab = scratch_acquire(ctx->tab_cap, stream);
         if (!ctx->tab) return PLK_ERR_OOM;
         ctx->tab_stream = stream;
@@ -1411,7 +1440,6 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
         ctx->tab_cap = entries * pt_bytes + 16;
         PLK_HIP_TRY(hipMalloc(&ctx->tab, ctx->tab_cap));
     }
-    ctx->ws.resize(1);
     PLK_TRY(msm_alloc_work<C>(ctx, ctx->ws[0], stream));
     msm_launch_table<C>(ctx, d_bases, d_zero, d_extra, n_extra, stream);
     PLK_HIP_TRY(hipGetLastError());
@@ -1540,7 +1568,7 @@ static int msm_configure(plk_msm_ctx* ctx, int curve, size_t n, unsigned window_
 }
 
 int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, unsigned flags, hipStream_t stream,
-                            plk_msm_ctx** out_ctx, const void* d_extra, size_t n_extra) {
+                            plk_msm_ctx** out_ctx, const void* d_extra, size_t n_extra, const size_t* also_n, int also_count) {
     if (!out_ctx) return set_error(PLK_ERR_INVALID_ARG, "null out_ctx");
     *out_ctx = nullptr;
     if (curve_limbs(curve) < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
@@ -1553,11 +1581,11 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     ctx->device = dev;
     int rc = msm_configure(ctx, curve, n, window_bits, (flags & PLK_MSM_TABLE_FREE) != 0);
     if (rc == PLK_OK) switch (curve) {
-        case PLK_CURVE_TWEEDLEDEE: rc = msm_precompute_t<TweedledeeCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream); break;
-        case PLK_CURVE_TWEEDLEDUM: rc = msm_precompute_t<TweedledumCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream); break;
-        case PLK_CURVE_PALLAS: rc = msm_precompute_t<PallasCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream); break;
-        case PLK_CURVE_VESTA: rc = msm_precompute_t<VestaCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream); break;
-        default: rc = msm_precompute_t<Bls12377Curve>(ctx, d_bases, d_zero, d_extra, n_extra, stream); break;
+        case PLK_CURVE_TWEEDLEDEE: rc = msm_precompute_t<TweedledeeCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream, also_n, also_count); break;
+        case PLK_CURVE_TWEEDLEDUM: rc = msm_precompute_t<TweedledumCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream, also_n, also_count); break;
+        case PLK_CURVE_PALLAS: rc = msm_precompute_t<PallasCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream, also_n, also_count); break;
+        case PLK_CURVE_VESTA: rc = msm_precompute_t<VestaCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream, also_n, also_count); break;
+        default: rc = msm_precompute_t<Bls12377Curve>(ctx, d_bases, d_zero, d_extra, n_extra, stream, also_n, also_count); break;
     }
     if (rc != PLK_OK) {
         delete ctx;
@@ -1737,7 +1765,10 @@ static void work_done(MsmWork& w, hipStream_t stream) {
     w.used = true;
 }
 
-int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream) {
+// ready (optional): one event per scalar vector; vector b is not touched before ready[b] has completed (the host-pointer entry
+// point copies vector b + 1 through PCIe while vector b is being reduced)
+int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
+                         hipEvent_t* ready) {
     if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
     if (n_scalars != ctx->n)
         return set_error(PLK_ERR_SIZE_MISMATCH, "scalars.len() = %zu but the precomputation holds %zu generators (curve_msm.rs:67)", n_scalars, ctx->n);
@@ -1747,6 +1778,7 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
     std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t L = (size_t)curve_limbs(ctx->curve);
     auto run_one = [&](unsigned b, MsmWork& w, hipStream_t st, int phases) -> int {
+        if (ready && (phases & PH_ORDER)) PLK_HIP_TRY(hipStreamWaitEvent(st, ready[b], 0));
         const uint8_t* sc = (const uint8_t*)d_scalars + (size_t)b * ctx->n * 32;
         uint8_t* oxy = (uint8_t*)d_out_xy + (size_t)b * 2 * L * 8;
         uint8_t* oz = (uint8_t*)d_out_zero + b;
@@ -1900,22 +1932,25 @@ int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void
     return PLK_OK;
 }
 
-size_t msm_partials_bytes(int curve, unsigned batch) {
+size_t msm_partials_bytes(int curve, unsigned slots) {
     const int L = curve_limbs(curve);
     if (L < 0) return 0;
-    return ((size_t)batch * 2 * L * 8 + batch + 15) & ~(size_t)15;
+    return ((size_t)slots * 2 * L * 8 + slots + 15) & ~(size_t)15;
 }
-int msm_combine_partials_dev_impl(int curve, unsigned world, unsigned batch, const void* d_gathered, void* d_out_xy, void* d_out_zero, hipStream_t stream) {
+int msm_combine_partials_dev_impl(int curve, unsigned world, unsigned batch, unsigned whole_per_rank, const void* d_gathered, void* d_out_xy, void* d_out_zero,
+                                  hipStream_t stream) {
     if (curve_limbs(curve) < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (batch == 0) return PLK_OK;
     if (world == 0 || !d_gathered || !d_out_xy || !d_out_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer or world = 0");
+    if ((size_t)whole_per_rank * world > batch) return set_error(PLK_ERR_INVALID_ARG, "whole_per_rank %u x world %u exceeds the batch %u", whole_per_rank, world, batch);
     PLK_TRY(ensure_device());
-    const size_t rec = msm_partials_bytes(curve, batch);
+    const unsigned slots = whole_per_rank + (batch - whole_per_rank * world);
+    const size_t rec = msm_partials_bytes(curve, slots);
     switch (curve) {
-#define CASE(ID, C)                                                                                                                           \
-    case ID:                                                                                                                                  \
-        k_combine_partials<C><<<batch, 64, 64 * 4 * C::FP::NL * 4, stream>>>((const uint8_t*)d_gathered, rec, world, batch, (uint4*)d_out_xy, \
-                                                                             (uint8_t*)d_out_zero);                                           \
+#define CASE(ID, C)                                                                                                                                     \
+    case ID:                                                                                                                                            \
+        k_combine_partials<C><<<batch, 64, 64 * 4 * C::FP::NL * 4, stream>>>((const uint8_t*)d_gathered, rec, world, slots, whole_per_rank,            \
+                                                                             (uint4*)d_out_xy, (uint8_t*)d_out_zero);                                   \
         break;
         CASE(PLK_CURVE_TWEEDLEDEE, TweedledeeCurve)
         CASE(PLK_CURVE_TWEEDLEDUM, TweedledumCurve)
@@ -1925,6 +1960,31 @@ int msm_combine_partials_dev_impl(int curve, unsigned world, unsigned batch, con
 #undef CASE
     }
     PLK_HIP_TRY(hipGetLastError());
+    return PLK_OK;
+}
+
+// workspaces for batches of up to `count` vectors, allocated ahead of the first batched execution
+int msm_reserve_workspaces_impl(plk_msm_ctx* ctx, unsigned count, hipStream_t stream) {
+    if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
+    PLK_TRY(ensure_device());
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (count > (unsigned)TAIL_MAX) count = TAIL_MAX;
+    while (ctx->ws.size() < count) {
+        ctx->ws.emplace_back();
+        int rc;
+        switch (ctx->curve) {
+            case PLK_CURVE_TWEEDLEDEE: rc = msm_alloc_work<TweedledeeCurve>(ctx, ctx->ws.back(), stream); break;
+            case PLK_CURVE_TWEEDLEDUM: rc = msm_alloc_work<TweedledumCurve>(ctx, ctx->ws.back(), stream); break;
+            case PLK_CURVE_PALLAS: rc = msm_alloc_work<PallasCurve>(ctx, ctx->ws.back(), stream); break;
+            case PLK_CURVE_VESTA: rc = msm_alloc_work<VestaCurve>(ctx, ctx->ws.back(), stream); break;
+            default: rc = msm_alloc_work<Bls12377Curve>(ctx, ctx->ws.back(), stream); break;
+        }
+        if (rc != PLK_OK) {
+            ctx->ws.back().release();
+            ctx->ws.pop_back();
+            return rc;
+        }
+    }
     return PLK_OK;
 }
 

@@ -16,6 +16,7 @@
 // every operation is exact modulo p and the result is reduced to the unique representative at the end, so it is
 // bit-identical to the reference's (field arithmetic is exact and associative; only the grouping differs).
 // get_subgroup_shift (partition.rs:140-153) draws its k_i from ChaCha8: they are inputs here.
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -286,7 +287,7 @@ template <class P> struct ReducedSink {
     }
 };
 // Base4SumGate's running sum, computed = 4 computed + limb over the seven limbs (base_4_sum.rs:44-48)
-template <int I, class P, int B, class D> PLK_DI auto base4_chain(const Lz<P, B>& computed, const D (&l)[NUM_WIRES]) {
+template <int I, class P, int B, class LW> PLK_DI auto base4_chain(const Lz<P, B>& computed, const LW& l) {
     if constexpr (I == NUM_WIRES - 2) return computed;
     else return base4_chain<I + 1>(lz_tame(computed.quad() + l[2 + I]), l);
 }
@@ -297,24 +298,37 @@ template <int I, class P, int B, class D> PLK_DI auto base4_chain(const Lz<P, B>
 // 101010, has no constraints: buffer.rs:26-33): a filter kept alive for the whole kernel costs nine registers.
 // gate groups (a kernel evaluates a subset: the live set of all ten gates is several register files wide)
 constexpr int GATES_RESCUE = 1, GATES_ENDO = 2, GATES_BASE4_ARITH = 4, GATES_ADD_PUBLIC = 8, GATES_DBL_CONST = 16, GATES_ALL = 31;
-template <class P, class D, int MASK, class Sink>
-PLK_DI void all_constraints(const D (&k)[NUM_CONSTANTS], const D (&l)[NUM_WIRES], const D (&r)[4], const D& b2, const D& b3, const D& zeta, const D& a_coeff,
+// The inputs of a point are READ WHERE A GATE USES THEM: k / l / r are rows of the prover's tables (or plain arrays, in
+// k_all_constraints) indexed through operator[], every mention a load and a re-slicing into the working form (~80
+// instructions against ~220 for a product).  An input held from the top of the kernel costs nine registers for its whole
+// length; 21 of them are 189 - with the working set of a gate that is a whole register file and one wave per SIMD.
+template <class P> struct LazyRow {
+    const uint4* base;
+    size_t stride, i;
+    PLK_DI Lz<P, 16> operator[](int j) const { return lz_load<P>(base, (size_t)j * stride + i); }
+};
+template <class P, class D, int MASK, class K, class LW, class RW, class Sink>
+PLK_DI void all_constraints(const K& k, const LW& l, const RW& r, const D& b2, const D& b3, const D& zeta, const D& a_coeff,
                             const uint4* __restrict__ small, Sink& sink) {
     const auto one = lz_one<P>();
     if constexpr ((MASK & GATES_RESCUE) != 0) {  // RescueStepAGate 00, rescue_a.rs:38-69, and RescueStepBGate 01, rescue_b.rs:30-58
         const auto nk0 = one - k[0];
+        const D k1 = k[1];
         Lz<P, 8> mds[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) mds[i] = lz_table<P>(small, i);  // mds[v - 1] = 1 / v; entry (r, c) = 1 / (4 + r - c), mds.rs:63-77
         // row i of the MDS matrix times (v0 .. v3), plus the round constant, against the right gate's wire i
 #define PLK_MDS_ROW(i, v0, v1, v2, v3) (k[2 + i] + (mds[3 + i] * v0 + mds[2 + i] * v1 + mds[1 + i] * v2 + mds[i] * v3) - r[i])
-        sink.template gate<7>(nk0 * (one - k[1]),                                                         //
-                              l[4].pow5() - l[0], PLK_MDS_ROW(0, l[4], l[5], l[6], l[7]),                 //
-                              l[5].pow5() - l[1], PLK_MDS_ROW(1, l[4], l[5], l[6], l[7]),                 //
-                              l[6].pow5() - l[2], PLK_MDS_ROW(2, l[4], l[5], l[6], l[7]),                 //
-                              l[7].pow5() - l[3], PLK_MDS_ROW(3, l[4], l[5], l[6], l[7]));
+        {
+            const D l4 = l[4], l5 = l[5], l6 = l[6], l7 = l[7];
+            sink.template gate<7>(nk0 * (one - k1),                                           //
+                                  l4.pow5() - l[0], PLK_MDS_ROW(0, l4, l5, l6, l7),           //
+                                  l5.pow5() - l[1], PLK_MDS_ROW(1, l4, l5, l6, l7),           //
+                                  l6.pow5() - l[2], PLK_MDS_ROW(2, l4, l5, l6, l7),           //
+                                  l7.pow5() - l[3], PLK_MDS_ROW(3, l4, l5, l6, l7));
+        }
         const auto e0 = l[0].pow5(), e1 = l[1].pow5(), e2 = l[2].pow5(), e3 = l[3].pow5();
-        sink.template gate<8>(nk0 * k[1], PLK_MDS_ROW(0, e0, e1, e2, e3), PLK_MDS_ROW(1, e0, e1, e2, e3), PLK_MDS_ROW(2, e0, e1, e2, e3),
+        sink.template gate<8>(nk0 * k1, PLK_MDS_ROW(0, e0, e1, e2, e3), PLK_MDS_ROW(1, e0, e1, e2, e3), PLK_MDS_ROW(2, e0, e1, e2, e3),
                               PLK_MDS_ROW(3, e0, e1, e2, e3));
 #undef PLK_MDS_ROW
     }
@@ -340,7 +354,8 @@ PLK_DI void all_constraints(const D (&k)[NUM_CONSTANTS], const D (&l)[NUM_WIRES]
             const auto two = one.dbl();
             const auto three = two + one;
             // (limb - 0) (limb - 1) (limb - 2) (limb - 3), times ONE in the reference
-#define PLK_B4(i) (l[2 + i] * (l[2 + i] - one) * (l[2 + i] - two) * (l[2 + i] - three))
+            auto b4 = [&](const D& limb) { return limb * (limb - one) * (limb - two) * (limb - three); };
+#define PLK_B4(i) b4(l[2 + i])
             sink.template gate<3>(p100 * (one - k[3]), (base4_chain<0>(l[0], l) - l[1]).rs(), PLK_B4(0), PLK_B4(1), PLK_B4(2), PLK_B4(3), PLK_B4(4), PLK_B4(5),
                                   PLK_B4(6));
 #undef PLK_B4
@@ -417,8 +432,9 @@ template <class P> PLK_DI Lz<P, 16> scalar_at(const uint32_t (*s_sc)[FzCfg<P>::N
 //   PASS 1: CurveEndo, Base4Sum, Arithmetic         -> part +=
 //   PASS 2: CurveAdd, PublicInput, CurveDbl, Constant, the permutation argument and L_1, reduce_with_powers -> out
 // The sum over the gates and the powers of alpha commute (ReducedSink), every value is exact: same result as one loop.
-template <class P, int PASS>
-__global__ void __launch_bounds__(128) k_vanishing_points(const uint4* __restrict__ constants, const uint4* __restrict__ wires, const uint4* __restrict__ s_sigma,
+// WAVES: waves per SIMD the register allocation is held to (2: at most 256 registers per lane)
+template <class P, int PASS, int WAVES>
+__global__ void __launch_bounds__(128, WAVES) k_vanishing_points(const uint4* __restrict__ constants, const uint4* __restrict__ wires, const uint4* __restrict__ s_sigma,
                                                           const uint4* __restrict__ z, const uint4* __restrict__ xs_lo_z, const uint4* __restrict__ xs_hi_z,
                                                           const uint4* __restrict__ l1, const uint4* __restrict__ small, PlonkScalars sc, int log_degree,
                                                           uint32_t* __restrict__ part, uint4* __restrict__ out) {
@@ -431,15 +447,13 @@ __global__ void __launch_bounds__(128) k_vanishing_points(const uint4* __restric
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;
     const size_t i_right = (i + 8) & (n8 - 1), i_below = (i + 8 * GRID_WIDTH) & (n8 - 1);
-    // every input is named here; what the gates of this launch do not read is never loaded
-    D k[NUM_CONSTANTS], l[NUM_WIRES], r[4];
-#pragma unroll
-    for (int j = 0; j < NUM_CONSTANTS; ++j) k[j] = lz_load<P>(constants, (size_t)j * n8 + i);
-#pragma unroll
-    for (int j = 0; j < NUM_WIRES; ++j) l[j] = lz_load<P>(wires, (size_t)j * n8 + i);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = lz_load<P>(wires, (size_t)j * n8 + i_right);
-    const D b2 = lz_load<P>(wires, (size_t)2 * n8 + i_below), b3 = lz_load<P>(wires, (size_t)3 * n8 + i_below);
+    // the rows a gate reads from: local constants, local wires, the right gate's wires (loaded where they are used)
+    const LazyRow<P> k{constants, n8, i}, l{wires, n8, i}, r{wires, n8, i_right};
+    D b2{fz_zero<P>()}, b3{fz_zero<P>()};
+    if constexpr ((MASK & GATES_ENDO) != 0) {
+        b2 = lz_load<P>(wires, (size_t)2 * n8 + i_below);
+        b3 = lz_load<P>(wires, (size_t)3 * n8 + i_below);
+    }
     const D alpha = scalar_at<P>(s_sc, 6);
     ReducedSink<P> sink{alpha, Term<P>{fz_zero<P>()}};
     all_constraints<P, D, MASK>(k, l, r, b2, b3, scalar_at<P>(s_sc, 9), scalar_at<P>(s_sc, 10), small, sink);
@@ -461,8 +475,9 @@ __global__ void __launch_bounds__(128) k_vanishing_points(const uint4* __restric
         for (int j = 0; j < NUM_ROUTED_WIRES; ++j) {  // plonk.rs:428-437
             const auto s_id = scalar_at<P>(s_sc, j) * x;
             const D s_sig = lz_load<P>(s_sigma, (size_t)j * n8 + i);
-            f_prime = f_prime * (l[j] + beta * s_id + gamma);
-            g_prime = g_prime * (l[j] + beta * s_sig + gamma);
+            const D lj = l[j];
+            f_prime = f_prime * (lj + beta * s_id + gamma);
+            g_prime = g_prime * (lj + beta * s_sig + gamma);
         }
         const auto v_shift_term = f_prime * z_x - g_prime * z_gz;  // plonk.rs:438
         // reduce_with_powers over [z_1_term, v_shift_term, constraint terms] (plonk.rs:440-447, plonk_util.rs:27-33)
@@ -514,13 +529,21 @@ static int vanishing_points_t(unsigned log_degree, const void* d_constants, cons
     void* part = scratch_acquire(limb_bytes(n8, FzCfg<P>::NZ), stream);
     if (!part) return PLK_ERR_OOM;
     const unsigned blocks = (unsigned)((n8 + 127) / 128);
-#define PLK_VANISH(PASS)                                                                                                                                  \
-    k_vanishing_points<P, PASS><<<blocks, 128, 0, stream>>>((const uint4*)d_constants, (const uint4*)d_wires, (const uint4*)d_s_sigma, (const uint4*)d_z, \
-                                                            (const uint4*)t->xs_lo_z, (const uint4*)t->xs_hi_z, (const uint4*)t->l1, (const uint4*)t->small, sc, \
-                                                            (int)log_degree, (uint32_t*)part, (uint4*)d_out)
-    PLK_VANISH(0);
-    PLK_VANISH(1);
-    PLK_VANISH(2);
+    static const int waves = getenv("PLK_VANISH_WAVES") ? atoi(getenv("PLK_VANISH_WAVES")) : 2;
+#define PLK_VANISH(PASS, WAVES)                                                                                                                           \
+    k_vanishing_points<P, PASS, WAVES><<<blocks, 128, 0, stream>>>((const uint4*)d_constants, (const uint4*)d_wires, (const uint4*)d_s_sigma,           \
+                                                                   (const uint4*)d_z, (const uint4*)t->xs_lo_z, (const uint4*)t->xs_hi_z,               \
+                                                                   (const uint4*)t->l1, (const uint4*)t->small, sc, (int)log_degree, (uint32_t*)part, \
+                                                                   (uint4*)d_out)
+    if (waves >= 2) {
+        PLK_VANISH(0, 2);
+        PLK_VANISH(1, 2);
+        PLK_VANISH(2, 2);
+    } else {
+        PLK_VANISH(0, 1);
+        PLK_VANISH(1, 1);
+        PLK_VANISH(2, 1);
+    }
 #undef PLK_VANISH
     const hipError_t e = hipGetLastError();
     scratch_release(part, stream);

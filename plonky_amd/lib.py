@@ -60,7 +60,7 @@ SYMBOLS = [
     ("plk_msm", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("plk_curve_sum_affine", _i, [_i, _sz, _vp, _vp, _vp, _vp]),
     ("plk_msm_partials_bytes", _sz, [_i, _u]),
-    ("plk_msm_combine_partials_dev", _i, [_i, _u, _u, _vp, _vp, _vp, _vp]),
+    ("plk_msm_combine_partials_dev", _i, [_i, _u, _u, _u, _vp, _vp, _vp, _vp]),
     ("plk_msm_table_digits", _i, [_i, _u]),
     ("plk_msm_precompute_table", _i, [_i, _sz, _vp, _vp, _u, _vp, _vp]),
     ("plk_msm_precompute_table_dev", _i, [_i, _sz, _vp, _vp, _u, _vp, _vp, _vp]),

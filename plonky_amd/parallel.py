@@ -24,39 +24,85 @@ def _backend():
     return dist.get_backend() if dist.is_initialized() else None
 
 
+class BatchPlan:
+    """How `batch` scalar vectors against the same n generators are dealt out over `world` ranks (include/plonky_hip.h):
+    floor(batch / world) WHOLE vectors per rank (vector v belongs to rank v mod world, slot v // world there) - they need no
+    exchange beyond handing the result over and keep the window a full-size MSM deserves - and the remaining batch mod world
+    vectors SHARDED by contiguous base range (slot whole + j on every rank).  9 wire polynomials on 8 GPUs: one whole vector
+    per rank and an eighth of the ninth.  A single MSM on N GPUs: the sharded case alone."""
+
+    def __init__(self, batch, world, rank, n):
+        self.batch, self.world, self.rank, self.n = batch, world, rank, n
+        self.whole = batch // world
+        self.sharded = batch - self.whole * world
+        self.slots = self.whole + self.sharded
+        self.own = [rank + k * world for k in range(self.whole)]
+        self.rem = list(range(self.whole * world, batch))
+        self.lo, self.hi = shard_bounds(n, rank, world)
+        # whole vectors need every generator on every rank; a purely sharded job only its own base range
+        self.full_context = self.whole > 0
+        self.n_local = n if self.full_context else self.hi - self.lo
+        self.first = 0 if self.full_context else self.lo
+
+    def local_scalars(self, vectors):
+        """vectors: (batch, n, 4) uint64 host array of ALL scalar vectors -> this rank's (slots, n_local, 4) array: its whole
+        vectors, then its share of the sharded ones (over the full context: the vector with zeros outside [lo, hi) - a zero
+        scalar has no digits, so it costs an MSM nothing)."""
+        import numpy as np
+        out = np.zeros((self.slots, self.n_local, 4), dtype=np.uint64)
+        for k, v in enumerate(self.own):
+            out[k] = vectors[v]
+        for j, v in enumerate(self.rem):
+            if self.full_context:
+                out[self.whole + j, self.lo:self.hi] = vectors[v, self.lo:self.hi]
+            else:
+                out[self.whole + j] = vectors[v, self.lo:self.hi]
+        return out
+
+    def pairs_local(self):
+        """scalar-point pairs this rank reduces per step"""
+        return self.whole * self.n + self.sharded * (self.hi - self.lo)
+
+
 class PartialExchange:
     """The exchange step of the sharded MSM with every buffer allocated once.
 
-    `send` is this rank's record in the layout of plk_msm_partials_bytes (include/plonky_hip.h): batch affine points
-    then batch identity flags.  `out_xy` / `out_zero` are views INTO it, so plk_msm_execute_dev writes its results straight
-    into the send buffer of the collective; gather() is the one all_gather_into_tensor; combine() adds the ranks' partial
-    points on the device (plk_msm_combine_partials_dev).  No packing, no allocation, no host round trip inside a step
-    (except the host staging gloo needs for device tensors)."""
+    `send` is this rank's record in the layout of plk_msm_partials_bytes (include/plonky_hip.h): `slots` affine points then
+    `slots` identity flags.  `out_xy` / `out_zero` are views INTO it, so plk_msm_execute_dev writes its results straight
+    into the send buffer of the collective; gather() is the one all_gather_into_tensor; combine() produces the `batch` results
+    on the device (plk_msm_combine_partials_dev: whole vectors copied from their owner, sharded ones summed over the ranks).
+    No packing, no allocation, no host round trip inside a step (except the host staging gloo needs for device tensors)."""
 
-    def __init__(self, curve, batch, device="cuda"):
+    def __init__(self, curve, batch, device="cuda", whole_per_rank=0, world=None, rank=None):
         from . import lib as _lib
         from .api import _CURVE_LIMBS
-        self.curve, self.batch = curve, batch
+        self.curve, self.batch, self.whole = curve, batch, whole_per_rank
         self.L = _CURVE_LIMBS[curve]
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.rec = int(_lib.load().plk_msm_partials_bytes(curve, batch))
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.real_world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
+        self.slots = whole_per_rank + (batch - whole_per_rank * self.world)
+        assert 0 < self.slots <= batch
+        self.rec = int(_lib.load().plk_msm_partials_bytes(curve, self.slots))
         assert self.rec > 0 and self.rec % 16 == 0
         dev = torch.device(device)
         self.send = torch.zeros(self.rec, dtype=torch.uint8, device=dev)
         self.recv = torch.zeros(self.world * self.rec, dtype=torch.uint8, device=dev)
-        pts = batch * 2 * self.L * 8
-        self.out_xy = self.send[:pts].view(torch.int64).view(batch, 2, self.L)
-        self.out_zero = self.send[pts:pts + batch]
+        pts = self.slots * 2 * self.L * 8
+        self.out_xy = self.send[:pts].view(torch.int64).view(self.slots, 2, self.L)
+        self.out_zero = self.send[pts:pts + self.slots]
         self.sum_xy = torch.empty((batch, 2, self.L), dtype=torch.int64, device=dev)
         self.sum_zero = torch.empty((batch,), dtype=torch.uint8, device=dev)
+        self.recv.view(self.world, self.rec)[:, pts:pts + self.slots] = 1  # until a record arrives its points are the identity
         self._host = None
         if dev.type == "cuda" and _backend() == "gloo":
             self._host = (torch.zeros(self.rec, dtype=torch.uint8).pin_memory(), torch.zeros(self.world * self.rec, dtype=torch.uint8).pin_memory())
 
     def gather(self):
-        """ONE collective: every rank's record to every rank."""
-        if self.world == 1:
-            self.recv.copy_(self.send)
+        """ONE collective: every rank's record to every rank.  (An emulated rank - world > the real world size - fills its own
+        slot of the gathered buffer only: the copy stands in for the collective.)"""
+        if self.real_world == 1:
+            self.recv[self.rank * self.rec:(self.rank + 1) * self.rec].copy_(self.send)
         elif self._host is not None:
             hs, hr = self._host
             hs.copy_(self.send)  # synchronises the current stream
@@ -67,20 +113,20 @@ class PartialExchange:
         return self.recv
 
     def combine(self):
-        """Sum of the ranks' partial points per scalar vector -> (sum_xy (batch, 2, L), sum_zero (batch,)) on the device."""
+        """The `batch` results in vector order -> (sum_xy (batch, 2, L), sum_zero (batch,)) on the device."""
         from . import lib as _lib
         assert self.recv.is_cuda, "the point sum runs on the GPU (there is no CPU path)"
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(_lib.load().plk_msm_combine_partials_dev(self.curve, self.world, self.batch, ctypes.c_void_p(self.recv.data_ptr()),
+        _lib.check(_lib.load().plk_msm_combine_partials_dev(self.curve, self.world, self.batch, self.whole, ctypes.c_void_p(self.recv.data_ptr()),
                                                             ctypes.c_void_p(self.sum_xy.data_ptr()), ctypes.c_void_p(self.sum_zero.data_ptr()), st))
         return self.sum_xy, self.sum_zero
 
     def partials(self):
-        """Views of the gathered records: (world, batch, 2, L) int64 and (world, batch) uint8."""
+        """Views of the gathered records: (world, slots, 2, L) int64 and (world, slots) uint8."""
         rows = self.recv.view(self.world, self.rec)
-        pts = self.batch * 2 * self.L * 8
-        xy = rows[:, :pts].contiguous().view(torch.int64).view(self.world, self.batch, 2, self.L)
-        return xy, rows[:, pts:pts + self.batch].contiguous()
+        pts = self.slots * 2 * self.L * 8
+        xy = rows[:, :pts].contiguous().view(torch.int64).view(self.world, self.slots, 2, self.L)
+        return xy, rows[:, pts:pts + self.slots].contiguous()
 
 
 def all_gather_points(xy, zero):

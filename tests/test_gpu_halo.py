@@ -99,7 +99,8 @@ def _run_argument(c, n, freeze_log, seed):
         u_inv = ol.field_unop(f.field_id, "inverse", us[j].reshape(1, 4))[0]
         arg.round_fold(us[j], u_inv)
         assert len(arg) == n >> (j + 1)
-        states.append(arg.frozen)
+        # the state after the fold: halo_a, halo_b always; halo_g while it is still folded explicitly (kept scaled inside)
+        states.append((arg.frozen, arg.read(with_g=not arg.frozen)))
     fa, fb, fg, fgz = arg.read()
     arg.free()
     return (g, h, up, a, b, us, blind), lrs, states, (fa, fb, fg, fgz)
@@ -109,14 +110,15 @@ def _oracle_argument(c, inputs):
     g, h, up, a, b, us, blind = inputs
     f = c.scalar
     n = a.shape[0]
-    lrs = []
+    lrs, states = [], []
     gz = np.zeros(n, dtype=np.uint8)
     for j in range(n.bit_length() - 1):
         exp, ez = ol.halo_round_lr(c.curve_id, f.field_id, a, b, g, h, up, blind[2 * j], blind[2 * j + 1])
         lrs.append((exp, ez))
         u_inv = ol.field_unop(f.field_id, "inverse", us[j].reshape(1, 4))[0]
         a, b, g, gz = ol.halo_round_fold(c.curve_id, f.field_id, a, b, g, us[j], u_inv)
-    return lrs, (a, b, g, gz)
+        states.append((a, b, g, gz))
+    return lrs, states, (a, b, g, gz)
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
@@ -129,13 +131,17 @@ def test_halo_argument_capi_matches_oracle(c, n, freeze_log):
     from plonky_amd import device as dev
     dev.init(0)
     inputs, lrs, states, (fa, fb, fg, fgz) = _run_argument(c, n, freeze_log if freeze_log != 63 else 1, 4000 + n)
-    exp_lrs, (ea, eb, eg, egz) = _oracle_argument(c, inputs)
+    exp_lrs, exp_states, (ea, eb, eg, egz) = _oracle_argument(c, inputs)
     for j, ((lr, z), (elr, ez)) in enumerate(zip(lrs, exp_lrs)):
         assert list(z) == list(ez) and np.array_equal(lr, elr), "round %d" % j
+    for j, ((frozen, got), exp) in enumerate(zip(states, exp_states)):
+        assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]), "halo_a / halo_b after round %d" % j
+        if not frozen:
+            assert np.array_equal(got[2], exp[2]) and np.array_equal(got[3], np.asarray(exp[3], dtype=np.uint8)), "halo_g after round %d" % j
     assert np.array_equal(fa, ea) and np.array_equal(fb, eb)
     assert np.array_equal(fgz, np.asarray(egz, dtype=np.uint8)) and np.array_equal(fg, eg)
     if n >= 4 and freeze_log in (3, 5):
-        assert not states[0] and states[-1]   # explicit folds first, frozen generators at the end
+        assert not states[0][0] and states[-1][0]   # explicit folds first, frozen generators at the end
 
 
 def test_halo_argument_2p16_closed_form():

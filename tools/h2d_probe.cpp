@@ -32,7 +32,7 @@ int main() {
             const size_t chunk = chunk_mib << 20;
             char name[64]; snprintf(name, sizeof name, "chunked staging %zu MiB, 1 thread", chunk_mib);
             rep(name, [&] {
-                hipEvent_t ev[2]; for (auto& e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                hipEvent_t ev[2]; for (int q = 0; q < 2; ++q) CK(hipEventCreateWithFlags(&ev[q], hipEventDisableTiming));
                 for (size_t off = 0, k = 0; off < bytes; off += chunk, ++k) {
                     const size_t len = bytes - off < chunk ? bytes - off : chunk;
                     char* st = pin + (k & 1) * chunk;
@@ -41,14 +41,14 @@ int main() {
                     CK(hipMemcpyAsync((char*)d + off, st, len, hipMemcpyHostToDevice, s));
                     CK(hipEventRecord(ev[k & 1], s));
                 }
-                CK(hipStreamSynchronize(s)); for (auto& e : ev) CK(hipEventDestroy(e));
+                CK(hipStreamSynchronize(s)); for (int q = 0; q < 2; ++q) CK(hipEventDestroy(ev[q]));
             });
         }
         for (int nt : {2, 4, 8}) {
             char name[64]; snprintf(name, sizeof name, "chunked staging 8 MiB, %d copy threads", nt);
             rep(name, [&] {
                 const size_t chunk = (size_t)8 << 20;
-                hipEvent_t ev[2]; for (auto& e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                hipEvent_t ev[2]; for (int q = 0; q < 2; ++q) CK(hipEventCreateWithFlags(&ev[q], hipEventDisableTiming));
                 for (size_t off = 0, k = 0; off < bytes; off += chunk, ++k) {
                     const size_t len = bytes - off < chunk ? bytes - off : chunk;
                     char* st = pin + (k & 1) * chunk;
@@ -60,7 +60,7 @@ int main() {
                     CK(hipMemcpyAsync((char*)d + off, st, len, hipMemcpyHostToDevice, s));
                     CK(hipEventRecord(ev[k & 1], s));
                 }
-                CK(hipStreamSynchronize(s)); for (auto& e : ev) CK(hipEventDestroy(e));
+                CK(hipStreamSynchronize(s)); for (int q = 0; q < 2; ++q) CK(hipEventDestroy(ev[q]));
             });
         }
         rep("D2H to pinned (upper bound)", [&] { CK(hipMemcpyAsync(pin, d, bytes, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); });

@@ -22,7 +22,8 @@ g0 = np.stack([m(BASE, G[0]), m(BASE, G[1])]); dd = np.stack([m(BASE, D[0]), m(B
 Gd = dev.gen_bases_dev(CURVE, n, g0, dd)
 H, U = _mul(p, 11, G), _mul(p, 13, G)
 Hm, Um = np.stack([m(BASE, H[0]), m(BASE, H[1])]), np.stack([m(BASE, U[0]), m(BASE, U[1])])
-us = [1 + 17 * j for j in range(log_n)]
+# full-size challenges (a small u would make the generator fold of its round unrealistically cheap)
+us = [synth.to_int(row) % r or 1 for row in synth.rand_field(SCAL, 3, log_n)]
 ums = [(m(SCAL, u), m(SCAL, pow(u, -1, r))) for u in us]
 bl = [(m(SCAL, 100 + j), m(SCAL, 200 + j)) for j in range(log_n)]
 def run(freeze_log, per_round=None):
