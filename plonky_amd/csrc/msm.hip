@@ -290,8 +290,13 @@ __global__ void __launch_bounds__(ORD_THREADS) k_ord_count(const uint4* __restri
 // level 1, step 2: one block per bin row: in-place exclusive scan over the tiles; the block that finishes last turns the
 // bin totals into the bin offsets bin_base[0..nbins] (exclusive scan; bin_base[nbins] = number of entries) and into the
 // level-2 segment table seg_base[0..nbins] (a bin of t entries has ceil(t / ORD_SEG) segments).
+// It also fixes the accumulation's chunk length for THIS execution from the number of entries actually present (dyn_chunk[0]):
+// the lanes the context was laid out for share them, so a sparse vector (a slice of a sharded commitment, a zero-padded
+// quotient chunk, Z = 1) runs short chains on all lanes instead of full-length chains on a few - the accumulation of a
+// lane is a dependency chain, its length is the kernel's duration.
 __global__ void __launch_bounds__(256) k_ord_scan1(uint32_t* __restrict__ cnt1, uint32_t nt1, int nbins, uint32_t* __restrict__ bin_total,
-                                                   uint32_t* __restrict__ bin_base, uint32_t* __restrict__ seg_base, uint32_t* __restrict__ done_counter) {
+                                                   uint32_t* __restrict__ bin_base, uint32_t* __restrict__ seg_base, uint32_t* __restrict__ done_counter,
+                                                   uint32_t* __restrict__ dyn_chunk, uint32_t chunk_cfg, uint32_t lanes_cfg) {
     __shared__ uint32_t s_sum[256];
     __shared__ uint32_t s_bins[ORD_MAX_BINS];
     __shared__ bool s_last;
@@ -321,7 +326,14 @@ __global__ void __launch_bounds__(256) k_ord_scan1(uint32_t* __restrict__ cnt1, 
     const uint32_t last_total = s_bins[nbins - 1];
     block_excl_scan4(s_bins, nbins, s_sum);
     for (int k = threadIdx.x; k < nbins; k += 256) bin_base[k] = s_bins[k];
-    if (threadIdx.x == 0) bin_base[nbins] = s_bins[nbins - 1] + last_total;
+    if (threadIdx.x == 0) {
+        const uint32_t total = s_bins[nbins - 1] + last_total;
+        bin_base[nbins] = total;
+        uint32_t ch = lanes_cfg ? (total + lanes_cfg - 1) / lanes_cfg : chunk_cfg;
+        if (ch < 8u) ch = 8u;
+        if (ch > chunk_cfg) ch = chunk_cfg;
+        dyn_chunk[0] = ch;
+    }
     __syncthreads();
     for (int k = threadIdx.x; k < nbins; k += 256) s_bins[k] = (vt[k] + ORD_SEG - 1) / ORD_SEG;
     __syncthreads();
@@ -550,14 +562,15 @@ PLK_DI uint32_t next_bucket(const uint32_t* __restrict__ off, uint32_t b, uint32
 }
 template <class C>
 PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ off,
-                                uint4* __restrict__ p_start, uint4* __restrict__ p_head, uint8_t* __restrict__ head_live, uint32_t buckets, uint32_t chunk,
-                                int wshift, uint32_t n_sub, uint4* s_head, uint8_t* s_parked) {
+                                uint4* __restrict__ p_start, uint4* __restrict__ p_head, uint8_t* __restrict__ head_live, uint32_t buckets,
+                                const uint32_t* __restrict__ dyn_chunk, int wshift, uint32_t n_sub, uint4* s_head, uint8_t* s_parked) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     constexpr int RU = raw_u4<FP>();
     const int tid = threadIdx.x;
     const uint32_t lane = blockIdx.x * blockDim.x + tid;
     const uint32_t total = off[buckets];
+    const uint32_t chunk = dyn_chunk[0];
     const uint64_t begin64 = (uint64_t)lane * chunk;
     const bool active = begin64 < total;
     XyzzZ<FP> acc = xyzzz_identity<FP>();
@@ -631,10 +644,11 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
 template <class C>
 __global__ void __launch_bounds__(ACC_THREADS) k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
                                                                 const uint32_t* __restrict__ off, uint4* __restrict__ p_start, uint4* __restrict__ p_head,
-                                                                uint8_t* __restrict__ head_live, uint32_t buckets, uint32_t chunk, int wshift, uint32_t n_sub) {
+                                                                uint8_t* __restrict__ head_live, uint32_t buckets, const uint32_t* __restrict__ dyn_chunk,
+                                                                int wshift, uint32_t n_sub) {
     __shared__ uint4 s_head[ACC_THREADS * raw_u4<typename C::FP>()];
     __shared__ uint8_t s_parked[ACC_THREADS];
-    msm_accumulate_body<C>(tab, sorted, off, p_start, p_head, head_live, buckets, chunk, wshift, n_sub, s_head, s_parked);
+    msm_accumulate_body<C>(tab, sorted, off, p_start, p_head, head_live, buckets, dyn_chunk, wshift, n_sub, s_head, s_parked);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -668,6 +682,7 @@ struct TailSlot {
     uint4* plane_part;
     uint4* win_pts;
     uint32_t* final_done;  // windows finished by k_msm_final (the last one adds them up); zero between executions
+    const uint32_t* dyn_chunk;  // entries per accumulation lane of this execution (k_ord_scan1)
     uint4* out_xy;
     uint8_t* out_zero;
 };
@@ -693,8 +708,9 @@ PLK_DI bool bucket_heads(const uint32_t* __restrict__ off, uint32_t b, uint32_t 
 
 // heavy[0] = number of work items, heavy[1] = number of heavy buckets;
 // items at heavy[2 + 2k] = bucket, heavy[3 + 2k] = chunk index; heavy bucket ids at heavy[2 + 2 cap + k]
-__global__ void __launch_bounds__(256) k_msm_heavy_list(TailBatch tb, uint32_t buckets, uint32_t chunk, uint32_t cap) {
+__global__ void __launch_bounds__(256) k_msm_heavy_list(TailBatch tb, uint32_t buckets, uint32_t cap) {
     const uint32_t* __restrict__ off = tb.s[blockIdx.y].off;
+    const uint32_t chunk = tb.s[blockIdx.y].dyn_chunk[0];
     uint32_t* __restrict__ heavy = tb.s[blockIdx.y].heavy;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= buckets) return;
@@ -726,10 +742,11 @@ template <class FP> PLK_DI XyzzZ<FP> block256_sum(XyzzZ<FP> acc, uint4* s_pts) {
 
 // one workgroup per (bucket, chunk) item: chunk partial -> heavy_part[item]
 template <class C>
-__global__ void __launch_bounds__(256) k_msm_heavy_chunks(TailBatch tb, uint32_t chunk, uint32_t cap) {
+__global__ void __launch_bounds__(256) k_msm_heavy_chunks(TailBatch tb, uint32_t cap) {
     using FP = typename C::FP;
     constexpr int RU = raw_u4<FP>();
     __shared__ uint4 s_pts[4 * RU];
+    const uint32_t chunk = tb.s[blockIdx.y].dyn_chunk[0];
     const uint4* __restrict__ p_head = tb.s[blockIdx.y].p_head;
     const uint32_t* __restrict__ off = tb.s[blockIdx.y].off;
     const uint32_t* __restrict__ heavy = tb.s[blockIdx.y].heavy;
@@ -771,11 +788,12 @@ __global__ void __launch_bounds__(256) k_msm_heavy_final(TailBatch tb, uint32_t 
 // 2^lpb_log-th head, shuffles combine).  PACKED: the result goes to bucket[] in the packed exchange format (operand of the
 // plane sums); else it stays in p_start[] raw, which is only rewritten when something was added (or the bucket is empty).
 template <class C, bool PACKED>
-__global__ void __launch_bounds__(256) k_msm_assemble(TailBatch tb, uint32_t buckets, uint32_t chunk, int lpb_log) {
+__global__ void __launch_bounds__(256) k_msm_assemble(TailBatch tb, uint32_t buckets, int lpb_log) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     constexpr int RU = raw_u4<FP>();
     const TailSlot& sl = tb.s[blockIdx.y];
+    const uint32_t chunk = sl.dyn_chunk[0];
     if (blockIdx.x == 0 && threadIdx.x < 2) sl.heavy[threadIdx.x] = 0;  // the counters of k_msm_heavy_list are free again
     if (blockIdx.x == 0 && threadIdx.x == 2) *sl.final_done = 0;        // and so is k_msm_final's (left at zero by its last block anyway)
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1234,6 +1252,9 @@ struct plk_msm_ctx {
     std::vector<MsmWork> ws;   // ws[0] at precompute; a batched execution allocates one per MSM of a group (<= TAIL_MAX)
     size_t ws_bytes = 0;       // size of one workspace slab
     std::mutex mu;             // one enqueue at a time per context
+    hipStream_t tail_stream = nullptr;  // batched executions: the reduction of vector k runs here, under the accumulation of vector k + 1
+    hipEvent_t ev_tail = nullptr;
+    std::vector<hipEvent_t> ev_acc;
     // optional per-kernel timing (HIP events on the launch stream) for bench.py's roofline
     bool profiling = false;
     static constexpr int N_STAGES = 7;  // order: count + scan | scatter | bins; accumulate; heavy + assemble + lines; planes; final
@@ -1254,6 +1275,12 @@ struct plk_msm_ctx {
             (void)hipFree(tab);
         }
         for (MsmWork& w : ws) w.release();
+        if (tail_stream) {
+            (void)hipStreamSynchronize(tail_stream);
+            (void)hipStreamDestroy(tail_stream);
+        }
+        if (ev_tail) (void)hipEventDestroy(ev_tail);
+        for (hipEvent_t e : ev_acc) (void)hipEventDestroy(e);
         for (auto* v : {&prof_sets, &prof_free})
             for (auto& set : *v)
                 for (hipEvent_t e : set) (void)hipEventDestroy(e);
@@ -1626,6 +1653,7 @@ static TailSlot tail_slot(const plk_msm_ctx* ctx, const MsmWork& w, void* d_out_
     t.plane_part = (uint4*)w.plane_part;
     t.win_pts = (uint4*)w.win_pts;
     t.final_done = (uint32_t*)w.meta + (1024 + 1025 + 1025 + 1);
+    t.dyn_chunk = (const uint32_t*)w.meta + (1024 + 1025 + 1025 + 2);
     t.out_xy = (uint4*)d_out_xy;
     t.out_zero = (uint8_t*)d_out_zero;
     return t;
@@ -1637,19 +1665,19 @@ static int msm_reduce_t(plk_msm_ctx* ctx, TailBatch tb, hipStream_t stream, Mark
     const uint32_t buckets = ctx->buckets;
     const unsigned cnt = (unsigned)tb.count;
     // hot buckets of a skewed scalar distribution (none for uniform scalars: the three launches then exit at once)
-    k_msm_heavy_list<<<dim3((buckets + 255) / 256, cnt), 256, 0, stream>>>(tb, buckets, ctx->chunk, ctx->heavy_cap);
-    k_msm_heavy_chunks<C><<<dim3(256, cnt), 256, 0, stream>>>(tb, ctx->chunk, ctx->heavy_cap);
+    k_msm_heavy_list<<<dim3((buckets + 255) / 256, cnt), 256, 0, stream>>>(tb, buckets, ctx->heavy_cap);
+    k_msm_heavy_chunks<C><<<dim3(256, cnt), 256, 0, stream>>>(tb, ctx->heavy_cap);
     k_msm_heavy_final<C><<<dim3(64, cnt), 256, 0, stream>>>(tb, ctx->heavy_cap);
     const unsigned ab = (unsigned)((((size_t)buckets << ctx->lpb_log) + 255) / 256);
     if (ctx->two_level) {
         const uint32_t nbg = (1u << (ctx->L + ctx->H)) >> ctx->g_log;  // groups per window (rows; as many for the columns)
         const unsigned wins = ctx->table_free ? (unsigned)ctx->windows : 1u;
-        k_msm_assemble<C, false><<<dim3(ab, cnt), 256, 0, stream>>>(tb, buckets, ctx->chunk, ctx->lpb_log);
+        k_msm_assemble<C, false><<<dim3(ab, cnt), 256, 0, stream>>>(tb, buckets, ctx->lpb_log);
         k_msm_gsum<C><<<dim3((2 * nbg + 127) / 128, cnt, wins), 128, 0, stream>>>(tb, ctx->L, ctx->H, ctx->g_log);
         const size_t lanes = ((size_t)2 << ctx->H) << (ctx->lpl_log + 2);
         k_msm_lsum<C><<<dim3((unsigned)((lanes + 255) / 256), cnt, wins), 256, 0, stream>>>(tb, ctx->L, ctx->H, ctx->g_log, ctx->lpl_log);
     } else {
-        k_msm_assemble<C, true><<<dim3(ab, cnt), 256, 0, stream>>>(tb, buckets, ctx->chunk, ctx->lpb_log);
+        k_msm_assemble<C, true><<<dim3(ab, cnt), 256, 0, stream>>>(tb, buckets, ctx->lpb_log);
     }
     PLK_HIP_TRY(hipGetLastError());
     mark();
@@ -1719,7 +1747,8 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
             }
         } guard{halves, ev, ctx, stream};
         k_ord_count<C><<<o.nt1, ORD_THREADS, 0, stream>>>((const uint4*)d_scalars, n, o, (uint32_t*)w.cnt1);
-        k_ord_scan1<<<o.nbins, 256, 0, stream>>>((uint32_t*)w.cnt1, o.nt1, o.nbins, bin_total, bin_base, seg_base, done_counter);
+        k_ord_scan1<<<o.nbins, 256, 0, stream>>>((uint32_t*)w.cnt1, o.nt1, o.nbins, bin_total, bin_base, seg_base, done_counter, done_counter + 2,
+                                                 ctx->chunk, (uint32_t)(ctx->max_lanes > 2 ? ctx->max_lanes - 2 : 1));
         PLK_HIP_TRY(hipGetLastError());
         mark();
         k_ord_scatter<C><<<o.nt1, ORD_THREADS, 0, stream>>>((const uint4*)d_scalars, n, o, (const uint32_t*)w.cnt1, bin_base, (uint2*)w.tmp);
@@ -1744,7 +1773,7 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
         // the entry count is only known on the device: launch for the upper bound, lanes past it exit
         const unsigned ablocks = (unsigned)((ctx->max_lanes + ACC_THREADS - 1) / ACC_THREADS);
         k_msm_accumulate<C><<<ablocks, ACC_THREADS, 0, stream>>>((const uint4*)ctx->tab, (const uint32_t*)w.sorted, off, (uint4*)w.p_start, (uint4*)w.p_head,
-                                                                 (uint8_t*)w.head_live, buckets, ctx->chunk, ctx->table_free ? ctx->c - 1 : 31,
+                                                                 (uint8_t*)w.head_live, buckets, done_counter + 2, ctx->table_free ? ctx->c - 1 : 31,
                                                                  ctx->table_free ? (uint32_t)n : 0u);
         PLK_HIP_TRY(hipGetLastError());
     }
@@ -1820,6 +1849,51 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
             group = (unsigned)ctx->ws.size();  // make do with what fits (at least the workspace of the precomputation)
             break;
         }
+    }
+    auto reduce = [&](const TailBatch& tb, hipStream_t st) -> int {
+        auto nomark = [] {};
+        switch (ctx->curve) {
+            case PLK_CURVE_TWEEDLEDEE: return msm_reduce_t<TweedledeeCurve>(ctx, tb, st, nomark);
+            case PLK_CURVE_TWEEDLEDUM: return msm_reduce_t<TweedledumCurve>(ctx, tb, st, nomark);
+            case PLK_CURVE_PALLAS: return msm_reduce_t<PallasCurve>(ctx, tb, st, nomark);
+            case PLK_CURVE_VESTA: return msm_reduce_t<VestaCurve>(ctx, tb, st, nomark);
+            default: return msm_reduce_t<Bls12377Curve>(ctx, tb, st, nomark);
+        }
+    };
+    // Pipelined reductions: the reduction of a vector is mostly latency (chains on few points) plus
+    // 0.1 ms of full-width row / column sums; on a second stream it runs under the ordering and accumulation of the NEXT vector
+    // instead of after the last one.  The caller's stream waits for the second stream before the call returns.
+    static const bool pipeline_tails = getenv("PLK_MSM_NO_TAIL_PIPELINE") == nullptr;
+    if (pipeline_tails) {
+        if (!ctx->tail_stream) PLK_HIP_TRY(hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking));
+        if (!ctx->ev_tail) PLK_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming));
+        while (ctx->ev_acc.size() < group) {
+            hipEvent_t e = nullptr;
+            PLK_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->ev_acc.push_back(e);
+        }
+        for (unsigned g0 = 0; g0 < batch; g0 += group) {
+            const unsigned cnt = batch - g0 < group ? batch - g0 : group;
+            // the workspaces of the previous group are free again when its reductions are done
+            if (g0) {
+                PLK_HIP_TRY(hipEventRecord(ctx->ev_tail, ctx->tail_stream));
+                PLK_HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_tail, 0));
+            }
+            for (unsigned k = 0; k < cnt; ++k) {
+                const unsigned b = g0 + k;
+                PLK_TRY(run_one(b, ctx->ws[k], stream, PH_ORDER | PH_ACC));
+                PLK_HIP_TRY(hipEventRecord(ctx->ev_acc[k], stream));
+                PLK_HIP_TRY(hipStreamWaitEvent(ctx->tail_stream, ctx->ev_acc[k], 0));
+                TailBatch tb;
+                tb.count = 1;
+                tb.s[0] = tail_slot(ctx, ctx->ws[k], (uint8_t*)d_out_xy + (size_t)b * 2 * L * 8, (uint8_t*)d_out_zero + b);
+                PLK_TRY(reduce(tb, ctx->tail_stream));
+            }
+        }
+        PLK_HIP_TRY(hipEventRecord(ctx->ev_tail, ctx->tail_stream));
+        PLK_HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_tail, 0));
+        for (unsigned k = 0; k < group && k < ctx->ws.size(); ++k) work_done(ctx->ws[k], stream);
+        return PLK_OK;
     }
     for (unsigned g0 = 0; g0 < batch; g0 += group) {
         const unsigned cnt = batch - g0 < group ? batch - g0 : group;

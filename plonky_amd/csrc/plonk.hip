@@ -297,7 +297,8 @@ template <int I, class P, int B, class LW> PLK_DI auto base4_chain(const Lz<P, B
 // Prefix filters (gates/mod.rs:289-300) are formed where they are used, along the prefix tree of gates/mod.rs:1-16 (BufferGate,
 // 101010, has no constraints: buffer.rs:26-33): a filter kept alive for the whole kernel costs nine registers.
 // gate groups (a kernel evaluates a subset: the live set of all ten gates is several register files wide)
-constexpr int GATES_RESCUE = 1, GATES_ENDO = 2, GATES_BASE4_ARITH = 4, GATES_ADD_PUBLIC = 8, GATES_DBL_CONST = 16, GATES_ALL = 31;
+constexpr int GATES_RESCUE_A = 1, GATES_ENDO = 2, GATES_BASE4_ARITH = 4, GATES_ADD_PUBLIC = 8, GATES_DBL_CONST = 16, GATES_RESCUE_B = 32, GATES_ALL = 63;
+constexpr int GATES_RESCUE = GATES_RESCUE_A | GATES_RESCUE_B;
 // The inputs of a point are READ WHERE A GATE USES THEM: k / l / r are rows of the prover's tables (or plain arrays, in
 // k_all_constraints) indexed through operator[], every mention a load and a re-slicing into the working form (~80
 // instructions against ~220 for a product).  An input held from the top of the kernel costs nine registers for its whole
@@ -319,7 +320,7 @@ PLK_DI void all_constraints(const K& k, const LW& l, const RW& r, const D& b2, c
         for (int i = 0; i < 7; ++i) mds[i] = lz_table<P>(small, i);  // mds[v - 1] = 1 / v; entry (r, c) = 1 / (4 + r - c), mds.rs:63-77
         // row i of the MDS matrix times (v0 .. v3), plus the round constant, against the right gate's wire i
 #define PLK_MDS_ROW(i, v0, v1, v2, v3) (k[2 + i] + (mds[3 + i] * v0 + mds[2 + i] * v1 + mds[1 + i] * v2 + mds[i] * v3) - r[i])
-        {
+        if constexpr ((MASK & GATES_RESCUE_A) != 0) {
             const D l4 = l[4], l5 = l[5], l6 = l[6], l7 = l[7];
             sink.template gate<7>(nk0 * (one - k1),                                           //
                                   l4.pow5() - l[0], PLK_MDS_ROW(0, l4, l5, l6, l7),           //
@@ -327,9 +328,11 @@ PLK_DI void all_constraints(const K& k, const LW& l, const RW& r, const D& b2, c
                                   l6.pow5() - l[2], PLK_MDS_ROW(2, l4, l5, l6, l7),           //
                                   l7.pow5() - l[3], PLK_MDS_ROW(3, l4, l5, l6, l7));
         }
-        const auto e0 = l[0].pow5(), e1 = l[1].pow5(), e2 = l[2].pow5(), e3 = l[3].pow5();
-        sink.template gate<8>(nk0 * k1, PLK_MDS_ROW(0, e0, e1, e2, e3), PLK_MDS_ROW(1, e0, e1, e2, e3), PLK_MDS_ROW(2, e0, e1, e2, e3),
-                              PLK_MDS_ROW(3, e0, e1, e2, e3));
+        if constexpr ((MASK & GATES_RESCUE_B) != 0) {
+            const auto e0 = l[0].pow5(), e1 = l[1].pow5(), e2 = l[2].pow5(), e3 = l[3].pow5();
+            sink.template gate<8>(nk0 * k1, PLK_MDS_ROW(0, e0, e1, e2, e3), PLK_MDS_ROW(1, e0, e1, e2, e3), PLK_MDS_ROW(2, e0, e1, e2, e3),
+                                  PLK_MDS_ROW(3, e0, e1, e2, e3));
+        }
 #undef PLK_MDS_ROW
     }
     if constexpr ((MASK & GATES_ENDO) != 0) {  // CurveEndoGate 11, curve_endo.rs:96-141
@@ -424,23 +427,24 @@ template <class P> PLK_DI Lz<P, 16> scalar_at(const uint32_t (*s_sc)[FzCfg<P>::N
     return r;
 }
 
-// plonk.rs:392-453, one lane per point of the 8n domain, in PASSES launches.  The ten gates, the permutation argument and their
+// plonk.rs:392-453, one lane per point of the 8n domain, in FIVE launches.  The ten gates, the permutation argument and their
 // inputs (21 + 10 elements per point) are several register files wide; evaluated in one piece the kernel spills to scratch
 // and, at one wave per SIMD, waits out every reload.  A launch evaluates a group of gates and hands the running sum on (limb
-// form, 48 B per point, in `part`):
-//   PASS 0: both Rescue gates                       -> part
-//   PASS 1: CurveEndo, Base4Sum, Arithmetic         -> part +=
-//   PASS 2: CurveAdd, PublicInput, CurveDbl, Constant, the permutation argument and L_1, reduce_with_powers -> out
+// form, 48 B per point, in `part`); its inputs are read where a gate uses them (LazyRow), so a launch fits the 256
+// registers of two waves per SIMD:
+//   PASS 0: RescueStepA   PASS 1: RescueStepB   PASS 2: CurveEndo, Base4Sum, Arithmetic   PASS 3: CurveAdd, PublicInput, CurveDbl,
+//   Constant   PASS 4: the permutation argument, L_1 and reduce_with_powers -> out
 // The sum over the gates and the powers of alpha commute (ReducedSink), every value is exact: same result as one loop.
-// WAVES: waves per SIMD the register allocation is held to (2: at most 256 registers per lane)
-template <class P, int PASS, int WAVES>
-__global__ void __launch_bounds__(128, WAVES) k_vanishing_points(const uint4* __restrict__ constants, const uint4* __restrict__ wires, const uint4* __restrict__ s_sigma,
-                                                          const uint4* __restrict__ z, const uint4* __restrict__ xs_lo_z, const uint4* __restrict__ xs_hi_z,
-                                                          const uint4* __restrict__ l1, const uint4* __restrict__ small, PlonkScalars sc, int log_degree,
-                                                          uint32_t* __restrict__ part, uint4* __restrict__ out) {
+constexpr int VANISH_PASSES = 5;
+template <class P, int PASS>
+__global__ void __launch_bounds__(128, 2) k_vanishing_points(const uint4* __restrict__ constants, const uint4* __restrict__ wires, const uint4* __restrict__ s_sigma,
+                                                             const uint4* __restrict__ z, const uint4* __restrict__ xs_lo_z, const uint4* __restrict__ xs_hi_z,
+                                                             const uint4* __restrict__ l1, const uint4* __restrict__ small, PlonkScalars sc, int log_degree,
+                                                             uint32_t* __restrict__ part, uint4* __restrict__ out) {
     static_assert(P::NL == 8, "256-bit scalar fields");
     using D = Lz<P, 16>;
-    constexpr int MASK = PASS == 0 ? GATES_RESCUE : PASS == 1 ? (GATES_ENDO | GATES_BASE4_ARITH) : (GATES_ADD_PUBLIC | GATES_DBL_CONST);
+    constexpr int MASK = PASS == 0 ? GATES_RESCUE_A : PASS == 1 ? GATES_RESCUE_B : PASS == 2 ? (GATES_ENDO | GATES_BASE4_ARITH)
+                         : PASS == 3 ? (GATES_ADD_PUBLIC | GATES_DBL_CONST) : 0;
     __shared__ uint32_t s_sc[NUM_SCALARS][FzCfg<P>::NZ];
     stage_scalars<P>(sc, s_sc);
     const size_t n8 = (size_t)8 << log_degree;
@@ -449,22 +453,24 @@ __global__ void __launch_bounds__(128, WAVES) k_vanishing_points(const uint4* __
     const size_t i_right = (i + 8) & (n8 - 1), i_below = (i + 8 * GRID_WIDTH) & (n8 - 1);
     // the rows a gate reads from: local constants, local wires, the right gate's wires (loaded where they are used)
     const LazyRow<P> k{constants, n8, i}, l{wires, n8, i}, r{wires, n8, i_right};
-    D b2{fz_zero<P>()}, b3{fz_zero<P>()};
-    if constexpr ((MASK & GATES_ENDO) != 0) {
-        b2 = lz_load<P>(wires, (size_t)2 * n8 + i_below);
-        b3 = lz_load<P>(wires, (size_t)3 * n8 + i_below);
-    }
     const D alpha = scalar_at<P>(s_sc, 6);
-    ReducedSink<P> sink{alpha, Term<P>{fz_zero<P>()}};
-    all_constraints<P, D, MASK>(k, l, r, b2, b3, scalar_at<P>(s_sc, 9), scalar_at<P>(s_sc, 10), small, sink);
-    if constexpr (PASS == 0) {
-        limbs_store<P>(part, i, sink.total.v);  // < 2.5p (two gates)
-    } else if constexpr (PASS == 1) {
-        const Lz<P, 20> before{limbs_load<P>(part, i)};
-        limbs_store<P>(part, i, (before + sink.total).v);  // five gates so far: < 6.25p
+    if constexpr (PASS < 4) {
+        D b2{fz_zero<P>()}, b3{fz_zero<P>()};
+        if constexpr ((MASK & GATES_ENDO) != 0) {
+            b2 = lz_load<P>(wires, (size_t)2 * n8 + i_below);
+            b3 = lz_load<P>(wires, (size_t)3 * n8 + i_below);
+        }
+        ReducedSink<P> sink{alpha, Term<P>{fz_zero<P>()}};
+        all_constraints<P, D, MASK>(k, l, r, b2, b3, scalar_at<P>(s_sc, 9), scalar_at<P>(s_sc, 10), small, sink);
+        if constexpr (PASS == 0) {
+            limbs_store<P>(part, i, sink.total.v);  // one gate: < 1.25p
+        } else {
+            // gates so far: 1 (PASS 1), 2 (PASS 2), 5 (PASS 3), each below 1.25p
+            const Lz<P, PASS == 1 ? 10 : PASS == 2 ? 20 : 50> before{limbs_load<P>(part, i)};
+            limbs_store<P>(part, i, (before + sink.total).v);
+        }
     } else {
-        const Lz<P, 50> before{limbs_load<P>(part, i)};
-        const auto total = before + sink.total;  // < 6.25p + 12.5p
+        const Lz<P, 90> total{limbs_load<P>(part, i)};  // nine gates with constraints: < 11.25p
         const auto one = lz_one<P>();
         const auto x = lz_table<P>(xs_lo_z, i & (((size_t)1 << XS_LO_LOG) - 1)) * lz_table<P>(xs_hi_z, i >> XS_LO_LOG);  // hi[0] = 1
         const D z_x = lz_load<P>(z, i), z_gz = lz_load<P>(z, i_right);
@@ -529,21 +535,15 @@ static int vanishing_points_t(unsigned log_degree, const void* d_constants, cons
     void* part = scratch_acquire(limb_bytes(n8, FzCfg<P>::NZ), stream);
     if (!part) return PLK_ERR_OOM;
     const unsigned blocks = (unsigned)((n8 + 127) / 128);
-    static const int waves = getenv("PLK_VANISH_WAVES") ? atoi(getenv("PLK_VANISH_WAVES")) : 2;
-#define PLK_VANISH(PASS, WAVES)                                                                                                                           \
-    k_vanishing_points<P, PASS, WAVES><<<blocks, 128, 0, stream>>>((const uint4*)d_constants, (const uint4*)d_wires, (const uint4*)d_s_sigma,           \
-                                                                   (const uint4*)d_z, (const uint4*)t->xs_lo_z, (const uint4*)t->xs_hi_z,               \
-                                                                   (const uint4*)t->l1, (const uint4*)t->small, sc, (int)log_degree, (uint32_t*)part, \
-                                                                   (uint4*)d_out)
-    if (waves >= 2) {
-        PLK_VANISH(0, 2);
-        PLK_VANISH(1, 2);
-        PLK_VANISH(2, 2);
-    } else {
-        PLK_VANISH(0, 1);
-        PLK_VANISH(1, 1);
-        PLK_VANISH(2, 1);
-    }
+#define PLK_VANISH(PASS)                                                                                                                                  \
+    k_vanishing_points<P, PASS><<<blocks, 128, 0, stream>>>((const uint4*)d_constants, (const uint4*)d_wires, (const uint4*)d_s_sigma, (const uint4*)d_z, \
+                                                            (const uint4*)t->xs_lo_z, (const uint4*)t->xs_hi_z, (const uint4*)t->l1, (const uint4*)t->small, sc, \
+                                                            (int)log_degree, (uint32_t*)part, (uint4*)d_out)
+    PLK_VANISH(0);
+    PLK_VANISH(1);
+    PLK_VANISH(2);
+    PLK_VANISH(3);
+    PLK_VANISH(4);
 #undef PLK_VANISH
     const hipError_t e = hipGetLastError();
     scratch_release(part, stream);

@@ -108,7 +108,15 @@ def _rank_hip(rank, world, port, n, batch, q):
         for _ in range(2):  # the buffers are reused from step to step
             xy, zero = parallel.msm_sharded_hip(pre, dev.to_device(np.ascontiguousarray(sv[:, lo:hi])), exchange=ex)
         part_xy, part_z = ex.partials()
-        q.put((rank, xy, zero, dev.to_host(part_xy), part_z.cpu().numpy()))
+        # the same three vectors through the batch plan: one whole vector per rank, the third sharded by base range
+        plan = parallel.BatchPlan(batch, world, rank, n)
+        bases_all = dev.gen_bases_dev(0, n, _pt(c, G), _pt(c, D))
+        pre_all = dev.msm_precompute_dev(0, bases_all)
+        ex2 = parallel.PartialExchange(0, batch, "cuda", whole_per_rank=plan.whole)
+        dev.msm_execute_dev(pre_all, dev.to_device(plan.local_scalars(sv)), ex2.out_xy, ex2.out_zero)
+        ex2.gather()
+        hxy, hz = ex2.combine()
+        q.put((rank, xy, zero, dev.to_host(part_xy), part_z.cpu().numpy(), dev.to_host(hxy), hz.cpu().numpy()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -139,10 +147,12 @@ def test_sharded_msm_hip_world_size_2_one_gpu():
     D = br.ec_mul(c, 4242, G)
     sv = np.stack([synth.rand_field(1, 0x77 + k, n) for k in range(batch)])
     from plonky_amd import parallel
-    for rank, xy, zero, part_xy, part_z in res:
+    for rank, xy, zero, part_xy, part_z, hxy, hz in res:
         assert part_xy.shape == (world, batch, 2, 4) and not part_z.any()
         for k in range(batch):
             assert zero[k] == 0 and tuple(from_mont_arr(c.base, xy[k])) == closed_form_msm(0, sv[k], G, D), (rank, k)
+            # whole vectors handed over by their owner + the sharded remainder: the same global results
+            assert int(hz[k]) == 0 and np.array_equal(hxy[k], xy[k]), (rank, k)
             for r in range(world):  # the gathered records hold every rank's partial result, in rank order
                 lo, hi = parallel.shard_bounds(n, r, world)
                 assert tuple(from_mont_arr(c.base, part_xy[r, k])) == closed_form_msm(0, sv[k, lo:hi], G, D, first=lo), (rank, k, r)
@@ -181,4 +191,7 @@ def test_bench_emulated_rank():
                           "--warmup", "1"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
-    assert r["emulated_rank"]["rank"] == 3 and r["emulated_rank"]["n_local"] == (1 << 16) // 8 and all(r["checks"].values())
+    e = r["emulated_rank"]
+    # nine vectors on eight ranks: one whole vector and an eighth of the ninth per rank (parallel.BatchPlan)
+    assert e["rank"] == 3 and e["whole_vectors"] == 1 and e["sharded_vectors"] == 1 and e["pairs_local"] == (1 << 16) + (1 << 16) // 8
+    assert all(r["checks"].values())

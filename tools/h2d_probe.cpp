@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <utility>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -67,6 +68,32 @@ int main() {
         rep("D2H to pageable (runtime)", [&] { CK(hipMemcpyAsync(src, d, bytes, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); });
         rep("D2H to pinned, then memcpy (round 2)", [&] { CK(hipMemcpyAsync(pin, d, bytes, hipMemcpyDeviceToHost, s)); CK(hipStreamSynchronize(s)); memcpy(src, pin, bytes); });
         free(src); CK(hipFree(d)); CK(hipHostFree(pin));
+    }
+    // the shape of plk_ntt_batch: nine 32 MiB buffers, each uploaded and downloaded, on three streams round-robin
+    {
+        const size_t bytes = (size_t)32 << 20; const int nb = 9;
+        hipStream_t st[3]; for (int q = 0; q < 3; ++q) CK(hipStreamCreateWithFlags(&st[q], hipStreamNonBlocking));
+        void* d; CK(hipMalloc(&d, bytes * nb));
+        std::vector<char*> pag(nb), pin(nb);
+        for (int b = 0; b < nb; ++b) { pag[b] = (char*)malloc(bytes); memset(pag[b], b, bytes); CK(hipHostMalloc((void**)&pin[b], bytes, hipHostMallocDefault)); memset(pin[b], b, bytes); }
+        auto pipe = [&](std::vector<char*>& h, bool reg) {
+            double t0 = now();
+            if (reg) for (int b = 0; b < nb; ++b) CK(hipHostRegister(h[b], bytes, hipHostRegisterDefault));
+            double t_enq0 = now();
+            for (int b = 0; b < nb; ++b) {
+                CK(hipMemcpyAsync((char*)d + b * bytes, h[b], bytes, hipMemcpyHostToDevice, st[b % 3]));
+                CK(hipMemcpyAsync(h[b], (char*)d + b * bytes, bytes, hipMemcpyDeviceToHost, st[b % 3]));
+            }
+            double t_enq = now() - t_enq0;
+            for (int q = 0; q < 3; ++q) CK(hipStreamSynchronize(st[q]));
+            if (reg) for (int b = 0; b < nb; ++b) CK(hipHostUnregister(h[b]));
+            return std::make_pair(now() - t0, t_enq);
+        };
+        for (int rep = 0; rep < 2; ++rep) {
+            auto a = pipe(pin, false); printf("9 x (H2D + D2H) 32 MiB on 3 streams, pinned:               %8.3f ms (enqueue %.3f ms)\n", a.first * 1e3, a.second * 1e3);
+            auto b = pipe(pag, true);  printf("9 x (H2D + D2H) 32 MiB on 3 streams, registered pageable:  %8.3f ms (enqueue %.3f ms)\n", b.first * 1e3, b.second * 1e3);
+            auto c = pipe(pag, false); printf("9 x (H2D + D2H) 32 MiB on 3 streams, plain pageable:       %8.3f ms (enqueue %.3f ms)\n", c.first * 1e3, c.second * 1e3);
+        }
     }
     return 0;
 }
