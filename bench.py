@@ -8,6 +8,9 @@ step    one pass of the hot path over one batch of synthetic input (--workload):
                   units (no collective); the MSM is a global N * 2^20-pair MSM sharded by contiguous base range: every rank
                   reduces its own 2^20 pairs, ONE packed all-gather of the N affine partial results and a local point sum.
           ntt / msm   one component alone.
+          quotient  the two heaviest kernels of the callers either side of the path, with their own
+                  roofline entries: the 8n-point loop of Prover::vanishing_poly (plonk.rs:392-453) for a circuit of 2^log_n gates
+                  (2^(log_n + 3) points) and the generator fold of the first IPA round (halo.rs:119-123) over 2^(log_n - 1) pairs.
           commit9 BASELINE configs[3]: the 9-wire commitment batch of poly_commit.rs:52-66 - nine 2^20 scalar vectors against
                   the same 2^20 generators.  N > 1: STRONG scaling - the generators are sharded by base range (each rank holds
                   2^20 / N of them and the matching slice of every vector), one packed all-gather of 9 partial points.
@@ -82,7 +85,7 @@ def load_ceilings():
 def cpu_baseline(workload, cv):
     """The oracle (C++ restatement of the reference algorithm, persistent worker pool) timed on this host's cores on a bounded
     sample: the full 2^20 NTT (T = 1 and the best of a thread sweep, 10 timed runs each after a warm-up run) and the MSM with the
-    reference's w = 11 tables prebuilt: 2^20 pairs at the best thread count (10 runs) and 2^16 pairs at T = 1 (3 runs)."""
+    reference's w = 11 tables prebuilt: 2^20 pairs at the best thread count (10 runs) and 2^18 pairs at T = 1 (10 runs)."""
     import numpy as np
     from oracle import bigint_ref as br, oracle_lib as ol
     from plonky_amd import synth
@@ -136,12 +139,15 @@ def cpu_baseline(workload, cv):
         t_all = timed(lambda: pre.execute(s, parallel=True, threads=best[1]), 10)
         out["msm_mpairs_per_s"] = (1 << lm) / t_all / 1e6
         out["msm_threads"] = best[1]
-        l1 = 16
+        # one thread: ~6 s per 2^20-pair execution on this class of host, so ten timed runs at full size would be a minute of the
+        # "10 - 30 s of CPU work" this baseline is bounded to: 2^18 pairs (the rate per pair is flat in n at fixed w), ten runs
+        l1 = min(lm, 18)
         pre1 = pre if lm == l1 else ol.MsmPrecomputation(cv["curve"], bases[: 1 << l1], 11, threads=th_all)
-        t_one = timed(lambda: pre1.execute(s[: 1 << l1], parallel=True, threads=1), 3)
+        t_one = timed(lambda: pre1.execute(s[: 1 << l1], parallel=True, threads=1), 10)
         out["msm_mpairs_per_s_1_thread"] = (1 << l1) / t_one / 1e6
         used.append(best[1])
-        out["msm_sample"] = "2^%d-pair msm_execute_parallel, w = 11 tables prebuilt, median of 10 at T = %d; T = 1: 2^%d pairs, median of 3" % (lm, best[1], l1)
+        out["msm_sample"] = ("2^%d-pair msm_execute_parallel, w = 11 tables prebuilt, median of 10 at T = %d; T = 1: 2^%d pairs, median of 10 "
+                             "(2^20 at T = 1 is ~6 s per run: outside the bounded sample)" % (lm, best[1], l1))
     out["cores"] = max(used) if used else 1
     n_units, t_units = 0.0, 0.0
     if "ntt_melems_per_s" in out:
@@ -161,7 +167,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["both", "ntt", "msm", "commit9"], default="both")
+    ap.add_argument("--workload", choices=["both", "ntt", "msm", "commit9", "quotient"], default="both")
     ap.add_argument("--curve", choices=sorted(CURVES), default="tweedledee")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--shard", action="store_true", help="--workload msm: strong scaling - ONE 2^log_n MSM, generators sharded by base range")
@@ -207,7 +213,116 @@ def main(argv=None):
     return run(args)
 
 
+def run_quotient(args):
+    """--workload quotient: k_vanishing_points (five launches per call) and k_fold_pairs_glv, timed with HIP events on the launch
+    stream, priced against the same ceilings as the headline kernels.  One GPU; correctness of both is the GPU suite's business
+    (tests/test_gpu_plonk.py, tests/test_gpu_halo.py) - here the fold is checked by its closed form, the numerator by determinism."""
+    import numpy as np
+    import torch
+    from plonky_amd import device as dev, lib, synth
+    from plonky_amd.selfcheck import GENERATORS, _add, _mul
+    from plonky_amd.synth import MODULI
+    assert args.gpus == 1 and torch.cuda.is_available()
+    dev.init(0)
+    F, CURVE = 1, 0          # the circuit's scalar field is TweedledumBase (Tweedledee's scalar field)
+    log_degree = args.log_n                 # a circuit of 2^log_n gates: 8n = 2^(log_n + 3) points, first IPA round = 2^(log_n - 1) pairs
+    n8 = 8 << log_degree
+    rnd = lambda seed, rows: dev.to_device(synth.rand_field(F, seed, rows * n8)).reshape(rows, n8, 4)
+    consts, wires, sigma, z = rnd(1, 6), rnd(2, 9), rnd(3, 6), rnd(4, 1).reshape(n8, 4)
+    k_is = synth.rand_field(F, 9, 6)
+    alpha, beta, gamma, zeta = synth.rand_field(F, 10, 4)
+    a_coeff = np.zeros(4, dtype=np.uint64)
+    out = torch.empty((n8, 4), dtype=torch.int64, device="cuda")
+    vanish = lambda: dev.vanishing_points_dev(F, log_degree, consts, wires, sigma, z, k_is, alpha, beta, gamma, zeta, a_coeff, out=out)
+    p = MODULI[0]
+    G = GENERATORS[CURVE]
+    D = _mul(p, 424242, G)
+    g0 = np.stack([synth.mont(0, G[0]), synth.mont(0, G[1])])
+    dd = np.stack([synth.mont(0, D[0]), synth.mont(0, D[1])])
+    m = max(1, (1 << log_degree) // 2)
+    gens = dev.gen_bases_dev(CURVE, 2 * m, g0, dd)
+    u = synth.rand_field(F, 11, 1)[0]
+    r = MODULI[F]
+    ui = synth.to_int(u) * pow(1 << 256, -1, r) % r
+    u_inv = np.array(synth.mont(F, pow(ui, -1, r)), dtype=np.uint64)
+    fold = lambda: dev.fold_generators_dev(CURVE, gens[:m].contiguous(), gens[m:].contiguous(), u_inv, u)
+
+    def timed(fn, steps, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    t0 = time.perf_counter()
+    v_ms = timed(vanish, args.steps, args.warmup)
+    f_ms = timed(fold, max(1, args.steps // 2), 1)
+    elapsed = time.perf_counter() - t0
+    first = out.clone()
+    vanish()
+    g2, gz2 = fold()
+    torch.cuda.synchronize()
+    # fold closed form: [u^-1] (G0 + i D) + [u] (G0 + (m + i) D) = [u^-1 + u] G0 + [u^-1 i + u (m + i)] D, checked at i = 0 and i = m - 1
+    ok = True
+    for i in (0, m - 1):
+        exp = _add(p, _mul(p, (pow(ui, -1, r) + ui) % r, G), _mul(p, (pow(ui, -1, r) * i + ui * (m + i)) % r, D))
+        got = dev.to_host(g2[i])
+        ok = ok and (synth.from_mont(0, got[0]), synth.from_mont(0, got[1])) == exp
+    checks = {"fold_closed_form_bit_exact": bool(ok and not gz2.any().item()), "vanishing_points_deterministic": bool(torch.equal(first, out))}
+    ceil = load_ceilings()
+    ceil_ok = bool(ceil) and not ceil.get("stale")
+    peak = ceil.get("fz_mul_gops", {}).get("tweedledee") if ceil_ok else None
+    mad_peak = ceil.get("mad_u64_u32_glaneops") if ceil_ok else None
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_quotient.json")) as fh:
+            pmc = json.load(fh)
+    except (OSError, ValueError):
+        pass
+    src_hash = kernel_source_hash()
+
+    def traffic(k):
+        e = pmc.get(k)
+        return (e["bytes_per_call"], e.get("source")) if e and pmc.get("kernel_source_sha") == src_hash and e.get("log_n") == args.log_n else (None, None)
+
+
+    def entry(kernel, modmul_per_unit, units, ms, alg_bytes, note):
+        gmm = modmul_per_unit * units / (ms * 1e-3) / 1e9
+        tr, trs = traffic(kernel)
+        return {"kernel": kernel, "bound": "valu", "achieved": gmm, "peak": peak, "unit": "G modmul/s", "frac": gmm / peak if peak else None,
+                "mad_issue_frac": gmm * 126 / mad_peak if mad_peak else None, "launch_ms": ms, "traffic": tr, "traffic_source": trs,
+                "hbm": {"achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": alg_bytes}, "note": note}
+
+    rooflines = {
+        "vanishing_points": entry("k_vanishing_points", 170.0, n8, v_ms, 30.0 * 32 * n8,
+                                  "five launches per call (launch_ms = the call); ~170 field multiplications per point (DESIGN.md 4c); algorithmic bytes: "
+                                  "29 elements read + 1 written per point"),
+        "fold_pairs": entry("k_fold_pairs_glv", 1830.0, m, f_ms, 3.0 * 64 * m,
+                            "scaled fold lo + [u^2] hi along the endomorphism: ~130 doublings (6M + 3S) + ~65 mixed additions (8M + 2S) + two inversions per pair"),
+    }
+    result = {
+        "metric": "MSM Mpairs/sec + NTT Melems/sec, 2^20 Tweedledee, 1/2/4/8 GPU", "value": n8 / (v_ms * 1e-3) / 1e6,
+        "unit": "M points/s of the quotient numerator (the fold is reported in components)", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": v_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "quotient numerator of a 2^%d-gate circuit (8n = 2^%d points) + generator fold of 2^%d pairs" % (log_degree, log_degree + 3, m.bit_length() - 1),
+                   "log_n": args.log_n, "curve": "tweedledee", "kernel_source_sha": src_hash},
+        "components": {"vanishing_points_ms": v_ms, "vanishing_mpoints_per_s": n8 / (v_ms * 1e-3) / 1e6, "fold_pairs_ms": f_ms,
+                       "fold_mpairs_per_s": m / (f_ms * 1e-3) / 1e6, "wall_s": elapsed},
+        "checks": checks, "roofline": rooflines["vanishing_points"], "rooflines": rooflines,
+    }
+    print(json.dumps(result), flush=True)
+    assert all(checks.values()), "self-check failed: %r" % checks
+
+
 def run(args):
+    if args.workload == "quotient":
+        return run_quotient(args)
     cv = CURVES[args.curve]
     CURVE, NTT_FIELD = cv["curve"], cv["ntt_field"]
 
@@ -464,6 +579,22 @@ def run(args):
             for _ in range(reps):
                 lib.check(L.plk_ntt(NTT_FIELD, args.log_n, 0, vp(hin[0].ctypes.data), vp(hout[1].ctypes.data)))
             host["host_ntt_ms"] = (time.perf_counter() - t1) / reps * 1e3
+            # the reference's own calling pattern: nine Rayon workers, one transform each (plonk_util.rs:173-176) - nine host threads,
+            # each on its own lane of the library (ctypes releases the GIL for the duration of a call)
+            import threading
+
+            def nine_threads():
+                ts = [threading.Thread(target=lambda b=b: lib.check(L.plk_ntt(NTT_FIELD, args.log_n, 0, vp(hin[b].ctypes.data), vp(hout[b].ctypes.data))))
+                      for b in range(9)]
+                for t in ts:
+                    t.start()
+                for t in ts:
+                    t.join()
+            nine_threads()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                nine_threads()
+            host["host_ntt9_nine_threads_ms"] = (time.perf_counter() - t1) / reps * 1e3
             if not args.no_check:
                 checks_host_ntt = bool(np.array_equal(hout[0], dev.to_host(y)) and np.array_equal(hout[8], hout[0]) and np.array_equal(hout[1], hout[0]))
                 host["_ntt_ok"] = checks_host_ntt
@@ -492,6 +623,9 @@ def run(args):
             del hs
         if "host_ntt9_ms" in host and "ntt_batch9_ms" in comp:
             host["host_ntt9_vs_max_pcie_device"] = host["host_ntt9_ms"] / max(host["host_ntt9_pcie_floor_ms"], comp["ntt_batch9_ms"])
+            # both directions carry 9 x 32 MiB; the link's two directions overlap only partly on this platform: nine pinned uploads
+            # + downloads on three streams take 8.9 ms (profiles/r03_h2d_probe.txt), 1.65 x the one-way time
+            host["host_ntt9_pinned_duplex_floor_ms"] = 8.9
         host["note"] = "host-pointer C ABI calls on pageable numpy buffers, one caller thread; pcie_floor = bytes one way / 56 GB/s"
         comp["host_pointer"] = host
     if do_msm:

@@ -441,7 +441,7 @@ def _g_rescue_b(p, k, l, r, b, zeta, a):
 PLONK_GATES = [
     ("10101", _g_curve_add), ("10111", _g_curve_dbl), ("11", _g_curve_endo), ("1000", _g_base4),
     ("101001", lambda p, k, l, r, b, zeta, a: [l[6 + i] - r[i] for i in range(3)]),       # PublicInputGate
-    ("101010", lambda p, k, l, r, b, zeta, a: []),                                           # BufferGate
+    ("101000", lambda p, k, l, r, b, zeta, a: []),                                           # BufferGate (buffer.rs:27)
     ("10110", lambda p, k, l, r, b, zeta, a: [k[5] - l[0]]),                                 # ConstantGate
     ("1001", lambda p, k, l, r, b, zeta, a: [k[4] * l[0] * l[1] + k[5] * l[2] - l[3]]),      # ArithmeticGate
     ("00", _g_rescue_a), ("01", _g_rescue_b),

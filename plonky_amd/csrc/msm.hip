@@ -1863,7 +1863,10 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
     // Pipelined reductions: the reduction of a vector is mostly latency (chains on few points) plus
     // 0.1 ms of full-width row / column sums; on a second stream it runs under the ordering and accumulation of the NEXT vector
     // instead of after the last one.  The caller's stream waits for the second stream before the call returns.
-    static const bool pipeline_tails = getenv("PLK_MSM_NO_TAIL_PIPELINE") == nullptr;
+    // Measured (profiles/r03_commit9_scaling.txt): SLOWER than one shared reduction at the end - 12.85 against 12.38 ms for nine
+    // 2^20 vectors, 2.52 against 2.21 ms for a rank's share of them at eight ranks: the accumulation is sized as exactly one round
+    // of lanes, and every slot a reduction workgroup takes sends part of that round into a second one.  Off unless asked for.
+    static const bool pipeline_tails = getenv("PLK_MSM_TAIL_PIPELINE") != nullptr;
     if (pipeline_tails) {
         if (!ctx->tail_stream) PLK_HIP_TRY(hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking));
         if (!ctx->ev_tail) PLK_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming));

@@ -57,6 +57,7 @@ struct NttPassArgs {
     int scale;        // 1: multiply outputs by *scale_ptr (single-pass inverse)
     int skip;         // first pass of a zero-padded transform: the first `skip` stages only replicate (see tile_stages)
     int tw_global;    // 1: the stage twiddles do not fit in LDS next to the tile: they are read from the inner table (L1 / L2)
+    int shuffle;      // 1: the first two radix-4 steps of a tile are joined by wave shuffles instead of an LDS round trip
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -219,9 +220,68 @@ PLK_DI size_t tile_tw_index(const NttPassArgs& a, const TileGeom& t, int e) {
 // `first_stage` > 0: the tile starts at that stage (zero-padded input: when only the rows p < A / 2^k of a column are non-zero,
 // the bit-reversed placement puts them at every 2^k-th slot and the first k butterfly stages pair every value with a zero:
 // (a, 0) -> (a, a).  They are pure replication, done by the loads; polynomials_to_values_padded has k = 3).
+// one radix-4 step in registers.  x[0..3]: the elements at rows i0, i0 + st, i0 + 2 st, i0 + 3 st; on return the outputs for
+// the same rows.  FIRST: the step with half-size h = 1 (unit twiddles w_2^0, w_4^0: one multiplication, exactly normalised inputs).
+template <class P, bool FIRST>
+PLK_DI void radix4_step(Fz<P> (&x)[4], const Fz<P>& wa, const Fz<P>& wb0, const Fz<P>& wb1) {
+    if constexpr (!FIRST) {
+        // Carries are moved twice per step instead of eight times (fz_add_nc / fz_sub_nc): LDS holds limbs up to
+        // MUL_LIMB_MAX = 2.5 * 2^30 + 16; x1 and x3 go straight into a multiplication by a table entry; x0 and x2 are
+        // carried (limbs < 2^29 + 8) and every sum below stays within the bound:
+        //   y0, y2 <= 2^29 + 8 + 2^29;   y1, y3 <= 2^29 + 8 + 2^30 (borrow 2^29 + limb of 2p);   outputs <= y + 2^30.
+        // stage with half-size h: pairs (x0, x1), (x2, x3), twiddle w_{2h}^j for both
+        fz_carry<P>(x[0]);
+        fz_carry<P>(x[2]);
+        x[1] = fz_mul<P>(x[1], wa);
+        x[3] = fz_mul<P>(x[3], wa);
+        const Fz<P> y0 = fz_add_nc<P>(x[0], x[1]), y1 = fz_sub_nc<P, 1, 29>(x[0], x[1]);
+        Fz<P> y2 = fz_add_nc<P>(x[2], x[3]), y3 = fz_sub_nc<P, 1, 29>(x[2], x[3]);
+        // stage with half-size 2h: pairs (y0, y2) with w_{4h}^j and (y1, y3) with w_{4h}^(j+h)
+        y3 = fz_mul<P>(y3, wb1);
+        x[1] = fz_add_nc<P>(y1, y3);
+        x[3] = fz_sub_nc<P, 1, 29>(y1, y3);
+        y2 = fz_mul<P>(y2, wb0);
+        x[0] = fz_add_nc<P>(y0, y2);
+        x[2] = fz_sub_nc<P, 1, 29>(y0, y2);
+    } else {
+        // first step of a tile: the inputs are exactly normalised (canonical, or products below 1.01p), the
+        // twiddles w_2^0 and w_4^0 are 1: one multiplication; y2 = x2 + x3 is below 2.1p with limbs <= 2^30 - 2
+        const Fz<P> y0 = fz_add_nc<P>(x[0], x[1]), y1 = fz_sub_nc<P, 1, 29>(x[0], x[1]);
+        const Fz<P> y2 = fz_add_nc<P>(x[2], x[3]);
+        Fz<P> y3 = fz_sub_nc<P, 1, 29>(x[2], x[3]);
+        y3 = fz_mul<P>(y3, wb1);
+        x[1] = fz_add_nc<P>(y1, y3);           // <= 2^29 + 2^30 + 2^29
+        x[3] = fz_sub_nc<P, 1, 29>(y1, y3);    // <= 2^29 + 2^30 + 2^30
+        x[0] = fz_add_nc<P>(y0, y2);           // <= 2^31
+        x[2] = fz_sub_nc<P, 2, 30>(y0, y2);    // <= 2^30 + 2^30 + 2^29
+    }
+}
+// Exchange between the four lanes {l, l + d, l + 2d, l + 3d} of a wave (t = the lane's place among them): on entry lane t holds
+// o[0..3], on return x[k] = (lane k's) o[t] - a 4 x 4 transposition in two butterfly rounds of wave shuffles, two elements
+// each way per round.  This is what carries the outputs of the first radix-4 step of a tile to the lanes of the second one
+// WITHOUT the LDS round trip and its barrier ("wavefront butterfly shuffles").
+template <class P> PLK_DI void quad_transpose(Fz<P> (&v)[4], int t, int d) {
+    constexpr int NZ = FzCfg<P>::NZ;
+    const bool b0 = (t & 1) != 0, b1 = (t & 2) != 0;
+#pragma unroll
+    for (int l = 0; l < NZ; ++l) {
+        // round A (distance d): keep one of each pair (v0, v1), (v2, v3), trade the other
+        const uint32_t s0 = b0 ? v[0].l[l] : v[1].l[l], s1 = b0 ? v[2].l[l] : v[3].l[l];
+        const uint32_t r0 = (uint32_t)__shfl_xor((int)s0, d), r1 = (uint32_t)__shfl_xor((int)s1, d);
+        const uint32_t a0 = b0 ? r0 : v[0].l[l], a1 = b0 ? v[1].l[l] : r0, a2 = b0 ? r1 : v[2].l[l], a3 = b0 ? v[3].l[l] : r1;
+        // round B (distance 2d): pairs (a0, a2), (a1, a3)
+        const uint32_t u0 = b1 ? a0 : a2, u1 = b1 ? a1 : a3;
+        const uint32_t q0 = (uint32_t)__shfl_xor((int)u0, 2 * d), q1 = (uint32_t)__shfl_xor((int)u1, 2 * d);
+        v[0].l[l] = b1 ? q0 : a0;
+        v[1].l[l] = b1 ? q1 : a1;
+        v[2].l[l] = b1 ? a2 : q0;
+        v[3].l[l] = b1 ? a3 : q1;
+    }
+}
+
 template <class P>
 PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw, int tid, int log_a, int log_q, int tile_elems, int first_stage, const uint4* __restrict__ g_tw,
-                        bool tw_global) {
+                        bool tw_global, bool shuffle) {
     const int Q = 1 << log_q, half_a = (1 << log_a) >> 1;
     // w_A^e, e < A / 2
     auto stage_tw = [&](int e) -> Fz<P> {
@@ -230,49 +290,53 @@ PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw, int tid, int log_
         return lds_load<P>(s_tw, half_a, e);
     };
     int log_h = first_stage;
+    // The first FOUR stages without an LDS round trip in the middle: step h = 1 in registers, its outputs handed to the lanes
+    // of step h = 4 by wave shuffles (the four lanes of a group are Q apart), step h = 4 in registers, then LDS.
+    if (shuffle && log_h == 0 && log_a >= 4 && (tile_elems >> 2) == NTT_THREADS && (4 << log_q) <= 64) {
+        const int q = tid & (Q - 1), pq = tid >> log_q;
+        Fz<P> x[4];
+        {
+            const int i0 = ((pq << 2) << log_q) + q, st = Q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = lds_load<P>(s_dat, TILE, i0 + k * st);
+            const Fz<P> wb1 = stage_tw(1 << (log_a - 2));
+            radix4_step<P, true>(x, wb1, wb1, wb1);
+        }
+        quad_transpose<P>(x, pq & 3, Q);
+        {
+            const int h = 4, j = pq & 3, blk = pq >> 2;
+            const int i0 = (((blk << 4) + j) << log_q) + q, st = h << log_q;
+            const Fz<P> wa = stage_tw(j << (log_a - 3)), wb1 = stage_tw((j + h) << (log_a - 4)), wb0 = stage_tw(j << (log_a - 4));
+            radix4_step<P, false>(x, wa, wb0, wb1);
+            // every lane of the workgroup has read its step-1 inputs before any of these stores can land: the exchange above
+            // is wave-wide, but lanes of OTHER waves may still be loading - they load rows 4 pq .. 4 pq + 3 of their own pq only,
+            // and the rows written here, 16 blk + j + 4 k, belong to the four pq of THIS lane group: no overlap across waves
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lds_store<P>(s_dat, TILE, i0 + k * st, x[k]);
+        }
+        __syncthreads();
+        log_h = 4;
+    }
     for (; log_h + 1 < log_a; log_h += 2) {
         const int h = 1 << log_h;
         for (int qd = tid; qd < (tile_elems >> 2); qd += NTT_THREADS) {
             const int q = qd & (Q - 1), pq = qd >> log_q;
             const int j = pq & (h - 1), blk = pq >> log_h;
             const int i0 = (((blk << (log_h + 2)) + j) << log_q) + q, st = h << log_q;
-            Fz<P> x0 = lds_load<P>(s_dat, TILE, i0), x1 = lds_load<P>(s_dat, TILE, i0 + st);
-            Fz<P> x2 = lds_load<P>(s_dat, TILE, i0 + 2 * st), x3 = lds_load<P>(s_dat, TILE, i0 + 3 * st);
+            Fz<P> x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = lds_load<P>(s_dat, TILE, i0 + k * st);
             if (log_h > 0) {
-                // Carries are moved twice per step instead of eight times (fz_add_nc / fz_sub_nc): LDS holds limbs up to
-                // MUL_LIMB_MAX = 2.5 * 2^30 + 16; x1 and x3 go straight into a multiplication by a table entry; x0 and x2 are
-                // carried (limbs < 2^29 + 8) and every sum below stays within the bound:
-                //   y0, y2 <= 2^29 + 8 + 2^29;   y1, y3 <= 2^29 + 8 + 2^30 (borrow 2^29 + limb of 2p);   outputs <= y + 2^30.
-                // stage with half-size h: pairs (x0, x1), (x2, x3), twiddle w_{2h}^j for both
                 const Fz<P> wa = stage_tw(j << (log_a - 1 - log_h));
-                fz_carry<P>(x0);
-                fz_carry<P>(x2);
-                x1 = fz_mul<P>(x1, wa);
-                x3 = fz_mul<P>(x3, wa);
-                const Fz<P> y0 = fz_add_nc<P>(x0, x1), y1 = fz_sub_nc<P, 1, 29>(x0, x1);
-                Fz<P> y2 = fz_add_nc<P>(x2, x3), y3 = fz_sub_nc<P, 1, 29>(x2, x3);
-                // stage with half-size 2h: pairs (y0, y2) with w_{4h}^j and (y1, y3) with w_{4h}^(j+h)
                 const Fz<P> wb1 = stage_tw((j + h) << (log_a - 2 - log_h));
-                y3 = fz_mul<P>(y3, wb1);
-                lds_store<P>(s_dat, TILE, i0 + st, fz_add_nc<P>(y1, y3));
-                lds_store<P>(s_dat, TILE, i0 + 3 * st, fz_sub_nc<P, 1, 29>(y1, y3));
                 const Fz<P> wb0 = stage_tw(j << (log_a - 2 - log_h));
-                y2 = fz_mul<P>(y2, wb0);
-                lds_store<P>(s_dat, TILE, i0, fz_add_nc<P>(y0, y2));
-                lds_store<P>(s_dat, TILE, i0 + 2 * st, fz_sub_nc<P, 1, 29>(y0, y2));
+                radix4_step<P, false>(x, wa, wb0, wb1);
             } else {
-                // first step of a tile: the inputs are exactly normalised (canonical, or products below 1.01p), the
-                // twiddles w_2^0 and w_4^0 are 1: one multiplication; y2 = x2 + x3 is below 2.1p with limbs <= 2^30 - 2
-                const Fz<P> y0 = fz_add_nc<P>(x0, x1), y1 = fz_sub_nc<P, 1, 29>(x0, x1);
-                const Fz<P> y2 = fz_add_nc<P>(x2, x3);
-                Fz<P> y3 = fz_sub_nc<P, 1, 29>(x2, x3);
                 const Fz<P> wb1 = stage_tw((j + h) << (log_a - 2 - log_h));
-                y3 = fz_mul<P>(y3, wb1);
-                lds_store<P>(s_dat, TILE, i0 + st, fz_add_nc<P>(y1, y3));           // <= 2^29 + 2^30 + 2^29
-                lds_store<P>(s_dat, TILE, i0 + 3 * st, fz_sub_nc<P, 1, 29>(y1, y3));  // <= 2^29 + 2^30 + 2^30
-                lds_store<P>(s_dat, TILE, i0, fz_add_nc<P>(y0, y2));                  // <= 2^31
-                lds_store<P>(s_dat, TILE, i0 + 2 * st, fz_sub_nc<P, 2, 30>(y0, y2));  // <= 2^30 + 2^30 + 2^29
+                radix4_step<P, true>(x, wb1, wb1, wb1);
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lds_store<P>(s_dat, TILE, i0 + k * st, x[k]);
         }
         __syncthreads();
     }
@@ -369,7 +433,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const void* in, void* 
         lds_store<P>(s_dat, TILE, by_slot ? e : tile_in_slot(a, e), x);
     }
     __syncthreads();
-    tile_stages<P>(s_dat, s_tw, tid, log_a, log_q, tile_elems, (HOOKS && !IN_LIMBS) ? a.skip : 0, inner_tw, a.tw_global != 0);
+    tile_stages<P>(s_dat, s_tw, tid, log_a, log_q, tile_elems, (HOOKS && !IN_LIMBS) ? a.skip : 0, inner_tw, a.tw_global != 0, a.shuffle != 0);
     const Fz<P> scale = fz_from_fe<P>(fe_load<P>(scale_ptr));
     for (int e = tid; e < tile_elems; e += NTT_THREADS) {
         const size_t g = tile_out_index(a, tg, e);
@@ -600,6 +664,8 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
         std::pair<hipEvent_t, hipEvent_t> pev;
         const bool prof = prof_begin(stream, pev);
         size_t lds_bytes = ((size_t)FzCfg<P>::NZ * TILE + (size_t)FzCfg<P>::NZ * ((size_t)1 << a.log_a) / 2) * 4;
+        static const int shuffle_mode = getenv("PLK_NTT_SHUFFLE") ? atoi(getenv("PLK_NTT_SHUFFLE")) : 0;
+        a.shuffle = shuffle_mode;
         a.tw_global = 0;
         if (lds_bytes > NTT_LDS_MAX) {
             a.tw_global = 1;

@@ -295,7 +295,7 @@ template <int I, class P, int B, class LW> PLK_DI auto base4_chain(const Lz<P, B
 // k: local constants [6]; l: local wires [9]; r: right wires (only indices 0..3 are read by any gate); b2, b3: below wires 2, 3
 // (only CurveEndoGate reads below, curve_endo.rs:115-117); small: 1/1 .. 1/7 (R'-form table).
 // Prefix filters (gates/mod.rs:289-300) are formed where they are used, along the prefix tree of gates/mod.rs:1-16 (BufferGate,
-// 101010, has no constraints: buffer.rs:26-33): a filter kept alive for the whole kernel costs nine registers.
+// PREFIX 101000 in the code - buffer.rs:27; the doc comment of gates/mod.rs says 101010 -, has no constraints: buffer.rs:26-33): a filter kept alive for the whole kernel costs nine registers.
 // gate groups (a kernel evaluates a subset: the live set of all ten gates is several register files wide)
 constexpr int GATES_RESCUE_A = 1, GATES_ENDO = 2, GATES_BASE4_ARITH = 4, GATES_ADD_PUBLIC = 8, GATES_DBL_CONST = 16, GATES_RESCUE_B = 32, GATES_ALL = 63;
 constexpr int GATES_RESCUE = GATES_RESCUE_A | GATES_RESCUE_B;

@@ -28,13 +28,30 @@ def per_kernel(path, counter):
     return out
 
 
-def main(fetch_db, write_db, log_n, out_path):
+def main(fetch_db, write_db, log_n, out_path, mode="headline"):
     f = per_kernel(fetch_db, "FETCH_SIZE")
     w = per_kernel(write_db, "WRITE_SIZE")
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import kernel_source_hash
     res = {"kernel_source_sha": kernel_source_hash(), "curve": "tweedledee"}
+    if mode == "quotient":
+        # --workload quotient: the vanishing points are FIVE launches per call (all instantiations of k_vanishing_points summed,
+        # divided by the number of calls = dispatches / 5); the fold is one launch per call.  Both read wide coalesced streams
+        # (16 bytes per lane from row-major tables / point arrays): FETCH_SIZE is doubled, as for the NTT pass kernel.
+        for short, per_call, note in (("k_vanishing_points", 5, "sum over the five launches of a call"), ("k_fold_pairs_glv", 1, "one launch per call")):
+            fk = [k for k in f if short in k]
+            wk = [k for k in w if short in k]
+            if not fk or not wk:
+                continue
+            calls = sum(f[k][1] for k in fk) / per_call
+            fb = sum(f[k][0] for k in fk) / calls * 1024.0 * 2.0
+            wb = sum(w[k][0] for k in wk) / (sum(w[k][1] for k in wk) / per_call) * 1024.0
+            res[short] = {"log_n": int(log_n), "fetch_bytes_per_call": fb, "write_bytes_per_call": wb, "bytes_per_call": fb + wb, "calls_sampled": calls,
+                          "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (wide coalesced streams, gfx950 correction); " + note}
+        json.dump(res, open(out_path, "w"), indent=1)
+        print(json.dumps(res, indent=1))
+        return
     for short, fetch_factor, note in (("k_ntt_pass", 2.0, "FETCH_SIZE x2 (wide coalesced stream, gfx950 correction)"),
                                       ("k_msm_accumulate", 1.0, "FETCH_SIZE uncorrected (random 64-byte gathers, uncalibrated pattern)")):
         fk = [k for k in f if short in k]
@@ -50,4 +67,4 @@ def main(fetch_db, write_db, log_n, out_path):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])
