@@ -303,8 +303,9 @@ def run_quotient(args):
         "vanishing_points": entry("k_vanishing_points", 170.0, n8, v_ms, 30.0 * 32 * n8,
                                   "five launches per call (launch_ms = the call); ~170 field multiplications per point (DESIGN.md 4c); algorithmic bytes: "
                                   "29 elements read + 1 written per point"),
-        "fold_pairs": entry("k_fold_pairs_glv", 1830.0, m, f_ms, 3.0 * 64 * m,
-                            "scaled fold lo + [u^2] hi along the endomorphism: ~130 doublings (6M + 3S) + ~65 mixed additions (8M + 2S) + two inversions per pair"),
+        "fold_pairs": entry("k_fold_pairs_glv", 2570.0, m, f_ms, 3.0 * 64 * m,
+                            "G' = [u^-1] G_lo + [u] G_hi along the endomorphism (plk_curve_fold_pairs_dev): ~130 doublings (6M + 3S) + ~130 mixed additions "
+                            "(8M + 2S) + two inversions per pair; the argument behind the C ABI folds scaled, lo + [u^2] hi: ~65 additions"),
     }
     result = {
         "metric": "MSM Mpairs/sec + NTT Melems/sec, 2^20 Tweedledee, 1/2/4/8 GPU", "value": n8 / (v_ms * 1e-3) / 1e6,

@@ -307,6 +307,14 @@ int plk_halo_free(plk_halo_ctx* ctx);
  * wave-wide sum).  mismatches[8] receives the number of disagreements per case: all zero on a healthy build. */
 int plk_selftest_quad(int curve, const uint64_t* pts_xy, size_t n, unsigned quads, unsigned* mismatches);
 
+/* ---- checked build --------------------------------------------------------------------------------- */
+/* libplonky_hip_checked.so (make -C plonky_amd/csrc checked) is the same library with -DPLK_CHECKED: every index the MSM's
+ * ordering and accumulation kernels compute into their work arrays and tables is compared with its bound, a violation is
+ * counted and the access skipped.  plk_checked_build() tells the two builds apart (1 / 0); plk_checked_failures() returns
+ * the violation counters per guarded site (counts[8]; all zero in the normal build, which has no guards). */
+int plk_checked_build(void);
+int plk_checked_failures(unsigned* counts);
+
 /* ---- measurement hooks (bench.py's roofline: per-kernel durations from HIP events recorded on the
  *      launch stream around each kernel; no effect on results) ------------------------------- */
 /* NTT pass kernel: enable, run transforms, then read the summed duration and the number of launches

@@ -32,6 +32,8 @@ int msm_reserve_workspaces_impl(plk_msm_ctx* ctx, unsigned count, hipStream_t st
 int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void* d_zero, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_gen_bases_dev_impl(int curve, size_t n, uint64_t first, const void* d_g0d, void* d_out, hipStream_t stream);
 size_t msm_partials_bytes(int curve, unsigned batch);
+int checked_build_impl();
+int checked_failures_impl(unsigned* counts);
 int msm_combine_partials_dev_impl(int curve, unsigned world, unsigned batch, unsigned whole_per_rank, const void* d_gathered, void* d_out_xy, void* d_out_zero,
                                   hipStream_t stream);
 int curve_fold_pairs_dev_impl(int curve, size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero,
@@ -1061,6 +1063,10 @@ int plk_selftest_quad(int curve, const uint64_t* pts_xy, size_t n, unsigned quad
     PLK_HIP_TRY(hipMemcpy(dp.p, pts_xy, n * 2 * L * 8, hipMemcpyHostToDevice));
     return selftest_quad_dev_impl(curve, dp.p, (uint32_t)n, quads, mismatches);
 }
+
+// ---- checked build ----
+int plk_checked_build(void) { return checked_build_impl(); }
+int plk_checked_failures(unsigned* counts) { return checked_failures_impl(counts); }
 
 // ---- measurement hooks ----
 int plk_ntt_set_profiling(int enable) { return ntt_set_profiling_impl(enable); }

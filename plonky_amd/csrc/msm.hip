@@ -43,6 +43,18 @@
 
 namespace plk {
 
+// -DPLK_CHECKED (make checked -> libplonky_hip_checked.so; SURVEY.md section 5: the reference's debug assertions and overflow
+// checks have no equivalent in a release kernel): every index the ordering and accumulation kernels compute into sorted[],
+// tmp[], the tables and the bucket arrays is compared with its bound; a violation is counted per site and the access is
+// skipped.  plk_checked_failures() reads the counters.  In the normal build the guards compile to nothing.
+#ifdef PLK_CHECKED
+__device__ unsigned g_plk_chk[8];
+#define PLK_CHK(cond, site) (!(cond) ? (atomicAdd(&g_plk_chk[site], 1u), false) : true)
+#else
+#define PLK_CHK(cond, site) (true)
+#endif
+enum { CHK_TMP_INDEX = 0, CHK_TILE_STAGE = 1, CHK_SORTED_INDEX = 2, CHK_SEG_STAGE = 3, CHK_TABLE_INDEX = 4, CHK_BUCKET = 5, CHK_ENTRY_RANGE = 6 };
+
 constexpr int MSM_MAX_PLANE_PARTS = 16;  // blocks per bit-plane in the reduction (planes * parts quads must fit the final block)
 constexpr int MSM_TF_MAX_WINDOW = 16;  // table-free mode: every window has its own 2^(c-1) buckets
 constexpr int MSM_MAX_WINDOW = 21;   // c - 1 <= 10 coarse + 11 fine bits in the partition (ORD_MAX_BINS, ORD_MAX_FINE)
@@ -153,6 +165,7 @@ struct OrdCfg {
     uint32_t sub;            // sub-tiles per tile (one block walks them in turn)
     uint32_t nt1;            // tiles
     int raw_signed;          // 1: the "scalars" are half scalars of a GLV split: canonical magnitude, sign in bit 255 (glv.cuh)
+    uint32_t entries_cap;    // n_eff * windows: size of tmp[] / sorted[] and of the table (checked build)
 };
 
 template <class SP> PLK_DI void ord_park_scalar(const uint4* __restrict__ scalars, size_t i, uint32_t* s_lim, int tid, bool raw_signed) {
@@ -383,8 +396,10 @@ __global__ void __launch_bounds__(ORD_THREADS) k_ord_scatter(const uint4* __rest
             uint32_t carry = 0;
             for (int j = 0; j < cfg.windows; ++j) {
                 const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
-                if (code != CODE_INVALID)
-                    s_ent[s_base[code >> (cfg.fine_bits + 1)] + s_rank[j * cfg.spt + tid]] = make_uint2(code, (uint32_t)((size_t)j * n + i));
+                if (code != CODE_INVALID) {
+                    const uint32_t slot = s_base[code >> (cfg.fine_bits + 1)] + s_rank[j * cfg.spt + tid];
+                    if (PLK_CHK(slot < (uint32_t)ORD_TILE, CHK_TILE_STAGE)) s_ent[slot] = make_uint2(code, (uint32_t)((size_t)j * n + i));
+                }
             }
         }
         __syncthreads();
@@ -392,7 +407,8 @@ __global__ void __launch_bounds__(ORD_THREADS) k_ord_scatter(const uint4* __rest
         for (uint32_t sidx = tid; sidx < total; sidx += ORD_THREADS) {
             const uint2 e = s_ent[sidx];
             const uint32_t bin = e.x >> (cfg.fine_bits + 1);
-            tmp[s_gbase[bin] + (sidx - s_base[bin])] = e;
+            const uint32_t at = s_gbase[bin] + (sidx - s_base[bin]);
+            if (PLK_CHK(at < cfg.entries_cap, CHK_TMP_INDEX)) tmp[at] = e;
         }
         __syncthreads();
         for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_gbase[k] += s_cnt[k];  // this sub-tile's entries of bin k
@@ -436,7 +452,7 @@ __global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_count(const uint2* 
 __global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_scatter(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bin_base,
                                                                      const uint32_t* __restrict__ seg_base, int fine_bits, int nbins, uint32_t buckets,
                                                                      const uint32_t* __restrict__ cnt2, uint32_t* __restrict__ off,
-                                                                     uint32_t* __restrict__ sorted) {
+                                                                     uint32_t* __restrict__ sorted, uint32_t entries_cap) {
     __shared__ uint32_t s_glob[1 << ORD_MAX_FINE], s_loc[1 << ORD_MAX_FINE], s_cur[1 << ORD_MAX_FINE];
     __shared__ uint32_t s_tmp[ORD_BIN_THREADS];
     __shared__ uint32_t s_out[ORD_SEG];
@@ -484,14 +500,17 @@ __global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_scatter(const uint2
         const uint2 e = tmp[p];
         const uint32_t f = (e.x >> 1) & fmask;
         const uint32_t idx = atomicAdd(&s_cur[f], 1u);
-        s_out[idx] = (e.y << 1) | (e.x & 1u);
-        s_fine[idx] = (uint16_t)f;
+        if (PLK_CHK(idx < ORD_SEG, CHK_SEG_STAGE)) {
+            s_out[idx] = (e.y << 1) | (e.x & 1u);
+            s_fine[idx] = (uint16_t)f;
+        }
     }
     __syncthreads();
     const uint32_t count = hi - lo;
     for (uint32_t i = tid; i < count; i += ORD_BIN_THREADS) {
         const uint32_t f = s_fine[i];
-        sorted[s_glob[f] + (i - s_loc[f])] = s_out[i];
+        const uint32_t at = s_glob[f] + (i - s_loc[f]);
+        if (PLK_CHK(at < entries_cap, CHK_SORTED_INDEX)) sorted[at] = s_out[i];
     }
 }
 
@@ -563,7 +582,7 @@ PLK_DI uint32_t next_bucket(const uint32_t* __restrict__ off, uint32_t b, uint32
 template <class C>
 PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ off,
                                 uint4* __restrict__ p_start, uint4* __restrict__ p_head, uint8_t* __restrict__ head_live, uint32_t buckets,
-                                const uint32_t* __restrict__ dyn_chunk, int wshift, uint32_t n_sub, uint4* s_head, uint8_t* s_parked) {
+                                const uint32_t* __restrict__ dyn_chunk, int wshift, uint32_t n_sub, uint4* s_head, uint8_t* s_parked, uint32_t tab_entries) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     constexpr int RU = raw_u4<FP>();
@@ -593,15 +612,17 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
         const uint32_t ent_sub = (b >> wshift) * n_sub;
         // Software pipeline: the table gather for entry k+1 (two dependent loads: index, then a random
         // 64/96-byte point) is issued before the ~10^4-cycle addition of entry k.
+        (void)PLK_CHK(b < buckets && end <= total, CHK_ENTRY_RANGE);
         uint32_t ent = sorted[begin];
         Fe<FP> x, y;
-        bool ident = affine_load<FP>(tab + (size_t)((ent >> 1) - ent_sub) * 2 * W, x, y);
+        bool ident = true;
+        if (PLK_CHK((ent >> 1) - ent_sub < tab_entries, CHK_TABLE_INDEX)) ident = affine_load<FP>(tab + (size_t)((ent >> 1) - ent_sub) * 2 * W, x, y);
         for (uint32_t k = begin; k < end; ++k) {
             if (k == next) {  // entry k opens a new bucket: the piece of the old one is closed
                 if (head) {
                     xyzzz_store_raw<FP>(s_head + tid * RU, acc);
                     parked = true;
-                } else {
+                } else if (PLK_CHK(b < buckets, CHK_BUCKET)) {
                     xyzzz_store_raw<FP>(p_start + (size_t)b * RU, acc);
                 }
                 head = false;
@@ -617,7 +638,9 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
                 const uint32_t nb = k + 1 == next ? next_bucket(off, b, buckets, k + 1) : b;
                 const uint32_t nsub = (nb >> wshift) * n_sub;
                 ent = sorted[k + 1];
-                ident = affine_load<FP>(tab + (size_t)((ent >> 1) - nsub) * 2 * W, x, y);
+                ident = true;
+                if (PLK_CHK((ent >> 1) - nsub < tab_entries && nb < buckets, CHK_TABLE_INDEX))
+                    ident = affine_load<FP>(tab + (size_t)((ent >> 1) - nsub) * 2 * W, x, y);
             }
             if (cident) continue;
             Fz<FP> xz = fz_from_fe<FP>(cx), yz = fz_from_fe<FP>(cy);
@@ -645,10 +668,10 @@ template <class C>
 __global__ void __launch_bounds__(ACC_THREADS) k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
                                                                 const uint32_t* __restrict__ off, uint4* __restrict__ p_start, uint4* __restrict__ p_head,
                                                                 uint8_t* __restrict__ head_live, uint32_t buckets, const uint32_t* __restrict__ dyn_chunk,
-                                                                int wshift, uint32_t n_sub) {
+                                                                int wshift, uint32_t n_sub, uint32_t tab_entries) {
     __shared__ uint4 s_head[ACC_THREADS * raw_u4<typename C::FP>()];
     __shared__ uint8_t s_parked[ACC_THREADS];
-    msm_accumulate_body<C>(tab, sorted, off, p_start, p_head, head_live, buckets, dyn_chunk, wshift, n_sub, s_head, s_parked);
+    msm_accumulate_body<C>(tab, sorted, off, p_start, p_head, head_live, buckets, dyn_chunk, wshift, n_sub, s_head, s_parked, tab_entries);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -823,11 +846,27 @@ __global__ void __launch_bounds__(256) k_msm_assemble(TailBatch tb, uint32_t buc
 // Two-level weighting, step 1: partial row and column sums over groups of G = 2^g_log buckets, one lane per group.
 // lanes [0, NB / G): row hi, group g: buckets (hi << L) + g G + k;   lanes [NB / G, 2 NB / G): column lo, group g:
 // buckets ((g G + k) << L) + lo (adjacent lanes = adjacent columns = adjacent addresses).
+// A bucket as the accumulation left it: its start piece plus the head pieces that are still live (k_msm_assemble's job, done
+// where the bucket is read: at c = 20 one bucket in ~350 has a live head piece, so a separate pass over 2^19 buckets mostly
+// reads offsets).  Empty buckets are the identity (their p_start slot was never written); buckets with more than HEAVY_HEADS
+// head pieces were made whole by k_msm_heavy_final.
+template <class FP> PLK_DI XyzzZ<FP> bucket_value(const TailSlot& sl, uint32_t b, uint32_t chunk) {
+    constexpr int RU = raw_u4<FP>();
+    uint32_t first, ns;
+    if (!bucket_heads(sl.off, b, chunk, first, ns)) return xyzzz_identity<FP>();
+    XyzzZ<FP> v = xyzzz_load_raw<FP>(sl.p_start + (size_t)b * RU);
+    if (ns <= HEAVY_HEADS)
+        for (uint32_t h = 0; h < ns; ++h)
+            if (sl.head_live[first + h]) v = xyzzz_add<FP>(v, xyzzz_load_raw<FP>(sl.p_head + (size_t)(first + h) * RU));
+    return v;
+}
 template <class C>
 __global__ void __launch_bounds__(128) k_msm_gsum(TailBatch tb, int L, int H, int g_log) {
     using FP = typename C::FP;
     constexpr int RU = raw_u4<FP>();
     const TailSlot& sl = tb.s[blockIdx.y];
+    if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 2) *sl.final_done = 0;  // k_msm_final's counter (left at zero by its last block anyway)
+    const uint32_t chunk = sl.dyn_chunk[0];
     const uint32_t nbg = (1u << (L + H)) >> g_log;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * nbg) return;
@@ -853,11 +892,11 @@ __global__ void __launch_bounds__(128) k_msm_gsum(TailBatch tb, int L, int H, in
     }
     // the load of element k + 1 is in flight while element k is added
     XyzzZ<FP> acc = xyzzz_identity<FP>();
-    XyzzZ<FP> nxt = xyzzz_load_raw<FP>(sl.p_start + (size_t)b0 * RU);
+    XyzzZ<FP> nxt = bucket_value<FP>(sl, b0, chunk);
     for (uint32_t k = 0; k < G; ++k) {
         XyzzZ<FP> cur = nxt;
         const uint32_t b = b0 + k * bstep;
-        if (k + 1 < G) nxt = xyzzz_load_raw<FP>(sl.p_start + (size_t)(b + bstep) * RU);
+        if (k + 1 < G) nxt = bucket_value<FP>(sl, b + bstep, chunk);
         acc = xyzzz_add<FP>(acc, cur);
     }
     xyzzz_store_raw<FP>(dst, acc);
@@ -873,6 +912,7 @@ __global__ void __launch_bounds__(256) k_msm_lsum(TailBatch tb, int L, int H, in
     constexpr int W = FP::NL / 4;
     constexpr int RU = raw_u4<FP>();
     const TailSlot& sl = tb.s[blockIdx.y];
+    if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x < 2) sl.heavy[threadIdx.x] = 0;  // the counters of k_msm_heavy_list are free again
     const uint32_t wb = 1u << H;
     const uint32_t nbg = (1u << (L + H)) >> g_log;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1563,6 +1603,7 @@ static int msm_configure(plk_msm_ctx* ctx, int curve, size_t n, unsigned window_
         o.nt1 = (uint32_t)((n_eff + (size_t)o.spt * o.sub - 1) / ((size_t)o.spt * o.sub));
         if (o.nt1 == 0) o.nt1 = 1;
         o.raw_signed = glv ? 1 : 0;
+        o.entries_cap = (uint32_t)(n_eff * (size_t)windows);
     }
     // tail geometry
     ctx->two_level = c - 1 >= 12;
@@ -1672,7 +1713,7 @@ static int msm_reduce_t(plk_msm_ctx* ctx, TailBatch tb, hipStream_t stream, Mark
     if (ctx->two_level) {
         const uint32_t nbg = (1u << (ctx->L + ctx->H)) >> ctx->g_log;  // groups per window (rows; as many for the columns)
         const unsigned wins = ctx->table_free ? (unsigned)ctx->windows : 1u;
-        k_msm_assemble<C, false><<<dim3(ab, cnt), 256, 0, stream>>>(tb, buckets, ctx->lpb_log);
+        // no k_msm_assemble here: the row / column sums read the pieces themselves (bucket_value)
         k_msm_gsum<C><<<dim3((2 * nbg + 127) / 128, cnt, wins), 128, 0, stream>>>(tb, ctx->L, ctx->H, ctx->g_log);
         const size_t lanes = ((size_t)2 << ctx->H) << (ctx->lpl_log + 2);
         k_msm_lsum<C><<<dim3((unsigned)((lanes + 255) / 256), cnt, wins), 256, 0, stream>>>(tb, ctx->L, ctx->H, ctx->g_log, ctx->lpl_log);
@@ -1760,7 +1801,7 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
             const unsigned segs = (unsigned)(n * (size_t)o.windows / ORD_SEG + o.nbins + 1);
             k_ord_bin_count<<<segs, ORD_BIN_THREADS, 0, stream>>>((const uint2*)w.tmp, bin_base, seg_base, o.fine_bits, o.nbins, (uint32_t*)w.cnt2);
             k_ord_bin_scatter<<<segs + o.nbins, ORD_BIN_THREADS, 0, stream>>>((const uint2*)w.tmp, bin_base, seg_base, o.fine_bits, o.nbins, buckets,
-                                                                              (const uint32_t*)w.cnt2, off, (uint32_t*)w.sorted);
+                                                                              (const uint32_t*)w.cnt2, off, (uint32_t*)w.sorted, o.entries_cap);
         }
         PLK_HIP_TRY(hipGetLastError());
         guard.armed = false;
@@ -1774,7 +1815,9 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
         const unsigned ablocks = (unsigned)((ctx->max_lanes + ACC_THREADS - 1) / ACC_THREADS);
         k_msm_accumulate<C><<<ablocks, ACC_THREADS, 0, stream>>>((const uint4*)ctx->tab, (const uint32_t*)w.sorted, off, (uint4*)w.p_start, (uint4*)w.p_head,
                                                                  (uint8_t*)w.head_live, buckets, done_counter + 2, ctx->table_free ? ctx->c - 1 : 31,
-                                                                 ctx->table_free ? (uint32_t)n : 0u);
+                                                                 ctx->table_free ? (uint32_t)n : 0u,
+                                                                 // tabled: sorted[] entries index the table; table-free: the table holds the n_eff points, sorted[] the entries
+                                                                 ctx->table_free ? (uint32_t)ctx->n_eff : o.entries_cap);
         PLK_HIP_TRY(hipGetLastError());
     }
     mark();
@@ -2037,6 +2080,25 @@ int msm_combine_partials_dev_impl(int curve, unsigned world, unsigned batch, uns
 #undef CASE
     }
     PLK_HIP_TRY(hipGetLastError());
+    return PLK_OK;
+}
+
+int checked_build_impl() {
+#ifdef PLK_CHECKED
+    return 1;
+#else
+    return 0;
+#endif
+}
+// counts[8]: violations per guarded site since the library was loaded (all zero in the normal build, which has no guards)
+int checked_failures_impl(unsigned* counts) {
+    if (!counts) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    for (int k = 0; k < 8; ++k) counts[k] = 0;
+#ifdef PLK_CHECKED
+    PLK_TRY(ensure_device());
+    PLK_HIP_TRY(hipDeviceSynchronize());
+    PLK_HIP_TRY(hipMemcpyFromSymbol(counts, HIP_SYMBOL(g_plk_chk), 8 * sizeof(unsigned)));
+#endif
     return PLK_OK;
 }
 

@@ -86,6 +86,8 @@ SYMBOLS = [
     ("plk_halo_read", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("plk_halo_free", _i, [_vp]),
     ("plk_selftest_quad", _i, [_i, _vp, _sz, _u, _vp]),
+    ("plk_checked_build", _i, []),
+    ("plk_checked_failures", _i, [_vp]),
     ("plk_ntt_set_profiling", _i, [_i]),
     ("plk_ntt_get_timings", _i, [_vp, _vp]),
     ("plk_msm_set_profiling", _i, [_vp, _i]),
@@ -102,8 +104,8 @@ class PlonkyHipError(RuntimeError):
 
 
 def build(force=False):
-    """Compile libplonky_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    args = ["make", "-C", _CSRC, "-j8"]
+    """Compile libplonky_hip.so and its checked twin (-DPLK_CHECKED) for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", _CSRC, "-j8", "all", "checked"]
     if force:
         args.append("-B")
     subprocess.check_call(args, stdout=subprocess.DEVNULL)
