@@ -664,8 +664,11 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
     }
     head_live[lane] = (head || (parked && tid == 0)) ? 1 : 0;
 }
+#ifndef PLK_ACC_WAVES
+#define PLK_ACC_WAVES 1  // waves per SIMD the register allocation of the accumulation is held to (tuning builds: variants/)
+#endif
 template <class C>
-__global__ void __launch_bounds__(ACC_THREADS) k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(ACC_THREADS, PLK_ACC_WAVES) k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
                                                                 const uint32_t* __restrict__ off, uint4* __restrict__ p_start, uint4* __restrict__ p_head,
                                                                 uint8_t* __restrict__ head_live, uint32_t buckets, const uint32_t* __restrict__ dyn_chunk,
                                                                 int wshift, uint32_t n_sub, uint32_t tab_entries) {
@@ -846,27 +849,11 @@ __global__ void __launch_bounds__(256) k_msm_assemble(TailBatch tb, uint32_t buc
 // Two-level weighting, step 1: partial row and column sums over groups of G = 2^g_log buckets, one lane per group.
 // lanes [0, NB / G): row hi, group g: buckets (hi << L) + g G + k;   lanes [NB / G, 2 NB / G): column lo, group g:
 // buckets ((g G + k) << L) + lo (adjacent lanes = adjacent columns = adjacent addresses).
-// A bucket as the accumulation left it: its start piece plus the head pieces that are still live (k_msm_assemble's job, done
-// where the bucket is read: at c = 20 one bucket in ~350 has a live head piece, so a separate pass over 2^19 buckets mostly
-// reads offsets).  Empty buckets are the identity (their p_start slot was never written); buckets with more than HEAVY_HEADS
-// head pieces were made whole by k_msm_heavy_final.
-template <class FP> PLK_DI XyzzZ<FP> bucket_value(const TailSlot& sl, uint32_t b, uint32_t chunk) {
-    constexpr int RU = raw_u4<FP>();
-    uint32_t first, ns;
-    if (!bucket_heads(sl.off, b, chunk, first, ns)) return xyzzz_identity<FP>();
-    XyzzZ<FP> v = xyzzz_load_raw<FP>(sl.p_start + (size_t)b * RU);
-    if (ns <= HEAVY_HEADS)
-        for (uint32_t h = 0; h < ns; ++h)
-            if (sl.head_live[first + h]) v = xyzzz_add<FP>(v, xyzzz_load_raw<FP>(sl.p_head + (size_t)(first + h) * RU));
-    return v;
-}
 template <class C>
 __global__ void __launch_bounds__(128) k_msm_gsum(TailBatch tb, int L, int H, int g_log) {
     using FP = typename C::FP;
     constexpr int RU = raw_u4<FP>();
     const TailSlot& sl = tb.s[blockIdx.y];
-    if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 2) *sl.final_done = 0;  // k_msm_final's counter (left at zero by its last block anyway)
-    const uint32_t chunk = sl.dyn_chunk[0];
     const uint32_t nbg = (1u << (L + H)) >> g_log;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * nbg) return;
@@ -892,11 +879,11 @@ __global__ void __launch_bounds__(128) k_msm_gsum(TailBatch tb, int L, int H, in
     }
     // the load of element k + 1 is in flight while element k is added
     XyzzZ<FP> acc = xyzzz_identity<FP>();
-    XyzzZ<FP> nxt = bucket_value<FP>(sl, b0, chunk);
+    XyzzZ<FP> nxt = xyzzz_load_raw<FP>(sl.p_start + (size_t)b0 * RU);
     for (uint32_t k = 0; k < G; ++k) {
         XyzzZ<FP> cur = nxt;
         const uint32_t b = b0 + k * bstep;
-        if (k + 1 < G) nxt = bucket_value<FP>(sl, b + bstep, chunk);
+        if (k + 1 < G) nxt = xyzzz_load_raw<FP>(sl.p_start + (size_t)(b + bstep) * RU);
         acc = xyzzz_add<FP>(acc, cur);
     }
     xyzzz_store_raw<FP>(dst, acc);
@@ -912,7 +899,6 @@ __global__ void __launch_bounds__(256) k_msm_lsum(TailBatch tb, int L, int H, in
     constexpr int W = FP::NL / 4;
     constexpr int RU = raw_u4<FP>();
     const TailSlot& sl = tb.s[blockIdx.y];
-    if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x < 2) sl.heavy[threadIdx.x] = 0;  // the counters of k_msm_heavy_list are free again
     const uint32_t wb = 1u << H;
     const uint32_t nbg = (1u << (L + H)) >> g_log;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1713,7 +1699,10 @@ static int msm_reduce_t(plk_msm_ctx* ctx, TailBatch tb, hipStream_t stream, Mark
     if (ctx->two_level) {
         const uint32_t nbg = (1u << (ctx->L + ctx->H)) >> ctx->g_log;  // groups per window (rows; as many for the columns)
         const unsigned wins = ctx->table_free ? (unsigned)ctx->windows : 1u;
-        // no k_msm_assemble here: the row / column sums read the pieces themselves (bucket_value)
+        // (Reading the pieces directly in the row / column sums - no k_msm_assemble pass - was built and measured in round 3: the merge of
+        // the rare live head pieces, inlined or out of line, takes k_msm_gsum from ~100 to 226-232 registers, and the tail went from
+        // 0.228 to 0.259 ms.  The separate 44 us pass stays.)
+        k_msm_assemble<C, false><<<dim3(ab, cnt), 256, 0, stream>>>(tb, buckets, ctx->lpb_log);
         k_msm_gsum<C><<<dim3((2 * nbg + 127) / 128, cnt, wins), 128, 0, stream>>>(tb, ctx->L, ctx->H, ctx->g_log);
         const size_t lanes = ((size_t)2 << ctx->H) << (ctx->lpl_log + 2);
         k_msm_lsum<C><<<dim3((unsigned)((lanes + 255) / 256), cnt, wins), 256, 0, stream>>>(tb, ctx->L, ctx->H, ctx->g_log, ctx->lpl_log);
