@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(ORD_THREADS) k_ord_count(const uint4* __restri
 // lane is a dependency chain, its length is the kernel's duration.
 __global__ void __launch_bounds__(256) k_ord_scan1(uint32_t* __restrict__ cnt1, uint32_t nt1, int nbins, uint32_t* __restrict__ bin_total,
                                                    uint32_t* __restrict__ bin_base, uint32_t* __restrict__ seg_base, uint32_t* __restrict__ done_counter,
-                                                   uint32_t* __restrict__ dyn_chunk, uint32_t chunk_cfg, uint32_t lanes_cfg) {
+                                                   uint32_t* __restrict__ dyn_chunk, uint32_t chunk_cfg, uint32_t lanes_cfg, uint32_t* __restrict__ off_direct) {
     __shared__ uint32_t s_sum[256];
     __shared__ uint32_t s_bins[ORD_MAX_BINS];
     __shared__ bool s_last;
@@ -338,10 +338,14 @@ __global__ void __launch_bounds__(256) k_ord_scan1(uint32_t* __restrict__ cnt1, 
     __syncthreads();
     const uint32_t last_total = s_bins[nbins - 1];
     block_excl_scan4(s_bins, nbins, s_sum);
-    for (int k = threadIdx.x; k < nbins; k += 256) bin_base[k] = s_bins[k];
+    for (int k = threadIdx.x; k < nbins; k += 256) {
+        bin_base[k] = s_bins[k];
+        if (off_direct) off_direct[k] = s_bins[k];  // one-level ordering: the bins are the buckets
+    }
     if (threadIdx.x == 0) {
         const uint32_t total = s_bins[nbins - 1] + last_total;
         bin_base[nbins] = total;
+        if (off_direct) off_direct[nbins] = total;
         uint32_t ch = lanes_cfg ? (total + lanes_cfg - 1) / lanes_cfg : chunk_cfg;
         if (ch < 8u) ch = 8u;
         if (ch > chunk_cfg) ch = chunk_cfg;
@@ -363,7 +367,8 @@ __global__ void __launch_bounds__(256) k_ord_scan1(uint32_t* __restrict__ cnt1, 
 // lanes store to consecutive slots of the same (tile, bin) run
 template <class C>
 __global__ void __launch_bounds__(ORD_THREADS) k_ord_scatter(const uint4* __restrict__ scalars, size_t n, OrdCfg cfg, const uint32_t* __restrict__ cnt1,
-                                                             const uint32_t* __restrict__ bin_base, uint2* __restrict__ tmp) {
+                                                             const uint32_t* __restrict__ bin_base, uint2* __restrict__ tmp,
+                                                             uint32_t* __restrict__ sorted_direct) {
     using SP = typename C::SP;
     __shared__ uint32_t s_lim[8 * ORD_THREADS];
     __shared__ uint32_t s_cnt[ORD_MAX_BINS], s_base[ORD_MAX_BINS], s_gbase[ORD_MAX_BINS];
@@ -408,7 +413,10 @@ __global__ void __launch_bounds__(ORD_THREADS) k_ord_scatter(const uint4* __rest
             const uint2 e = s_ent[sidx];
             const uint32_t bin = e.x >> (cfg.fine_bits + 1);
             const uint32_t at = s_gbase[bin] + (sidx - s_base[bin]);
-            if (PLK_CHK(at < cfg.entries_cap, CHK_TMP_INDEX)) tmp[at] = e;
+            if (PLK_CHK(at < cfg.entries_cap, CHK_TMP_INDEX)) {
+                if (sorted_direct) sorted_direct[at] = (e.y << 1) | (e.x & 1u);  // one-level ordering: this IS the bucket order
+                else tmp[at] = e;
+            }
         }
         __syncthreads();
         for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_gbase[k] += s_cnt[k];  // this sub-tile's entries of bin k
@@ -717,7 +725,7 @@ struct TailBatch {
     TailSlot s[TAIL_MAX];
 };
 
-constexpr uint32_t HEAVY_HEADS = 32;   // more head pieces than this: the bucket is summed by workgroups
+constexpr uint32_t HEAVY_HEADS = 32;   // more head pieces than this PER LANE of k_msm_assemble (2^lpb_log lanes per bucket): the bucket is summed by workgroups
 constexpr uint32_t HEAVY_CHUNK = 2048;
 
 // head pieces of bucket b: lanes first .. first + count - 1
@@ -734,7 +742,7 @@ PLK_DI bool bucket_heads(const uint32_t* __restrict__ off, uint32_t b, uint32_t 
 
 // heavy[0] = number of work items, heavy[1] = number of heavy buckets;
 // items at heavy[2 + 2k] = bucket, heavy[3 + 2k] = chunk index; heavy bucket ids at heavy[2 + 2 cap + k]
-__global__ void __launch_bounds__(256) k_msm_heavy_list(TailBatch tb, uint32_t buckets, uint32_t cap) {
+__global__ void __launch_bounds__(256) k_msm_heavy_list(TailBatch tb, uint32_t buckets, uint32_t cap, int lpb_log) {
     const uint32_t* __restrict__ off = tb.s[blockIdx.y].off;
     const uint32_t chunk = tb.s[blockIdx.y].dyn_chunk[0];
     uint32_t* __restrict__ heavy = tb.s[blockIdx.y].heavy;
@@ -742,7 +750,9 @@ __global__ void __launch_bounds__(256) k_msm_heavy_list(TailBatch tb, uint32_t b
     if (b >= buckets) return;
     uint32_t first, ns;
     bucket_heads(off, b, chunk, first, ns);
-    if (ns <= HEAVY_HEADS) return;
+    // (a small MSM - an IPA round over frozen generators: 2^10 buckets of ~190 entries, 8-entry chunks - has 24-48 head pieces in
+    // EVERY bucket; k_msm_assemble takes up to 32 per lane, so with 8 lanes per bucket nothing there is heavy)
+    if (ns <= (HEAVY_HEADS << lpb_log)) return;
     const uint32_t chunks = (ns + HEAVY_CHUNK - 1) / HEAVY_CHUNK;
     const uint32_t at = atomicAdd(&heavy[0], chunks);
     const uint32_t hb = atomicAdd(&heavy[1], 1u);
@@ -830,7 +840,7 @@ __global__ void __launch_bounds__(256) k_msm_assemble(TailBatch tb, uint32_t buc
         uint32_t first, ns;
         nonempty = bucket_heads(sl.off, b, chunk, first, ns);
         uint32_t live = 0;
-        if (ns <= HEAVY_HEADS)  // heavier buckets are already whole (k_msm_heavy_final)
+        if (ns <= (HEAVY_HEADS << lpb_log))  // heavier buckets are already whole (k_msm_heavy_final)
             for (uint32_t h = part; h < ns; h += 1u << lpb_log) live |= sl.head_live[first + h] ? (1u << (h >> lpb_log)) : 0u;  // ns <= 32
         touched = live != 0;
         if (lpb_log > 0 || PACKED || touched) {
@@ -1574,7 +1584,8 @@ static int msm_configure(plk_msm_ctx* ctx, int curve, size_t n, unsigned window_
         // partition geometry from the number of bucket slots: <= 512 coarse bins (one workgroup each at level 2), the rest fine
         const uint32_t want = ctx->table_free ? ctx->wbuckets * (uint32_t)ctx->windows : ctx->wbuckets;
         const int bits = ilog2_ceil(want);
-        int coarse = bits < 9 ? bits : 9;
+        // up to 2^10 bucket slots: ONE level - the coarse bins are the buckets, the first level's output is the bucket order
+        int coarse = bits <= 10 ? bits : 9;
         if (bits - coarse > ORD_MAX_FINE) coarse = bits - ORD_MAX_FINE;
         OrdCfg& o = ctx->ord;
         o.c = c;
@@ -1692,7 +1703,7 @@ static int msm_reduce_t(plk_msm_ctx* ctx, TailBatch tb, hipStream_t stream, Mark
     const uint32_t buckets = ctx->buckets;
     const unsigned cnt = (unsigned)tb.count;
     // hot buckets of a skewed scalar distribution (none for uniform scalars: the three launches then exit at once)
-    k_msm_heavy_list<<<dim3((buckets + 255) / 256, cnt), 256, 0, stream>>>(tb, buckets, ctx->heavy_cap);
+    k_msm_heavy_list<<<dim3((buckets + 255) / 256, cnt), 256, 0, stream>>>(tb, buckets, ctx->heavy_cap, ctx->lpb_log);
     k_msm_heavy_chunks<C><<<dim3(256, cnt), 256, 0, stream>>>(tb, ctx->heavy_cap);
     k_msm_heavy_final<C><<<dim3(64, cnt), 256, 0, stream>>>(tb, ctx->heavy_cap);
     const unsigned ab = (unsigned)((((size_t)buckets << ctx->lpb_log) + 255) / 256);
@@ -1777,14 +1788,16 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
             }
         } guard{halves, ev, ctx, stream};
         k_ord_count<C><<<o.nt1, ORD_THREADS, 0, stream>>>((const uint4*)d_scalars, n, o, (uint32_t*)w.cnt1);
+        const bool one_level = o.fine_bits == 0;
         k_ord_scan1<<<o.nbins, 256, 0, stream>>>((uint32_t*)w.cnt1, o.nt1, o.nbins, bin_total, bin_base, seg_base, done_counter, done_counter + 2,
-                                                 ctx->chunk, (uint32_t)(ctx->max_lanes > 2 ? ctx->max_lanes - 2 : 1));
+                                                 ctx->chunk, (uint32_t)(ctx->max_lanes > 2 ? ctx->max_lanes - 2 : 1), one_level ? off : nullptr);
         PLK_HIP_TRY(hipGetLastError());
         mark();
-        k_ord_scatter<C><<<o.nt1, ORD_THREADS, 0, stream>>>((const uint4*)d_scalars, n, o, (const uint32_t*)w.cnt1, bin_base, (uint2*)w.tmp);
+        k_ord_scatter<C><<<o.nt1, ORD_THREADS, 0, stream>>>((const uint4*)d_scalars, n, o, (const uint32_t*)w.cnt1, bin_base, (uint2*)w.tmp,
+                                                            one_level ? (uint32_t*)w.sorted : nullptr);
         PLK_HIP_TRY(hipGetLastError());
         mark();
-        {
+        if (!one_level) {
             // the number of segments is only known on the device: launch for the upper bound (+ nbins blocks that write the
             // offsets of the empty bins), blocks past the end exit
             const unsigned segs = (unsigned)(n * (size_t)o.windows / ORD_SEG + o.nbins + 1);

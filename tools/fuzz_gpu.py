@@ -11,19 +11,54 @@ from oracle import bigint_ref as br, oracle_lib as ol
 from tests.util import ints_to_array
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-rng = random.Random(int(os.environ.get("FUZZ_SEED", "12345")))
+# Every case draws from its OWN generator, seeded from (FUZZ_SEED, case index): a failure names its case seed, and
+# FUZZ_CASE=<seed> replays exactly that case.  The summary keeps every 100th case seed and the first / last of every family.
+MASTER = int(os.environ.get("FUZZ_SEED", "12345"))
+REPLAY = os.environ.get("FUZZ_CASE")
 CURVES = [br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377, br.PALLAS, br.VESTA]
 FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.PALLAS_BASE, br.VESTA_BASE]
 t_end = time.time() + budget
-counts = {"msm": 0, "ntt": 0, "poly": 0, "fold": 0, "plonk": 0, "misc": 0}
+counts = {"msm": 0, "ntt": 0, "poly": 0, "fold": 0, "plonk": 0, "misc": 0, "halo": 0}
+seeds = {k: [] for k in counts}
 
 
 def mont(f, vals):
     return ints_to_array([f.to_mont(v % f.p) for v in vals], f.n_limbs)
 
 
-while time.time() < t_end:
-    kind = rng.choice(["msm", "msm", "ntt", "poly", "fold", "plonk", "misc"])
+def halo_case(rng):
+    """a whole inner-product argument behind the C ABI (plk_halo_*) against the oracle's composition, random freeze point"""
+    from plonky_amd import device as dev
+    c = rng.choice([br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377])
+    f = c.scalar
+    n = rng.choice([1, 2, 4, 8, 32, 128])
+    G = (c.gx, c.gy)
+    pt = lambda P: np.array([c.base.mont_limbs(P[0]), c.base.mont_limbs(P[1])], dtype=np.uint64)
+    g = ol.gen_bases(c.curve_id, n, pt(G), pt(br.ec_mul(c, rng.randrange(1, 1 << 40), G))).reshape(n, 2, c.base.n_limbs)
+    h, up = pt(br.ec_mul(c, rng.randrange(1, 1 << 40), G)), pt(br.ec_mul(c, rng.randrange(1, 1 << 40), G))
+    a, b = ol.rand_field(f.field_id, rng.randrange(1 << 30), n), ol.rand_field(f.field_id, rng.randrange(1 << 30), n)
+    rounds = n.bit_length() - 1
+    us = ol.rand_field(f.field_id, rng.randrange(1 << 30), max(rounds, 1))
+    bl = ol.rand_field(f.field_id, rng.randrange(1 << 30), 2 * max(rounds, 1))
+    arg = dev.HaloArgument(c.curve_id, dev.to_device(a), dev.to_device(b), dev.to_device(g), h, up, freeze_log=rng.choice([0, 1, 2, 3, 5]))
+    gz = np.zeros(n, dtype=np.uint8)
+    for j in range(rounds):
+        lr, z = arg.round_lr(bl[2 * j], bl[2 * j + 1])
+        exp, ez = ol.halo_round_lr(c.curve_id, f.field_id, a, b, g, h, up, bl[2 * j], bl[2 * j + 1])
+        assert list(z) == list(ez) and np.array_equal(lr, exp), ("halo lr", c.name, n, j)
+        u_inv = ol.field_unop(f.field_id, "inverse", us[j].reshape(1, 4))[0]
+        arg.round_fold(us[j], u_inv)
+        a, b, g, gz = ol.halo_round_fold(c.curve_id, f.field_id, a, b, g, us[j], u_inv)
+    fa, fb, fg, fgz = arg.read()
+    arg.free()
+    assert np.array_equal(fa, a) and np.array_equal(fb, b) and np.array_equal(fg, g) and np.array_equal(fgz, np.asarray(gz, dtype=np.uint8)), ("halo final", c.name, n)
+
+
+def one_case(rng):
+    kind = rng.choice(["msm", "msm", "ntt", "poly", "fold", "plonk", "misc", "halo"])
+    if kind == "halo":
+        halo_case(rng)
+        return kind
     if kind == "msm":
         c = rng.choice(CURVES)
         n = rng.choice([1, 2, 3, 7, 33, 100, 257, 1000, 3000, 5000])
@@ -134,5 +169,23 @@ while time.time() < t_end:
             p2, z2 = ol.scalar_mul(c.curve_id, sb, pts[m + i], 0)
             exp, ez = ol.affine_add(c.curve_id, p1, z1, p2, z2)
             assert int(gz[i]) == ez and (ez or np.array_equal(got[i], exp)), ("fold", c.name, m, i)
+    return kind
+
+
+case_idx = 0
+while time.time() < t_end:
+    case_seed = int(REPLAY, 0) if REPLAY else (MASTER * 1000003 + case_idx * 7919 + 1) & ((1 << 62) - 1)
+    case_idx += 1
+    try:
+        kind = one_case(random.Random(case_seed))
+    except Exception:
+        print("FAILED case %d: replay with FUZZ_CASE=%#x" % (case_idx - 1, case_seed), flush=True)
+        raise
     counts[kind] += 1
-print("fuzz ok:", counts)
+    seeds[kind].append(case_seed)
+    if REPLAY:
+        break
+print("fuzz ok (FUZZ_SEED=%d, %d cases):" % (MASTER, case_idx), counts)
+for k, v in seeds.items():
+    if v:
+        print("  %-5s %6d cases  first %#x  last %#x  every 100th: %s" % (k, len(v), v[0], v[-1], " ".join("%#x" % x for x in v[::100][:40])))
