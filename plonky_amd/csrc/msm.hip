@@ -1343,6 +1343,19 @@ static int choose_window(size_t n, int curve) {
     // the smallest window with the same number of digits (fewer buckets for the same additions)
     const int bits = scalar_bits(curve) + 1;
     while (c > 3 && (bits + c - 2) / (c - 1) == (bits + c - 1) / c) --c;
+    // Small and medium inputs: no SHORT TOP WINDOW.  The smallest c for a digit count leaves the top window the fewest bits
+    // (24 windows of 11: 3 bits; 18 of 15: one) and every scalar's top digit lands in a handful of buckets, which then go
+    // through the heavy-bucket path: ~120 us of workgroup-wide sums whatever the size (profiles/r03_ipa_frozen_round_kernels.txt:
+    // a fifth of an IPA round over frozen generators).  Take the next width whose top window holds at least half a window
+    // (2^14: 13, 2^16 / 2^17: 16).  From 2^18 on the choice above stands (measured in round 2: the fixed cost is small there).
+    if (lg < 18)
+        for (int t = c; t <= c + 4 && t <= 16; ++t) {
+            const int top = bits - ((bits + t - 1) / t - 1) * t;
+            if (2 * top >= t) {
+                c = t;
+                break;
+            }
+        }
     if (const char* e = getenv("PLK_MSM_WINDOW")) c = atoi(e);
     if (c < 3) c = 3;
     if (c > MSM_MAX_WINDOW) c = MSM_MAX_WINDOW;
