@@ -1335,27 +1335,40 @@ static int ilog2_ceil(uint64_t v) {
 static int choose_window(size_t n, int curve) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
-    // ceil((BITS + 1) / c) additions per scalar against 2 * 2^(c-1) additions in the reduction: c = lg n is the balance point for
-    // the sizes that matter (2^20: 13 windows, 2^19 buckets); small inputs keep the buckets well below the entry count
-    int c = lg >= 18 ? lg : lg - 4 + (lg >= 14 ? (lg - 12) / 2 : 0);
-    if (c < 3) c = 3;
-    if (c > MSM_MAX_WINDOW) c = MSM_MAX_WINDOW;
-    // the smallest window with the same number of digits (fewer buckets for the same additions)
     const int bits = scalar_bits(curve) + 1;
-    while (c > 3 && (bits + c - 2) / (c - 1) == (bits + c - 1) / c) --c;
-    // Small and medium inputs: no SHORT TOP WINDOW.  The smallest c for a digit count leaves the top window the fewest bits
-    // (24 windows of 11: 3 bits; 18 of 15: one) and every scalar's top digit lands in a handful of buckets, which then go
-    // through the heavy-bucket path: ~120 us of workgroup-wide sums whatever the size (profiles/r03_ipa_frozen_round_kernels.txt:
-    // a fifth of an IPA round over frozen generators).  Take the next width whose top window holds at least half a window
-    // (2^14: 13, 2^16 / 2^17: 16).  From 2^18 on the choice above stands (measured in round 2: the fixed cost is small there).
-    if (lg < 18)
-        for (int t = c; t <= c + 4 && t <= 16; ++t) {
-            const int top = bits - ((bits + t - 1) / t - 1) * t;
-            if (2 * top >= t) {
+    auto digits = [&](int c) { return (bits + c - 1) / c; };
+    auto top_bits = [&](int c) { return bits - (digits(c) - 1) * c; };
+    int c;
+    if (lg >= 14) {
+        // From 2^14 generators on the window minimises a count of field multiplications: digits(c) mixed additions per scalar
+        // (10 each) + two full additions per bucket in the reduction (14 each) + a tenth on top of the accumulation when the TOP
+        // WINDOW IS SHORT (fewer than c / 2 bits: every scalar's top digit lands in a handful of buckets, which go through the
+        // heavy-bucket path - ~120 us of workgroup-wide sums whatever the size; 24 windows of 11 leave the top one 3 bits, 18
+        // of 15 one bit).  Measured in round 3 (profiles/r03_commit9_scaling.txt, r03_window_sweeps.txt): 2^14: 13 (0.41 ms
+        // against 0.52 at 11), 2^16 / 2^17 / 2^18: 16 (0.53 against 0.68 at 14; 0.88 against 1.01 at 18), 2^19 (BLS12-377): 17,
+        // 2^20 and up: 20 (13 additions per scalar, 2^19 buckets: round 2).
+        double best = 0;
+        c = 0;
+        for (int t = 10; t <= MSM_MAX_WINDOW - 1; ++t) {
+            const double acc = 10.0 * (double)n * digits(t);
+            const double cost = acc + 28.0 * (double)((size_t)1 << (t - 1)) + (2 * top_bits(t) < t ? 0.1 * acc : 0.0);
+            if (c == 0 || cost < best) {
+                best = cost;
+                c = t;
+            }
+        }
+    } else {
+        c = lg - 4;
+        if (c < 3) c = 3;
+        // the smallest window with the same number of digits (fewer buckets for the same additions) ...
+        while (c > 3 && digits(c - 1) == digits(c)) --c;
+        // ... unless that leaves the top window short: then the next width whose top window holds at least half a window
+        for (int t = c; t <= c + 4 && t <= 16; ++t)
+            if (2 * top_bits(t) >= t) {
                 c = t;
                 break;
             }
-        }
+    }
     if (const char* e = getenv("PLK_MSM_WINDOW")) c = atoi(e);
     if (c < 3) c = 3;
     if (c > MSM_MAX_WINDOW) c = MSM_MAX_WINDOW;
