@@ -65,16 +65,19 @@ def test_constraint_counts():
 
 
 def test_prefixes_as_in_the_reference_code():
-    """gates/mod.rs:1-16 documents a prefix code; the code itself gives CurveAddGate 10101 (curve_add.rs:60, the comment says
-    101000), which is a prefix of BufferGate's 101010 (buffer.rs:24; no constraints, so nothing is double counted).  The
-    restatement follows the code: every other pair is prefix-free."""
+    """The doc comment of gates/mod.rs:1-16 lists CurveAddGate as 101000 and BufferGate as 101010; the CODE gives CurveAddGate
+    10101 (curve_add.rs:39) and BufferGate 101000 (buffer.rs:27).  The restatements follow the code, whose prefixes are prefix-free
+    (the doc comment's pair would not be: 10101 is a prefix of 101010)."""
     names = ["curve_add", "curve_dbl", "curve_endo", "base_4_sum", "public_input", "buffer", "constant", "arithmetic", "rescue_a", "rescue_b"]
+    by_name = dict(zip(names, (gb for gb, _ in br.PLONK_GATES)))
+    assert by_name["curve_add"] == "10101" and by_name["buffer"] == "101000" and by_name["public_input"] == "101001"
     clashes = set()
     for g, (gb, _) in enumerate(br.PLONK_GATES):
         for h, (hb, _) in enumerate(br.PLONK_GATES):
             if g != h and hb.startswith(gb):
                 clashes.add((names[g], names[h]))
-    assert clashes == {("curve_add", "buffer")}
+    assert clashes == set()
+    assert "101010".startswith(by_name["curve_add"])  # what the doc comment's BufferGate prefix would have collided with
 
 
 def _prefix_consts(gate, extra):
