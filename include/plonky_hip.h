@@ -259,6 +259,16 @@ int plk_field_from_bytes(int field, const uint8_t* bytes, size_t count, uint64_t
 int plk_curve_point_to_bytes(int curve, const uint64_t* xy, const uint8_t* zero, size_t count, uint8_t* out_bytes);
 int plk_curve_point_from_bytes(int curve, const uint8_t* bytes, size_t count, uint64_t* out_xy, uint8_t* out_zero, uint8_t* status);
 
+/* r = log_inputs rounds of that fold at once, in the scaled form halo.hip keeps its generators in:
+ *     out_i = g_i + sum_{t = 1 .. 2^r - 1} [s_t] g_{i + t n_out},   i < n_out,
+ * g = 2^r n_out affine points (+ optional identity flags), the 2^r scalars in DEVICE memory (4 limbs each, Montgomery, scalar
+ * field), the scalar of input t at index bitreverse_r(t); entry 0 is not read.  With s_t = the product of u_k^2 over the
+ * rounds k whose challenge index t picked the upper half in, [prod u_k^-1] out_i is halo_g_i after r rounds of halo.rs:119-123.
+ * One doubling chain per OUTPUT (Straus over its 2^r inputs) instead of one per output of every round.  Curves with the
+ * endomorphism only (not BLS12-377: PLK_ERR_INVALID_ARG); 1 <= r <= 4; in place (d_out = d_g) is allowed. */
+int plk_curve_fold_multi_dev(int curve, size_t n_out, unsigned log_inputs, const void* d_g_xy, const void* d_g_zero, const void* d_scalars,
+                             void* d_out_xy, void* d_out_zero, void* stream);
+
 /* ---- scalar side of an IPA round  (src/halo.rs:63-118) --------------------------------------------------- */
 /* Field::inner_product (field.rs:213-221): *d_out = sum_i a[i] b[i] (one element, device memory).  Asynchronous on `stream`.
  * The point side of a round is plk_msm (msm_parallel on fresh generators: L_j, R_j, halo.rs:87-93) and
@@ -285,6 +295,21 @@ int plk_field_fold_slices_dev(int field, const void* d_lo, const void* d_hi, con
 typedef struct plk_halo_ctx plk_halo_ctx;
 int plk_halo_begin_dev(int curve, size_t n, const void* d_halo_a, const void* d_halo_b, const void* d_halo_g_xy, const void* d_halo_g_zero,
                        const uint64_t* pedersen_h_xy, const uint64_t* u_prime_xy, unsigned freeze_log, void* stream, plk_halo_ctx** out_ctx);
+/* The same argument when the caller still holds the window tables of pedersen_g it committed with (plonk.rs:65
+ * `pedersen_g_msm_precomputation`: a tabled plk_msm_ctx of this curve whose first n generators are halo_g; it must outlive the lead
+ * rounds and is only read).  The first `lead_rounds` rounds (0 = default 3; <= 4; fewer when the vectors are short; none on
+ * BLS12-377) leave the generators untouched: L_j / R_j are one batched MSM over those tables with challenge-expanded scalars, and
+ * the generators of all lead rounds are then folded at once (plk_curve_fold_multi_dev).  Same L_j, R_j, halo_a, halo_b, halo_g as
+ * plk_halo_begin_dev gives, bit for bit; plk_halo_frozen() is 1 during the lead rounds as well (halo_g cannot be read then).
+ * h_index / u_index / u_prime_scalar (optional: PLK_NO_INDEX, PLK_NO_INDEX, NULL): when the tables were built over
+ * [pedersen_g .., pedersen_h, U ..] - the circuit's fixed generators (plonk.rs:46-51) - the positions of pedersen_h and of U in
+ * them (both >= n) and the scalar x = halo_n(u_scaling bits) with u_prime = [x] U (halo.rs:46-47, 4 limbs, Montgomery, scalar
+ * field; the CALLER vouches for that relation).  [l_j] H + [<a, b>] U' then are two more scalars of the same MSM; without them
+ * they are computed beside it (one lane each, ~1 ms, mostly hidden). */
+#define PLK_NO_INDEX ((size_t)-1)
+int plk_halo_begin_tabled_dev(int curve, size_t n, const void* d_halo_a, const void* d_halo_b, const void* d_halo_g_xy, const void* d_halo_g_zero,
+                              plk_msm_ctx* pedersen_g_tables, const uint64_t* pedersen_h_xy, const uint64_t* u_prime_xy, size_t h_index, size_t u_index,
+                              const uint64_t* u_prime_scalar, unsigned freeze_log, unsigned lead_rounds, void* stream, plk_halo_ctx** out_ctx);
 /* Same with host vectors (halo_g_zero may be NULL). */
 int plk_halo_begin(int curve, size_t n, const uint64_t* halo_a, const uint64_t* halo_b, const uint64_t* halo_g_xy, const uint8_t* halo_g_zero,
                    const uint64_t* pedersen_h_xy, const uint64_t* u_prime_xy, unsigned freeze_log, plk_halo_ctx** out_ctx);

@@ -14,7 +14,10 @@ struct plk_halo_ctx;
 namespace plk {
 
 int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, const void* d_g, const void* d_gz, const uint64_t* h_xy,
-                        const uint64_t* u_xy, unsigned freeze_log, hipStream_t stream, plk_halo_ctx** out);
+                        const uint64_t* u_xy, unsigned freeze_log, hipStream_t stream, plk_halo_ctx** out, plk_msm_ctx* tables = nullptr,
+                        unsigned lead_rounds = 0, size_t h_index = (size_t)-1, size_t u_index = (size_t)-1, const uint64_t* u_prime_scalar = nullptr);
+int curve_fold_multi_dev_impl(int curve, size_t n_out, int r_bits, const void* d_g, const void* d_gz, const void* d_ratios, void* d_out_xy,
+                              void* d_out_zero, hipStream_t stream);
 int halo_round_lr_impl(plk_halo_ctx* c, const uint64_t* l_blind, const uint64_t* r_blind, uint64_t* lr_xy, uint8_t* lr_zero);
 int halo_round_fold_impl(plk_halo_ctx* c, const uint64_t* u_j, const uint64_t* u_j_inv);
 size_t halo_len_impl(const plk_halo_ctx* c);
@@ -1012,6 +1015,17 @@ int plk_field_fold_slices_dev(int field, const void* d_lo, const void* d_hi, con
 int plk_halo_begin_dev(int curve, size_t n, const void* d_halo_a, const void* d_halo_b, const void* d_halo_g_xy, const void* d_halo_g_zero,
                        const uint64_t* pedersen_h_xy, const uint64_t* u_prime_xy, unsigned freeze_log, void* stream, plk_halo_ctx** out_ctx) {
     return halo_begin_dev_impl(curve, n, d_halo_a, d_halo_b, d_halo_g_xy, d_halo_g_zero, pedersen_h_xy, u_prime_xy, freeze_log, as_stream(stream), out_ctx);
+}
+int plk_halo_begin_tabled_dev(int curve, size_t n, const void* d_halo_a, const void* d_halo_b, const void* d_halo_g_xy, const void* d_halo_g_zero,
+                              plk_msm_ctx* pedersen_g_tables, const uint64_t* pedersen_h_xy, const uint64_t* u_prime_xy, size_t h_index, size_t u_index,
+                              const uint64_t* u_prime_scalar, unsigned freeze_log, unsigned lead_rounds, void* stream, plk_halo_ctx** out_ctx) {
+    if (!pedersen_g_tables) return set_error(PLK_ERR_INVALID_ARG, "null tables");
+    return halo_begin_dev_impl(curve, n, d_halo_a, d_halo_b, d_halo_g_xy, d_halo_g_zero, pedersen_h_xy, u_prime_xy, freeze_log, as_stream(stream), out_ctx,
+                               pedersen_g_tables, lead_rounds, h_index, u_index, u_prime_scalar);
+}
+int plk_curve_fold_multi_dev(int curve, size_t n_out, unsigned log_inputs, const void* d_g_xy, const void* d_g_zero, const void* d_scalars, void* d_out_xy,
+                             void* d_out_zero, void* stream) {
+    return curve_fold_multi_dev_impl(curve, n_out, (int)log_inputs, d_g_xy, d_g_zero, d_scalars, d_out_xy, d_out_zero, as_stream(stream));
 }
 int plk_halo_begin(int curve, size_t n, const uint64_t* halo_a, const uint64_t* halo_b, const uint64_t* halo_g_xy, const uint8_t* halo_g_zero,
                    const uint64_t* pedersen_h_xy, const uint64_t* u_prime_xy, unsigned freeze_log, plk_halo_ctx** out_ctx) {

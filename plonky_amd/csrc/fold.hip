@@ -281,6 +281,196 @@ template <class C> __global__ void k_fold_digits(ScalarPair sp, const uint32_t* 
     }
 }
 
+// ---- 2^r-to-1 fold ------------------------------------------------------------------------------------------------------
+// r rounds of an inner-product argument folded at once (halo.hip keeps L_j / R_j of those rounds on the caller's commitment
+// tables, so the folded generators of the rounds in between are never needed):
+//   out_i = G_i + sum_{t = 1 .. T - 1} [s_t] G_{i + t n_out},   T = 2^r, the same T - 1 scalars for every i
+// (the scaled form of halo.rs:119-123 applied r times: s_t = the product of u_k^2 over the rounds k in which index i + t n_out fell
+// into the upper half).  Straus: ONE chain of ~128 doublings per output shared by all its inputs, and per input the joint sparse
+// form of its scalar's two endomorphism halves over (Q, phi Q) - ~64 additions.  Sequential pair folds pay the doubling chain per
+// output of every round (n/2 + n/4 + ... chains instead of n/T): 47 % fewer field multiplications at r = 3.
+// Two kernels: k_fold_multi_prep writes, per input, Q and Q - phi(Q) as affine points in R'-form (pairs of inputs share an
+// inversion); k_fold_multi_glv streams them (64 coalesced bytes per addition) - a lane holds its accumulator and one operand,
+// not the 2 x 4 precomputed points of the pair kernel.
+constexpr int FOLD_MULTI_MAX_LOG = 4;
+constexpr int FOLD_MULTI_MAX = 1 << FOLD_MULTI_MAX_LOG;
+struct MultiDigits {
+    int cols;                                       // columns, LEAST significant first
+    int pad[3];
+    uint32_t beta[2][16];                           // beta, beta^2 as Fz limbs (R'-form)
+    int8_t d[FOLD_MULTI_MAX - 1][FOLD_MAX_COLS];    // input t (1 .. T - 1): (u0 + 1) * 3 + (u1 + 1) over (Q, phi Q); 4 = empty column
+};
+
+// thread t of one block: the digits of scalar t.  ratios: 2^r_bits scalars (Montgomery), the scalar of input t at index bitrev_r(t)
+template <class C> __global__ void __launch_bounds__(64) k_fold_multi_digits(const uint32_t* __restrict__ ratios, int r_bits, MultiDigits* out) {
+    using SP = typename C::SP;
+    using FP = typename C::FP;
+    if constexpr (C::Glv::ENABLED) {
+        __shared__ int s_cols;
+        const int t = threadIdx.x, T = 1 << r_bits;
+        if (t == 0) {
+            s_cols = 0;
+            Fe<FP> bc;
+#pragma unroll
+            for (int k = 0; k < FP::NL; ++k) bc.v[k] = C::Glv::BETA[k];
+            const Fe<FP> beta_r = fe_from_canonical<FP>(bc);
+            const Fz<FP> b1 = fz_from_fe<FP>(to_rprime<FP>(beta_r)), b2 = fz_from_fe<FP>(to_rprime<FP>(fe_sqr<FP>(beta_r)));
+            for (int k = 0; k < FzCfg<FP>::NZ; ++k) {
+                out->beta[0][k] = b1.l[k];
+                out->beta[1][k] = b2.l[k];
+            }
+        }
+        __syncthreads();
+        if (t >= 1 && t < T) {
+            int rev = 0;
+            for (int k = 0; k < r_bits; ++k) rev |= ((t >> k) & 1) << (r_bits - 1 - k);
+            Fe<SP> s;
+            for (int i = 0; i < 8; ++i) s.v[i] = ratios[rev * 8 + i];
+            s = fe_to_canonical<SP>(s);
+            uint32_t k1[8], k2[8];
+            glv_split<typename C::Glv>(s.v, k1, k2);
+            const int s1 = (k1[7] >> 31) ? -1 : 1, s2 = (k2[7] >> 31) ? -1 : 1;
+            k1[7] &= 0x7fffffffu;
+            k2[7] &= 0x7fffffffu;
+            int8_t ua[FOLD_MAX_COLS], ub[FOLD_MAX_COLS];
+            const int n = joint_sparse_form(k1, k2, ua, ub);
+            for (int k = 0; k < FOLD_MAX_COLS; ++k) out->d[t - 1][k] = k < n ? (int8_t)((ua[k] * s1 + 1) * 3 + (ub[k] * s2 + 1)) : (int8_t)4;
+            atomicMax(&s_cols, n);
+        }
+        __syncthreads();
+        if (t == 0) out->cols = s_cols;
+    }
+}
+
+// input j of `count` (points first + j of g): pp[j] = the point, dp[j] = point - phi(point), affine, x then y, canonical R'-form words.
+// Lane l takes inputs l and l + ceil(count / 2): one inversion for both.  An identity input leaves its slots unwritten (never read).
+template <class C>
+__global__ void __launch_bounds__(128) k_fold_multi_prep(const uint4* __restrict__ g, const uint8_t* __restrict__ gz, size_t first, size_t count,
+                                                         uint4* __restrict__ pp, uint4* __restrict__ dp) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    if constexpr (C::Glv::ENABLED) {
+        const size_t half = (count + 1) / 2;
+        const size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (l >= half) return;
+        const size_t j1 = l, j2 = l + half;
+        const bool has2 = j2 < count;
+        const size_t a1 = first + j1, a2 = first + (has2 ? j2 : j1);
+        const Fe<FP> px = fe_load<FP>(g + a1 * 2 * W), py = fe_load<FP>(g + a1 * 2 * W + W);
+        const Fe<FP> qx = fe_load<FP>(g + a2 * 2 * W), qy = fe_load<FP>(g + a2 * 2 * W + W);
+        const bool pi = gz ? gz[a1] != 0 : false, qi = !has2 || (gz ? gz[a2] != 0 : false);
+        Fe<FP> bc;
+#pragma unroll
+        for (int k = 0; k < FP::NL; ++k) bc.v[k] = C::Glv::BETA[k];
+        const Fe<FP> beta_r = fe_from_canonical<FP>(bc);
+        const Fe<FP> bm1 = fe_sub<FP>(beta_r, fe_one<FP>());
+        const Fe<FP> dpv = pi ? fe_one<FP>() : fe_mul<FP>(bm1, px), dqv = qi ? fe_one<FP>() : fe_mul<FP>(bm1, qx);
+        const Fe<FP> inv = fe_inv_safegcd<FP>(fe_mul<FP>(dpv, dqv));
+        auto emit = [&](const Fe<FP>& x, const Fe<FP>& y, const Fe<FP>& inv_x, size_t j) {
+            // Q - phi(Q): slope (-y - y) / (beta x - x)
+            const Fe<FP> lam = fe_mul<FP>(fe_neg<FP>(fe_dbl<FP>(y)), inv_x);
+            const Fe<FP> x3 = fe_sub<FP>(fe_sub<FP>(fe_sqr<FP>(lam), x), fe_mul<FP>(beta_r, x));
+            const Fe<FP> y3 = fe_sub<FP>(fe_mul<FP>(lam, fe_sub<FP>(x, x3)), y);
+            fe_store<FP>(pp + j * 2 * W, to_rprime<FP>(x));
+            fe_store<FP>(pp + j * 2 * W + W, to_rprime<FP>(y));
+            fe_store<FP>(dp + j * 2 * W, to_rprime<FP>(x3));
+            fe_store<FP>(dp + j * 2 * W + W, to_rprime<FP>(y3));
+        };
+        if (!pi) emit(px, py, fe_mul<FP>(inv, dqv), j1);
+        if (!qi) emit(qx, qy, fe_mul<FP>(inv, dpv), j2);
+    }
+}
+
+template <class C>
+__global__ void __launch_bounds__(128) k_fold_multi_glv(const uint4* __restrict__ g, const uint8_t* __restrict__ gz, size_t n_out, int T,
+                                                        const uint4* __restrict__ pp, const uint4* __restrict__ dp, const MultiDigits* __restrict__ dg,
+                                                        uint4* __restrict__ out_xy, uint8_t* __restrict__ out_zero) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    constexpr int NZ = FzCfg<FP>::NZ;
+    if constexpr (C::Glv::ENABLED) {
+        const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= n_out) return;
+        uint32_t ident = 0;  // bit t: input t is the identity
+        if (gz)
+            for (int t = 0; t < T; ++t) ident |= gz[i + (size_t)t * n_out] ? (1u << t) : 0u;
+        XyzzZ<FP> acc = xyzzz_identity<FP>();
+        const int cols = dg->cols;
+        for (int k = cols - 1; k >= 0; --k) {
+            acc = xyzzz_dbl<FP>(acc);
+            for (int t = 1; t < T; ++t) {
+                const int code = dg->d[t - 1][k];  // uniform over the grid
+                if (code == 4) continue;
+                if ((ident >> t) & 1u) continue;   // per lane: the addition below is masked
+                const int u0 = code / 3 - 1, u1 = code % 3 - 1;
+                // (1, 0) Q   (0, 1) phi Q = (beta x, y)   (1, 1) Q + phi Q = (beta^2 x, -y)   (1, -1) Q - phi Q
+                const bool diff = u0 != 0 && u1 != 0 && u0 != u1;
+                const uint4* src = (diff ? dp : pp) + ((size_t)(t - 1) * n_out + i) * 2 * W;
+                Fz<FP> tx = fz_from_fe<FP>(fe_load<FP>(src)), ty = fz_from_fe<FP>(fe_load<FP>(src + W));
+                bool neg = u0 != 0 ? u0 < 0 : u1 < 0;
+                if (u0 == 0 || (u1 != 0 && u0 == u1)) {
+                    const int which = u0 == 0 ? 0 : 1;
+                    Fz<FP> b;
+#pragma unroll
+                    for (int q = 0; q < NZ; ++q) b.l[q] = dg->beta[which][q];
+                    tx = fz_mul<FP>(tx, b);
+                    if (which == 1) neg = !neg;
+                }
+                if (neg) ty = fz_neg_canonical<FP>(ty);
+                xyzzz_madd<FP>(acc, tx, ty);
+            }
+        }
+        if (!(ident & 1u)) {
+            const Fz<FP> x0 = fz_from_fe<FP>(to_rprime<FP>(fe_load<FP>(g + i * 2 * W))), y0 = fz_from_fe<FP>(to_rprime<FP>(fe_load<FP>(g + i * 2 * W + W)));
+            xyzzz_madd<FP>(acc, x0, y0);
+        }
+        emit_affine<FP>(acc, out_xy + i * 2 * W, out_zero + i);
+    }
+}
+
+template <class C>
+static int fold_multi_t(size_t n_out, int r_bits, const void* d_g, const void* d_gz, const void* d_ratios, void* d_out_xy, void* d_out_zero, hipStream_t stream) {
+    if constexpr (!C::Glv::ENABLED) {
+        return set_error(PLK_ERR_INVALID_ARG, "the 2^r-to-1 fold runs along the curve endomorphism: not on this curve");
+    } else {
+        constexpr size_t PT = (size_t)2 * C::FP::NL * 4;
+        const int T = 1 << r_bits;
+        const size_t count = (size_t)(T - 1) * n_out;
+        uint8_t* work = (uint8_t*)scratch_acquire(2 * count * PT + sizeof(MultiDigits) + 256, stream);
+        if (!work) return PLK_ERR_OOM;
+        uint4* pp = (uint4*)work;
+        uint4* dp = (uint4*)(work + count * PT);
+        MultiDigits* dg = (MultiDigits*)(work + ((2 * count * PT + 255) & ~(size_t)255));
+        k_fold_multi_digits<C><<<1, 64, 0, stream>>>((const uint32_t*)d_ratios, r_bits, dg);
+        const size_t half = (count + 1) / 2;
+        k_fold_multi_prep<C><<<(unsigned)((half + 127) / 128), 128, 0, stream>>>((const uint4*)d_g, (const uint8_t*)d_gz, n_out, count, pp, dp);
+        k_fold_multi_glv<C><<<(unsigned)((n_out + 127) / 128), 128, 0, stream>>>((const uint4*)d_g, (const uint8_t*)d_gz, n_out, T, pp, dp, dg,
+                                                                                 (uint4*)d_out_xy, (uint8_t*)d_out_zero);
+        hipError_t e = hipGetLastError();
+        scratch_release(work, stream);
+        if (e != hipSuccess) return set_error(PLK_ERR_HIP, "fold launch failed: %s", hipGetErrorString(e));
+        return PLK_OK;
+    }
+}
+
+// out_i = g_i + sum_{t = 1 .. 2^r_bits - 1} [ratio_t] g_{i + t n_out}, i < n_out; d_ratios: 2^r_bits scalars in device memory
+// (Montgomery, scalar field), the scalar of input t at index bitrev(t) (entry 0 is not read).  In place (d_out = d_g) is fine.
+int curve_fold_multi_dev_impl(int curve, size_t n_out, int r_bits, const void* d_g, const void* d_gz, const void* d_ratios, void* d_out_xy,
+                              void* d_out_zero, hipStream_t stream) {
+    if (r_bits < 1 || r_bits > FOLD_MULTI_MAX_LOG) return set_error(PLK_ERR_INVALID_ARG, "fold of 2^%d inputs per output: 1 <= r <= %d", r_bits, FOLD_MULTI_MAX_LOG);
+    if (n_out == 0) return PLK_OK;
+    if (!d_g || !d_ratios || !d_out_xy || !d_out_zero) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
+    PLK_TRY(ensure_device());
+    switch (curve) {
+        case PLK_CURVE_TWEEDLEDEE: return fold_multi_t<TweedledeeCurve>(n_out, r_bits, d_g, d_gz, d_ratios, d_out_xy, d_out_zero, stream);
+        case PLK_CURVE_TWEEDLEDUM: return fold_multi_t<TweedledumCurve>(n_out, r_bits, d_g, d_gz, d_ratios, d_out_xy, d_out_zero, stream);
+        case PLK_CURVE_BLS12_377: return fold_multi_t<Bls12377Curve>(n_out, r_bits, d_g, d_gz, d_ratios, d_out_xy, d_out_zero, stream);
+        case PLK_CURVE_PALLAS: return fold_multi_t<PallasCurve>(n_out, r_bits, d_g, d_gz, d_ratios, d_out_xy, d_out_zero, stream);
+        case PLK_CURVE_VESTA: return fold_multi_t<VestaCurve>(n_out, r_bits, d_g, d_gz, d_ratios, d_out_xy, d_out_zero, stream);
+    }
+    return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+}
+
 template <class C>
 static int fold_pairs_t(size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero, const uint64_t* a_mont,
                         const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream, const void* d_scalars, int plus_lo) {

@@ -24,6 +24,11 @@
 //    (the identity behind halo_s, plonk_util.rs:311-339): L_j and R_j are the two scalar vectors of ONE batched tabled MSM
 //    over the frozen set with the scalars a_i s_j, and the final generator is one more MSM with the scalars s_j.  Same group
 //    elements as the reference's, so the affine results are bit-identical.
+//  * LEAD rounds (plk_halo_begin_tabled_dev: the caller hands over the window tables of pedersen_g it commits with,
+//    plonk.rs:65 `pedersen_g_msm_precomputation`): the same identity from the other end.  For the first r rounds the generators stay
+//    what they are and L_j / R_j are one batched MSM over the CALLER's tables with the scalars a_i s_j (+ [l] H + [<a, b>] U' from
+//    the pair kernel on side streams); then ONE 2^r-to-1 fold (fold.hip) forms G^(r) - a single doubling chain per output instead
+//    of one per output of every round - and the long rounds above continue from there.
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -47,6 +52,14 @@ void msm_ctx_delete(plk_msm_ctx* ctx);
 int curve_fold_pairs_dev_impl(int curve, size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero,
                               const uint64_t* a_mont, const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream,
                               const void* d_scalars = nullptr, int plus_lo = 0);
+int curve_fold_multi_dev_impl(int curve, size_t n_out, int r_bits, const void* d_g, const void* d_gz, const void* d_ratios, void* d_out_xy,
+                              void* d_out_zero, hipStream_t stream);
+size_t msm_ctx_len(const plk_msm_ctx* ctx);
+int msm_ctx_curve(const plk_msm_ctx* ctx);
+int msm_ctx_table_free(const plk_msm_ctx* ctx);
+size_t msm_partials_bytes(int curve, unsigned slots);
+int msm_combine_partials_dev_impl(int curve, unsigned world, unsigned batch, unsigned whole_per_rank, const void* d_gathered, void* d_out_xy, void* d_out_zero,
+                                  hipStream_t stream);
 
 constexpr int HALO_PART_BLOCKS = 256;
 struct HaloScalar {
@@ -103,9 +116,11 @@ __global__ void __launch_bounds__(256) k_halo_prepare(const uint4* __restrict__ 
 }
 // the two inner products from their partial sums; the blinding factor and the inner product become the scalars of H and U':
 // s[cnt] = blinding factor, s[cnt + 1] = inner product
+// ip_scale (lead rounds with H and the fixed generator U inside the caller's tables, U' = [x] U): the blinding factor goes to index
+// cnt, the inner product TIMES x to index cnt2
 template <class P>
 __global__ void __launch_bounds__(64) k_halo_close(const uint4* __restrict__ part, unsigned blocks, HaloScalar l_blind, HaloScalar r_blind, size_t cnt,
-                                                   uint4* __restrict__ sL, uint4* __restrict__ sR) {
+                                                   uint4* __restrict__ sL, uint4* __restrict__ sR, size_t cnt2 = 0, const uint4* __restrict__ ip_scale = nullptr) {
     constexpr int W = P::NL / 4;
     __shared__ uint4 s_acc[2 * 64 * W];
     Fe<P> accL = fe_zero<P>(), accR = fe_zero<P>();
@@ -132,10 +147,17 @@ __global__ void __launch_bounds__(64) k_halo_close(const uint4* __restrict__ par
             l.v[k] = l_blind.v[k];
             r.v[k] = r_blind.v[k];
         }
+        if (ip_scale) {
+            const Fe<P> x = fe_load<P>(ip_scale);
+            accL = fe_mul<P>(accL, x);
+            accR = fe_mul<P>(accR, x);
+        } else {
+            cnt2 = cnt + 1;
+        }
         fe_store<P>(sL + cnt * W, l);
-        fe_store<P>(sL + (cnt + 1) * W, accL);
+        fe_store<P>(sL + cnt2 * W, accL);
         fe_store<P>(sR + cnt * W, r);
-        fe_store<P>(sR + (cnt + 1) * W, accR);
+        fe_store<P>(sR + cnt2 * W, accR);
     }
 }
 // halo_a' = u^-1 a_hi + u a_lo, halo_b' = u^-1 b_lo + u b_hi in place (element i of the low half only depends on elements i and
@@ -167,6 +189,13 @@ __global__ void __launch_bounds__(256) k_halo_fold_scalars(uint4* __restrict__ a
         fe_store<P>(coef + i * W, fe_mul<P>(fe_load<P>(coef + i * W), low ? uinv : u));
     }
 }
+// lead rounds: after round k (done = k - 1 rounds before it) the scalar of every index that fell into the upper half this round gains
+// u_k^2 (dsc[1], just written by k_halo_fold_scalars): ratios[t + 2^done] = ratios[t] u^2, t < 2^done
+template <class P> __global__ void __launch_bounds__(64) k_halo_lead_ratios(uint4* __restrict__ ratios, int done, const uint4* __restrict__ dsc) {
+    constexpr int W = P::NL / 4;
+    const int t = threadIdx.x;
+    if (t < (1 << done)) fe_store<P>(ratios + ((size_t)t + ((size_t)1 << done)) * W, fe_mul<P>(fe_load<P>(ratios + (size_t)t * W), fe_load<P>(dsc + 1 * W)));
+}
 // coef[i] = *src (the running scale when the generators are frozen), or 1 when src is null
 template <class P> __global__ void __launch_bounds__(256) k_halo_fill(uint4* __restrict__ coef, size_t count, const uint4* __restrict__ src) {
     constexpr int W = P::NL / 4;
@@ -180,22 +209,31 @@ struct plk_halo_ctx {
     int curve = 0, sfield = 0, L = 4;
     size_t n0 = 0, n = 0;       // initial / current length of halo_a, halo_b, halo_g
     unsigned freeze_log = 14;
-    hipStream_t stream = nullptr, side = nullptr;
-    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    hipStream_t stream = nullptr, side = nullptr, side2 = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_side2 = nullptr;
     uint8_t* slab = nullptr;    // one allocation: a | b | g | gz | extra | scal | part | out | coef | dsc
     uint8_t *a = nullptr, *b = nullptr, *g = nullptr, *gz = nullptr, *extra = nullptr, *scal = nullptr, *part = nullptr, *out = nullptr, *coef = nullptr;
-    uint8_t* dsc = nullptr;     // 4 scalars: [0] unused (the fold's first scalar), [1] u^2, [2] the running scale c, [3] zero
+    uint8_t* dsc = nullptr;     // 4 scalars: [0] unused (the fold's first scalar), [1] u^2, [2] the running scale c, [3] zero, [4] x with U' = [x] U (lead rounds)
     size_t scal_stride = 0;     // bytes between the L and the R scalar vector
     plk_msm_ctx *mL = nullptr, *mR = nullptr;  // table-free contexts of the long rounds, rebound every round
     bool frozen = false;
     size_t m0 = 0;              // frozen generator count
     plk_msm_ctx* mT = nullptr;  // tables over [G^(f), H, U']
     uint8_t* pin = nullptr;     // pinned staging for the results that cross PCIe
+    // lead rounds over the caller's tables (not owned): `lead_left` of `lead_total` still to come; m0 = n0 meanwhile
+    plk_msm_ctx* lead_ctx = nullptr;
+    unsigned lead_total = 0, lead_left = 0;
+    size_t lead_n = 0;          // generators in the caller's context (>= n0; the scalars of the others stay zero)
+    bool lead_inside = false;   // H and U sit in the caller's tables (indices lead_h, lead_u; U' = [x] U, x at dsc[4]): no side work
+    size_t lead_h = 0, lead_u = 0;
+    uint8_t *ratios = nullptr, *rec = nullptr, *hu = nullptr;  // 2^lead_total fold scalars | two partial-sum records | [l, <a,b>] x 2
+    size_t rec_bytes = 0;
     bool lr_done = false;
     std::mutex mu;
     ~plk_halo_ctx() {
         if (stream) (void)hipStreamSynchronize(stream);
         if (side) (void)hipStreamSynchronize(side);
+        if (side2) (void)hipStreamSynchronize(side2);
         if (mL) plk::msm_ctx_delete(mL);
         if (mR) plk::msm_ctx_delete(mR);
         if (mT) plk::msm_ctx_delete(mT);
@@ -203,7 +241,9 @@ struct plk_halo_ctx {
         if (pin) (void)hipHostFree(pin);
         if (ev_main) (void)hipEventDestroy(ev_main);
         if (ev_side) (void)hipEventDestroy(ev_side);
+        if (ev_side2) (void)hipEventDestroy(ev_side2);
         if (side) (void)hipStreamDestroy(side);
+        if (side2) (void)hipStreamDestroy(side2);
     }
 };
 
@@ -242,7 +282,8 @@ static int halo_freeze(plk_halo_ctx* c) {
 }
 
 int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, const void* d_g, const void* d_gz, const uint64_t* h_xy,
-                        const uint64_t* u_xy, unsigned freeze_log, hipStream_t stream, plk_halo_ctx** out) {
+                        const uint64_t* u_xy, unsigned freeze_log, hipStream_t stream, plk_halo_ctx** out, plk_msm_ctx* tables, unsigned lead_rounds,
+                        size_t h_index, size_t u_index, const uint64_t* u_prime_scalar) {
     if (!out) return set_error(PLK_ERR_INVALID_ARG, "null out");
     *out = nullptr;
     const int L = curve_limbs(curve);
@@ -261,12 +302,39 @@ int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, c
     c->freeze_log = freeze_log ? freeze_log : 14u;
     const size_t pt = (size_t)2 * L * 8;
     const size_t fz = (size_t)1 << (c->freeze_log > 40 ? 40 : c->freeze_log);
-    const size_t m0_max = n < fz ? n : fz;                 // frozen set: at most min(n, 2^freeze_log) generators
-    const size_t cnt_max = (n / 2 > m0_max ? n / 2 : m0_max) + 2;
+    // lead rounds: how many, if any
+    unsigned lead = 0;
+    if (tables) {
+        if (msm_ctx_curve(tables) != curve || msm_ctx_table_free(tables) || msm_ctx_len(tables) < n)
+            return set_error(PLK_ERR_INVALID_ARG, "the tables handed to the argument must be a tabled context of this curve over at least %zu generators", n);
+        lead = lead_rounds ? lead_rounds : 3u;
+        if (const char* e = getenv("PLK_HALO_LEAD")) lead = (unsigned)atoi(e);
+        if (lead > 4) lead = 4;
+        while (lead > 0 && (n >> lead) < 2 * fz) --lead;  // the long rounds take over above the freezing length
+        switch (curve) {  // the 2^r-to-1 fold runs along the endomorphism
+            case PLK_CURVE_TWEEDLEDEE: case PLK_CURVE_TWEEDLEDUM: case PLK_CURVE_PALLAS: case PLK_CURVE_VESTA: break;
+            default: lead = 0;
+        }
+    }
+    c->lead_total = c->lead_left = lead;
+    c->lead_ctx = lead ? tables : nullptr;
+    c->lead_n = lead ? msm_ctx_len(tables) : 0;
+    if (lead && u_prime_scalar && h_index != (size_t)-1 && u_index != (size_t)-1) {
+        if (h_index < n || u_index < n || h_index >= c->lead_n || u_index >= c->lead_n || h_index == u_index)
+            return set_error(PLK_ERR_INVALID_ARG, "pedersen_h / U must be generators %zu .. %zu of the tables (behind halo_g), got %zu and %zu", n, c->lead_n - 1,
+                             h_index, u_index);
+        c->lead_inside = true;
+        c->lead_h = h_index;
+        c->lead_u = u_index;
+    }
+    c->rec_bytes = msm_partials_bytes(curve, 2);
+    const size_t m0_max = lead ? n : (n < fz ? n : fz);  // frozen set: at most min(n, 2^freeze_log) generators; lead rounds: all of them
+    const size_t cnt_max = lead ? c->lead_n : (n / 2 > m0_max ? n / 2 : m0_max) + 2;
     c->scal_stride = cnt_max * 32;
     struct Part { uint8_t** p; size_t bytes; } parts[] = {
         {&c->a, n * 32}, {&c->b, n * 32}, {&c->g, n * pt}, {&c->gz, n}, {&c->extra, 2 * pt}, {&c->scal, 2 * c->scal_stride},
-        {&c->part, (size_t)2 * HALO_PART_BLOCKS * 32}, {&c->out, 2 * pt + 16}, {&c->coef, m0_max * 32}, {&c->dsc, 4 * 32},
+        {&c->part, (size_t)2 * HALO_PART_BLOCKS * 32}, {&c->out, 2 * pt + 16}, {&c->coef, m0_max * 32}, {&c->dsc, 5 * 32},
+        {&c->ratios, (size_t)16 * 32}, {&c->rec, 2 * c->rec_bytes}, {&c->hu, 4 * 32},
     };
     size_t total = 0;
     for (auto& p : parts) total += (p.bytes + 255) & ~(size_t)255;
@@ -278,8 +346,10 @@ int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, c
     }
     PLK_HIP_TRY(hipHostMalloc((void**)&c->pin, 4 * pt + 64 + 2 * 32, hipHostMallocDefault));
     PLK_HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    PLK_HIP_TRY(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
     PLK_HIP_TRY(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
     PLK_HIP_TRY(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+    PLK_HIP_TRY(hipEventCreateWithFlags(&c->ev_side2, hipEventDisableTiming));
     PLK_HIP_TRY(hipMemcpyAsync(c->a, d_a, n * 32, hipMemcpyDeviceToDevice, stream));
     PLK_HIP_TRY(hipMemcpyAsync(c->b, d_b, n * 32, hipMemcpyDeviceToDevice, stream));
     PLK_HIP_TRY(hipMemcpyAsync(c->g, d_g, n * pt, hipMemcpyDeviceToDevice, stream));
@@ -288,7 +358,11 @@ int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, c
     memcpy(c->pin, h_xy, pt);
     memcpy(c->pin + pt, u_xy, pt);
     PLK_HIP_TRY(hipMemcpyAsync(c->extra, c->pin, 2 * pt, hipMemcpyHostToDevice, stream));
-    PLK_HIP_TRY(hipMemsetAsync(c->dsc, 0, 4 * 32, stream));
+    PLK_HIP_TRY(hipMemsetAsync(c->dsc, 0, 5 * 32, stream));
+    if (c->lead_inside) {
+        memcpy(c->pin + 2 * pt, u_prime_scalar, 32);
+        PLK_HIP_TRY(hipMemcpyAsync(c->dsc + 4 * 32, c->pin + 2 * pt, 32, hipMemcpyHostToDevice, stream));
+    }
     HALO_FIELD_SWITCH(c->sfield, (k_halo_fill<P><<<1, 256, 0, stream>>>((uint4*)(c->dsc + 2 * 32), 1, nullptr)));  // c = 1
     PLK_HIP_TRY(hipGetLastError());
     if (n >= 2) {
@@ -296,11 +370,21 @@ int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, c
             PLK_TRY(halo_freeze(c));
         } else {
             // the two table-free contexts of the long rounds, sized for every round they will be rebound to
+            const size_t n1 = n >> lead;  // length when the long rounds start
             size_t also[64];
             int cnt = 0;
-            for (size_t len = n / 2; len > fz; len /= 2) also[cnt++] = len / 2 + 2;
-            PLK_TRY(msm_precompute_dev_impl(curve, n / 2 + 2, c->g + (n / 2) * pt, c->gz + n / 2, 0, PLK_MSM_TABLE_FREE, stream, &c->mL, c->extra, 2, also, cnt));
-            PLK_TRY(msm_precompute_dev_impl(curve, n / 2 + 2, c->g, c->gz, 0, PLK_MSM_TABLE_FREE, stream, &c->mR, c->extra, 2, also, cnt));
+            for (size_t len = n1 / 2; len > fz; len /= 2) also[cnt++] = len / 2 + 2;
+            PLK_TRY(msm_precompute_dev_impl(curve, n1 / 2 + 2, c->g + (n1 / 2) * pt, c->gz + n1 / 2, 0, PLK_MSM_TABLE_FREE, stream, &c->mL, c->extra, 2, also, cnt));
+            PLK_TRY(msm_precompute_dev_impl(curve, n1 / 2 + 2, c->g, c->gz, 0, PLK_MSM_TABLE_FREE, stream, &c->mR, c->extra, 2, also, cnt));
+        }
+        if (lead) {
+            // every generator keeps the coefficient 1 for now; generators of the caller's context beyond n never get a scalar
+            c->m0 = n;
+            HALO_FIELD_SWITCH(c->sfield, (k_halo_fill<P><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((uint4*)c->coef, n, nullptr),
+                                          k_halo_fill<P><<<1, 256, 0, stream>>>((uint4*)c->ratios, 1, nullptr)));
+            PLK_HIP_TRY(hipGetLastError());
+            PLK_HIP_TRY(hipMemsetAsync(c->scal, 0, 2 * c->scal_stride, stream));
+            PLK_TRY(msm_reserve_workspaces_impl(tables, 2, stream));
         }
     }
     PLK_HIP_TRY(hipStreamSynchronize(stream));  // the staging copy of H, U' is consumed
@@ -314,20 +398,45 @@ int halo_round_lr_impl(plk_halo_ctx* c, const uint64_t* l_blind, const uint64_t*
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->n < 2) return set_error(PLK_ERR_INVALID_ARG, "the argument is finished (length %zu)", c->n);
     const size_t m = c->n / 2, pt = (size_t)2 * c->L * 8;
-    const size_t m0 = c->frozen ? c->m0 : 0, cnt = c->frozen ? c->m0 : m;
+    const bool lead = c->lead_left > 0;
+    const size_t m0 = (c->frozen || lead) ? c->m0 : 0, cnt = c->frozen ? c->m0 : m;
     uint8_t* sL = c->scal;
-    uint8_t* sR = c->scal + (c->frozen ? (cnt + 2) * 32 : c->scal_stride);  // frozen: the two vectors back to back, one batched call
+    // frozen / lead rounds: the two vectors back to back, one batched call
+    uint8_t* sR = c->scal + (lead ? c->lead_n * 32 : c->frozen ? (cnt + 2) * 32 : c->scal_stride);
     const size_t work = m > m0 ? m : m0;
     unsigned blocks = (unsigned)((work + 255) / 256);
     if (blocks > HALO_PART_BLOCKS) blocks = HALO_PART_BLOCKS;
     const HaloScalar lb = to_halo_scalar(l_blind), rb = to_halo_scalar(r_blind);
     HALO_FIELD_SWITCH(c->sfield, (k_halo_prepare<P><<<blocks, 256, 0, c->stream>>>((const uint4*)c->a, (const uint4*)c->b, m, m0, (const uint4*)c->coef,
                                                                                      (const uint4*)(c->dsc + 2 * 32), (uint4*)sL, (uint4*)sR, (uint4*)c->part),
-                                  k_halo_close<P><<<1, 64, 0, c->stream>>>((const uint4*)c->part, blocks, lb, rb, cnt, (uint4*)sL, (uint4*)sR)));
+                                  k_halo_close<P><<<1, 64, 0, c->stream>>>((const uint4*)c->part, blocks, lb, rb, !lead ? cnt : c->lead_inside ? c->lead_h : 0,
+                                                                           (uint4*)(lead && !c->lead_inside ? c->hu : sL),
+                                                                           (uint4*)(lead && !c->lead_inside ? c->hu + 64 : sR), c->lead_u,
+                                                                           (const uint4*)(lead && c->lead_inside ? c->dsc + 4 * 32 : nullptr))));
     PLK_HIP_TRY(hipGetLastError());
     uint8_t* out_xy = c->out;
     uint8_t* out_z = c->out + 2 * pt;
-    if (c->frozen) {
+    if (lead && c->lead_inside) {
+        // H and U are generators of the caller's tables: their scalars went into the two vectors, the MSM gives L_j and R_j whole
+        PLK_TRY(msm_execute_dev_impl(c->lead_ctx, 2, sL, c->lead_n, out_xy, out_z, c->stream));
+    } else if (lead) {
+        // record 0: <a s, G> from the caller's tables; record 1: [l] H + [<a, b>] U' (one lane each, ~130 doublings: two side
+        // streams, hidden behind the MSM); L_j, R_j = the sums of the two records
+        uint8_t* r0 = c->rec;
+        uint8_t* r1 = c->rec + c->rec_bytes;
+        PLK_HIP_TRY(hipEventRecord(c->ev_main, c->stream));
+        PLK_HIP_TRY(hipStreamWaitEvent(c->side, c->ev_main, 0));
+        PLK_HIP_TRY(hipStreamWaitEvent(c->side2, c->ev_main, 0));
+        static const bool dbg_skip = getenv("PLK_HALO_DEBUG_NO_HU") != nullptr;
+        if (!dbg_skip) PLK_TRY(curve_fold_pairs_dev_impl(c->curve, 1, c->extra, nullptr, c->extra + pt, nullptr, nullptr, nullptr, r1, r1 + 2 * pt, c->side, c->hu, 0));
+        PLK_HIP_TRY(hipEventRecord(c->ev_side, c->side));
+        if (!dbg_skip) PLK_TRY(curve_fold_pairs_dev_impl(c->curve, 1, c->extra, nullptr, c->extra + pt, nullptr, nullptr, nullptr, r1 + pt, r1 + 2 * pt + 1, c->side2, c->hu + 64, 0));
+        PLK_HIP_TRY(hipEventRecord(c->ev_side2, c->side2));
+        PLK_TRY(msm_execute_dev_impl(c->lead_ctx, 2, sL, c->lead_n, r0, r0 + 2 * pt, c->stream));
+        PLK_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_side, 0));
+        PLK_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_side2, 0));
+        PLK_TRY(msm_combine_partials_dev_impl(c->curve, 2, 2, 0, c->rec, out_xy, out_z, c->stream));
+    } else if (c->frozen) {
         PLK_TRY(msm_execute_dev_impl(c->mT, 2, sL, c->m0 + 2, out_xy, out_z, c->stream));
     } else {
         // L on the caller's stream, R on the side stream: below ~2^16 points each is a dependency chain, not throughput
@@ -355,16 +464,33 @@ int halo_round_fold_impl(plk_halo_ctx* c, const uint64_t* u_j, const uint64_t* u
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->n < 2) return set_error(PLK_ERR_INVALID_ARG, "the argument is finished (length %zu)", c->n);
     const size_t m = c->n / 2, pt = (size_t)2 * c->L * 8;
-    const size_t m0 = c->frozen ? c->m0 : 0;
+    const bool lead = c->lead_left > 0;
+    const size_t m0 = (c->frozen || lead) ? c->m0 : 0;
     const size_t work = m > m0 ? m : m0;
     HALO_FIELD_SWITCH(c->sfield, (k_halo_fold_scalars<P><<<(unsigned)((work + 255) / 256), 256, 0, c->stream>>>(
                                      (uint4*)c->a, (uint4*)c->b, m, to_halo_scalar(u_j), to_halo_scalar(u_j_inv), (uint4*)c->coef, m0,
                                      (uint4*)(c->frozen ? nullptr : c->dsc))));
     PLK_HIP_TRY(hipGetLastError());
-    if (!c->frozen) {
+    if (lead) {
+        HALO_FIELD_SWITCH(c->sfield, (k_halo_lead_ratios<P><<<1, 64, 0, c->stream>>>((uint4*)c->ratios, (int)(c->lead_total - c->lead_left), (const uint4*)c->dsc)));
+        PLK_HIP_TRY(hipGetLastError());
+        if (--c->lead_left == 0) {
+            // the generators of the r rounds at once, scaled like the pairwise folds: G^(r) = [c] G~, c = prod u_k^-1 (dsc[2])
+            PLK_TRY(curve_fold_multi_dev_impl(c->curve, m, (int)c->lead_total, c->g, c->gz, c->ratios, c->g, c->gz, c->stream));
+            c->m0 = 0;
+            c->lead_ctx = nullptr;
+        }
+    } else if (!c->frozen) {
         // G'_i = [u^-1] G_lo_i + [u] G_hi_i = [u^-1] (G_lo_i + [u^2] G_hi_i): the scaled fold G~'_i = G~_lo_i + [u^2] G~_hi_i in place
         // (pair i only touches elements i and m + i); u^2 and the new scale c u^-1 were just written to dsc
-        PLK_TRY(curve_fold_pairs_dev_impl(c->curve, m, c->g, c->gz, c->g + m * pt, c->gz + m, nullptr, nullptr, c->g, c->gz, c->stream, c->dsc, 1));
+        // (long vectors: the 2-to-1 case of the streaming kernel where the curve has the endomorphism - 3 waves per SIMD instead of 1:
+        // 6.8 against 7.8 ms for 2^19 pairs, 1.93 against 2.01 for 2^17; below that its three launches are the longer chain: 1.73
+        // against 1.07 ms for 2^16 pairs.  Its scalar sits at index bitreverse(1) = 1 of dsc)
+        static const bool pair_kernel = getenv("PLK_HALO_PAIR_FOLD") != nullptr;
+        if (c->curve != PLK_CURVE_BLS12_377 && !pair_kernel && m >= ((size_t)1 << 17))
+            PLK_TRY(curve_fold_multi_dev_impl(c->curve, m, 1, c->g, c->gz, c->dsc, c->g, c->gz, c->stream));
+        else
+            PLK_TRY(curve_fold_pairs_dev_impl(c->curve, m, c->g, c->gz, c->g + m * pt, c->gz + m, nullptr, nullptr, c->g, c->gz, c->stream, c->dsc, 1));
     }
     c->n = m;
     c->lr_done = false;
@@ -373,7 +499,7 @@ int halo_round_fold_impl(plk_halo_ctx* c, const uint64_t* u_j, const uint64_t* u
 }
 
 size_t halo_len_impl(const plk_halo_ctx* c) { return c ? c->n : 0; }
-int halo_frozen_impl(const plk_halo_ctx* c) { return c && c->frozen ? 1 : 0; }
+int halo_frozen_impl(const plk_halo_ctx* c) { return c && (c->frozen || c->lead_left > 0) ? 1 : 0; }
 
 // current halo_a, halo_b (n scalars each) and - while the generators are still folded explicitly - halo_g (n points + flags);
 // with n == 1 and frozen generators the single generator is the MSM <s, G^(f)>
@@ -386,7 +512,10 @@ int halo_read_impl(plk_halo_ctx* c, uint64_t* a, uint64_t* b, uint64_t* g_xy, ui
     if (b) PLK_HIP_TRY(hipMemcpyAsync(b, c->b, c->n * 32, hipMemcpyDeviceToHost, c->stream));
     if (g_xy || g_zero) {
         if (!g_xy || !g_zero) return set_error(PLK_ERR_INVALID_ARG, "g_xy and g_zero go together");
-        if (!c->frozen) {
+        if (c->lead_left > 0) {
+            return set_error(PLK_ERR_INVALID_ARG, "the generators are untouched during the %u lead rounds over the caller's tables: halo_g exists again after them",
+                             c->lead_total);
+        } else if (!c->frozen) {
             // halo_g_i = [c] G~_i: the pairwise kernel with the scalars (c, 0) over (G~_i, G~_i)
             uint8_t* tmp = (uint8_t*)scratch_acquire(c->n * (pt + 1), c->stream);
             if (!tmp) return PLK_ERR_OOM;

@@ -186,6 +186,20 @@ def fold_generators_dev(curve, g_lo, g_hi, scalar_lo, scalar_hi, lo_zero=None, h
     return out, oz
 
 
+def fold_generators_multi_dev(curve, g, scalars, log_inputs, g_zero=None):
+    """out_i = g_i + sum_{t >= 1} [s_t] g_{i + t n_out}, n_out = len(g) >> log_inputs (plk_curve_fold_multi_dev): g (n, 2, L) CUDA,
+    scalars (2^log_inputs, 4) CUDA int64 (Montgomery, scalar field) with the scalar of input t at index bitreverse(t)."""
+    assert g.is_cuda and g.is_contiguous() and scalars.is_cuda and scalars.is_contiguous() and scalars.shape[0] == 1 << log_inputs
+    n_out = g.shape[0] >> log_inputs
+    assert n_out << log_inputs == g.shape[0]
+    out = torch.empty((n_out,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+    oz = torch.empty((n_out,), dtype=torch.uint8, device=g.device)
+    _lib.check(_lib.load().plk_curve_fold_multi_dev(curve, n_out, log_inputs, ctypes.c_void_p(g.data_ptr()),
+                                                    ctypes.c_void_p(g_zero.data_ptr()) if g_zero is not None else None,
+                                                    ctypes.c_void_p(scalars.data_ptr()), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(oz.data_ptr()), _stream()))
+    return out, oz
+
+
 def halo_round_lr_dev(curve, halo_a, halo_b, halo_g, pedersen_h, u_prime, l_blinding, r_blinding, g_zero=None):
     """L_j = <a_lo, G_hi> + [l_j] H + [<a_lo, b_hi>] U',  R_j = <a_hi, G_lo> + [r_j] H + [<a_hi, b_lo>] U' (halo.rs:86-93).
     halo_a / halo_b: (n, 4) scalars, halo_g: (n, 2, L) affine generators (g_zero: (n,) identity flags or None); pedersen_h /
@@ -256,7 +270,8 @@ class HaloArgument:
     calls round_lr(l_j, r_j) (possibly again, halo.rs:83-114) and round_fold(u_j, u_j^-1).  halo_a / halo_b: (n, 4) int64
     CUDA tensors (Montgomery, scalar field); halo_g: (n, 2, L); g_zero: (n,) uint8 or None; pedersen_h / u_prime: (2, L) host."""
 
-    def __init__(self, curve, halo_a, halo_b, halo_g, pedersen_h, u_prime, g_zero=None, freeze_log=0):
+    def __init__(self, curve, halo_a, halo_b, halo_g, pedersen_h, u_prime, g_zero=None, freeze_log=0, tables=None, lead_rounds=0, h_index=None, u_index=None,
+                 u_prime_scalar=None):
         for t in (halo_a, halo_b, halo_g):
             assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()
         n = halo_a.shape[0]
@@ -266,9 +281,22 @@ class HaloArgument:
         u = np.ascontiguousarray(u_prime, dtype=np.uint64).reshape(2, self.L)
         ctx = ctypes.c_void_p()
         zp = ctypes.c_void_p(g_zero.data_ptr()) if g_zero is not None else None
-        _lib.check(_lib.load().plk_halo_begin_dev(curve, n, ctypes.c_void_p(halo_a.data_ptr()), ctypes.c_void_p(halo_b.data_ptr()),
-                                                  ctypes.c_void_p(halo_g.data_ptr()), zp, h.ctypes.data_as(ctypes.c_void_p),
-                                                  u.ctypes.data_as(ctypes.c_void_p), freeze_log, _stream(), ctypes.byref(ctx)))
+        if tables is not None:
+            # tables: the MsmPrecomputation (msm_precompute_dev) of pedersen_g the caller commits with - the first rounds run over it
+            # h_index / u_index / u_prime_scalar: pedersen_h and the fixed generator U inside those tables, u_prime = [u_prime_scalar] U
+            self._tables = tables  # must outlive the lead rounds
+            NO = ctypes.c_size_t(-1).value
+            inside = u_prime_scalar is not None and h_index is not None and u_index is not None
+            xs = _limbs(u_prime_scalar) if inside else None
+            _lib.check(_lib.load().plk_halo_begin_tabled_dev(curve, n, ctypes.c_void_p(halo_a.data_ptr()), ctypes.c_void_p(halo_b.data_ptr()),
+                                                             ctypes.c_void_p(halo_g.data_ptr()), zp, tables._ctx, h.ctypes.data_as(ctypes.c_void_p),
+                                                             u.ctypes.data_as(ctypes.c_void_p), h_index if inside else NO, u_index if inside else NO,
+                                                             xs.ctypes.data_as(ctypes.c_void_p) if inside else None, freeze_log, lead_rounds, _stream(),
+                                                             ctypes.byref(ctx)))
+        else:
+            _lib.check(_lib.load().plk_halo_begin_dev(curve, n, ctypes.c_void_p(halo_a.data_ptr()), ctypes.c_void_p(halo_b.data_ptr()),
+                                                      ctypes.c_void_p(halo_g.data_ptr()), zp, h.ctypes.data_as(ctypes.c_void_p),
+                                                      u.ctypes.data_as(ctypes.c_void_p), freeze_log, _stream(), ctypes.byref(ctx)))
         self._ctx = ctx
 
     def __len__(self):

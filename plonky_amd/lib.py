@@ -78,6 +78,8 @@ SYMBOLS = [
     ("plk_field_inner_product_dev", _i, [_i, _vp, _vp, _sz, _vp, _vp]),
     ("plk_field_fold_slices_dev", _i, [_i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     ("plk_halo_begin_dev", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp, _vp]),
+    ("plk_halo_begin_tabled_dev", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _u, _u, _vp, _vp]),
+    ("plk_curve_fold_multi_dev", _i, [_i, _sz, _u, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("plk_halo_begin", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _u, _vp]),
     ("plk_halo_round_lr", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("plk_halo_round_fold", _i, [_vp, _vp, _vp]),

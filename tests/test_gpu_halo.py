@@ -81,15 +81,32 @@ def test_halo_whole_argument_closed_form():
 
 
 # ---- the argument behind the C ABI (plk_halo_*): device-resident vectors, frozen generators for the short rounds ----
-def _run_argument(c, n, freeze_log, seed):
-    """All rounds through plk_halo_*; returns the per-round (L_j, R_j) and the final (a, b, g)."""
+def _run_argument(c, n, freeze_log, seed, tabled=False, lead_rounds=0, extra_generators=0, inside=False):
+    """All rounds through plk_halo_*; returns the per-round (L_j, R_j) and the final (a, b, g).  tabled: the first rounds run over
+    the caller's commitment tables (plk_halo_begin_tabled_dev), which may hold more generators than the argument uses; inside:
+    pedersen_h and the fixed generator U are among them, u_prime = [x] U."""
     from plonky_amd import device as dev
     g, h, up, a, b, _ = _setup(c, n, seed)
     f = c.scalar
     rounds = n.bit_length() - 1
     us = ol.rand_field(f.field_id, seed + 50, max(rounds, 1))
     blind = ol.rand_field(f.field_id, seed + 60, 2 * max(rounds, 1))
-    arg = dev.HaloArgument(c.curve_id, dev.to_device(a), dev.to_device(b), dev.to_device(g), h, up, freeze_log=freeze_log)
+    tables, kw = None, {}
+    if tabled:
+        L = c.base.n_limbs
+        more = ol.gen_bases(c.curve_id, extra_generators, h, up).reshape(extra_generators, 2, L) if extra_generators else np.zeros((0, 2, L), dtype=np.uint64)
+        gens = [g, more]
+        if inside:
+            G = (c.gx, c.gy)
+            pt = lambda P: np.array([c.base.mont_limbs(P[0]), c.base.mont_limbs(P[1])], dtype=np.uint64)
+            ubase = br.ec_mul(c, 0x2468ACE + seed, G)
+            x_int = (0x1234567 + seed) * 0x9E3779B97F4A7C15F39CC0605CEDC835 % f.p
+            up = pt(br.ec_mul(c, x_int, ubase))
+            gens += [h.reshape(1, 2, L), pt(ubase).reshape(1, 2, L)]
+            kw = dict(h_index=n + extra_generators, u_index=n + extra_generators + 1, u_prime_scalar=np.array(f.mont_limbs(x_int), dtype=np.uint64))
+        tables = dev.msm_precompute_dev(c.curve_id, dev.to_device(np.concatenate(gens)))
+    arg = dev.HaloArgument(c.curve_id, dev.to_device(a), dev.to_device(b), dev.to_device(g), h, up, freeze_log=freeze_log, tables=tables,
+                           lead_rounds=lead_rounds, **kw)
     lrs, states = [], []
     for j in range(rounds):
         lr, z = arg.round_lr(blind[2 * j], blind[2 * j + 1])
@@ -144,7 +161,100 @@ def test_halo_argument_capi_matches_oracle(c, n, freeze_log):
         assert not states[0][0] and states[-1][0]   # explicit folds first, frozen generators at the end
 
 
-def test_halo_argument_2p16_closed_form():
+@pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("inside", [False, True], ids=["hu_beside", "hu_inside"])
+@pytest.mark.parametrize("n,freeze_log,lead,extra", [(256, 3, 0, 0), (256, 3, 4, 1), (256, 5, 0, 3), (64, 1, 1, 0), (128, 2, 2, 0), (16, 63, 0, 0), (4, 0, 0, 0)])
+def test_halo_argument_over_the_callers_tables(c, n, freeze_log, lead, extra, inside):
+    """plk_halo_begin_tabled_dev: the first rounds over the caller's commitment tables (one batched MSM with challenge-expanded
+    scalars + the H / U' terms), the generators of those rounds folded at once (2^r-to-1), then the usual regimes - every
+    L_j / R_j, halo_a / halo_b after every round, halo_g whenever it exists and the final triple, bit for bit against the oracle.
+    BLS12-377 (no endomorphism) and short vectors fall back to the plain path.  hu_inside: pedersen_h and U are generators of the
+    tables (u_prime = [x] U), their terms are two more scalars of the same MSM."""
+    pytest.importorskip("torch")
+    from plonky_amd import device as dev
+    dev.init(0)
+    inputs, lrs, states, (fa, fb, fg, fgz) = _run_argument(c, n, freeze_log if freeze_log != 63 else 1, 6000 + n + lead, tabled=True, lead_rounds=lead,
+                                                           extra_generators=extra, inside=inside)
+    exp_lrs, exp_states, (ea, eb, eg, egz) = _oracle_argument(c, inputs)
+    for j, ((lr, z), (elr, ez)) in enumerate(zip(lrs, exp_lrs)):
+        assert list(z) == list(ez) and np.array_equal(lr, elr), "round %d" % j
+    seen_g = 0
+    for j, ((frozen, got), exp) in enumerate(zip(states, exp_states)):
+        assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]), "halo_a / halo_b after round %d" % j
+        if not frozen:
+            seen_g += 1
+            assert np.array_equal(got[2], exp[2]) and np.array_equal(got[3], np.asarray(exp[3], dtype=np.uint8)), "halo_g after round %d" % j
+    assert np.array_equal(fa, ea) and np.array_equal(fb, eb)
+    assert np.array_equal(fgz, np.asarray(egz, dtype=np.uint8)) and np.array_equal(fg, eg)
+    if c is not br.BLS12_377 and n >= 64:
+        fz = 1 << (freeze_log if freeze_log != 63 else 1)
+        want = min(lead or 3, 4)
+        while want and (n >> want) < 2 * fz:
+            want -= 1
+        assert want >= 1 and seen_g >= 1
+        assert states[0][0] == (want >= 2)   # still in the lead rounds after the first fold (no halo_g) when there are several
+
+
+@pytest.mark.parametrize("c", [br.TWEEDLEDEE, br.TWEEDLEDUM], ids=lambda c: c.name)
+@pytest.mark.parametrize("r,n_out", [(1, 1), (1, 37), (2, 5), (3, 64), (4, 3)])
+def test_fold_multi_matches_big_integers(c, r, n_out):
+    """plk_curve_fold_multi_dev: out_i = g_i + sum_t [s_t] g_{i + t n_out} against Python integers - random points, identity
+    inputs, the same point in every slot (additions that meet doublings and inverses) and the edge scalars 0, 1, r - 1."""
+    pytest.importorskip("torch")
+    from plonky_amd import device as dev
+    dev.init(0)
+    f = c.scalar
+    T = 1 << r
+    n = T * n_out
+    G = (c.gx, c.gy)
+    L = c.base.n_limbs
+    rng = np.random.default_rng(900 + 17 * r + n_out)
+    ks = [int(x) for x in rng.integers(1, 1 << 62, size=n)]
+    for i in range(0, n, 7):
+        ks[i] = ks[0]                       # repeated points
+    pts = [br.ec_mul(c, k, G) for k in ks]
+    zero = np.zeros(n, dtype=np.uint8)
+    zero[3 % n] = 1
+    if n > 8:
+        zero[n - 1] = 1
+    g = np.array([[c.base.mont_limbs(P[0]), c.base.mont_limbs(P[1])] for P in pts], dtype=np.uint64).reshape(n, 2, L)
+    sc_ints = [int.from_bytes(rng.bytes(32), "little") % f.p for _ in range(T)]
+    for t, v in zip(range(1, T), [0, 1, f.p - 1]):
+        sc_ints[t] = v
+    rev = lambda t: int(format(t, "0%db" % r)[::-1], 2)
+    sc = np.zeros((T, 4), dtype=np.uint64)
+    for t in range(T):
+        sc[rev(t)] = f.mont_limbs(sc_ints[t])
+    out, oz = dev.fold_generators_multi_dev(c.curve_id, dev.to_device(g), dev.to_device(sc), r, g_zero=__import__("torch").from_numpy(zero).cuda())
+    out, oz = dev.to_host(out), oz.cpu().numpy()
+    for i in range(n_out):
+        acc = None if zero[i] else pts[i]
+        for t in range(1, T):
+            j = i + t * n_out
+            if zero[j] or sc_ints[t] == 0:
+                continue
+            term = br.ec_mul(c, sc_ints[t], pts[j])
+            acc = br.ec_add(c, acc, term)
+        if acc is None:
+            assert oz[i] == 1, i
+        else:
+            assert oz[i] == 0 and tuple(from_mont_arr(c.base, out[i])) == acc, i
+
+
+def test_fold_multi_needs_the_endomorphism():
+    pytest.importorskip("torch")
+    import torch
+    from plonky_amd import device as dev, lib
+    dev.init(0)
+    c = br.BLS12_377
+    g = torch.zeros((4, 2, c.base.n_limbs), dtype=torch.int64, device="cuda")
+    sc = torch.zeros((2, 4), dtype=torch.int64, device="cuda")
+    with pytest.raises(Exception, match="endomorphism"):
+        dev.fold_generators_multi_dev(c.curve_id, g, sc, 1)
+
+
+@pytest.mark.parametrize("tabled,freeze_log", [(False, 0), (True, 12)])
+def test_halo_argument_2p16_closed_form(tabled, freeze_log):
     """A whole 2^16 argument through both regimes (explicit folds down to 2^14, frozen below): the final generator is
     <s, G> with s_i = prod_j u_j^(+-1) by the bits of i, G_i = G0 + i D: [sum s_i] G0 + [sum i s_i] D on Python integers."""
     pytest.importorskip("torch")
@@ -163,7 +273,9 @@ def test_halo_argument_2p16_closed_form():
     b = synth.rand_field(f.field_id, 12, n)
     us = synth.rand_field(f.field_id, 13, log_n)
     bl = synth.rand_field(f.field_id, 14, 2)
-    arg = dev.HaloArgument(c.curve_id, dev.to_device(a), dev.to_device(b), g, pt(br.ec_mul(c, 77, G)), pt(br.ec_mul(c, 78, G)))
+    tables = dev.msm_precompute_dev(c.curve_id, g) if tabled else None   # three lead rounds, explicit folds 2^13 -> 2^12, frozen below
+    arg = dev.HaloArgument(c.curve_id, dev.to_device(a), dev.to_device(b), g, pt(br.ec_mul(c, 77, G)), pt(br.ec_mul(c, 78, G)), freeze_log=freeze_log,
+                           tables=tables)
     u_ints = [f.from_mont(limbs_to_int(r)) for r in us]
     for j in range(log_n):
         lr, z = arg.round_lr(bl[0], bl[1])
