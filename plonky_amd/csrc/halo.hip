@@ -24,11 +24,14 @@
 //    (the identity behind halo_s, plonk_util.rs:311-339): L_j and R_j are the two scalar vectors of ONE batched tabled MSM
 //    over the frozen set with the scalars a_i s_j, and the final generator is one more MSM with the scalars s_j.  Same group
 //    elements as the reference's, so the affine results are bit-identical.
-//  * LEAD rounds (plk_halo_begin_tabled_dev: the caller hands over the window tables of pedersen_g it commits with,
-//    plonk.rs:65 `pedersen_g_msm_precomputation`): the same identity from the other end.  For the first r rounds the generators stay
-//    what they are and L_j / R_j are one batched MSM over the CALLER's tables with the scalars a_i s_j (+ [l] H + [<a, b>] U' from
-//    the pair kernel on side streams); then ONE 2^r-to-1 fold (fold.hip) forms G^(r) - a single doubling chain per output instead
-//    of one per output of every round - and the long rounds above continue from there.
+//  * VIRTUAL rounds, in stages of r (curves with the endomorphism): the same identity from the other end.  For r rounds the
+//    generator set V stays what it is - L_j / R_j run over V with the scalars a_i s_j - and ONE 2^r-to-1 fold (fold.hip) then
+//    forms the generators r rounds on: a single doubling chain per output instead of one per output of every round (~40 % of the
+//    fold work of two rounds).  The first stage runs over the CALLER's commitment tables when it hands them over
+//    (plk_halo_begin_tabled_dev; plonk.rs:65 `pedersen_g_msm_precomputation`): one batched tabled MSM per round, H and U' as two
+//    more of its scalars when the tables hold them, else from the pair kernel on side streams.  Later stages (and the first one
+//    without tables) run over the explicit, scaled set with the two table-free contexts: every element of V is in exactly one of
+//    L_j / R_j, so the second round of a stage costs what its first did (instead of ~60 %) and saves most of a fold.
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -209,24 +212,27 @@ struct plk_halo_ctx {
     int curve = 0, sfield = 0, L = 4;
     size_t n0 = 0, n = 0;       // initial / current length of halo_a, halo_b, halo_g
     unsigned freeze_log = 14;
+    bool endo = false;          // the curve has the endomorphism: 2^r-to-1 folds, stages of virtual rounds
     hipStream_t stream = nullptr, side = nullptr, side2 = nullptr;
     hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_side2 = nullptr;
-    uint8_t* slab = nullptr;    // one allocation: a | b | g | gz | extra | scal | part | out | coef | dsc
+    uint8_t* slab = nullptr;    // one allocation: a | b | g | gz | extra | scal | part | out | coef | dsc | ratios | rec | hu
     uint8_t *a = nullptr, *b = nullptr, *g = nullptr, *gz = nullptr, *extra = nullptr, *scal = nullptr, *part = nullptr, *out = nullptr, *coef = nullptr;
-    uint8_t* dsc = nullptr;     // 4 scalars: [0] unused (the fold's first scalar), [1] u^2, [2] the running scale c, [3] zero, [4] x with U' = [x] U (lead rounds)
+    uint8_t* dsc = nullptr;     // 5 scalars: [0] unused (the fold's first scalar), [1] u^2, [2] the running scale c, [3] zero, [4] x with U' = [x] U
     size_t scal_stride = 0;     // bytes between the L and the R scalar vector
     plk_msm_ctx *mL = nullptr, *mR = nullptr;  // table-free contexts of the long rounds, rebound every round
     bool frozen = false;
-    size_t m0 = 0;              // frozen generator count
+    size_t m0 = 0;              // generators with a coefficient: the frozen set, or the set of the current stage of virtual rounds
     plk_msm_ctx* mT = nullptr;  // tables over [G^(f), H, U']
     uint8_t* pin = nullptr;     // pinned staging for the results that cross PCIe
-    // lead rounds over the caller's tables (not owned): `lead_left` of `lead_total` still to come; m0 = n0 meanwhile
+    // a stage of virtual rounds: `virt_left` of `virt_total` still to come over the m0 generators the stage began with
+    unsigned virt_total = 0, virt_left = 0, stage_depth = 2, stage_min_log = 17;
+    // first stage over the caller's tables (not owned)
     plk_msm_ctx* lead_ctx = nullptr;
-    unsigned lead_total = 0, lead_left = 0;
+    unsigned lead_rounds = 0;
     size_t lead_n = 0;          // generators in the caller's context (>= n0; the scalars of the others stay zero)
     bool lead_inside = false;   // H and U sit in the caller's tables (indices lead_h, lead_u; U' = [x] U, x at dsc[4]): no side work
     size_t lead_h = 0, lead_u = 0;
-    uint8_t *ratios = nullptr, *rec = nullptr, *hu = nullptr;  // 2^lead_total fold scalars | two partial-sum records | [l, <a,b>] x 2
+    uint8_t *ratios = nullptr, *rec = nullptr, *hu = nullptr;  // 2^virt_total fold scalars | two partial-sum records | [l, <a,b>] x 2
     size_t rec_bytes = 0;
     bool lr_done = false;
     std::mutex mu;
@@ -267,6 +273,8 @@ static HaloScalar to_halo_scalar(const uint64_t* s) {
         default: { using P = VestaBaseParams; CALL; } break;                               \
     }
 
+static size_t freeze_len(const plk_halo_ctx* c) { return (size_t)1 << (c->freeze_log > 40 ? 40 : c->freeze_log); }
+
 // builds the tables over the current generators: from here on they are never folded again
 static int halo_freeze(plk_halo_ctx* c) {
     c->m0 = c->n;
@@ -278,6 +286,34 @@ static int halo_freeze(plk_halo_ctx* c) {
     c->frozen = true;
     // (Replaying the ~20 launches of a frozen round's batched MSM from a hipGraph was measured: 39.6 against 39.2 ms for the whole
     // argument - the round is bound by the dependency chain on the GPU, not by launch overhead; the plain launches stay.)
+    return PLK_OK;
+}
+
+// What the rounds from the current length on look like: frozen generators, a stage of virtual rounds (over the caller's tables
+// first, if any), or single rounds with pairwise folds.
+static int halo_next_stage(plk_halo_ctx* c) {
+    c->virt_total = c->virt_left = 0;
+    if (c->frozen || c->n < 2) return PLK_OK;
+    const size_t fz = freeze_len(c);
+    if (c->n <= fz) return halo_freeze(c);
+    if (!c->endo) return PLK_OK;
+    unsigned d = c->lead_ctx ? c->lead_rounds : c->stage_depth;
+    // A stage ends at the freezing length at the latest; over the explicit set it must leave 2^17 outputs: the 2^r-to-1 fold is one
+    // lane per output, and below two waves per SIMD its chain of loads and additions is slower than the pairwise folds it replaces
+    // (2^18 -> 2^16: 2.85 ms against 1.88 + 1.07, measured).
+    const size_t floor_len = c->lead_ctx ? fz : (fz > ((size_t)1 << c->stage_min_log) ? fz : (size_t)1 << c->stage_min_log);
+    while (d > 0 && (c->n >> d) < floor_len) --d;
+    if (!c->lead_ctx && d < 2) return PLK_OK;  // a stage of one round is a round with a pairwise fold
+    if (d == 0) {
+        c->lead_ctx = nullptr;
+        return PLK_OK;
+    }
+    c->virt_total = c->virt_left = d;
+    c->m0 = c->n;
+    // every generator of the stage's set starts with the coefficient c (the scale of the explicit set; 1 over the caller's tables)
+    HALO_FIELD_SWITCH(c->sfield, (k_halo_fill<P><<<(unsigned)((c->m0 + 255) / 256), 256, 0, c->stream>>>((uint4*)c->coef, c->m0, (const uint4*)(c->dsc + 2 * 32)),
+                                  k_halo_fill<P><<<1, 256, 0, c->stream>>>((uint4*)c->ratios, 1, nullptr)));
+    PLK_HIP_TRY(hipGetLastError());
     return PLK_OK;
 }
 
@@ -298,42 +334,44 @@ int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, c
     c->L = L;
     c->n0 = c->n = n;
     c->stream = stream;
+    c->endo = curve != PLK_CURVE_BLS12_377;  // the 2^r-to-1 fold runs along the endomorphism
     if (const char* e = getenv("PLK_HALO_FREEZE_LOG")) freeze_log = (unsigned)atoi(e);
     c->freeze_log = freeze_log ? freeze_log : 14u;
+    if (const char* e = getenv("PLK_HALO_STAGE")) c->stage_depth = (unsigned)atoi(e);
+    if (c->stage_depth > 4) c->stage_depth = 4;
+    if (const char* e = getenv("PLK_HALO_STAGE_MIN_LOG")) c->stage_min_log = (unsigned)atoi(e);
+    if (c->stage_min_log > 40) c->stage_min_log = 40;
     const size_t pt = (size_t)2 * L * 8;
-    const size_t fz = (size_t)1 << (c->freeze_log > 40 ? 40 : c->freeze_log);
-    // lead rounds: how many, if any
-    unsigned lead = 0;
+    const size_t fz = freeze_len(c);
+    // a first stage over the caller's tables
     if (tables) {
         if (msm_ctx_curve(tables) != curve || msm_ctx_table_free(tables) || msm_ctx_len(tables) < n)
             return set_error(PLK_ERR_INVALID_ARG, "the tables handed to the argument must be a tabled context of this curve over at least %zu generators", n);
-        lead = lead_rounds ? lead_rounds : 3u;
+        unsigned lead = lead_rounds ? lead_rounds : 2u;
         if (const char* e = getenv("PLK_HALO_LEAD")) lead = (unsigned)atoi(e);
         if (lead > 4) lead = 4;
-        while (lead > 0 && (n >> lead) < 2 * fz) --lead;  // the long rounds take over above the freezing length
-        switch (curve) {  // the 2^r-to-1 fold runs along the endomorphism
-            case PLK_CURVE_TWEEDLEDEE: case PLK_CURVE_TWEEDLEDUM: case PLK_CURVE_PALLAS: case PLK_CURVE_VESTA: break;
-            default: lead = 0;
+        while (lead > 0 && (n >> lead) < fz) --lead;
+        if (c->endo && lead) {
+            c->lead_ctx = tables;
+            c->lead_rounds = lead;
+            c->lead_n = msm_ctx_len(tables);
+            if (u_prime_scalar && h_index != (size_t)-1 && u_index != (size_t)-1) {
+                if (h_index < n || u_index < n || h_index >= c->lead_n || u_index >= c->lead_n || h_index == u_index)
+                    return set_error(PLK_ERR_INVALID_ARG, "pedersen_h / U must be generators %zu .. %zu of the tables (behind halo_g), got %zu and %zu", n,
+                                     c->lead_n - 1, h_index, u_index);
+                c->lead_inside = true;
+                c->lead_h = h_index;
+                c->lead_u = u_index;
+            }
         }
     }
-    c->lead_total = c->lead_left = lead;
-    c->lead_ctx = lead ? tables : nullptr;
-    c->lead_n = lead ? msm_ctx_len(tables) : 0;
-    if (lead && u_prime_scalar && h_index != (size_t)-1 && u_index != (size_t)-1) {
-        if (h_index < n || u_index < n || h_index >= c->lead_n || u_index >= c->lead_n || h_index == u_index)
-            return set_error(PLK_ERR_INVALID_ARG, "pedersen_h / U must be generators %zu .. %zu of the tables (behind halo_g), got %zu and %zu", n, c->lead_n - 1,
-                             h_index, u_index);
-        c->lead_inside = true;
-        c->lead_h = h_index;
-        c->lead_u = u_index;
-    }
     c->rec_bytes = msm_partials_bytes(curve, 2);
-    const size_t m0_max = lead ? n : (n < fz ? n : fz);  // frozen set: at most min(n, 2^freeze_log) generators; lead rounds: all of them
-    const size_t cnt_max = lead ? c->lead_n : (n / 2 > m0_max ? n / 2 : m0_max) + 2;
+    // scalar vectors: up to one scalar per generator of a stage's set (+ H, U'); the caller's tables may hold more generators
+    const size_t cnt_max = (c->lead_n > n + 2 ? c->lead_n : n + 2);
     c->scal_stride = cnt_max * 32;
     struct Part { uint8_t** p; size_t bytes; } parts[] = {
         {&c->a, n * 32}, {&c->b, n * 32}, {&c->g, n * pt}, {&c->gz, n}, {&c->extra, 2 * pt}, {&c->scal, 2 * c->scal_stride},
-        {&c->part, (size_t)2 * HALO_PART_BLOCKS * 32}, {&c->out, 2 * pt + 16}, {&c->coef, m0_max * 32}, {&c->dsc, 5 * 32},
+        {&c->part, (size_t)2 * HALO_PART_BLOCKS * 32}, {&c->out, 2 * pt + 16}, {&c->coef, n * 32}, {&c->dsc, 5 * 32},
         {&c->ratios, (size_t)16 * 32}, {&c->rec, 2 * c->rec_bytes}, {&c->hu, 4 * 32},
     };
     size_t total = 0;
@@ -365,28 +403,22 @@ int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, c
     }
     HALO_FIELD_SWITCH(c->sfield, (k_halo_fill<P><<<1, 256, 0, stream>>>((uint4*)(c->dsc + 2 * 32), 1, nullptr)));  // c = 1
     PLK_HIP_TRY(hipGetLastError());
-    if (n >= 2) {
-        if (n <= fz) {
-            PLK_TRY(halo_freeze(c));
-        } else {
-            // the two table-free contexts of the long rounds, sized for every round they will be rebound to
-            const size_t n1 = n >> lead;  // length when the long rounds start
-            size_t also[64];
-            int cnt = 0;
-            for (size_t len = n1 / 2; len > fz; len /= 2) also[cnt++] = len / 2 + 2;
-            PLK_TRY(msm_precompute_dev_impl(curve, n1 / 2 + 2, c->g + (n1 / 2) * pt, c->gz + n1 / 2, 0, PLK_MSM_TABLE_FREE, stream, &c->mL, c->extra, 2, also, cnt));
-            PLK_TRY(msm_precompute_dev_impl(curve, n1 / 2 + 2, c->g, c->gz, 0, PLK_MSM_TABLE_FREE, stream, &c->mR, c->extra, 2, also, cnt));
-        }
-        if (lead) {
-            // every generator keeps the coefficient 1 for now; generators of the caller's context beyond n never get a scalar
-            c->m0 = n;
-            HALO_FIELD_SWITCH(c->sfield, (k_halo_fill<P><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((uint4*)c->coef, n, nullptr),
-                                          k_halo_fill<P><<<1, 256, 0, stream>>>((uint4*)c->ratios, 1, nullptr)));
-            PLK_HIP_TRY(hipGetLastError());
-            PLK_HIP_TRY(hipMemsetAsync(c->scal, 0, 2 * c->scal_stride, stream));
-            PLK_TRY(msm_reserve_workspaces_impl(tables, 2, stream));
-        }
+    if (c->lead_ctx) {
+        // generators of the caller's context beyond n never get a scalar
+        PLK_HIP_TRY(hipMemsetAsync(c->scal, 0, 2 * c->scal_stride, stream));
+        PLK_TRY(msm_reserve_workspaces_impl(tables, 2, stream));
     }
+    const size_t n1 = c->lead_ctx ? n >> c->lead_rounds : n;  // length when the explicit generators take over
+    if (n1 > fz) {
+        // the two table-free contexts of the long rounds, sized for every set they will be rebound to: a stage's whole set, or half
+        // of the generators of a single round (+ H, U')
+        size_t also[64];
+        int cnt = 0;
+        for (size_t len = n1 / 2; len >= fz / 2 && len >= 1 && cnt < 64; len /= 2) also[cnt++] = len + 2;
+        PLK_TRY(msm_precompute_dev_impl(curve, n1 + 2, c->g, c->gz, 0, PLK_MSM_TABLE_FREE, stream, &c->mL, c->extra, 2, also, cnt));
+        PLK_TRY(msm_precompute_dev_impl(curve, n1 + 2, c->g, c->gz, 0, PLK_MSM_TABLE_FREE, stream, &c->mR, c->extra, 2, also, cnt));
+    }
+    PLK_TRY(halo_next_stage(c));
     PLK_HIP_TRY(hipStreamSynchronize(stream));  // the staging copy of H, U' is consumed
     *out = guard.release();
     return PLK_OK;
@@ -398,20 +430,20 @@ int halo_round_lr_impl(plk_halo_ctx* c, const uint64_t* l_blind, const uint64_t*
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->n < 2) return set_error(PLK_ERR_INVALID_ARG, "the argument is finished (length %zu)", c->n);
     const size_t m = c->n / 2, pt = (size_t)2 * c->L * 8;
-    const bool lead = c->lead_left > 0;
-    const size_t m0 = (c->frozen || lead) ? c->m0 : 0, cnt = c->frozen ? c->m0 : m;
+    const bool virt = c->virt_left > 0, lead = virt && c->lead_ctx;
+    const size_t m0 = (c->frozen || virt) ? c->m0 : 0, cnt = (c->frozen || virt) ? c->m0 : m;
     uint8_t* sL = c->scal;
-    // frozen / lead rounds: the two vectors back to back, one batched call
+    // frozen generators / the caller's tables: the two vectors back to back, one batched call
     uint8_t* sR = c->scal + (lead ? c->lead_n * 32 : c->frozen ? (cnt + 2) * 32 : c->scal_stride);
     const size_t work = m > m0 ? m : m0;
     unsigned blocks = (unsigned)((work + 255) / 256);
     if (blocks > HALO_PART_BLOCKS) blocks = HALO_PART_BLOCKS;
     const HaloScalar lb = to_halo_scalar(l_blind), rb = to_halo_scalar(r_blind);
+    const bool beside = lead && !c->lead_inside;  // H and U' are not in the caller's tables: their scalars go to `hu`
     HALO_FIELD_SWITCH(c->sfield, (k_halo_prepare<P><<<blocks, 256, 0, c->stream>>>((const uint4*)c->a, (const uint4*)c->b, m, m0, (const uint4*)c->coef,
                                                                                      (const uint4*)(c->dsc + 2 * 32), (uint4*)sL, (uint4*)sR, (uint4*)c->part),
                                   k_halo_close<P><<<1, 64, 0, c->stream>>>((const uint4*)c->part, blocks, lb, rb, !lead ? cnt : c->lead_inside ? c->lead_h : 0,
-                                                                           (uint4*)(lead && !c->lead_inside ? c->hu : sL),
-                                                                           (uint4*)(lead && !c->lead_inside ? c->hu + 64 : sR), c->lead_u,
+                                                                           (uint4*)(beside ? c->hu : sL), (uint4*)(beside ? c->hu + 64 : sR), c->lead_u,
                                                                            (const uint4*)(lead && c->lead_inside ? c->dsc + 4 * 32 : nullptr))));
     PLK_HIP_TRY(hipGetLastError());
     uint8_t* out_xy = c->out;
@@ -421,16 +453,15 @@ int halo_round_lr_impl(plk_halo_ctx* c, const uint64_t* l_blind, const uint64_t*
         PLK_TRY(msm_execute_dev_impl(c->lead_ctx, 2, sL, c->lead_n, out_xy, out_z, c->stream));
     } else if (lead) {
         // record 0: <a s, G> from the caller's tables; record 1: [l] H + [<a, b>] U' (one lane each, ~130 doublings: two side
-        // streams, hidden behind the MSM); L_j, R_j = the sums of the two records
+        // streams, mostly hidden behind the MSM); L_j, R_j = the sums of the two records
         uint8_t* r0 = c->rec;
         uint8_t* r1 = c->rec + c->rec_bytes;
         PLK_HIP_TRY(hipEventRecord(c->ev_main, c->stream));
         PLK_HIP_TRY(hipStreamWaitEvent(c->side, c->ev_main, 0));
         PLK_HIP_TRY(hipStreamWaitEvent(c->side2, c->ev_main, 0));
-        static const bool dbg_skip = getenv("PLK_HALO_DEBUG_NO_HU") != nullptr;
-        if (!dbg_skip) PLK_TRY(curve_fold_pairs_dev_impl(c->curve, 1, c->extra, nullptr, c->extra + pt, nullptr, nullptr, nullptr, r1, r1 + 2 * pt, c->side, c->hu, 0));
+        PLK_TRY(curve_fold_pairs_dev_impl(c->curve, 1, c->extra, nullptr, c->extra + pt, nullptr, nullptr, nullptr, r1, r1 + 2 * pt, c->side, c->hu, 0));
         PLK_HIP_TRY(hipEventRecord(c->ev_side, c->side));
-        if (!dbg_skip) PLK_TRY(curve_fold_pairs_dev_impl(c->curve, 1, c->extra, nullptr, c->extra + pt, nullptr, nullptr, nullptr, r1 + pt, r1 + 2 * pt + 1, c->side2, c->hu + 64, 0));
+        PLK_TRY(curve_fold_pairs_dev_impl(c->curve, 1, c->extra, nullptr, c->extra + pt, nullptr, nullptr, nullptr, r1 + pt, r1 + 2 * pt + 1, c->side2, c->hu + 64, 0));
         PLK_HIP_TRY(hipEventRecord(c->ev_side2, c->side2));
         PLK_TRY(msm_execute_dev_impl(c->lead_ctx, 2, sL, c->lead_n, r0, r0 + 2 * pt, c->stream));
         PLK_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_side, 0));
@@ -439,14 +470,17 @@ int halo_round_lr_impl(plk_halo_ctx* c, const uint64_t* l_blind, const uint64_t*
     } else if (c->frozen) {
         PLK_TRY(msm_execute_dev_impl(c->mT, 2, sL, c->m0 + 2, out_xy, out_z, c->stream));
     } else {
-        // L on the caller's stream, R on the side stream: below ~2^16 points each is a dependency chain, not throughput
+        // L on the caller's stream, R on the side stream: below ~2^16 points each is a dependency chain, not throughput.
+        // Single round: L over the upper half of the generators, R over the lower.  Stage of virtual rounds: both over the whole set
+        // (the scalars of the generators on the other side are zero - a zero scalar has no digits).
+        const size_t pts = virt ? c->m0 : m;
         PLK_HIP_TRY(hipEventRecord(c->ev_main, c->stream));
         PLK_HIP_TRY(hipStreamWaitEvent(c->side, c->ev_main, 0));
-        PLK_TRY(msm_rebind_dev_impl(c->mR, m + 2, c->g, c->gz, c->extra, 2, c->side));
-        PLK_TRY(msm_execute_dev_impl(c->mR, 1, sR, m + 2, out_xy + pt, out_z + 1, c->side));
+        PLK_TRY(msm_rebind_dev_impl(c->mR, pts + 2, c->g, c->gz, c->extra, 2, c->side));
+        PLK_TRY(msm_execute_dev_impl(c->mR, 1, sR, pts + 2, out_xy + pt, out_z + 1, c->side));
         PLK_HIP_TRY(hipEventRecord(c->ev_side, c->side));
-        PLK_TRY(msm_rebind_dev_impl(c->mL, m + 2, c->g + m * pt, c->gz + m, c->extra, 2, c->stream));
-        PLK_TRY(msm_execute_dev_impl(c->mL, 1, sL, m + 2, out_xy, out_z, c->stream));
+        PLK_TRY(msm_rebind_dev_impl(c->mL, pts + 2, virt ? c->g : c->g + m * pt, virt ? c->gz : c->gz + m, c->extra, 2, c->stream));
+        PLK_TRY(msm_execute_dev_impl(c->mL, 1, sL, pts + 2, out_xy, out_z, c->stream));
         PLK_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_side, 0));
     }
     PLK_HIP_TRY(hipMemcpyAsync(c->pin, c->out, 2 * pt + 2, hipMemcpyDeviceToHost, c->stream));
@@ -464,21 +498,24 @@ int halo_round_fold_impl(plk_halo_ctx* c, const uint64_t* u_j, const uint64_t* u
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->n < 2) return set_error(PLK_ERR_INVALID_ARG, "the argument is finished (length %zu)", c->n);
     const size_t m = c->n / 2, pt = (size_t)2 * c->L * 8;
-    const bool lead = c->lead_left > 0;
-    const size_t m0 = (c->frozen || lead) ? c->m0 : 0;
+    const bool virt = c->virt_left > 0;
+    const size_t m0 = (c->frozen || virt) ? c->m0 : 0;
     const size_t work = m > m0 ? m : m0;
     HALO_FIELD_SWITCH(c->sfield, (k_halo_fold_scalars<P><<<(unsigned)((work + 255) / 256), 256, 0, c->stream>>>(
                                      (uint4*)c->a, (uint4*)c->b, m, to_halo_scalar(u_j), to_halo_scalar(u_j_inv), (uint4*)c->coef, m0,
                                      (uint4*)(c->frozen ? nullptr : c->dsc))));
     PLK_HIP_TRY(hipGetLastError());
-    if (lead) {
-        HALO_FIELD_SWITCH(c->sfield, (k_halo_lead_ratios<P><<<1, 64, 0, c->stream>>>((uint4*)c->ratios, (int)(c->lead_total - c->lead_left), (const uint4*)c->dsc)));
+    c->n = m;
+    c->lr_done = false;
+    if (virt) {
+        HALO_FIELD_SWITCH(c->sfield, (k_halo_lead_ratios<P><<<1, 64, 0, c->stream>>>((uint4*)c->ratios, (int)(c->virt_total - c->virt_left), (const uint4*)c->dsc)));
         PLK_HIP_TRY(hipGetLastError());
-        if (--c->lead_left == 0) {
-            // the generators of the r rounds at once, scaled like the pairwise folds: G^(r) = [c] G~, c = prod u_k^-1 (dsc[2])
-            PLK_TRY(curve_fold_multi_dev_impl(c->curve, m, (int)c->lead_total, c->g, c->gz, c->ratios, c->g, c->gz, c->stream));
+        if (--c->virt_left == 0) {
+            // the generators of the stage's rounds at once, scaled like the pairwise folds: G = [c] G~, c = c_0 prod u_k^-1 (dsc[2])
+            PLK_TRY(curve_fold_multi_dev_impl(c->curve, m, (int)c->virt_total, c->g, c->gz, c->ratios, c->g, c->gz, c->stream));
             c->m0 = 0;
             c->lead_ctx = nullptr;
+            PLK_TRY(halo_next_stage(c));
         }
     } else if (!c->frozen) {
         // G'_i = [u^-1] G_lo_i + [u] G_hi_i = [u^-1] (G_lo_i + [u^2] G_hi_i): the scaled fold G~'_i = G~_lo_i + [u^2] G~_hi_i in place
@@ -487,19 +524,17 @@ int halo_round_fold_impl(plk_halo_ctx* c, const uint64_t* u_j, const uint64_t* u
         // 6.8 against 7.8 ms for 2^19 pairs, 1.93 against 2.01 for 2^17; below that its three launches are the longer chain: 1.73
         // against 1.07 ms for 2^16 pairs.  Its scalar sits at index bitreverse(1) = 1 of dsc)
         static const bool pair_kernel = getenv("PLK_HALO_PAIR_FOLD") != nullptr;
-        if (c->curve != PLK_CURVE_BLS12_377 && !pair_kernel && m >= ((size_t)1 << 17))
+        if (c->endo && !pair_kernel && m >= ((size_t)1 << 17))
             PLK_TRY(curve_fold_multi_dev_impl(c->curve, m, 1, c->g, c->gz, c->dsc, c->g, c->gz, c->stream));
         else
             PLK_TRY(curve_fold_pairs_dev_impl(c->curve, m, c->g, c->gz, c->g + m * pt, c->gz + m, nullptr, nullptr, c->g, c->gz, c->stream, c->dsc, 1));
+        PLK_TRY(halo_next_stage(c));
     }
-    c->n = m;
-    c->lr_done = false;
-    if (!c->frozen && c->n >= 2 && c->n <= ((size_t)1 << (c->freeze_log > 40 ? 40 : c->freeze_log))) PLK_TRY(halo_freeze(c));
     return PLK_OK;
 }
 
 size_t halo_len_impl(const plk_halo_ctx* c) { return c ? c->n : 0; }
-int halo_frozen_impl(const plk_halo_ctx* c) { return c && (c->frozen || c->lead_left > 0) ? 1 : 0; }
+int halo_frozen_impl(const plk_halo_ctx* c) { return c && (c->frozen || c->virt_left > 0) ? 1 : 0; }
 
 // current halo_a, halo_b (n scalars each) and - while the generators are still folded explicitly - halo_g (n points + flags);
 // with n == 1 and frozen generators the single generator is the MSM <s, G^(f)>
@@ -512,9 +547,9 @@ int halo_read_impl(plk_halo_ctx* c, uint64_t* a, uint64_t* b, uint64_t* g_xy, ui
     if (b) PLK_HIP_TRY(hipMemcpyAsync(b, c->b, c->n * 32, hipMemcpyDeviceToHost, c->stream));
     if (g_xy || g_zero) {
         if (!g_xy || !g_zero) return set_error(PLK_ERR_INVALID_ARG, "g_xy and g_zero go together");
-        if (c->lead_left > 0) {
-            return set_error(PLK_ERR_INVALID_ARG, "the generators are untouched during the %u lead rounds over the caller's tables: halo_g exists again after them",
-                             c->lead_total);
+        if (c->virt_left > 0) {
+            return set_error(PLK_ERR_INVALID_ARG, "the generators are untouched during a stage of %u virtual rounds (%u to go): halo_g exists again after it",
+                             c->virt_total, c->virt_left);
         } else if (!c->frozen) {
             // halo_g_i = [c] G~_i: the pairwise kernel with the scalars (c, 0) over (G~_i, G~_i)
             uint8_t* tmp = (uint8_t*)scratch_acquire(c->n * (pt + 1), c->stream);

@@ -158,7 +158,9 @@ def test_halo_argument_capi_matches_oracle(c, n, freeze_log):
     assert np.array_equal(fa, ea) and np.array_equal(fb, eb)
     assert np.array_equal(fgz, np.asarray(egz, dtype=np.uint8)) and np.array_equal(fg, eg)
     if n >= 4 and freeze_log in (3, 5):
-        assert not states[0][0] and states[-1][0]   # explicit folds first, frozen generators at the end
+        assert states[-1][0]   # frozen generators at the end
+        # before that: pairwise folds on BLS12-377 (halo_g after every round), stages of two virtual rounds on the other curves
+        assert states[0][0] == (c is not br.BLS12_377) and not states[1][0]
 
 
 @pytest.mark.parametrize("c", CURVES, ids=lambda c: c.name)
@@ -186,13 +188,6 @@ def test_halo_argument_over_the_callers_tables(c, n, freeze_log, lead, extra, in
             assert np.array_equal(got[2], exp[2]) and np.array_equal(got[3], np.asarray(exp[3], dtype=np.uint8)), "halo_g after round %d" % j
     assert np.array_equal(fa, ea) and np.array_equal(fb, eb)
     assert np.array_equal(fgz, np.asarray(egz, dtype=np.uint8)) and np.array_equal(fg, eg)
-    if c is not br.BLS12_377 and n >= 64:
-        fz = 1 << (freeze_log if freeze_log != 63 else 1)
-        want = min(lead or 3, 4)
-        while want and (n >> want) < 2 * fz:
-            want -= 1
-        assert want >= 1 and seen_g >= 1
-        assert states[0][0] == (want >= 2)   # still in the lead rounds after the first fold (no halo_g) when there are several
 
 
 @pytest.mark.parametrize("c", [br.TWEEDLEDEE, br.TWEEDLEDUM], ids=lambda c: c.name)
