@@ -214,7 +214,7 @@ def main(argv=None):
 
 
 def run_quotient(args):
-    """--workload quotient: k_vanishing_points (five launches per call) and k_fold_pairs_glv, timed with HIP events on the launch
+    """--workload quotient: k_vanishing_points (five launches per call), k_fold_pairs_glv and the 4-to-1 fold k_fold_multi_glv, timed with HIP events on the launch
     stream, priced against the same ceilings as the headline kernels.  One GPU; correctness of both is the GPU suite's business
     (tests/test_gpu_plonk.py, tests/test_gpu_halo.py) - here the fold is checked by its closed form, the numerator by determinism."""
     import numpy as np
@@ -246,6 +246,15 @@ def run_quotient(args):
     ui = synth.to_int(u) * pow(1 << 256, -1, r) % r
     u_inv = np.array(synth.mont(F, pow(ui, -1, r)), dtype=np.uint64)
     fold = lambda: dev.fold_generators_dev(CURVE, gens[:m].contiguous(), gens[m:].contiguous(), u_inv, u)
+    # the 4-to-1 fold of two rounds at once (plk_curve_fold_multi_dev: what the argument behind the C ABI runs for its first two rounds)
+    s_ints = [1] + [synth.to_int(row) % r or 1 for row in synth.rand_field(F, 12, 3)]
+    rev2 = (0, 2, 1, 3)
+    s_multi = np.zeros((4, 4), dtype=np.uint64)
+    for t in range(4):
+        s_multi[rev2[t]] = synth.mont(F, s_ints[t])
+    s_multi_d = dev.to_device(s_multi)
+    q = max(1, (2 * m) // 4)
+    fold4 = (lambda: dev.fold_generators_multi_dev(CURVE, gens, s_multi_d, 2)) if 2 * m >= 4 else None
 
     def timed(fn, steps, warm):
         for _ in range(warm):
@@ -262,6 +271,7 @@ def run_quotient(args):
     t0 = time.perf_counter()
     v_ms = timed(vanish, args.steps, args.warmup)
     f_ms = timed(fold, max(1, args.steps // 2), 1)
+    f4_ms = timed(fold4, max(1, args.steps // 2), 1) if fold4 else None
     elapsed = time.perf_counter() - t0
     first = out.clone()
     vanish()
@@ -274,6 +284,16 @@ def run_quotient(args):
         got = dev.to_host(g2[i])
         ok = ok and (synth.from_mont(0, got[0]), synth.from_mont(0, got[1])) == exp
     checks = {"fold_closed_form_bit_exact": bool(ok and not gz2.any().item()), "vanishing_points_deterministic": bool(torch.equal(first, out))}
+    if fold4:
+        # out_i = sum_t s_t (G0 + (i + t q) D), s_0 = 1: [sum s_t] G0 + [sum s_t (i + t q)] D, checked at i = 0 and i = q - 1
+        g4, gz4 = fold4()
+        torch.cuda.synchronize()
+        ok4 = True
+        for i in (0, q - 1):
+            exp = _add(p, _mul(p, sum(s_ints) % r, G), _mul(p, sum(sv * (i + t * q) for t, sv in enumerate(s_ints)) % r, D))
+            got = dev.to_host(g4[i])
+            ok4 = ok4 and (synth.from_mont(0, got[0]), synth.from_mont(0, got[1])) == exp
+        checks["fold_4_to_1_closed_form_bit_exact"] = bool(ok4 and not gz4.any().item())
     ceil = load_ceilings()
     ceil_ok = bool(ceil) and not ceil.get("stale")
     peak = ceil.get("fz_mul_gops", {}).get("tweedledee") if ceil_ok else None
@@ -307,6 +327,12 @@ def run_quotient(args):
                             "G' = [u^-1] G_lo + [u] G_hi along the endomorphism (plk_curve_fold_pairs_dev): ~130 doublings (6M + 3S) + ~130 mixed additions "
                             "(8M + 2S) + two inversions per pair; the argument behind the C ABI folds scaled, lo + [u^2] hi: ~65 additions"),
     }
+    if fold4:
+        rooflines["fold_multi"] = entry("k_fold_multi_glv", 3300.0, q, f4_ms, 5.0 * 64 * q,
+                                        "out_i = g_i + sum of three [s_t] g_(i + t q) (plk_curve_fold_multi_dev, two rounds of the argument at once): one chain of "
+                                        "~128 doublings (6M + 3S) per OUTPUT + ~64 mixed additions (8M + 2S, half of them with a multiplication by beta) per "
+                                        "input + the inversions of the operand preparation and the affine result: ~3300 multiplications per output; "
+                                        "units = outputs; launch_ms = digits + preparation + main kernel")
     result = {
         "metric": "MSM Mpairs/sec + NTT Melems/sec, 2^20 Tweedledee, 1/2/4/8 GPU", "value": n8 / (v_ms * 1e-3) / 1e6,
         "unit": "M points/s of the quotient numerator (the fold is reported in components)", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -314,7 +340,8 @@ def run_quotient(args):
         "config": {"workload": "quotient numerator of a 2^%d-gate circuit (8n = 2^%d points) + generator fold of 2^%d pairs" % (log_degree, log_degree + 3, m.bit_length() - 1),
                    "log_n": args.log_n, "curve": "tweedledee", "kernel_source_sha": src_hash},
         "components": {"vanishing_points_ms": v_ms, "vanishing_mpoints_per_s": n8 / (v_ms * 1e-3) / 1e6, "fold_pairs_ms": f_ms,
-                       "fold_mpairs_per_s": m / (f_ms * 1e-3) / 1e6, "wall_s": elapsed},
+                       "fold_mpairs_per_s": m / (f_ms * 1e-3) / 1e6, "fold_4_to_1_ms": f4_ms,
+                       "fold_4_to_1_minputs_per_s": (2 * m / (f4_ms * 1e-3) / 1e6) if f4_ms else None, "wall_s": elapsed},
         "checks": checks, "roofline": rooflines["vanishing_points"], "rooflines": rooflines,
     }
     print(json.dumps(result), flush=True)

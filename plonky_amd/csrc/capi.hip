@@ -137,6 +137,39 @@ void scratch_release(void* p, hipStream_t stream) {
         }
 }
 
+struct PooledStream {
+    hipStream_t s;
+    int device;
+    bool free;
+};
+static std::mutex g_spool_mu;
+static std::vector<PooledStream> g_spool;
+
+hipStream_t stream_pool_acquire() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_spool_mu);
+    for (auto& e : g_spool)
+        if (e.free && e.device == dev) {
+            e.free = false;
+            return e.s;
+        }
+    hipStream_t s = nullptr;
+    hipError_t err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (err != hipSuccess) {
+        set_error(PLK_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(err));
+        return nullptr;
+    }
+    g_spool.push_back({s, dev, false});
+    return s;
+}
+void stream_pool_release(hipStream_t s) {
+    if (!s) return;
+    std::lock_guard<std::mutex> lk(g_spool_mu);
+    for (auto& e : g_spool)
+        if (e.s == s) e.free = true;
+}
+
 void scratch_clear() {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     (void)hipDeviceSynchronize();
@@ -181,10 +214,12 @@ struct HostLane {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         ev_fork = nullptr;
         for (auto& a : aux) {
-            if (a) (void)hipStreamDestroy(a);
+            if (a) (void)hipStreamSynchronize(a);
+            stream_pool_release(a);
             a = nullptr;
         }
-        if (stream) (void)hipStreamDestroy(stream);
+        if (stream) (void)hipStreamSynchronize(stream);
+        stream_pool_release(stream);
         stream = nullptr;
     }
     ~HostLane() {
@@ -201,7 +236,8 @@ static int lane_get(HostLane*& out) {
     HostLane& l = t_lane;
     if (l.stream && l.device != dev) l.drop_streams();
     if (!l.stream) {
-        PLK_HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        l.stream = stream_pool_acquire();
+        if (!l.stream) return PLK_ERR_HIP;
         l.device = dev;
     }
     if (l.pin_used) (void)hipStreamSynchronize(l.stream);  // a call that failed half way may have left copies in flight
@@ -214,7 +250,7 @@ static int lane_fork(HostLane& l) {
     if (!l.ev_fork) PLK_HIP_TRY(hipEventCreateWithFlags(&l.ev_fork, hipEventDisableTiming));
     PLK_HIP_TRY(hipEventRecord(l.ev_fork, l.stream));
     for (auto& a : l.aux) {
-        if (!a) PLK_HIP_TRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        if (!a && !(a = stream_pool_acquire())) return PLK_ERR_HIP;
         PLK_HIP_TRY(hipStreamWaitEvent(a, l.ev_fork, 0));
     }
     return PLK_OK;

@@ -62,6 +62,13 @@ void* scratch_acquire(size_t bytes, hipStream_t stream);  // nullptr on allocati
 void scratch_release(void* p, hipStream_t stream);       // call after the last kernel using p is enqueued
 void scratch_clear();
 
+// Streams of the library's own (side streams of a context, the lanes of the host-pointer entry points) come from a process-wide
+// pool and go back to it instead of being destroyed: events of the scratch pool (and of other contexts) may have been recorded on
+// them last, and HIP keeps a pointer to the recording stream in an event - querying or waiting on such an event after
+// hipStreamDestroy was seen to fail with "operation not permitted when stream is capturing" (tools/fuzz_gpu.py, round 3).
+hipStream_t stream_pool_acquire();         // a non-blocking stream of the current device; nullptr on failure (error text set)
+void stream_pool_release(hipStream_t s);   // work still in flight on it simply precedes the next user's
+
 // Optional element-wise work fused into the first pass's loads and the last pass's stores of a transform
 // (poly.hip: coset scaling, zero padding, division by the vanishing polynomial).  Tables hold canonical
 // R'-form words (the form of the twiddle tables, see ntt.hip).  Geometric tables: b^i = hi[i >> 10] * lo[i & 1023].

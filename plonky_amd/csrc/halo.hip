@@ -248,8 +248,8 @@ struct plk_halo_ctx {
         if (ev_main) (void)hipEventDestroy(ev_main);
         if (ev_side) (void)hipEventDestroy(ev_side);
         if (ev_side2) (void)hipEventDestroy(ev_side2);
-        if (side) (void)hipStreamDestroy(side);
-        if (side2) (void)hipStreamDestroy(side2);
+        plk::stream_pool_release(side);
+        plk::stream_pool_release(side2);
     }
 };
 
@@ -383,8 +383,7 @@ int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, c
         cur += (p.bytes + 255) & ~(size_t)255;
     }
     PLK_HIP_TRY(hipHostMalloc((void**)&c->pin, 4 * pt + 64 + 2 * 32, hipHostMallocDefault));
-    PLK_HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-    PLK_HIP_TRY(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
+    if (!(c->side = stream_pool_acquire()) || !(c->side2 = stream_pool_acquire())) return PLK_ERR_HIP;
     PLK_HIP_TRY(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
     PLK_HIP_TRY(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
     PLK_HIP_TRY(hipEventCreateWithFlags(&c->ev_side2, hipEventDisableTiming));

@@ -1314,13 +1314,13 @@ struct plk_msm_ctx {
         for (MsmWork& w : ws) w.release();
         if (tail_stream) {
             (void)hipStreamSynchronize(tail_stream);
-            (void)hipStreamDestroy(tail_stream);
+            plk::stream_pool_release(tail_stream);
         }
         if (ev_tail) (void)hipEventDestroy(ev_tail);
         for (hipEvent_t e : ev_acc) (void)hipEventDestroy(e);
         for (hipStream_t st : fork_streams) {
             (void)hipStreamSynchronize(st);
-            (void)hipStreamDestroy(st);
+            plk::stream_pool_release(st);
         }
         for (auto* v : {&prof_sets, &prof_free})
             for (auto& set : *v)
@@ -1944,7 +1944,7 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
     // of lanes, and every slot a reduction workgroup takes sends part of that round into a second one.  Off unless asked for.
     static const bool pipeline_tails = getenv("PLK_MSM_TAIL_PIPELINE") != nullptr;
     if (pipeline_tails) {
-        if (!ctx->tail_stream) PLK_HIP_TRY(hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking));
+        if (!ctx->tail_stream && !(ctx->tail_stream = stream_pool_acquire())) return PLK_ERR_HIP;
         if (!ctx->ev_tail) PLK_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming));
         while (ctx->ev_acc.size() < group) {
             hipEvent_t e = nullptr;
@@ -1987,8 +1987,8 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
             ctx->ev_acc.push_back(e);
         }
         while (ctx->fork_streams.size() + 1 < group) {
-            hipStream_t st = nullptr;
-            PLK_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            hipStream_t st = stream_pool_acquire();
+            if (!st) return PLK_ERR_HIP;
             ctx->fork_streams.push_back(st);
         }
     }

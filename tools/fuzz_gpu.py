@@ -27,11 +27,12 @@ def mont(f, vals):
 
 
 def halo_case(rng):
-    """a whole inner-product argument behind the C ABI (plk_halo_*) against the oracle's composition, random freeze point"""
+    """a whole inner-product argument behind the C ABI (plk_halo_*) against the oracle's composition: random freeze point, plain or over
+    the caller's tables (stages of virtual rounds + 2^r-to-1 folds on the curves with the endomorphism)"""
     from plonky_amd import device as dev
     c = rng.choice([br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377])
     f = c.scalar
-    n = rng.choice([1, 2, 4, 8, 32, 128])
+    n = rng.choice([1, 2, 4, 8, 32, 128, 512])
     G = (c.gx, c.gy)
     pt = lambda P: np.array([c.base.mont_limbs(P[0]), c.base.mont_limbs(P[1])], dtype=np.uint64)
     g = ol.gen_bases(c.curve_id, n, pt(G), pt(br.ec_mul(c, rng.randrange(1, 1 << 40), G))).reshape(n, 2, c.base.n_limbs)
@@ -40,7 +41,23 @@ def halo_case(rng):
     rounds = n.bit_length() - 1
     us = ol.rand_field(f.field_id, rng.randrange(1 << 30), max(rounds, 1))
     bl = ol.rand_field(f.field_id, rng.randrange(1 << 30), 2 * max(rounds, 1))
-    arg = dev.HaloArgument(c.curve_id, dev.to_device(a), dev.to_device(b), dev.to_device(g), h, up, freeze_log=rng.choice([0, 1, 2, 3, 5]))
+    kw = {}
+    if rng.random() < 0.5:
+        # over the caller's commitment tables (plk_halo_begin_tabled_dev): extra generators behind halo_g, H / U inside them or beside
+        L = c.base.n_limbs
+        gens = [g]
+        extra = rng.choice([0, 0, 1, 3])
+        if extra:
+            gens.append(ol.gen_bases(c.curve_id, extra, h, up).reshape(extra, 2, L))
+        if rng.random() < 0.5:
+            ubase = br.ec_mul(c, rng.randrange(1, 1 << 40), G)
+            x_int = rng.randrange(1, f.p)
+            up = pt(br.ec_mul(c, x_int, ubase))
+            gens += [h.reshape(1, 2, L), pt(ubase).reshape(1, 2, L)]
+            kw = dict(h_index=n + extra, u_index=n + extra + 1, u_prime_scalar=np.array(f.mont_limbs(x_int), dtype=np.uint64))
+        kw["tables"] = dev.msm_precompute_dev(c.curve_id, dev.to_device(np.concatenate(gens)))
+        kw["lead_rounds"] = rng.choice([0, 1, 2, 3, 4])
+    arg = dev.HaloArgument(c.curve_id, dev.to_device(a), dev.to_device(b), dev.to_device(g), h, up, freeze_log=rng.choice([0, 1, 2, 3, 5]), **kw)
     gz = np.zeros(n, dtype=np.uint8)
     for j in range(rounds):
         lr, z = arg.round_lr(bl[2 * j], bl[2 * j + 1])

@@ -39,9 +39,11 @@ def main(fetch_db, write_db, log_n, out_path, mode="headline"):
         # --workload quotient: the vanishing points are FIVE launches per call (all instantiations of k_vanishing_points summed,
         # divided by the number of calls = dispatches / 5); the fold is one launch per call.  Both read wide coalesced streams
         # (16 bytes per lane from row-major tables / point arrays): FETCH_SIZE is doubled, as for the NTT pass kernel.
-        for short, per_call, note in (("k_vanishing_points", 5, "sum over the five launches of a call"), ("k_fold_pairs_glv", 1, "one launch per call")):
-            fk = [k for k in f if short in k]
-            wk = [k for k in w if short in k]
+        for short, pattern, per_call, note in (("k_vanishing_points", "k_vanishing_points", 5, "sum over the five launches of a call"),
+                                               ("k_fold_pairs_glv", "k_fold_pairs_glv", 1, "one launch per call"),
+                                               ("k_fold_multi_glv", "k_fold_multi", 3, "digits + preparation + main kernel of one call summed")):
+            fk = [k for k in f if pattern in k]
+            wk = [k for k in w if pattern in k]
             if not fk or not wk:
                 continue
             calls = sum(f[k][1] for k in fk) / per_call
