@@ -246,6 +246,52 @@ def test_fold_multi_matches_big_integers(c, r, n_out):
             assert oz[i] == 0 and tuple(from_mont_arr(c.base, out[i])) == acc, i
 
 
+def test_tabled_begin_rejects_what_it_cannot_use():
+    """plk_halo_begin_tabled_dev: a table-free context, tables of another curve, tables over fewer generators than the argument,
+    H / U positions inside halo_g, beyond the tables or equal - all PLK_ERR_INVALID_ARG with a text, nothing half-built."""
+    pytest.importorskip("torch")
+    from plonky_amd import device as dev
+    from plonky_amd.lib import PlonkyHipError
+    dev.init(0)
+    c = br.TWEEDLEDEE
+    n = 64
+    g, h, up, a, b, _ = _setup(c, n, 31)
+    L = c.base.n_limbs
+    more = ol.gen_bases(c.curve_id, 2, h, up).reshape(2, 2, L)
+    dg = dev.to_device(g)
+    args = (c.curve_id, dev.to_device(a), dev.to_device(b), dg, h, up)
+    full = dev.msm_precompute_dev(c.curve_id, dev.to_device(np.concatenate([g, more])))
+    x = np.array(c.scalar.mont_limbs(5), dtype=np.uint64)
+    with pytest.raises(PlonkyHipError, match="tabled context"):
+        dev.HaloArgument(*args, tables=dev.msm_precompute_dev(c.curve_id, dg, table_free=True))
+    with pytest.raises(PlonkyHipError, match="tabled context"):
+        dev.HaloArgument(*args, tables=dev.msm_precompute_dev(c.curve_id, dg[: n // 2].contiguous()))
+    g2 = _setup(br.TWEEDLEDUM, n, 31)[0]
+    with pytest.raises(PlonkyHipError, match="tabled context"):
+        dev.HaloArgument(*args, tables=dev.msm_precompute_dev(br.TWEEDLEDUM.curve_id, dev.to_device(g2)))
+    for hi, ui in ((n - 1, n), (n, n), (n, n + 2), (n + 5, n + 1)):
+        with pytest.raises(PlonkyHipError, match="generators"):
+            dev.HaloArgument(*args, tables=full, freeze_log=3, h_index=hi, u_index=ui, u_prime_scalar=x)
+    # ... and the same call with proper positions goes through
+    arg = dev.HaloArgument(*args, tables=full, freeze_log=3, h_index=n, u_index=n + 1, u_prime_scalar=x)
+    assert len(arg) == n and arg.frozen
+    arg.free()
+
+
+def test_fold_multi_rejects_bad_depths():
+    pytest.importorskip("torch")
+    import torch
+    from plonky_amd import device as dev, lib
+    from plonky_amd.lib import PlonkyHipError
+    dev.init(0)
+    c = br.TWEEDLEDEE
+    g = torch.zeros((32, 2, c.base.n_limbs), dtype=torch.int64, device="cuda")
+    for r in (0, 5):
+        sc = torch.zeros((1 << r, 4), dtype=torch.int64, device="cuda")
+        with pytest.raises(PlonkyHipError, match="1 <= r <= 4"):
+            dev.fold_generators_multi_dev(c.curve_id, g, sc, r)
+
+
 def test_fold_multi_needs_the_endomorphism():
     pytest.importorskip("torch")
     import torch

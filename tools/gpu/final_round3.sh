@@ -6,8 +6,10 @@ timeout 300 python tools/measure_ceilings.py $O > $O/ceilings.log 2>&1; tail -3 
 timeout 1200 python bench.py > $O/r03_bench.json 2> $O/r03_bench.err; python -c "
 import json; r=json.load(open('$O/r03_bench.json')); print('bench value', r['value'], 'ms/step', r['ms_per_step'], r['checks']); print(r['cpu_baseline'])" || tail -5 $O/r03_bench.err
 timeout 600 python bench.py --workload quotient --log-n 20 --steps 6 --warmup 2 > $O/r03_bench_quotient.json 2> $O/bench_quotient.err
-(echo "# python tools/ipa_probe.py 20 14 / 16 14 (1 x MI355X, final tree of round 3)"; timeout 600 python tools/ipa_probe.py 20 14 2>/dev/null; timeout 300 python tools/ipa_probe.py 16 14 2>/dev/null | head -1) > $O/r03_ipa.txt; head -3 $O/r03_ipa.txt
-(echo "# python tools/prover_pipeline_probe.py 17 / 20 (1 x MI355X, final tree of round 3)"; timeout 600 python tools/prover_pipeline_probe.py 17 2>/dev/null; timeout 600 python tools/prover_pipeline_probe.py 20 2>/dev/null) > $O/r03_pipeline.txt; tail -2 $O/r03_pipeline.txt
+(echo "# python tools/ipa_probe.py 20 14 tabled / 16 14 tabled (1 x MI355X, final tree of round 3): the plain argument, then the one over the prover's tables"; timeout 600 python tools/ipa_probe.py 20 14 tabled 2>/dev/null; timeout 300 python tools/ipa_probe.py 16 14 tabled 2>/dev/null | head -2) > $O/r03_ipa.txt; head -3 $O/r03_ipa.txt
+(echo "# python tools/prover_pipeline_probe.py 17 ipa / 20 ipa (1 x MI355X, final tree of round 3)"; timeout 600 python tools/prover_pipeline_probe.py 17 ipa 2>/dev/null; timeout 600 python tools/prover_pipeline_probe.py 20 ipa 2>/dev/null) > $O/r03_pipeline.txt; tail -3 $O/r03_pipeline.txt
+(export TMPDIR=/tmp; R=$PWD; cd /tmp; rm -rf $R/$O/pipa; rocprofv3 --kernel-trace --stats -d $R/$O/pipa -o ipa -- python $R/tools/ipa_probe.py 20 14 tabled > /dev/null 2>&1; cd $R
+ (echo "# rocprofv3 --kernel-trace --stats -- python tools/ipa_probe.py 20 14 tabled: three plain arguments and three over the prover's tables (2^20, 20 rounds each)"; python tools/rocpd_summary.py $(find $O/pipa -name "*.db" | head -1)) > $O/r03_ipa_kernels.txt 2>&1; rm -rf $O/pipa; head -8 $O/r03_ipa_kernels.txt | cut -c1-150)
 for N in 1 2 4 8; do
   timeout 300 python bench.py --workload commit9 --emulate-rank 0/$N --steps 10 --warmup 2 > $O/commit9_emu_$N.json 2> $O/commit9_emu_$N.err
   timeout 600 python bench.py --workload msm --shard --curve bls12_377 --log-n 22 --emulate-rank 0/$N --steps 5 --warmup 2 > $O/bls22_emu_$N.json 2> $O/bls22_emu_$N.err
