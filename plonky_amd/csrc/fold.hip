@@ -291,7 +291,9 @@ template <class C> __global__ void k_fold_digits(ScalarPair sp, const uint32_t* 
 // output of every round (n/2 + n/4 + ... chains instead of n/T): 47 % fewer field multiplications at r = 3.
 // Two kernels: k_fold_multi_prep writes, per input, Q and Q - phi(Q) as affine points in R'-form (pairs of inputs share an
 // inversion); k_fold_multi_glv streams them (64 coalesced bytes per addition) - a lane holds its accumulator and one operand,
-// not the 2 x 4 precomputed points of the pair kernel.
+// not the 2 x 4 precomputed points of the pair kernel.  Workgroups of ONE wave: at 2^16 outputs (one wave per SIMD on average) the waves
+// of two-wave workgroups were seen to share SIMDs while others idle - 2.85 ms against 1.82 ms for the 4-to-1 fold 2^18 -> 2^16
+// (tools/mul_latency.hip shows the same for a bare chain of doublings: 3.6 against 2.2 us per step).
 constexpr int FOLD_MULTI_MAX_LOG = 4;
 constexpr int FOLD_MULTI_MAX = 1 << FOLD_MULTI_MAX_LOG;
 struct MultiDigits {
@@ -345,7 +347,7 @@ template <class C> __global__ void __launch_bounds__(64) k_fold_multi_digits(con
 // input j of `count` (points first + j of g): pp[j] = the point, dp[j] = point - phi(point), affine, x then y, canonical R'-form words.
 // Lane l takes inputs l and l + ceil(count / 2): one inversion for both.  An identity input leaves its slots unwritten (never read).
 template <class C>
-__global__ void __launch_bounds__(128) k_fold_multi_prep(const uint4* __restrict__ g, const uint8_t* __restrict__ gz, size_t first, size_t count,
+__global__ void __launch_bounds__(64) k_fold_multi_prep(const uint4* __restrict__ g, const uint8_t* __restrict__ gz, size_t first, size_t count,
                                                          uint4* __restrict__ pp, uint4* __restrict__ dp) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
@@ -382,7 +384,7 @@ __global__ void __launch_bounds__(128) k_fold_multi_prep(const uint4* __restrict
 }
 
 template <class C>
-__global__ void __launch_bounds__(128) k_fold_multi_glv(const uint4* __restrict__ g, const uint8_t* __restrict__ gz, size_t n_out, int T,
+__global__ void __launch_bounds__(64) k_fold_multi_glv(const uint4* __restrict__ g, const uint8_t* __restrict__ gz, size_t n_out, int T,
                                                         const uint4* __restrict__ pp, const uint4* __restrict__ dp, const MultiDigits* __restrict__ dg,
                                                         uint4* __restrict__ out_xy, uint8_t* __restrict__ out_zero) {
     using FP = typename C::FP;
@@ -443,8 +445,8 @@ static int fold_multi_t(size_t n_out, int r_bits, const void* d_g, const void* d
         MultiDigits* dg = (MultiDigits*)(work + ((2 * count * PT + 255) & ~(size_t)255));
         k_fold_multi_digits<C><<<1, 64, 0, stream>>>((const uint32_t*)d_ratios, r_bits, dg);
         const size_t half = (count + 1) / 2;
-        k_fold_multi_prep<C><<<(unsigned)((half + 127) / 128), 128, 0, stream>>>((const uint4*)d_g, (const uint8_t*)d_gz, n_out, count, pp, dp);
-        k_fold_multi_glv<C><<<(unsigned)((n_out + 127) / 128), 128, 0, stream>>>((const uint4*)d_g, (const uint8_t*)d_gz, n_out, T, pp, dp, dg,
+        k_fold_multi_prep<C><<<(unsigned)((half + 63) / 64), 64, 0, stream>>>((const uint4*)d_g, (const uint8_t*)d_gz, n_out, count, pp, dp);
+        k_fold_multi_glv<C><<<(unsigned)((n_out + 63) / 64), 64, 0, stream>>>((const uint4*)d_g, (const uint8_t*)d_gz, n_out, T, pp, dp, dg,
                                                                                  (uint4*)d_out_xy, (uint8_t*)d_out_zero);
         hipError_t e = hipGetLastError();
         scratch_release(work, stream);

@@ -225,7 +225,7 @@ struct plk_halo_ctx {
     plk_msm_ctx* mT = nullptr;  // tables over [G^(f), H, U']
     uint8_t* pin = nullptr;     // pinned staging for the results that cross PCIe
     // a stage of virtual rounds: `virt_left` of `virt_total` still to come over the m0 generators the stage began with
-    unsigned virt_total = 0, virt_left = 0, stage_depth = 2, stage_min_log = 17;
+    unsigned virt_total = 0, virt_left = 0, stage_depth = 2, stage_min_log = 16;
     // first stage over the caller's tables (not owned)
     plk_msm_ctx* lead_ctx = nullptr;
     unsigned lead_rounds = 0;
@@ -298,9 +298,9 @@ static int halo_next_stage(plk_halo_ctx* c) {
     if (c->n <= fz) return halo_freeze(c);
     if (!c->endo) return PLK_OK;
     unsigned d = c->lead_ctx ? c->lead_rounds : c->stage_depth;
-    // A stage ends at the freezing length at the latest; over the explicit set it must leave 2^17 outputs: the 2^r-to-1 fold is one
-    // lane per output, and below two waves per SIMD its chain of loads and additions is slower than the pairwise folds it replaces
-    // (2^18 -> 2^16: 2.85 ms against 1.88 + 1.07, measured).
+    // A stage ends at the freezing length at the latest; over the explicit set it must leave 2^16 outputs: the 2^r-to-1 fold is one
+    // lane per output - a chain of ~320 point operations - and 2^16 -> 2^14 in one stage measured slower than the two rounds with
+    // pairwise folds it replaces (5.15 against 4.94 ms); 2^18 -> 2^16 pays (4.96 against 5.76 ms, with one-wave workgroups: fold.hip).
     const size_t floor_len = c->lead_ctx ? fz : (fz > ((size_t)1 << c->stage_min_log) ? fz : (size_t)1 << c->stage_min_log);
     while (d > 0 && (c->n >> d) < floor_len) --d;
     if (!c->lead_ctx && d < 2) return PLK_OK;  // a stage of one round is a round with a pairwise fold

@@ -569,6 +569,60 @@ template <class FP> PLK_DI XyzzZ<FP> xyzzz_load_raw(const uint4* src) {
     return r;
 }
 
+// Short generator lists (the frozen generators of an inner-product argument: 2^14 + 2 points): one lane per generator is a
+// dependency chain, and in k_msm_table a quarter of it is the inversion that brings every window back to affine before the next
+// c doublings.  Here the chain only doubles - c (windows - 1) doublings without a normalisation in between, every window's
+// XYZZ point parked in scratch memory - and a second kernel normalises all (window, generator) pairs side by side:
+// 1.75 -> 1.2 ms for 2^14 + 2 generators at c = 13 with a lane per generator, 0.65 ms on quads in one-wave workgroups (a chain of quad
+// doublings takes 3.6 us per step in two-wave workgroups at this occupancy, 2.2 us in one-wave ones: tools/mul_latency.hip).  Same points, so the same (unique) affine table entries.
+template <class C>
+__global__ void __launch_bounds__(64) k_msm_table_chain(const uint4* __restrict__ bases, const uint8_t* __restrict__ base_zero, uint4* __restrict__ tab,
+                                                         uint4* __restrict__ raw, size_t n, int c, int windows, size_t n_main, const uint4* __restrict__ extra) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    constexpr int RU = raw_u4<FP>();
+    // a quad per generator (ecz_coop.cuh): a doubling is 3 multiplications deep instead of 9
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const int ql = threadIdx.x & 3;
+    if (i >= n) return;
+    const uint4* src = i < n_main ? bases + i * 2 * W : extra + (i - n_main) * 2 * W;
+    const Fe<FP> xr = to_rprime<FP>(fe_load<FP>(src)), yr = to_rprime<FP>(fe_load<FP>(src + W));
+    const bool ident = (base_zero && i < n_main) ? base_zero[i] != 0 : false;
+    if (ql == 0) affine_store<FP>(tab + i * 2 * W, xr, yr, ident);
+    XyzzZ<FP> p = xyzzz_identity<FP>();
+    if (!ident) {
+        p.x = fz_from_fe<FP>(xr);
+        p.y = fz_from_fe<FP>(yr);
+        p.zz = fz_one_rprime<FP>();
+        p.zzz = p.zz;
+        p.inf = false;
+    }
+    for (int j = 1; j < windows; ++j) {
+        for (int k = 0; k < c; ++k) p = xyzzz_dbl_q<FP>(p, ql);
+        if (ql == 0) xyzzz_store_raw<FP>(raw + ((size_t)(j - 1) * n + i) * RU, p);
+    }
+}
+template <class C>
+__global__ void __launch_bounds__(64) k_msm_table_norm(const uint4* __restrict__ raw, uint4* __restrict__ tab, size_t n, int windows) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    constexpr int RU = raw_u4<FP>();
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)(windows - 1) * n) return;
+    const XyzzZ<FP> p = xyzzz_load_raw<FP>(raw + t * RU);
+    Fe<FP> xr = fe_zero<FP>(), yr = fe_zero<FP>();
+    if (!p.inf) {
+        // x = X / ZZ, y = Y / ZZZ with 1 / Z = ZZ / ZZZ (xyzz_to_affine, ec.cuh), all in R'-form
+        const Fe<FP> zzz_r = fz_to_fe_canonical<FP>(fz_mul<FP>(p.zzz, fz_const_rprime_to_r<FP>()));
+        const Fz<FP> i3 = fz_from_fe<FP>(to_rprime<FP>(fe_inv_safegcd<FP>(zzz_r)));
+        const Fz<FP> iz = fz_mul<FP>(p.zz, i3);
+        const Fz<FP> izz = fz_sqr<FP>(iz);
+        xr = fz_to_fe_canonical<FP>(fz_mul<FP>(p.x, izz));
+        yr = fz_to_fe_canonical<FP>(fz_mul<FP>(p.y, i3));
+    }
+    affine_store<FP>(tab + (n + t) * 2 * W, xr, yr, p.inf);   // entry (j, i) of the table sits at j n + i = n + t
+}
+
 // Head pieces are mostly short-lived: the head piece of lane l (closed at l's first bucket boundary) belongs to the last
 // bucket of lane l - 1, whose piece is still in registers when the loop ends.  Lanes therefore park a closed head piece in
 // LDS and their predecessor in the block adds it to its last piece before storing it: at c = 20 (26 entries per bucket,
@@ -971,6 +1025,8 @@ __global__ void __launch_bounds__(PLANE_THREADS) k_msm_planes(TailBatch tb, int 
 // (table-free mode) it doubles its window into place, 2^(c * window), and k_msm_combine adds the windows.
 constexpr int FINAL_FUSE_WINDOWS = 4;  // up to this many tail windows are added by the last block of k_msm_final itself
 constexpr int FINAL_THREADS = 512;  // <= 8 waves, so the compiler may use 256 VGPRs: the point arithmetic must not spill
+// (256-thread workgroups - one wave per SIMD - were measured for the planes and this kernel: the same 66 / 139 us at c = 20, and the
+// one-shot MSM with its 2 x 13 tail windows went from 2.8 to 4.4 ms)
 template <class C>
 __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int windows, int parts, int planes, int window_bits, int pair_shift) {
     using FP = typename C::FP;
@@ -1493,6 +1549,19 @@ template <class C> static void msm_launch_table(plk_msm_ctx* ctx, const void* d_
                                                 hipStream_t stream) {
     const size_t n = ctx->n;
     if (!n) return;
+    static const bool no_split = getenv("PLK_MSM_TABLE_FUSED") != nullptr;
+    if (!ctx->table_free && ctx->windows > 1 && n <= ((size_t)1 << 15) && !no_split) {
+        constexpr size_t RAW = (size_t)raw_u4<typename C::FP>() * 16;
+        const size_t entries = (size_t)(ctx->windows - 1) * n;
+        if (uint4* raw = (uint4*)scratch_acquire(entries * RAW, stream)) {
+            k_msm_table_chain<C><<<(unsigned)((4 * n + 63) / 64), 64, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)ctx->tab, raw, n,
+                                                                                 ctx->c, ctx->windows, n - n_extra, (const uint4*)d_extra);
+            k_msm_table_norm<C><<<(unsigned)((entries + 63) / 64), 64, 0, stream>>>(raw, (uint4*)ctx->tab, n, ctx->windows);
+            scratch_release(raw, stream);
+            return;
+        }
+        (void)hipGetLastError();  // no scratch memory: the fused kernel needs none
+    }
     k_msm_table<C><<<(unsigned)((n + 127) / 128), 128, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, (uint4*)ctx->tab, n, ctx->c,
                                                                    ctx->table_free ? 1 : ctx->windows, ctx->glv ? 1 : 0, n - n_extra, (const uint4*)d_extra);
 }

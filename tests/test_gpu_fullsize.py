@@ -61,6 +61,68 @@ def test_bls12_377_2p22_closed_form():
     pre.free()
 
 
+def test_halo_argument_2p20_two_routes_and_closed_form():
+    """The inner-product argument of one 2^20 opening (halo.rs:63-124) at BASELINE's size, twice: the plain
+    context (stage of two virtual rounds over the explicit generators, pairwise folds, frozen generators) and the one that starts over
+    the prover's commitment tables with pedersen_h and U inside them.  Every L_j / R_j and the final halo_a / halo_b / halo_g of the
+    two routes must agree bit for bit, and the final generator must be the closed form <s, G> = [sum s_i] G0 + [sum i s_i] D,
+    s_i = prod_j u_j^(+-1) by the bits of i (sum s_i = prod (u_j + u_j^-1); sum i s_i by the same product with one factor replaced)."""
+    torch = pytest.importorskip("torch")
+    from plonky_amd import device as dev
+    from plonky_amd.selfcheck import _add, _mul
+    dev.init(0)
+    c = br.TWEEDLEDEE
+    f = c.scalar
+    log_n = 20
+    n = 1 << log_n
+    p, r = c.base.p, f.p
+    G = (c.gx, c.gy)
+    kd = 0x51ED270B
+    D = br.ec_mul(c, kd, G)
+    gens = dev.gen_bases_dev(c.curve_id, n + 2, _pt(c, G), _pt(c, D))      # pedersen_g (n), pedersen_h, U
+    g = gens[:n].contiguous()
+    x_int = 0x1F3D5B79A2C4E6081F3D5B79A2C4E6081F3D5B79A2C4E608 % r
+    h_pt, u_pt = _pt(c, _mul(p, (1 + n * kd) % r, G)), _pt(c, _mul(p, x_int * (1 + (n + 1) * kd) % r, G))   # u_prime = [x] U
+    a, b = dev.to_device(synth.rand_field(f.field_id, 41, n)), dev.to_device(synth.rand_field(f.field_id, 42, n))
+    u_ints = [limbs_to_int(row) % r or 1 for row in synth.rand_field(f.field_id, 43, log_n)]
+    m = lambda v: np.array(f.mont_limbs(v), dtype=np.uint64)
+    us = [(m(u), m(pow(u, -1, r))) for u in u_ints]
+    bl = [(m(1000 + j), m(2000 + j)) for j in range(log_n)]
+    tables = dev.msm_precompute_dev(c.curve_id, gens)
+
+    def run(**kw):
+        arg = dev.HaloArgument(c.curve_id, a, b, g, h_pt, u_pt, **kw)
+        lrs = []
+        for j in range(log_n):
+            lrs.append(arg.round_lr(*bl[j]))
+            arg.round_fold(*us[j])
+        fin = arg.read()
+        arg.free()
+        return lrs, fin
+
+    plain_lr, plain_fin = run()
+    tab_lr, tab_fin = run(tables=tables, h_index=n, u_index=n + 1, u_prime_scalar=m(x_int))
+    for j, ((lr1, z1), (lr2, z2)) in enumerate(zip(plain_lr, tab_lr)):
+        assert np.array_equal(lr1, lr2) and np.array_equal(z1, z2) and not z1.any(), "round %d" % j
+    for x1, x2 in zip(plain_fin, tab_fin):
+        assert np.array_equal(x1, x2)
+    # closed form of the final generator: round j (j = 0 first) splits on bit log_n - 1 - j of the index; hi takes u_j, lo u_j^-1
+    inv = [pow(u, -1, r) for u in u_ints]
+    sum_s = 1
+    for u, ui in zip(u_ints, inv):
+        sum_s = sum_s * (u + ui) % r
+    sum_is = 0
+    for j, u in enumerate(u_ints):
+        term = (1 << (log_n - 1 - j)) * u % r
+        for k in range(log_n):
+            if k != j:
+                term = term * (u_ints[k] + inv[k]) % r
+        sum_is = (sum_is + term) % r
+    exp = _add(p, _mul(p, sum_s, G), _mul(p, sum_is * kd % r, G))
+    fa, fb, fg, fgz = tab_fin
+    assert int(fgz[0]) == 0 and tuple(from_mont_arr(c.base, fg[0])) == exp
+
+
 def test_sharded_msm_hip_nccl_world_size_1():
     """plonky_amd.parallel.msm_sharded_hip over the HIP path with backend nccl (= RCCL): base range of this rank, one packed
     all-gather, plk_curve_sum_affine.  One rank here; the CPU suite runs the same plumbing at world size 2 on gloo."""

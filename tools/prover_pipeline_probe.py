@@ -113,8 +113,13 @@ if WITH_IPA:
         t0 = time.perf_counter()
         arg = dev.HaloArgument(CURVE, halo_a, halo_b, g_only, Hm, Upm, tables=pre, h_index=n, u_index=n + 1, u_prime_scalar=m1(x_int))
         for j in range(log_n):
+            t1 = time.perf_counter()
             arg.round_lr(*bl[j])
+            t2 = time.perf_counter()
             arg.round_fold(*ums[j])
+            if os.environ.get("PROBE_ROUNDS"):
+                torch.cuda.synchronize()
+                print("    round at length %8d: L/R %.3f ms  fold %.3f ms" % (len(arg) * 2, (t2 - t1) * 1e3, (time.perf_counter() - t2) * 1e3))
         fin = arg.read()
         t = time.perf_counter() - t0
         arg.free()
