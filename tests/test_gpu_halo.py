@@ -246,6 +246,27 @@ def test_fold_multi_matches_big_integers(c, r, n_out):
             assert oz[i] == 0 and tuple(from_mont_arr(c.base, out[i])) == acc, i
 
 
+@pytest.mark.parametrize("c", [br.PALLAS, br.VESTA], ids=lambda c: c.name)
+def test_halo_argument_stages_on_pallas_and_vesta(c, monkeypatch):
+    """The two other curves with the endomorphism through the same stages: a tabled first stage with H / U inside the tables, a second
+    stage over the explicit generators (small stage floor), pairwise folds, frozen generators - against the oracle, round by round."""
+    pytest.importorskip("torch")
+    from plonky_amd import device as dev
+    dev.init(0)
+    monkeypatch.setenv("PLK_HALO_STAGE_MIN_LOG", "1")
+    n = 128
+    inputs, lrs, states, (fa, fb, fg, fgz) = _run_argument(c, n, 2, 7100, tabled=True, lead_rounds=2, extra_generators=1, inside=True)
+    exp_lrs, exp_states, (ea, eb, eg, egz) = _oracle_argument(c, inputs)
+    for j, ((lr, z), (elr, ez)) in enumerate(zip(lrs, exp_lrs)):
+        assert list(z) == list(ez) and np.array_equal(lr, elr), "round %d" % j
+    for j, ((frozen, got), exp) in enumerate(zip(states, exp_states)):
+        assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]), "halo_a / halo_b after round %d" % j
+        if not frozen:
+            assert np.array_equal(got[2], exp[2]) and np.array_equal(got[3], np.asarray(exp[3], dtype=np.uint8)), "halo_g after round %d" % j
+    assert np.array_equal(fa, ea) and np.array_equal(fb, eb)
+    assert np.array_equal(fgz, np.asarray(egz, dtype=np.uint8)) and np.array_equal(fg, eg)
+
+
 def test_tabled_begin_rejects_what_it_cannot_use():
     """plk_halo_begin_tabled_dev: a table-free context, tables of another curve, tables over fewer generators than the argument,
     H / U positions inside halo_g, beyond the tables or equal - all PLK_ERR_INVALID_ARG with a text, nothing half-built."""
