@@ -10,6 +10,8 @@ timeout 600 python bench.py --workload quotient --log-n 20 --steps 6 --warmup 2 
 (echo "# python tools/prover_pipeline_probe.py 17 ipa / 20 ipa (1 x MI355X, final tree of round 3)"; timeout 600 python tools/prover_pipeline_probe.py 17 ipa 2>/dev/null; timeout 600 python tools/prover_pipeline_probe.py 20 ipa 2>/dev/null) > $O/r03_pipeline.txt; tail -3 $O/r03_pipeline.txt
 (export TMPDIR=/tmp; R=$PWD; cd /tmp; rm -rf $R/$O/pipa; rocprofv3 --kernel-trace --stats -d $R/$O/pipa -o ipa -- python $R/tools/ipa_probe.py 20 14 tabled > /dev/null 2>&1; cd $R
  (echo "# rocprofv3 --kernel-trace --stats -- python tools/ipa_probe.py 20 14 tabled: three plain arguments and three over the prover's tables (2^20, 20 rounds each)"; python tools/rocpd_summary.py $(find $O/pipa -name "*.db" | head -1)) > $O/r03_ipa_kernels.txt 2>&1; rm -rf $O/pipa; head -8 $O/r03_ipa_kernels.txt | cut -c1-150)
+(export TMPDIR=/tmp; R=$PWD; cd /tmp; rm -rf $R/$O/ppipe; rocprofv3 --kernel-trace --stats -d $R/$O/ppipe -o pipe -- python $R/tools/prover_pipeline_probe.py 20 ipa > /dev/null 2>&1; cd $R
+ (echo "# rocprofv3 --kernel-trace --stats -- python tools/prover_pipeline_probe.py 20 ipa: every kernel of the hot path of a 2^20-gate proof (setup, two passes of the pipeline, two openings)"; python tools/rocpd_summary.py $(find $O/ppipe -name "*.db" | head -1)) > $O/r03_pipeline_kernels.txt 2>&1; rm -rf $O/ppipe; head -6 $O/r03_pipeline_kernels.txt | cut -c1-150)
 for N in 1 2 4 8; do
   timeout 300 python bench.py --workload commit9 --emulate-rank 0/$N --steps 10 --warmup 2 > $O/commit9_emu_$N.json 2> $O/commit9_emu_$N.err
   timeout 600 python bench.py --workload msm --shard --curve bls12_377 --log-n 22 --emulate-rank 0/$N --steps 5 --warmup 2 > $O/bls22_emu_$N.json 2> $O/bls22_emu_$N.err
