@@ -173,6 +173,7 @@ def parse_args(argv=None):
     ap.add_argument("--shard", action="store_true", help="--workload msm: strong scaling - ONE 2^log_n MSM, generators sharded by base range")
     ap.add_argument("--emulate-rank", default=None, metavar="r/N", help="run rank r's shard of the N-rank strong-scaling problem alone on one GPU")
     ap.add_argument("--same-device", action="store_true", help="all ranks on GPU 0, gloo backend (world-size-2 test on a one-GPU box)")
+    ap.add_argument("--no-parts", action="store_true", help="strong scaling: a rank's share of a sharded vector as a zero-padded full-length vector (round-3 start) instead of its base range")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--timed-only", action="store_true", help="run only the warm-up + timed region (for rocprofv3 --pmc passes)")
@@ -430,11 +431,17 @@ def run(args):
         oxy, oz = ex.out_xy, ex.out_zero
         exchange = world > 1 or shard_world > 1
 
+    # a rank that holds whole vectors AND a share of a sharded one passes the share with its base range (plk_msm_execute_parts_dev)
+    msm_parts = plan.parts(s) if (do_msm and plan is not None and plan.full_context and plan.sharded and not args.no_parts) else None
+
     def step():
         if do_ntt:
             dev.ntt_dev(NTT_FIELD, x, out=y)
         if do_msm:
-            dev.msm_execute_dev(pre, s, oxy, oz)
+            if msm_parts is not None:
+                dev.msm_execute_parts_dev(pre, msm_parts, oxy, oz)
+            else:
+                dev.msm_execute_dev(pre, s, oxy, oz)
             if exchange:
                 ex.gather()
                 ex.combine()

@@ -189,6 +189,14 @@ int plk_msm_execute_batch(plk_msm_ctx* ctx, unsigned batch, const uint64_t* cons
  * d_out_zero = batch bytes.  Asynchronous on `stream`. */
 int plk_msm_execute_dev(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero,
                         void* stream);
+/* The same batch when a vector only covers PART of the generators: result b = sum_{i < count[b]} scalars_b[i] * G[first[b] + i].
+ * first / count: host arrays of `batch` entries (first[b] + count[b] <= n); d_scalars: host array of `batch` DEVICE pointers
+ * (count[b] * 4 limbs each).  Tabled contexts only.  This is a rank's call in the multi-GPU split of a commitment batch
+ * (section "Multi-GPU" below): its whole vectors with (0, n), its share of a sharded vector with its base range; all vectors
+ * still share one reduction.  (Against the zero-padded full-length form of the same share it saves the ordering kernels n - count
+ * zero scalars to skip: 1 % of a rank's step at 8 ranks - zero scalars were cheap already - and the padded copy of the vector.) */
+int plk_msm_execute_parts_dev(plk_msm_ctx* ctx, unsigned batch, const uint64_t* first, const uint64_t* count, const void* const* d_scalars,
+                              void* d_out_xy, void* d_out_zero, void* stream);
 /* msm_parallel (curve_msm.rs:54-61): precompute + execute + free in one call. */
 int plk_msm(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, const uint64_t* scalars, uint64_t* out_xy,
             uint8_t* out_zero);

@@ -29,8 +29,13 @@ int field_op_impl(int field, int op, const uint64_t* a, const uint64_t* b, uint6
 int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, unsigned flags, hipStream_t stream,
                             plk_msm_ctx** out_ctx, const void* d_extra = nullptr, size_t n_extra = 0, const size_t* also_n = nullptr,
                             int also_count = 0);
+struct MsmParts {
+    const uint64_t* first;
+    const uint64_t* count;
+    const void* const* scalars;
+};
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
-                         hipEvent_t* ready = nullptr);
+                         hipEvent_t* ready = nullptr, const MsmParts* parts = nullptr);
 int msm_reserve_workspaces_impl(plk_msm_ctx* ctx, unsigned count, hipStream_t stream);
 int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void* d_zero, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_gen_bases_dev_impl(int curve, size_t n, uint64_t first, const void* d_g0d, void* d_out, hipStream_t stream);
@@ -755,6 +760,12 @@ unsigned plk_msm_ctx_window(const plk_msm_ctx* ctx) { return ctx ? msm_ctx_windo
 
 int plk_msm_execute_dev(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, void* stream) {
     return msm_execute_dev_impl(ctx, batch, d_scalars, n_scalars, d_out_xy, d_out_zero, as_stream(stream));
+}
+
+int plk_msm_execute_parts_dev(plk_msm_ctx* ctx, unsigned batch, const uint64_t* first, const uint64_t* count, const void* const* d_scalars, void* d_out_xy,
+                              void* d_out_zero, void* stream) {
+    MsmParts parts{first, count, d_scalars};
+    return msm_execute_dev_impl(ctx, batch, nullptr, 0, d_out_xy, d_out_zero, as_stream(stream), nullptr, &parts);
 }
 
 int plk_msm_execute_batch(plk_msm_ctx* ctx, unsigned batch, const uint64_t* const* scalars, size_t n_scalars, uint64_t* out_xy, uint8_t* out_zero) {

@@ -166,6 +166,8 @@ struct OrdCfg {
     uint32_t nt1;            // tiles
     int raw_signed;          // 1: the "scalars" are half scalars of a GLV split: canonical magnitude, sign in bit 255 (glv.cuh)
     uint32_t entries_cap;    // n_eff * windows: size of tmp[] / sorted[] and of the table (checked build)
+    uint32_t ent_stride;     // entry id of (window j, scalar i) = j * ent_stride + ent_first + i: the table index.  ent_stride = n_eff of the
+    uint32_t ent_first;      // context; ent_first > 0 when the scalars belong to generators first .. first + n - 1 only (plk_msm_execute_parts_dev)
 };
 
 template <class SP> PLK_DI void ord_park_scalar(const uint4* __restrict__ scalars, size_t i, uint32_t* s_lim, int tid, bool raw_signed) {
@@ -403,7 +405,7 @@ __global__ void __launch_bounds__(ORD_THREADS) k_ord_scatter(const uint4* __rest
                 const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
                 if (code != CODE_INVALID) {
                     const uint32_t slot = s_base[code >> (cfg.fine_bits + 1)] + s_rank[j * cfg.spt + tid];
-                    if (PLK_CHK(slot < (uint32_t)ORD_TILE, CHK_TILE_STAGE)) s_ent[slot] = make_uint2(code, (uint32_t)((size_t)j * n + i));
+                    if (PLK_CHK(slot < (uint32_t)ORD_TILE, CHK_TILE_STAGE)) s_ent[slot] = make_uint2(code, (uint32_t)((size_t)j * cfg.ent_stride + cfg.ent_first + i));
                 }
             }
         }
@@ -1701,6 +1703,8 @@ static int msm_configure(plk_msm_ctx* ctx, int curve, size_t n, unsigned window_
         if (o.nt1 == 0) o.nt1 = 1;
         o.raw_signed = glv ? 1 : 0;
         o.entries_cap = (uint32_t)(n_eff * (size_t)windows);
+        o.ent_stride = (uint32_t)n_eff;
+        o.ent_first = 0;
     }
     // tail geometry
     ctx->two_level = c - 1 >= 12;
@@ -1834,14 +1838,28 @@ static int msm_reduce_t(plk_msm_ctx* ctx, TailBatch tb, hipStream_t stream, Mark
     return PLK_OK;
 }
 
+// per-vector generator ranges of plk_msm_execute_parts_dev (host arrays of `batch` entries; scalars[b]: a device pointer)
+struct MsmParts {
+    const uint64_t* first;
+    const uint64_t* count;
+    const void* const* scalars;
+};
+
 // phases: 1 = bucket ordering, 2 = accumulation, 4 = reduction; 7 = the whole MSM on one stream
 constexpr int PH_ORDER = 1, PH_ACC = 2, PH_REDUCE = 4, PH_ALL = 7;
 template <class C>
 static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
-                         int phases = PH_ALL) {
-    const size_t n = ctx->n_eff;
+                         int phases = PH_ALL, size_t first = 0, size_t count = (size_t)-1) {
+    // count != -1: the scalars belong to generators first .. first + count - 1 (tabled contexts: the table index of an entry is its id)
+    const bool ranged = count != (size_t)-1;
+    const size_t n = ranged ? count : ctx->n_eff;
     const uint32_t buckets = ctx->buckets;
-    const OrdCfg& o = ctx->ord;
+    OrdCfg o = ctx->ord;
+    if (ranged) {
+        o.nt1 = (uint32_t)((n + (size_t)o.spt * o.sub - 1) / ((size_t)o.spt * o.sub));
+        if (o.nt1 == 0) o.nt1 = 1;
+        o.ent_first = (uint32_t)first;
+    }
     uint32_t* off = (uint32_t*)w.off;
     uint32_t* bin_total = (uint32_t*)w.meta;
     uint32_t* bin_base = bin_total + 1024;
@@ -1942,26 +1960,38 @@ static void work_done(MsmWork& w, hipStream_t stream) {
 // ready (optional): one event per scalar vector; vector b is not touched before ready[b] has completed (the host-pointer entry
 // point copies vector b + 1 through PCIe while vector b is being reduced)
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
-                         hipEvent_t* ready) {
+                         hipEvent_t* ready, const MsmParts* parts) {
     if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
-    if (n_scalars != ctx->n)
+    if (parts) {
+        // vector b: parts->count[b] scalars at parts->scalars[b] for the generators parts->first[b] .. (plk_msm_execute_parts_dev)
+        if (ctx->table_free) return set_error(PLK_ERR_INVALID_ARG, "a sub-range of the generators needs a tabled context");
+        if (!parts->first || !parts->count || !parts->scalars) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+        for (unsigned b = 0; b < batch; ++b) {
+            if (parts->first[b] > ctx->n || parts->count[b] > ctx->n - parts->first[b])
+                return set_error(PLK_ERR_SIZE_MISMATCH, "vector %u covers generators %llu .. +%llu but the precomputation holds %zu", b,
+                                 (unsigned long long)parts->first[b], (unsigned long long)parts->count[b], ctx->n);
+            if (parts->count[b] && !parts->scalars[b]) return set_error(PLK_ERR_INVALID_ARG, "null scalars in batch slot %u", b);
+        }
+    } else if (n_scalars != ctx->n) {
         return set_error(PLK_ERR_SIZE_MISMATCH, "scalars.len() = %zu but the precomputation holds %zu generators (curve_msm.rs:67)", n_scalars, ctx->n);
+    }
     if (batch == 0) return PLK_OK;
-    if ((ctx->n && !d_scalars) || !d_out_xy || !d_out_zero) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
+    if ((!parts && ctx->n && !d_scalars) || !d_out_xy || !d_out_zero) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
     PLK_TRY(ensure_device());
     std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t L = (size_t)curve_limbs(ctx->curve);
     auto run_one = [&](unsigned b, MsmWork& w, hipStream_t st, int phases) -> int {
         if (ready && (phases & PH_ORDER)) PLK_HIP_TRY(hipStreamWaitEvent(st, ready[b], 0));
-        const uint8_t* sc = (const uint8_t*)d_scalars + (size_t)b * ctx->n * 32;
+        const uint8_t* sc = parts ? (const uint8_t*)parts->scalars[b] : (const uint8_t*)d_scalars + (size_t)b * ctx->n * 32;
+        const size_t first = parts ? (size_t)parts->first[b] : 0, count = parts ? (size_t)parts->count[b] : (size_t)-1;
         uint8_t* oxy = (uint8_t*)d_out_xy + (size_t)b * 2 * L * 8;
         uint8_t* oz = (uint8_t*)d_out_zero + b;
         switch (ctx->curve) {
-            case PLK_CURVE_TWEEDLEDEE: return msm_execute_t<TweedledeeCurve>(ctx, w, sc, oxy, oz, st, phases);
-            case PLK_CURVE_TWEEDLEDUM: return msm_execute_t<TweedledumCurve>(ctx, w, sc, oxy, oz, st, phases);
-            case PLK_CURVE_PALLAS: return msm_execute_t<PallasCurve>(ctx, w, sc, oxy, oz, st, phases);
-            case PLK_CURVE_VESTA: return msm_execute_t<VestaCurve>(ctx, w, sc, oxy, oz, st, phases);
-            default: return msm_execute_t<Bls12377Curve>(ctx, w, sc, oxy, oz, st, phases);
+            case PLK_CURVE_TWEEDLEDEE: return msm_execute_t<TweedledeeCurve>(ctx, w, sc, oxy, oz, st, phases, first, count);
+            case PLK_CURVE_TWEEDLEDUM: return msm_execute_t<TweedledumCurve>(ctx, w, sc, oxy, oz, st, phases, first, count);
+            case PLK_CURVE_PALLAS: return msm_execute_t<PallasCurve>(ctx, w, sc, oxy, oz, st, phases, first, count);
+            case PLK_CURVE_VESTA: return msm_execute_t<VestaCurve>(ctx, w, sc, oxy, oz, st, phases, first, count);
+            default: return msm_execute_t<Bls12377Curve>(ctx, w, sc, oxy, oz, st, phases, first, count);
         }
     };
     static const bool no_batching = getenv("PLK_MSM_NO_OVERLAP") != nullptr;  // every MSM of a batch start to end, one by one

@@ -128,6 +128,26 @@ def msm_execute_dev(pre, scalars, out_xy=None, out_zero=None):
     return out_xy, out_zero
 
 
+def msm_execute_parts_dev(pre, parts, out_xy=None, out_zero=None):
+    """plk_msm_execute_parts_dev: parts = [(first, scalars)] with scalars an (count, 4) int64 CUDA tensor for the generators
+    first .. first + count - 1 of `pre` (a tabled precomputation).  One batched call, one shared reduction -> ((batch, 2, L), (batch,))."""
+    batch = len(parts)
+    L = _CURVE_LIMBS[pre.curve]
+    dev0 = parts[0][1].device
+    if out_xy is None:
+        out_xy = torch.empty((batch, 2, L), dtype=torch.int64, device=dev0)
+    if out_zero is None:
+        out_zero = torch.empty((batch,), dtype=torch.uint8, device=dev0)
+    first = np.array([p[0] for p in parts], dtype=np.uint64)
+    count = np.array([p[1].shape[0] for p in parts], dtype=np.uint64)
+    for _, t in parts:
+        assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.shape[-1] == 4
+    ptrs = (ctypes.c_void_p * batch)(*[p[1].data_ptr() for p in parts])
+    _lib.check(_lib.load().plk_msm_execute_parts_dev(pre._ctx, batch, first.ctypes.data_as(ctypes.c_void_p), count.ctypes.data_as(ctypes.c_void_p), ptrs,
+                                                     ctypes.c_void_p(out_xy.data_ptr()), ctypes.c_void_p(out_zero.data_ptr()), _stream()))
+    return out_xy, out_zero
+
+
 def vanishing_points_dev(field, log_degree, constants_8n, wire_values_8n, s_sigma_values_8n, plonk_z_points_8n, k_is, alpha, beta, gamma,
                          inner_zeta, inner_a, out=None):
     """Prover::vanishing_poly's 8n-point loop (plonk.rs:392-453) on device-resident tables: int64 CUDA tensors (6, 8n, 4),

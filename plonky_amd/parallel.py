@@ -59,6 +59,16 @@ class BatchPlan:
                 out[self.whole + j] = vectors[v, self.lo:self.hi]
         return out
 
+    def parts(self, local):
+        """local: this rank's (slots, n_local, 4) CUDA tensor (local_scalars) -> the (first, scalars) list of
+        device.msm_execute_parts_dev: whole vectors over all generators, sharded ones over their base range only (the slice of
+        the zero-padded row: the ordering kernels then read hi - lo scalars instead of n mostly zero ones)."""
+        out = [(0, local[k]) for k in range(self.whole)]
+        for j in range(self.sharded):
+            row = local[self.whole + j]
+            out.append((self.lo, row[self.lo:self.hi]) if self.full_context else (0, row))
+        return out
+
     def pairs_local(self):
         """scalar-point pairs this rank reduces per step"""
         return self.whole * self.n + self.sharded * (self.hi - self.lo)

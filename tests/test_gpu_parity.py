@@ -253,6 +253,39 @@ def test_msm_matches_oracle(c, n, win):
         got, gz = pa.msm_execute_parallel(pre_tf, scalars)  # the context is reusable
         assert gz == ez and np.array_equal(got, expected)
 
+@pytest.mark.parametrize("c", [br.TWEEDLEDEE, br.BLS12_377], ids=lambda c: c.name)
+def test_msm_execute_parts_matches_oracle(c):
+    """plk_msm_execute_parts_dev: vectors that cover only a sub-range of the precomputed generators (a rank's share of a sharded
+    commitment next to its whole vectors) - one batched call; every result against the oracle's MSM over exactly those generators.
+    Ranges at the start, in the middle, at the end, of length 0 and 1, and the whole list; errors for a range past the end and for
+    a table-free context."""
+    torch = pytest.importorskip("torch")
+    from plonky_amd import device as dev
+    from plonky_amd.lib import PlonkyHipError
+    dev.init(0)
+    n = 3000
+    G = (c.gx, c.gy)
+    pt = lambda P: np.array([c.base.mont_limbs(P[0]), c.base.mont_limbs(P[1])], dtype=np.uint64)
+    bases = ol.gen_bases(c.curve_id, n, pt(G), pt(br.ec_mul(c, 0x5150, G)))
+    pre = dev.msm_precompute_dev(c.curve_id, dev.to_device(bases.reshape(n, 2, -1)))
+    ranges = [(0, n), (0, 700), (1234, 1000), (n - 17, 17), (5, 0), (2999, 1), (0, n)]
+    vecs = [ol.rand_field(c.scalar.field_id, 900 + k, cnt) if cnt else np.zeros((0, 4), dtype=np.uint64) for k, (_, cnt) in enumerate(ranges)]
+    parts = [(first, dev.to_device(v).reshape(-1, 4)) for (first, _), v in zip(ranges, vecs)]
+    oxy, oz = dev.msm_execute_parts_dev(pre, parts)
+    got, gz = dev.to_host(oxy), oz.cpu().numpy()
+    for k, ((first, cnt), v) in enumerate(zip(ranges, vecs)):
+        if cnt == 0:
+            assert gz[k] == 1
+            continue
+        exp, ez = ol.MsmPrecomputation(c.curve_id, bases[first:first + cnt], 8, threads=8).execute(v, parallel=True, threads=8)
+        assert int(gz[k]) == ez and (ez or np.array_equal(got[k], exp)), (k, first, cnt)
+    with pytest.raises(PlonkyHipError, match="covers generators"):
+        dev.msm_execute_parts_dev(pre, [(n - 5, dev.to_device(vecs[1][:6]))])
+    tf = dev.msm_precompute_dev(c.curve_id, dev.to_device(bases.reshape(n, 2, -1)), table_free=True)
+    with pytest.raises(PlonkyHipError, match="tabled context"):
+        dev.msm_execute_parts_dev(tf, [(0, dev.to_device(vecs[1]))])
+
+
 
 def test_msm_parallel_one_shot():
     """msm_parallel (curve_msm.rs:54-61; the call of the IPA rounds, halo.rs:87-91, window 8 there): fresh generators,
