@@ -5,7 +5,8 @@
 //   * every thread: fft_with_precomputation_power_of_2 and its inverse on its own vector (round trip, bit exact), one
 //     msm_execute_parallel against the SHARED MsmPrecomputation, one msm_precompute + msm_execute + free of its own;
 //   * the results of the concurrent phase equal those of the same calls made one after the other;
-//   * linearity through the ABI: msm(s0 + s1) = msm(s0) + msm(s1)  (plk_field_op add in the scalar field, plk_curve_sum_affine).
+//   * linearity through the ABI: msm(s0 + s1) = msm(s0) + msm(s1)  (plk_field_op add in the scalar field, plk_curve_sum_affine);
+//   * one inner-product argument (plk_halo_*): its first L / R against one-shot MSMs, its final vectors against plain sums.
 // Generators are real curve points made through the ABI itself: [2^j] G from plk_msm_precompute_table, spread by
 // plk_curve_fold_pairs.  Exit code 0 and the line "capi_host: OK" on success.
 #include <cstdint>
@@ -144,6 +145,68 @@ int main() {
     if (plk_msm_execute(shared, s01.data(), n - 1, lhs, &lz) != PLK_ERR_SIZE_MISMATCH) {
         std::fprintf(stderr, "length mismatch not reported\n");
         return 1;
+    }
+    // the inner-product argument (halo.rs:63-124) through the ABI, checked through the ABI: halo_b = 0 makes both inner products 0, so
+    // L_1 = <a_lo, G_hi> + [l] H and R_1 = <a_hi, G_lo> + [r] H are one-shot plk_msm calls; with the challenges u_j = 1 the folds are sums:
+    // final halo_a = sum a_i (plk_field_op add, halving), final halo_g = sum G_i (plk_curve_sum_affine).  2048 generators, frozen below 2^8.
+    {
+        const size_t nh = 2048, half = nh / 2;
+        std::vector<uint64_t> ha, hb(nh * 4, 0), one_c(4, 0), one(4);
+        rand_elems(ha, nh, 0x1A10);
+        one_c[0] = 1;
+        CHECK(plk_field_op(SCALAR, 7, one_c.data(), nullptr, one.data(), 1));  // 1 in Montgomery form
+        const uint64_t* H = bases.data() + nh * 8;         // two more valid points of the list
+        const uint64_t* U = bases.data() + (nh + 1) * 8;
+        plk_halo_ctx* hc = nullptr;
+        CHECK(plk_halo_begin(CURVE, nh, ha.data(), hb.data(), bases.data(), nullptr, H, U, 8, &hc));
+        uint64_t lr[16], lbl[4], rbl[4];
+        uint8_t lrz[2];
+        uint64_t seed = 77;
+        for (int k = 0; k < 4; ++k) {
+            lbl[k] = splitmix(seed);
+            rbl[k] = splitmix(seed);
+        }
+        lbl[3] &= 0x3FFFFFFFFFFFFFFFull;
+        rbl[3] &= 0x3FFFFFFFFFFFFFFFull;
+        CHECK(plk_halo_round_lr(hc, lbl, rbl, lr, lrz));
+        // the same two points by msm_parallel over [half of G, H]
+        std::vector<uint64_t> pts((half + 1) * 8), sc((half + 1) * 4);
+        uint64_t want[8];
+        uint8_t wz = 0;
+        for (int side = 0; side < 2; ++side) {
+            std::memcpy(pts.data(), bases.data() + (side == 0 ? half : 0) * 8, half * 64);           // L: G_hi, R: G_lo
+            std::memcpy(pts.data() + half * 8, H, 64);
+            std::memcpy(sc.data(), ha.data() + (side == 0 ? 0 : half) * 4, half * 32);              // L: a_lo, R: a_hi
+            std::memcpy(sc.data() + half * 4, side == 0 ? lbl : rbl, 32);
+            CHECK(plk_msm(CURVE, half + 1, pts.data(), nullptr, sc.data(), want, &wz));
+            if (wz != lrz[side] || std::memcmp(want, lr + 8 * side, 64)) {
+                std::fprintf(stderr, "halo: %s_1 differs from the one-shot MSM\n", side == 0 ? "L" : "R");
+                return 1;
+            }
+        }
+        size_t len = nh;
+        while (len > 1) {
+            if (len != nh) CHECK(plk_halo_round_lr(hc, lbl, rbl, lr, lrz));
+            CHECK(plk_halo_round_fold(hc, one.data(), one.data()));
+            len /= 2;
+            if (plk_halo_len(hc) != len) {
+                std::fprintf(stderr, "halo: length %zu after a fold, expected %zu\n", plk_halo_len(hc), len);
+                return 1;
+            }
+        }
+        uint64_t a0[4], b0[4], g0[8], a_sum[4], g_sum[8];
+        uint8_t gz0 = 0, gsz = 0;
+        CHECK(plk_halo_read(hc, a0, b0, g0, &gz0));
+        CHECK(plk_halo_free(hc));
+        std::vector<uint64_t> acc(ha);
+        for (size_t l = nh / 2; l >= 1; l /= 2) CHECK(plk_field_op(SCALAR, 0, acc.data(), acc.data() + l * 4, acc.data(), l));  // pairwise sums, in place
+        std::memcpy(a_sum, acc.data(), 32);
+        CHECK(plk_curve_sum_affine(CURVE, nh, bases.data(), nullptr, g_sum, &gsz));
+        const uint64_t zero4[4] = {0, 0, 0, 0};
+        if (std::memcmp(a0, a_sum, 32) || std::memcmp(b0, zero4, 32) || gz0 != gsz || std::memcmp(g0, g_sum, 64)) {
+            std::fprintf(stderr, "halo: the final vectors differ from the sums\n");
+            return 1;
+        }
     }
     plk_msm_free(shared);
     plk_shutdown();
