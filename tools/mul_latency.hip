@@ -3,6 +3,7 @@
 //         accumulators (below) - no difference: a lone wave issues dependent v_mad_u64_u32 back to back;
 //   THR   the same two at 1, 2, 4 waves per SIMD;
 //   DBL   a chain of point doublings, one lane (xyzzz_dbl) against a quad (xyzzz_dbl_q);
+//   OVER  1024, 1025, ... one-wave workgroups: the 1025th wave shares a SIMD and every step of the chain takes 3.6 instead of 2.2 us;
 //   PLACE the same 1024 waves as workgroups of 1 .. 16 waves: with this small kernel two-wave workgroups run 1.6x slower than one- or
 //         four-wave ones (their waves share SIMDs); the library's kernels did not change when their workgroups were resized accordingly
 //         (fold, table, row / column sums, accumulation: all within noise) - their register use already spreads them.
@@ -136,6 +137,14 @@ int main() {
         hipEventRecord(e0); hipLaunchKernelGGL((k_dbl<TweedledeeBaseParams, 1>), dim3(blocks), dim3(threads), 0, 0, d, 12345u); hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("PLACE 1024 waves as %d workgroups of %d threads: quad doubling %.2f us\n", blocks, threads, ms * 1e3 / 200);
+    }
+    // one wave more than there are SIMDs (the frozen tables of an IPA: 2^14 + 2 generators = 1025 waves of quads)
+    for (int blocks : {1024, 1025, 1088, 1280, 1536}) {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL((k_dbl<TweedledeeBaseParams, 1>), dim3(blocks), dim3(64), 0, 0, d, 12345u); hipDeviceSynchronize();
+        hipEventRecord(e0); hipLaunchKernelGGL((k_dbl<TweedledeeBaseParams, 1>), dim3(blocks), dim3(64), 0, 0, d, 12345u); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("OVER %d one-wave workgroups: quad doubling %.2f us\n", blocks, ms * 1e3 / 200);
     }
     for (int blocks : {1, 512, 1024, 2048}) {
         const float t0 = run_dbl<TweedledeeBaseParams, 0>(d, blocks, 128), t1 = run_dbl<TweedledeeBaseParams, 1>(d, blocks, 128);
