@@ -137,6 +137,36 @@ def test_partial_exchange_record_layout_world_size_2_gloo():
         assert list(z[r]) == [(r + k) % 2 for k in range(batch)]
 
 
+def test_batch_plan_parts_cover_every_pair_once():
+    """parallel.BatchPlan: whole vectors per rank + the remainder sharded by base range; the (first, scalars) parts a rank hands to
+    plk_msm_execute_parts_dev are exactly its whole vectors and its slice of every sharded one - over all ranks every
+    (vector, generator) pair appears once, and the slices are views of the rank's local array (no copy)."""
+    import numpy as np
+    import torch
+    from plonky_amd import parallel
+    for batch, world, n in ((9, 8, 64), (9, 4, 50), (9, 2, 33), (1, 4, 40), (3, 3, 17), (5, 8, 16)):
+        vectors = np.arange(batch * n * 4, dtype=np.uint64).reshape(batch, n, 4) + 1
+        seen = np.zeros((batch, n), dtype=np.int64)
+        for rank in range(world):
+            plan = parallel.BatchPlan(batch, world, rank, n)
+            local = torch.from_numpy(plan.local_scalars(vectors).view(np.int64))
+            parts = plan.parts(local)
+            assert len(parts) == plan.slots
+            for k, (first, sc) in enumerate(parts):
+                v = plan.own[k] if k < plan.whole else plan.rem[k - plan.whole]
+                cnt = sc.shape[0]
+                if plan.full_context:
+                    assert (first, cnt) == ((0, n) if k < plan.whole else (plan.lo, plan.hi - plan.lo))
+                    assert sc.data_ptr() == local[k, first:].data_ptr()       # a view into the rank's array
+                    g0 = first
+                else:
+                    assert first == 0 and cnt == plan.n_local                 # the context itself only holds the rank's base range
+                    g0 = plan.lo
+                assert np.array_equal(sc.numpy().view(np.uint64), vectors[v, g0:g0 + cnt])
+                seen[v, g0:g0 + cnt] += 1
+        assert (seen == 1).all(), (batch, world, n)
+
+
 def test_bench_without_gpus_fails_loudly():
     """`python bench.py --gpus 2` as the driver types it: no assert on WORLD_SIZE - it spawns its ranks itself, and on a box
     without GPUs it exits non-zero naming the missing devices (there is no CPU path)."""
