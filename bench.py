@@ -41,9 +41,16 @@ LOG_N = 20
 SEED_NTT = 0xF70020
 SEED_MSM = 0x350020
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
-# integer-ALU ceilings are read from profiles/r03_field_op_costs.json (tools/bench_field.hip on this round's arithmetic headers,
+# integer-ALU ceilings are read from the newest profiles/rNN_field_op_costs.json (tools/bench_field.hip on this round's arithmetic headers,
 # tagged with the hash of those headers): fz_mul at 4 waves / SIMD per field and the raw v_mad_u64_u32 issue rate
-CEILINGS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_field_op_costs.json")
+def latest_profile(suffix):
+    """profiles/rNN_<suffix> of the highest round present (the files are named per round)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_" + suffix)))
+    return found[-1] if found else os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r00_" + suffix)
+
+
+CEILINGS_FILE = latest_profile("field_op_costs.json")
 MADS_PER_MODMUL = {4: 126, 6: 294}   # v_mad_u64_u32 per fz_mul: 9 limbs 81 + 45, 14 limbs 196 + 98 (fz.cuh)
 CURVES = {"tweedledee": dict(curve=0, ntt_field=0, scalar_field=1, base_field=0, limbs=4, scalar_bits=255, pair_bytes=96),
           "bls12_377": dict(curve=2, ntt_field=2, scalar_field=2, base_field=3, limbs=6, scalar_bits=253, pair_bytes=128)}
@@ -162,6 +169,95 @@ def cpu_baseline(workload, cv):
     return out
 
 
+def gpu_identity(torch, index):
+    """Which physical GPU a number comes from and what its clocks were: a 5-10 % kernel difference between two leases cannot be
+    told from box-to-box spread without it (round-3 review).  uuid from the HIP runtime; clocks / serial from rocm-smi when present."""
+    import subprocess
+    info = {}
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        info.update(name=pr.name, uuid=str(getattr(pr, "uuid", "")), cus=pr.multi_processor_count, hbm_gib=round(pr.total_memory / 2 ** 30, 1))
+    except Exception as e:  # noqa: BLE001
+        info["error"] = str(e)
+    try:
+        out = subprocess.run(["rocm-smi", "-d", str(index), "--showuniqueid", "--showserial", "--showclocks", "--showperflevel", "--showpower"],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=30).stdout
+        for line in out.splitlines():
+            low = line.lower()
+            for key, tag in (("unique id", "unique_id"), ("serial number", "serial"), ("sclk clock level", "sclk"), ("mclk clock level", "mclk"),
+                             ("performance level", "perf_level"), ("average graphics package power", "power_w"), ("current socket graphics package power", "power_w")):
+                if key in low and tag not in info:
+                    info[tag] = line.split(":")[-1].strip()
+    except Exception:  # noqa: BLE001
+        pass
+    return info
+
+
+def strong_case(curve_name, log_n, batch, world, rank, steps, warmup, gloo, solo):
+    """One STRONG-scaling problem - `batch` scalar vectors of 2^log_n against the same 2^log_n generators, split over `world` ranks
+    by parallel.BatchPlan (whole vectors + a base-range-sharded remainder; batch 1: the sharded case alone) - set up, timed for
+    `steps` steps after `warmup` and checked against the closed form of the WHOLE problem.  solo: this process runs the whole
+    problem alone as the world = 1 form (rank 0 measuring T_1 inside a multi-rank run; the other ranks wait at the caller's barrier).
+    Returns {"ms": per step (this rank), "ok": bool}.  BASELINE configs 4 (commit9) and 5 (one 2^22 BLS12-377 G1 MSM)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from plonky_amd import device as dev, parallel, synth
+    from plonky_amd.selfcheck import GENERATORS, closed_form_msm, _mul
+    from plonky_amd.synth import MODULI
+    cv = CURVES[curve_name]
+    CURVE = cv["curve"]
+    n = 1 << log_n
+    w_, r_ = (1, 0) if solo else (world, rank)
+    p = MODULI[cv["base_field"]]
+    G = GENERATORS[CURVE]
+    D = _mul(p, synth.to_int(synth.rand_field(cv["scalar_field"], SEED_MSM, 1)[0]) % MODULI[cv["scalar_field"]], G)
+    g0 = np.stack([synth.mont(cv["base_field"], G[0]), synth.mont(cv["base_field"], G[1])])
+    dd = np.stack([synth.mont(cv["base_field"], D[0]), synth.mont(cv["base_field"], D[1])])
+    plan = parallel.BatchPlan(batch, w_, r_, n)
+    s_host = np.stack([synth.rand_field(cv["scalar_field"], SEED_MSM + 0x900 + k, n) for k in range(batch)])
+    s = dev.to_device(plan.local_scalars(s_host))
+    bases = dev.gen_bases_dev(CURVE, plan.n_local, g0, dd, first=plan.first)
+    pre = dev.msm_precompute_dev(CURVE, bases)
+    ex = parallel.PartialExchange(CURVE, batch, "cuda", whole_per_rank=plan.whole, world=w_, rank=r_, solo=solo)
+    parts = plan.parts(s) if (plan.full_context and plan.sharded) else None
+
+    def step():
+        if parts is not None:
+            dev.msm_execute_parts_dev(pre, parts, ex.out_xy, ex.out_zero)
+        else:
+            dev.msm_execute_dev(pre, s, ex.out_xy, ex.out_zero)
+        ex.gather()
+        return ex.combine()
+
+    def sync():
+        torch.cuda.synchronize()
+        if not solo and world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gxy, gz = step()
+    sync()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    if not solo and world > 1:
+        t = torch.tensor([ms], dtype=torch.float64, device="cpu" if gloo else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+    got, gzh = dev.to_host(gxy), gz.cpu().numpy()
+    ok = not gzh.any()
+    for v in range(batch):
+        ok = ok and (synth.from_mont(cv["base_field"], got[v][0]), synth.from_mont(cv["base_field"], got[v][1])) == closed_form_msm(CURVE, s_host[v], G, D, first=0)
+    pre.free()
+    del bases, s, ex
+    torch.cuda.empty_cache()
+    return {"ms": ms, "ok": bool(ok)}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +273,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--timed-only", action="store_true", help="run only the warm-up + timed region (for rocprofv3 --pmc passes)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N GPUs from ONE process through the host-pointer C ABI (plk_init_devices: what an untouched plonk.rs gets): commit9, one sharded MSM and "
+                         "a transform batch over --gpus N devices against the same calls on one device")
+    ap.add_argument("--virtual-devices", action="store_true", help="--single-process on a box with fewer GPUs: PLK_VIRTUAL_DEVICES logical devices on GPU 0")
     return ap.parse_args(argv)
 
 
@@ -209,9 +309,101 @@ def spawn_ranks(args, argv):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
+    if args.single_process:
+        return run_single_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args, argv)
     return run(args)
+
+
+def single_process_case(L, lib, n_devices, log_n, reps, virtual=False):
+    """The in-library multi-GPU path (plonky_amd/csrc/multi.hip) through the HOST-POINTER entry points - exactly what an untouched
+    plonk.rs / poly_commit.rs reaches through the shim of INTEGRATION.md: plk_msm_precompute once, then per step nine commitments
+    in one plk_msm_execute_batch (BASELINE config 4), one plk_msm_execute (a single MSM, sharded by base range) and nine transforms
+    in one plk_ntt_batch; PCIe is inside every number.  Runs the same calls on ONE device first (plk_init) and then on the group
+    (plk_init_devices(n_devices)); results must agree bit for bit.  Returns the timings of both and their ratios."""
+    import ctypes
+    import numpy as np
+    from plonky_amd import api, synth
+    from plonky_amd.selfcheck import GENERATORS, _mul
+    from plonky_amd.synth import MODULI
+    vp = ctypes.c_void_p
+    n = 1 << log_n
+    p = MODULI[0]
+    G = GENERATORS[0]
+    D = _mul(p, 0x51761E, G)
+    # generators as HOST data (the reference's pedersen_g): G + i D built by the device once, read back
+    g0 = np.stack([synth.mont(0, G[0]), synth.mont(0, G[1])])
+    dd = np.stack([synth.mont(0, D[0]), synth.mont(0, D[1])])
+    lib.check(L.plk_init(0))
+    import torch
+    from plonky_amd import device as dev
+    bases = dev.to_host(dev.gen_bases_dev(0, n, g0, dd)).reshape(n, 2, 4).copy()
+    vecs = [np.ascontiguousarray(synth.rand_field(1, SEED_MSM + 0x900 + k, n)) for k in range(9)]
+    polys = [np.ascontiguousarray(synth.rand_field(0, SEED_NTT + k, n)) for k in range(9)]
+    outs = [np.zeros_like(polys[0]) for _ in range(9)]
+    sptr = (vp * 9)(*[a.ctypes.data for a in vecs])
+    iptr = (vp * 9)(*[a.ctypes.data for a in polys])
+    optr = (vp * 9)(*[a.ctypes.data for a in outs])
+
+    def measure():
+        ctx = vp()
+        t0 = time.perf_counter()
+        lib.check(L.plk_msm_precompute(0, n, vp(bases.ctypes.data), None, 0, ctypes.byref(ctx)))
+        t_pre = (time.perf_counter() - t0) * 1e3
+        xy9, z9 = np.zeros((9, 2, 4), dtype=np.uint64), np.zeros(9, dtype=np.uint8)
+        xy1, z1 = np.zeros((2, 4), dtype=np.uint64), np.zeros(1, dtype=np.uint8)
+        res = {"precompute_ms": t_pre}
+        for name, fn in (("commit9_ms", lambda: lib.check(L.plk_msm_execute_batch(ctx, 9, sptr, n, vp(xy9.ctypes.data), vp(z9.ctypes.data)))),
+                         ("msm_single_ms", lambda: lib.check(L.plk_msm_execute(ctx, vp(vecs[4].ctypes.data), n, vp(xy1.ctypes.data), vp(z1.ctypes.data)))),
+                         ("ntt9_ms", lambda: lib.check(L.plk_ntt_batch(0, log_n, 0, 9, iptr, optr)))):
+            fn()
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            res[name] = (time.perf_counter() - t0) / reps * 1e3
+        lib.check(L.plk_msm_free(ctx))
+        return res, (xy9.copy(), z9.copy(), xy1.copy(), z1.copy(), [o.copy() for o in outs])
+
+    one, r_one = measure()
+    L.plk_shutdown()
+    if virtual:
+        os.environ["PLK_VIRTUAL_DEVICES"] = str(n_devices)
+    lib.check(L.plk_init_devices(n_devices))
+    assert int(L.plk_device_count()) == n_devices
+    grp, r_grp = measure()
+    L.plk_shutdown()
+    same = (np.array_equal(r_one[0], r_grp[0]) and np.array_equal(r_one[1], r_grp[1]) and np.array_equal(r_one[2], r_grp[2]) and np.array_equal(r_one[3], r_grp[3])
+            and all(np.array_equal(a, b) for a, b in zip(r_one[4], r_grp[4])) and np.array_equal(r_grp[2], r_grp[0][4]) and not r_grp[1].any())
+    out = {"devices": n_devices, "virtual": bool(virtual), "log_n": log_n, "one_device": one, "group": grp, "bit_identical_to_one_device": bool(same),
+           "note": "host-pointer C ABI (pageable numpy buffers, PCIe inside): plk_msm_execute_batch of nine 2^log_n vectors, one plk_msm_execute, "
+                   "plk_ntt_batch of nine transforms; efficiency = T_one_device / (N T_group)"}
+    for k in ("commit9_ms", "msm_single_ms", "ntt9_ms"):
+        out["efficiency_" + k[:-3]] = one[k] / (n_devices * grp[k])
+    return out
+
+
+def run_single_process(args):
+    """python bench.py --gpus N --single-process [--virtual-devices]: ONE JSON line for the in-library multi-GPU path."""
+    import torch
+    from plonky_amd import lib
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    have = torch.cuda.device_count()
+    virtual = args.virtual_devices or have < args.gpus
+    L = lib.load()
+    r = single_process_case(L, lib, args.gpus, args.log_n, max(2, args.steps // 4), virtual)
+    pairs = 9 * (1 << args.log_n)
+    result = {"metric": "MSM Mpairs/sec + NTT Melems/sec, 2^20 Tweedledee, 1/2/4/8 GPU", "value": pairs / (r["group"]["commit9_ms"] * 1e-3) / 1e6,
+              "unit": "M pairs/s of the nine-vector commitment batch from HOST memory (PCIe inside), one process, %d devices" % args.gpus,
+              "n_gpus": args.gpus, "steps": max(2, args.steps // 4), "warmup": 2, "ms_per_step": r["group"]["commit9_ms"], "higher_is_better": True,
+              "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+              "config": {"workload": "single process, plk_init_devices(%d)%s: nine 2^%d-pair commitments per step through plk_msm_execute_batch (host pointers)"
+                                     % (args.gpus, " on virtual devices of GPU 0" if virtual else "", args.log_n), "log_n": args.log_n, "curve": "tweedledee",
+                         "gpu": gpu_identity(torch, 0)},
+              "components": r, "checks": {"bit_identical_to_one_device": r["bit_identical_to_one_device"]}}
+    print(json.dumps(result), flush=True)
+    assert r["bit_identical_to_one_device"]
 
 
 def run_quotient(args):
@@ -301,7 +493,7 @@ def run_quotient(args):
     mad_peak = ceil.get("mad_u64_u32_glaneops") if ceil_ok else None
     pmc = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_quotient.json")) as fh:
+        with open(latest_profile("pmc_traffic_quotient.json")) as fh:
             pmc = json.load(fh)
     except (OSError, ValueError):
         pass
@@ -456,16 +648,7 @@ def run(args):
         step()
     sync()
 
-    # per-kernel durations for the roofline: HIP events on the launch stream around each kernel, live in the timed region.
-    # A batched MSM (commit9) shares ONE reduction among its vectors, which the per-stage events would split up: its stage
-    # times are taken in a separate profiled pass after the timed region instead.
-    msm_live_profile = do_msm and batch == 1
-    if do_ntt:
-        L.plk_ntt_get_timings(None, None)
-        L.plk_ntt_set_profiling(1)
-    if msm_live_profile:
-        L.plk_msm_set_profiling(pre._ctx, 1)
-
+    # ---- the timed region: EXACTLY K steps, nothing of the harness inside (no per-kernel events) ----
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -476,6 +659,23 @@ def run(args):
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- the same K steps once more with HIP events on the launch stream around each kernel: the durations the rooflines use.
+    # The events cost launches of their own (8 per MSM, 2 per NTT pass): this region is reported as ms_per_step_profiled, never as
+    # the headline.  A batched MSM (commit9) shares ONE reduction among its vectors, which the per-stage events would split up:
+    # its stage times come from single executions further down.
+    msm_live_profile = do_msm and batch == 1
+    if do_ntt:
+        L.plk_ntt_get_timings(None, None)
+        L.plk_ntt_set_profiling(1)
+    if msm_live_profile:
+        L.plk_msm_set_profiling(pre._ctx, 1)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed_profiled = time.perf_counter() - t0
 
     ntt_kernel_ms = msm_stage_ms = None
     ntt_launches = 0
@@ -592,6 +792,43 @@ def run(args):
         comp["msm_parallel_one_shot_ms"] = (time.perf_counter() - t1) / reps * 1e3
         if not args.no_check:
             comp["_os_check"] = bool(torch.equal(oxy9[:1], oxy) and int(oz9[0].item()) == 0)
+    # ---- the opening argument of the same proof (halo.rs:63-124): all log2(n) rounds behind the C ABI, over
+    # the prover's commitment tables [pedersen_g .., pedersen_h, U] (plk_halo_begin_tabled_dev), full-size challenges ----
+    if do_msm_c and not strong and world == 1 and args.curve == "tweedledee" and args.log_n >= 12:
+        SCAL = cv["scalar_field"]
+        r_mod = MODULI[SCAL]
+        mm = lambda f, v: np.array(synth.mont(f, v), dtype=np.uint64)
+        pt = lambda P: np.stack([mm(cv["base_field"], P[0]), mm(cv["base_field"], P[1])])
+        x_int = 0x1F3D5B79A2C4E6081F3D5B79A2C4E6081F3D5B79A2C4E608 % r_mod
+        UB = _mul(p, 13, G)
+        Hh, Uu = _mul(p, 11, G), _mul(p, x_int, UB)
+        ha, hb = dev.to_device(synth.rand_field(SCAL, 1, n)), dev.to_device(synth.rand_field(SCAL, 2, n))
+        us = [synth.to_int(row) % r_mod or 1 for row in synth.rand_field(SCAL, 3, args.log_n)]
+        ums = [(mm(SCAL, u), mm(SCAL, pow(u, -1, r_mod))) for u in us]
+        bl = [(mm(SCAL, 100 + j), mm(SCAL, 200 + j)) for j in range(args.log_n)]
+        tables = dev.msm_precompute_dev(CURVE, torch.cat([bases, dev.to_device(pt(Hh)[None]), dev.to_device(pt(UB)[None])]))
+
+        def ipa():
+            t_0 = time.perf_counter()
+            arg = dev.HaloArgument(CURVE, ha, hb, bases, pt(Hh), pt(Uu), tables=tables, h_index=n, u_index=n + 1, u_prime_scalar=mm(SCAL, x_int))
+            lrs = []
+            for j in range(args.log_n):
+                lrs.append(arg.round_lr(*bl[j]))
+                arg.round_fold(*ums[j])
+            fin = arg.read()
+            t_ = time.perf_counter() - t_0
+            arg.free()
+            return t_, lrs, fin
+
+        ipa()
+        t_a, lr_a, fin_a = ipa()
+        t_b, lr_b, fin_b = ipa()
+        comp["ipa_ms"] = min(t_a, t_b) * 1e3
+        comp["ipa_note"] = "all %d rounds of one opening at n = 2^%d over the prover's tables (H, U inside), best of two; L / R back on the host every round" % (args.log_n, args.log_n)
+        if not args.no_check:
+            comp["_ipa_check"] = bool(all(np.array_equal(a[0], b[0]) for a, b in zip(lr_a, lr_b)) and all(np.array_equal(x_, y_) for x_, y_ in zip(fin_a, fin_b)))
+        tables.free()
+        del ha, hb
     # ---- the drop-in entry points: HOST pointers, PCIe included - what an unmodified plonk.rs gets (plonk_util.rs:169-231) ----
     if not args.timed_only and not strong and world == 1 and args.log_n >= 16:
         PCIE_GBS = 56.0  # measured both ways on this platform (profiles/r03_h2d_probe.txt)
@@ -699,6 +936,8 @@ def run(args):
                 checks["msm_batch9_equals_single"] = comp.pop("_b9_check")
             if "_os_check" in comp:
                 checks["msm_one_shot_equals_tabled"] = comp.pop("_os_check")
+            if "_ipa_check" in comp:
+                checks["ipa_deterministic"] = comp.pop("_ipa_check")
             if "_msm_ok" in comp.get("host_pointer", {}):
                 checks["host_pointer_msm_equals_device"] = comp["host_pointer"].pop("_msm_ok")
             if world > 1:
@@ -720,6 +959,39 @@ def run(args):
                         ok = ok and (synth.from_mont(cv["base_field"], tot[0]), synth.from_mont(cv["base_field"], tot[1])) == exp
                 checks["msm_global_sum_closed_form" if strong else "msm_global_sum_is_point"] = bool(ok)
 
+    # ---- N > 1, the driver's default line: the STRONG-scaling configurations of BASELINE.json as well (configs 4 and 5), each with
+    # its one-GPU time measured by rank 0 in this same run, and the number of ranks the RCCL communicator actually carries ----
+    multi = {}
+    if world > 1 and args.workload == "both" and not args.timed_only:
+        k_strong = max(3, args.steps // 4)
+        cases = {"commit9_strong": ("tweedledee", args.log_n, 9), "bls12_377_2p22_shard": ("bls12_377", min(22, args.log_n + 2), 1)}
+        for name, (cname, lg, bt) in cases.items():
+            rN = strong_case(cname, lg, bt, world, rank, k_strong, 2, gloo, solo=False)
+            r1 = strong_case(cname, lg, bt, world, rank, k_strong, 2, gloo, solo=True) if rank == 0 else None
+            sync()
+            multi[name + "_ms"] = rN["ms"]
+            checks[name + "_closed_form"] = rN["ok"]
+            if r1 is not None:
+                multi[name + "_one_gpu_ms"] = r1["ms"]
+                multi[name + "_efficiency"] = r1["ms"] / (world * rN["ms"])
+                checks[name + "_one_gpu_closed_form"] = r1["ok"]
+            multi[name + "_problem"] = "%d x 2^%d pairs, %s" % (bt, lg, cname)
+        ones = torch.ones(1, dtype=torch.int32, device="cpu" if gloo else "cuda")
+        dist.all_reduce(ones)
+        multi["rccl_ranks" if not gloo else "gloo_ranks"] = int(ones.item())
+        multi["backend"] = dist.get_backend()
+        # the in-library form of the same split: rank 0 alone drives all N GPUs from its one process through the host-pointer
+        # C ABI (plk_init_devices) while the other ranks wait; skipped when the ranks share a GPU
+        if not gloo and rank == 0 and torch.cuda.device_count() >= world:
+            try:
+                multi["single_process"] = single_process_case(L, lib, world, args.log_n, max(2, args.steps // 4))
+                checks["single_process_bit_identical"] = multi["single_process"]["bit_identical_to_one_device"]
+            except Exception as e:  # noqa: BLE001 - the spawned-rank numbers above stand on their own
+                multi["single_process"] = {"error": str(e)[:300]}
+            dev.init(device_index)
+        sync()
+        comp["multi_gpu"] = multi
+
     units_per_step = (n if do_ntt else 0) + (((plan.pairs_local() if args.emulate_rank else batch * n)) if do_msm else 0)
     value = (1 if strong else world) * units_per_step * args.steps / elapsed / 1e6
 
@@ -728,7 +1000,7 @@ def run(args):
     src_hash = kernel_source_hash()
     pmc = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as fh:
+        with open(latest_profile("pmc_traffic.json")) as fh:
             pmc = json.load(fh)
     except (OSError, ValueError):
         pass
@@ -745,7 +1017,7 @@ def run(args):
     valu_peak = ceil.get("fz_mul_gops", {}).get(args.curve) if ceil_ok else None        # G modmul/s: this round's fz_mul at 4 waves / SIMD
     mad_peak = ceil.get("mad_u64_u32_glaneops") if ceil_ok else None                     # G lane-ops/s: raw v_mad_u64_u32 issue rate
     mads = MADS_PER_MODMUL[cv["limbs"]]
-    ceil_src = ("profiles/r03_field_op_costs.json (arith_source_sha %s)" % ceil.get("arith_source_sha")) if ceil_ok else None
+    ceil_src = ("profiles/%s (arith_source_sha %s, gpu %s)" % (os.path.basename(CEILINGS_FILE), ceil.get("arith_source_sha"), ceil.get("gpu_uuid"))) if ceil_ok else None
 
     def valu_entry(kernel, gmm, executed_gmm, launch_ms, extra):
         e = {"kernel": kernel, "bound": "valu", "achieved": gmm, "peak": valu_peak, "unit": "G modmul/s",
@@ -799,13 +1071,14 @@ def run(args):
         "unit": "M units/s (1 unit = 1 NTT element or 1 MSM scalar-point pair; components below)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step_profiled": elapsed_profiled / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": wl, "log_n": args.log_n, "curve": args.curve,
                    "sharding": ("whole vectors per rank, the remainder sharded by base range; one packed all-gather + device point sum" if strong else
                                 "independent NTTs; MSM sharded by base range + one packed all-gather of partial points + device point sum") if world > 1 else "single GPU",
                    "backend": ("gloo (ranks share GPU 0)" if gloo else "nccl (RCCL)") if world > 1 else None,
-                   "seeds": {"ntt": SEED_NTT, "msm": SEED_MSM}, "kernel_source_sha": src_hash},
+                   "seeds": {"ntt": SEED_NTT, "msm": SEED_MSM}, "kernel_source_sha": src_hash, "gpu": gpu_identity(torch, device_index)},
         "components": comp,
         "checks": checks,
         "roofline": roofline,

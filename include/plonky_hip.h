@@ -56,8 +56,26 @@ extern "C" {
 #define PLK_CURVE_VESTA 4  /* src/curve/vesta_curve.rs: base VestaBase, scalars PallasBase */
 
 /* ---- library ---------------------------------------------------------------------------- */
-/* Select the device this process uses (one process per GPU; -1: from the environment variable PLK_DEVICE).  Idempotent. */
+/* Select the ONE device this process uses (one process per GPU; -1: from the environment variable PLK_DEVICE).  Idempotent. */
 int plk_init(int device);
+/* Run over SEVERAL GPUs from this one process (the reference's callers are one process with Rayon threads,
+ * plonk_util.rs:169-231, so the split over the GPUs of a node happens below this ABI).  n_devices > 0: the first n_devices visible
+ * devices; 0: the environment variable PLK_NGPU, else every visible device.  From then on
+ *   - plk_msm_precompute[_dev] of 2^PLK_MULTI_MIN_LOG_N (default 17) generators or more builds its tables on every device;
+ *   - plk_msm_execute / plk_msm_execute_batch / plk_msm_execute_dev over such a context deal the batch out as floor(batch / N)
+ *     WHOLE vectors per device plus the remaining batch mod N vectors SHARDED by contiguous base range (a single MSM is the
+ *     sharded case alone); every device uploads its own share over its own PCIe link (device-resident vectors travel peer to
+ *     peer), the partial results meet on the caller's device in one exchange record per device (plk_msm_partials_bytes) and are
+ *     combined there (plk_msm_combine_partials_dev);
+ *   - plk_ntt_batch / plk_ntt_padded_batch deal their independent transforms out round-robin (no exchange); single-transform
+ *     calls arriving from many host threads take the devices in turn;
+ *   - every other entry point runs on the calling thread's device: logical device 0 unless plk_set_thread_device chose another.
+ * Results are bit-identical to the one-device path.  PLK_VIRTUAL_DEVICES=k (k >= 2) makes k LOGICAL devices out of the one
+ * physical device PLK_DEVICE - separate contexts, worker threads and streams on the same GPU - so that a one-GPU machine runs
+ * the whole multi-device path (tests).  Call before creating contexts; contexts do not survive a change of the device group. */
+int plk_init_devices(int n_devices);
+int plk_device_count(void);                    /* logical devices in use (1 after plk_init) */
+int plk_set_thread_device(int logical_device); /* the _dev entry points of the calling thread run on this logical device */
 void plk_shutdown(void);
 /* Size gate for the binding: problems below 2^plk_min_gpu_log_n() elements / pairs stay on the reference's
  * own CPU path - the library itself has no CPU path.  Environment PLK_MIN_GPU_LOG_N, default 12.  plk_init(-1) takes the

@@ -59,6 +59,7 @@ def lib():
         L.orc_curve_generator.argtypes = [ctypes.c_int, ctypes.c_void_p]
         L.orc_curve_op.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint8, ctypes.c_void_p, ctypes.c_uint8,
                                    ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_scalar_mul_batch.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_affine_summation.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_void_p]
         L.orc_to_digits.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]
@@ -240,6 +241,16 @@ def affine_double(curve, a_xy, a_zero=0):
 
 def scalar_mul(curve, scalar_mont, a_xy, a_zero=0):
     return _curve_op(curve, 2, a_xy, a_zero, scalar_mont)
+
+
+def scalar_mul_batch(curve, scalars_mont, base_xy, threads=1):
+    """[s_i] base for every scalar (curve_multiplication.rs:5-70 once per scalar) -> ((n, 2, L) points, (n,) zero flags)."""
+    L = FIELD_LIMBS[CURVE_BASE_FIELD[curve]]
+    s = _u64(scalars_mont).reshape(-1, 4)
+    out = np.zeros((s.shape[0], 2, L), dtype=np.uint64)
+    oz = np.zeros(s.shape[0], dtype=np.uint8)
+    assert lib().orc_scalar_mul_batch(curve, s.shape[0], _p(s), _p(_u64(base_xy)), threads, _p(out), _p(oz)) == 0
+    return out, oz
 
 
 def mul_naive(curve, scalar_mont, a_xy, a_zero=0):

@@ -1388,6 +1388,22 @@ int orc_curve_op(int curve, int op, const u64* a_xy, uint8_t a_zero, const u64* 
     });
     return -1;
 }
+// out_i = [s_i] base for n Montgomery scalars: the reference's CurveScalar * ProjectivePoint (curve_multiplication.rs:5-70, w = 4)
+// once per scalar, spread over `threads` workers.  The parity tests use it for generators WITHOUT structure: G_i = [h_i] G for
+// seeded h_i (curve_msm.rs:218-241 tests the MSM over arbitrary generators against the sum of scalar multiplications).
+int orc_scalar_mul_batch(int curve, size_t n, const u64* scalars, const u64* base_xy, int threads, u64* out_xy, uint8_t* out_zero) {
+    CURVE_DISPATCH(curve, {
+        uint8_t bz = 0;
+        const ProjectivePoint<C> b = to_projective(ld_aff<C>(base_xy, &bz, 0));
+        const size_t chunk = 64, n_chunks = (n + chunk - 1) / chunk;
+        parallel_for(n_chunks, threads, [&](size_t c) {
+            for (size_t i = c * chunk; i < n && i < (c + 1) * chunk; ++i)
+                st_aff<C>(out_xy, out_zero, i, scalar_mul<C>(ld<typename C::Scalar>(scalars + i * C::Scalar::N), b).to_affine());
+        });
+        return 0;
+    });
+    return -1;
+}
 // mode 0 pairwise, 1 batch inversion, 2 best  (curve_summations.rs:18-158) -> affine
 int orc_affine_summation(int curve, int mode, size_t n, const u64* pts_xy, const uint8_t* zero, u64* out_xy, uint8_t* out_zero) {
     CURVE_DISPATCH(curve, {

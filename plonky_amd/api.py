@@ -52,6 +52,18 @@ def log2_strict(n):  # util.rs:12-19 (panics when n is not a power of two)
     return r
 
 
+def init_devices(n_devices=0):
+    """Run the host-pointer entry points over several GPUs from this one process (plk_init_devices): 0 = PLK_NGPU or every
+    visible device; with PLK_VIRTUAL_DEVICES=k, k logical devices on one physical GPU.  Returns the number of logical devices."""
+    L = _lib.load()
+    _lib.check(L.plk_init_devices(int(n_devices)))
+    return int(L.plk_device_count())
+
+
+def device_count():
+    return int(_lib.load().plk_device_count())
+
+
 def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 

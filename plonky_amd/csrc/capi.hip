@@ -3,10 +3,12 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 
 #include "common.h"
+#include "host_lane.h"
 
 struct plk_msm_ctx;
 struct plk_halo_ctx;
@@ -66,6 +68,12 @@ size_t msm_ctx_len(const plk_msm_ctx* ctx);
 unsigned msm_ctx_window(const plk_msm_ctx* ctx);
 int msm_ctx_curve(const plk_msm_ctx* ctx);
 void msm_ctx_delete(plk_msm_ctx* ctx);
+// multi.hip
+bool msm_ctx_is_multi(plk_msm_ctx* ctx);
+int msm_precompute_multi(int curve, size_t n, const void* bases, const void* zero, bool host_src, unsigned window_bits, hipStream_t caller_stream,
+                         plk_msm_ctx** out_ctx);
+int msm_execute_multi(plk_msm_ctx* ctx, unsigned batch, const void* const* vecs, bool host_src, size_t n, void* d_out_xy, void* d_out_zero,
+                      hipStream_t caller_stream);
 
 std::string& last_error_ref() {
     static thread_local std::string s;
@@ -177,6 +185,14 @@ void stream_pool_release(hipStream_t s) {
 
 void scratch_clear() {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < group_size(); ++d) {  // every device of the group is quiet before its buffers go
+        if (d && group_phys(d) == group_phys(d - 1)) continue;
+        (void)hipSetDevice(group_phys(d));
+        (void)hipDeviceSynchronize();
+    }
+    (void)hipSetDevice(cur);
     (void)hipDeviceSynchronize();
     for (auto& e : g_scratch) {
         if (e.in_call) continue;
@@ -190,56 +206,15 @@ void scratch_clear() {
     g_scratch.swap(keep);
 }
 
-// ---- host-pointer entry points: one lane per calling thread ----
-// The reference calls the hot path from Rayon workers (plonk_util.rs:173-189: nine transforms / commitments at once).  Every
-// host thread that enters through a host-pointer entry point owns a lane: non-blocking streams of its own, a small pinned
-// staging buffer, device buffers from the scratch pool.  Nothing goes through the null stream or through hipMalloc / hipFree
-// (both synchronise the whole device), so concurrent callers overlap on the GPU instead of queueing behind each other.
-//
-// The caller's buffers are pageable.  Measured on the MI355X box (profiles/r03_h2d_probe.txt): hipMemcpyAsync straight from /
-// to pageable memory runs at the pinned rate (56.5 GB/s both ways) where a staging memcpy + DMA - round 2's path - reaches
-// 21.9 GB/s; it blocks the calling thread, though.  Registered with hipHostRegister (57 GB/s INCLUDING registration and
-// deregistration) the copies are asynchronous, so ONE caller thread keeps several streams busy: the copy of scalar vector
-// k + 1 runs under the reduction of vector k, the upload of transform k + 1 under the download of transform k.  So: large
-// buffers are registered for the duration of the call and copied directly; only small pieces (results, flags) are staged.
-constexpr size_t PIN_CAP = (size_t)4 << 20;        // the staging buffer serves pieces up to this size
-constexpr size_t DIRECT_MIN = (size_t)64 << 10;    // larger pieces are copied straight from / to the caller's memory
-constexpr int LANE_AUX = 2;
-struct HostLane {
-    hipStream_t stream = nullptr;
-    hipStream_t aux[LANE_AUX] = {nullptr, nullptr};  // second / third stream of a call that pipelines copies and kernels
-    hipEvent_t ev_fork = nullptr;
-    std::vector<hipEvent_t> ev_ready;                 // per-vector "copy done" events of a batched MSM
-    int device = -1;
-    uint8_t* pin = nullptr;
-    size_t pin_bytes = 0, pin_used = 0;
-    void drop_streams() {
-        for (hipEvent_t e : ev_ready) (void)hipEventDestroy(e);
-        ev_ready.clear();
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        ev_fork = nullptr;
-        for (auto& a : aux) {
-            if (a) (void)hipStreamSynchronize(a);
-            stream_pool_release(a);
-            a = nullptr;
-        }
-        if (stream) (void)hipStreamSynchronize(stream);
-        stream_pool_release(stream);
-        stream = nullptr;
-    }
-    ~HostLane() {
-        if (pin) (void)hipHostFree(pin);
-        drop_streams();
-    }
-};
-static thread_local HostLane t_lane;
+// ---- host-pointer entry points: one lane per (calling thread, logical device) - host_lane.h ----
+static thread_local HostLane t_lanes[PLK_MAX_DEVICES];
 
-static int lane_get(HostLane*& out) {
+int lane_get(HostLane*& out) {
     PLK_TRY(ensure_device());
     int dev = 0;
     PLK_HIP_TRY(hipGetDevice(&dev));
-    HostLane& l = t_lane;
-    if (l.stream && l.device != dev) l.drop_streams();
+    HostLane& l = t_lanes[thread_logical_device()];
+    if (l.stream && l.device != dev) l.drop_streams();  // the group was re-initialised over other devices
     if (!l.stream) {
         l.stream = stream_pool_acquire();
         if (!l.stream) return PLK_ERR_HIP;
@@ -250,171 +225,36 @@ static int lane_get(HostLane*& out) {
     out = &l;
     return PLK_OK;
 }
-// the lane's extra streams, ordered after everything enqueued on the main one so far
-static int lane_fork(HostLane& l) {
-    if (!l.ev_fork) PLK_HIP_TRY(hipEventCreateWithFlags(&l.ev_fork, hipEventDisableTiming));
-    PLK_HIP_TRY(hipEventRecord(l.ev_fork, l.stream));
-    for (auto& a : l.aux) {
-        if (!a && !(a = stream_pool_acquire())) return PLK_ERR_HIP;
-        PLK_HIP_TRY(hipStreamWaitEvent(a, l.ev_fork, 0));
-    }
-    return PLK_OK;
-}
-static int lane_join(HostLane& l) {
-    hipError_t first = hipSuccess;
-    for (auto& a : l.aux)
-        if (a) {
-            const hipError_t e = hipStreamSynchronize(a);
-            if (first == hipSuccess) first = e;
-        }
-    const hipError_t e = hipStreamSynchronize(l.stream);
-    if (first == hipSuccess) first = e;
-    l.pin_used = 0;
-    PLK_HIP_TRY(first);
-    return PLK_OK;
-}
-// a caller buffer registered for the duration of a call: copies from / to it are asynchronous.  Registration can fail (the
-// range is registered already, exotic memory): the copies then simply block the calling thread - same result.
-struct HostPin {
-    void* p = nullptr;
-    HostPin() = default;
-    HostPin(const HostPin&) = delete;
-    HostPin& operator=(const HostPin&) = delete;
-    HostPin(HostPin&& o) noexcept : p(o.p) { o.p = nullptr; }
-    void pin(const void* ptr, size_t bytes) {
-        if (!ptr || bytes < ((size_t)1 << 20)) return;
-        if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void*>(ptr);
-        else (void)hipGetLastError();
-    }
-    ~HostPin() {
-        if (p) (void)hipHostUnregister(p);
-    }
-};
-// a piece of the lane's pinned buffer, valid until the lane is synchronised; nullptr when it does not fit
-static uint8_t* lane_stage(HostLane& l, size_t bytes) {
-    const size_t need = (l.pin_used + bytes + 255) & ~(size_t)255;
-    if (need > PIN_CAP) return nullptr;
-    if (need > l.pin_bytes) {
-        if (l.pin_used) return nullptr;  // pieces handed out earlier in this call are still in flight
-        size_t want = l.pin_bytes ? l.pin_bytes : ((size_t)256 << 10);
-        while (want < need) want *= 2;
-        if (l.pin) (void)hipHostFree(l.pin);
-        l.pin = nullptr;
-        l.pin_bytes = 0;
-        if (hipHostMalloc((void**)&l.pin, want, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        l.pin_bytes = want;
-    }
-    uint8_t* p = l.pin + l.pin_used;
-    l.pin_used = need;
-    return p;
-}
-static int lane_h2d(HostLane& l, void* d, const void* h, size_t bytes, hipStream_t st = nullptr) {
-    if (!bytes) return PLK_OK;
-    if (!st) st = l.stream;
-    uint8_t* stg = bytes < DIRECT_MIN ? lane_stage(l, bytes) : nullptr;
-    if (stg) {
-        memcpy(stg, h, bytes);
-        PLK_HIP_TRY(hipMemcpyAsync(d, stg, bytes, hipMemcpyHostToDevice, st));
-    } else {
-        PLK_HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st));  // pageable or registered: the pinned rate either way
-    }
-    return PLK_OK;
-}
-// device -> caller memory; `flush` pairs (staging piece, destination) are copied out by lane_finish after the synchronisation
-struct LaneOut {
-    uint8_t* st;
-    void* dst;
+
+struct PinEntry {
     size_t bytes;
+    unsigned refs;
 };
-static int lane_d2h(HostLane& l, std::vector<LaneOut>& outs, void* h, const void* d, size_t bytes, hipStream_t st = nullptr) {
-    if (!bytes) return PLK_OK;
-    if (!st) st = l.stream;
-    uint8_t* stg = bytes < DIRECT_MIN ? lane_stage(l, bytes) : nullptr;
-    if (stg) {
-        PLK_HIP_TRY(hipMemcpyAsync(stg, d, bytes, hipMemcpyDeviceToHost, st));
-        outs.push_back({stg, h, bytes});
-    } else {
-        PLK_HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, st));
+static std::mutex g_pin_mu;
+static std::map<const void*, PinEntry> g_pins;
+bool pin_registry_acquire(const void* ptr, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    auto it = g_pins.find(ptr);
+    if (it != g_pins.end()) {
+        if (it->second.bytes < bytes) return false;  // a longer range from the same start: not covered, copy synchronously
+        ++it->second.refs;
+        return true;
     }
-    return PLK_OK;
+    if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    g_pins[ptr] = PinEntry{bytes, 1u};
+    return true;
 }
-static int lane_finish(HostLane& l, std::vector<LaneOut>& outs) {
-    PLK_HIP_TRY(hipStreamSynchronize(l.stream));
-    for (const LaneOut& o : outs) memcpy(o.dst, o.st, o.bytes);
-    outs.clear();
-    l.pin_used = 0;
-    return PLK_OK;
-}
-// device buffer of a lane, from the scratch pool
-struct LaneBuf {
-    void* p = nullptr;
-    hipStream_t s = nullptr;
-    LaneBuf() = default;
-    LaneBuf(const LaneBuf&) = delete;
-    LaneBuf& operator=(const LaneBuf&) = delete;
-    ~LaneBuf() {
-        if (p) scratch_release(p, s);
+void pin_registry_release(const void* ptr) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    auto it = g_pins.find(ptr);
+    if (it == g_pins.end()) return;
+    if (--it->second.refs == 0) {
+        (void)hipHostUnregister(const_cast<void*>(ptr));
+        g_pins.erase(it);
     }
-    int alloc(size_t bytes, hipStream_t stream) {
-        s = stream;
-        p = scratch_acquire(bytes ? bytes : 16, stream);
-        return p ? PLK_OK : PLK_ERR_OOM;
-    }
-};
-// One host-pointer call on the calling thread's lane: device buffers, uploads, downloads, one synchronisation at the end.
-struct LaneCall {
-    HostLane* l = nullptr;
-    std::vector<LaneOut> outs;
-    std::vector<std::unique_ptr<LaneBuf>> bufs;
-    int begin() { return lane_get(l); }
-    hipStream_t stream() const { return l->stream; }
-    int tmp(void*& d, size_t bytes) {
-        bufs.emplace_back(new LaneBuf());
-        PLK_TRY(bufs.back()->alloc(bytes, l->stream));
-        d = bufs.back()->p;
-        return PLK_OK;
-    }
-    int in(void*& d, const void* h, size_t bytes) {
-        PLK_TRY(tmp(d, bytes));
-        return lane_h2d(*l, d, h, bytes);
-    }
-    int out(void* h, const void* d, size_t bytes) { return lane_d2h(*l, outs, h, d, bytes); }
-    int sync() {  // results of the kernels so far are needed on the host before the call goes on
-        PLK_TRY(lane_finish(*l, outs));
-        return PLK_OK;
-    }
-    bool done = false;
-    int finish() {
-        done = true;
-        return lane_finish(*l, outs);
-    }
-    ~LaneCall() {
-        if (l && !done) {  // an early return: nothing may stay in flight over the staging buffer or the caller's memory
-            (void)hipStreamSynchronize(l->stream);
-            l->pin_used = 0;
-        }
-    }
-};
-
-static std::atomic<int> g_device{-1};
-
-int ensure_device() {
-    int dev = g_device.load();
-    if (dev < 0) {
-        int count = 0;
-        hipError_t e = hipGetDeviceCount(&count);
-        if (e != hipSuccess || count <= 0)
-            return set_error(PLK_ERR_NO_DEVICE, "no HIP device visible (%s); the HIP path has no CPU fallback", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
-        int cur = 0;
-        if (hipGetDevice(&cur) != hipSuccess) cur = 0;
-        g_device.store(cur);
-        dev = cur;
-    }
-    PLK_HIP_TRY(hipSetDevice(dev));
-    return PLK_OK;
 }
 
 int field_limbs(int field) {
@@ -455,23 +295,14 @@ using namespace plk;
 
 extern "C" {
 
-int plk_init(int device) {
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0)
-        return set_error(PLK_ERR_NO_DEVICE, "no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
-    if (device == -1) {
-        const char* e = getenv("PLK_DEVICE");
-        device = e ? atoi(e) : 0;
-    }
-    if (device < 0 || device >= count) return set_error(PLK_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, count);
-    PLK_HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    PLK_HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return set_error(PLK_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
-    g_device.store(device);
-    return PLK_OK;
+int plk_init(int device) { return group_init_single(device); }
+int plk_init_devices(int n_devices) { return group_init(n_devices); }
+int plk_device_count(void) { return group_size(); }
+int plk_set_thread_device(int logical_device) {
+    if (logical_device < 0 || logical_device >= group_size())
+        return set_error(PLK_ERR_INVALID_ARG, "logical device %d out of range (%d in use)", logical_device, group_size());
+    set_thread_logical_device(logical_device);
+    return ensure_device();
 }
 
 void plk_shutdown(void) {
@@ -479,7 +310,7 @@ void plk_shutdown(void) {
     (void)poly_clear_cache_impl();
     (void)ntt_clear_cache_impl();
     scratch_clear();
-    g_device.store(-1);
+    group_shutdown();
 }
 
 const char* plk_last_error(void) { return last_error_ref().c_str(); }
@@ -524,6 +355,54 @@ int plk_ntt_dev(int field, unsigned log_n, int inverse, unsigned batch, const vo
     return ntt_dev_impl(field, log_n, inverse, batch, d_in, d_out, as_stream(stream));
 }
 
+// `batch` transforms from / to host memory on the calling thread's current device
+static int ntt_batch_local(int field, unsigned log_n, int inverse, unsigned batch, const uint64_t* const* in, uint64_t* const* out) {
+    if (batch == 0) return PLK_OK;
+    const size_t bytes = ((size_t)1 << log_n) * 32;
+    LaneCall c;
+    PLK_TRY(c.begin());
+    HostLane* l = c.l;
+    void* buf = nullptr;
+    PLK_TRY(c.tmp(buf, bytes * batch));
+    if (batch == 1 || bytes < ((size_t)1 << 20)) {
+        // one transform, or small ones: upload, one batched launch, download
+        for (unsigned b = 0; b < batch; ++b) PLK_TRY(lane_h2d(*l, (uint8_t*)buf + b * bytes, in[b], bytes));
+        PLK_TRY(ntt_dev_impl(field, log_n, inverse, batch, buf, buf, l->stream));
+        for (unsigned b = 0; b < batch; ++b) PLK_TRY(c.out(out[b], (uint8_t*)buf + b * bytes, bytes));
+        return c.finish();
+    }
+    // several large transforms (the nine wire polynomials, plonk_util.rs:169-190): PCIe is the long pole (2 x 32 MiB per 2^20
+    // transform against 0.13 ms of kernels), so transform b runs upload -> kernels -> download on stream b mod 3: the upload of
+    // the next transform and the download of the previous one share the link's two directions
+    for (unsigned b = 0; b < batch; ++b) {
+        c.pin(in[b], bytes);
+        if ((const void*)out[b] != (const void*)in[b]) c.pin(out[b], bytes);
+    }
+    PLK_TRY(lane_fork(*l));
+    for (unsigned b = 0; b < batch; ++b) {
+        hipStream_t st = b % 3 == 0 ? l->stream : l->aux[b % 3 - 1];
+        uint8_t* d = (uint8_t*)buf + b * bytes;
+        if (hipMemcpyAsync(d, in[b], bytes, hipMemcpyHostToDevice, st) != hipSuccess) return set_error(PLK_ERR_HIP, "upload of transform %u failed", b);
+        PLK_TRY(ntt_dev_impl(field, log_n, inverse, 1, d, d, st));
+        if (hipMemcpyAsync(out[b], d, bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return set_error(PLK_ERR_HIP, "download of transform %u failed", b);
+    }
+    PLK_TRY(lane_join(*l));  // before the registrations and the device buffer go
+    return c.finish();
+}
+
+// Units that need no exchange (transforms) over the devices of the group: unit b runs on device b mod N, every device's share in
+// one call of `local` on its worker thread.  A single unit - the reference's callers are nine Rayon threads with one transform
+// each (plonk_util.rs:173-189) - runs on the calling thread, the calls taking the devices in turn.
+static int deal_units(unsigned log_n, unsigned batch, const std::function<int(unsigned, unsigned)>& local) {
+    const int world = group_size();
+    if (world == 1 || log_n < multi_min_log_n()) return local(0, 1);
+    if (batch == 1) {
+        DeviceScope on(next_round_robin_device());
+        return local(0, 1);
+    }
+    return run_on_devices(world, [&](int d) -> int { return local((unsigned)d, (unsigned)world); });
+}
+
 int plk_ntt_batch(int field, unsigned log_n, int inverse, unsigned batch, const uint64_t* const* in, uint64_t* const* out) {
     if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
     if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
@@ -531,39 +410,16 @@ int plk_ntt_batch(int field, unsigned log_n, int inverse, unsigned batch, const 
     if (!in || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     for (unsigned b = 0; b < batch; ++b)
         if (!in[b] || !out[b]) return set_error(PLK_ERR_INVALID_ARG, "null pointer in batch slot %u", b);
-    HostLane* l = nullptr;
-    PLK_TRY(lane_get(l));
-    const size_t bytes = ((size_t)1 << log_n) * 32;
-    LaneBuf buf;
-    PLK_TRY(buf.alloc(bytes * batch, l->stream));
-    if (batch == 1 || bytes < ((size_t)1 << 20)) {
-        // one transform, or small ones: upload, one batched launch, download
-        for (unsigned b = 0; b < batch; ++b) PLK_TRY(lane_h2d(*l, (uint8_t*)buf.p + b * bytes, in[b], bytes));
-        int rc = ntt_dev_impl(field, log_n, inverse, batch, buf.p, buf.p, l->stream);
-        std::vector<LaneOut> outs;
-        for (unsigned b = 0; b < batch && rc == PLK_OK; ++b) rc = lane_d2h(*l, outs, out[b], (uint8_t*)buf.p + b * bytes, bytes);
-        const int rf = lane_finish(*l, outs);
-        return rc != PLK_OK ? rc : rf;
-    }
-    // several large transforms (the nine wire polynomials, plonk_util.rs:169-190): PCIe is the long pole (2 x 32 MiB per 2^20
-    // transform against 0.13 ms of kernels), so transform b runs upload -> kernels -> download on stream b mod 3: the upload of
-    // the next transform and the download of the previous one share the link's two directions
-    std::vector<HostPin> pins(2 * (size_t)batch);
-    for (unsigned b = 0; b < batch; ++b) {
-        pins[2 * b].pin(in[b], bytes);
-        if ((const void*)out[b] != (const void*)in[b]) pins[2 * b + 1].pin(out[b], bytes);
-    }
-    int rc = lane_fork(*l);
-    for (unsigned b = 0; b < batch && rc == PLK_OK; ++b) {
-        hipStream_t st = b % 3 == 0 ? l->stream : l->aux[b % 3 - 1];
-        uint8_t* d = (uint8_t*)buf.p + b * bytes;
-        if (hipMemcpyAsync(d, in[b], bytes, hipMemcpyHostToDevice, st) != hipSuccess) rc = set_error(PLK_ERR_HIP, "upload of transform %u failed", b);
-        if (rc == PLK_OK) rc = ntt_dev_impl(field, log_n, inverse, 1, d, d, st);
-        if (rc == PLK_OK && hipMemcpyAsync(out[b], d, bytes, hipMemcpyDeviceToHost, st) != hipSuccess)
-            rc = set_error(PLK_ERR_HIP, "download of transform %u failed", b);
-    }
-    const int rj = lane_join(*l);  // before the registrations and the device buffer go
-    return rc != PLK_OK ? rc : rj;
+    return deal_units(log_n, batch, [&](unsigned first, unsigned step) -> int {
+        if (step == 1) return ntt_batch_local(field, log_n, inverse, batch, in, out);
+        std::vector<const uint64_t*> mi;
+        std::vector<uint64_t*> mo;
+        for (unsigned b = first; b < batch; b += step) {
+            mi.push_back(in[b]);
+            mo.push_back(out[b]);
+        }
+        return ntt_batch_local(field, log_n, inverse, (unsigned)mi.size(), mi.data(), mo.data());
+    });
 }
 
 int plk_ntt(int field, unsigned log_n, int inverse, const uint64_t* in, uint64_t* out) {
@@ -576,37 +432,54 @@ int plk_ntt_padded_dev(int field, unsigned log_n, unsigned batch, const void* d_
     return ntt_padded_dev_impl(field, log_n, batch, d_in, in_len, in_stride, d_out, as_stream(stream));
 }
 
-int plk_ntt_padded_batch(int field, unsigned log_n, unsigned batch, const uint64_t* const* in, const size_t* n_in, uint64_t* const* out) {
-    if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
-    if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
+static int ntt_padded_batch_local(int field, unsigned log_n, unsigned batch, const uint64_t* const* in, const size_t* n_in, uint64_t* const* out) {
     if (batch == 0) return PLK_OK;
-    if (!in || !n_in || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     const size_t n = (size_t)1 << log_n;
     size_t max_in = 0;
-    for (unsigned b = 0; b < batch; ++b) {
-        if (n_in[b] > n) return set_error(PLK_ERR_INVALID_ARG, "n_in[%u] = %zu exceeds 2^%u", b, n_in[b], log_n);
-        if ((n_in[b] && !in[b]) || !out[b]) return set_error(PLK_ERR_INVALID_ARG, "null pointer in batch slot %u", b);
+    for (unsigned b = 0; b < batch; ++b)
         if (n_in[b] > max_in) max_in = n_in[b];
-    }
     LaneCall c;
     PLK_TRY(c.begin());
     void *din = nullptr, *dout = nullptr;
     PLK_TRY(c.tmp(din, max_in * 32 * batch));
     PLK_TRY(c.tmp(dout, n * 32 * batch));
-    std::vector<HostPin> pins(2 * (size_t)batch);
     for (unsigned b = 0; b < batch; ++b) {
         uint8_t* slot = (uint8_t*)din + (size_t)b * max_in * 32;
-        pins[2 * b].pin(in[b], n_in[b] * 32);
+        c.pin(in[b], n_in[b] * 32);
         PLK_TRY(lane_h2d(*c.l, slot, in[b], n_in[b] * 32));
         // shorter polynomials of the batch: F::ZERO is all-zero limbs in Montgomery form too
         if (n_in[b] < max_in) PLK_HIP_TRY(hipMemsetAsync(slot + n_in[b] * 32, 0, (max_in - n_in[b]) * 32, c.stream()));
     }
     PLK_TRY(ntt_padded_dev_impl(field, log_n, batch, din, max_in, max_in, dout, c.stream()));
     for (unsigned b = 0; b < batch; ++b) {
-        pins[2 * b + 1].pin(out[b], n * 32);
+        c.pin(out[b], n * 32);
         PLK_TRY(c.out(out[b], (uint8_t*)dout + (size_t)b * n * 32, n * 32));
     }
     return c.finish();
+}
+
+int plk_ntt_padded_batch(int field, unsigned log_n, unsigned batch, const uint64_t* const* in, const size_t* n_in, uint64_t* const* out) {
+    if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
+    if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
+    if (batch == 0) return PLK_OK;
+    if (!in || !n_in || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    const size_t n = (size_t)1 << log_n;
+    for (unsigned b = 0; b < batch; ++b) {
+        if (n_in[b] > n) return set_error(PLK_ERR_INVALID_ARG, "n_in[%u] = %zu exceeds 2^%u", b, n_in[b], log_n);
+        if ((n_in[b] && !in[b]) || !out[b]) return set_error(PLK_ERR_INVALID_ARG, "null pointer in batch slot %u", b);
+    }
+    return deal_units(log_n, batch, [&](unsigned first, unsigned step) -> int {
+        if (step == 1) return ntt_padded_batch_local(field, log_n, batch, in, n_in, out);
+        std::vector<const uint64_t*> mi;
+        std::vector<size_t> ml;
+        std::vector<uint64_t*> mo;
+        for (unsigned b = first; b < batch; b += step) {
+            mi.push_back(in[b]);
+            ml.push_back(n_in[b]);
+            mo.push_back(out[b]);
+        }
+        return ntt_padded_batch_local(field, log_n, (unsigned)mi.size(), mi.data(), ml.data(), mo.data());
+    });
 }
 
 int plk_ntt_padded(int field, unsigned log_n, const uint64_t* in, size_t n_in, uint64_t* out) {
@@ -683,12 +556,11 @@ int plk_plonk_vanishing_points(int field, unsigned log_degree, const uint64_t* c
     const size_t row = ((size_t)8 << log_degree) * 32;
     LaneCall c;
     PLK_TRY(c.begin());
-    HostPin pc, pw, ps, pz, po;
-    pc.pin(constants_8n, 6 * row);
-    pw.pin(wires_8n, 9 * row);
-    ps.pin(s_sigma_8n, 6 * row);
-    pz.pin(plonk_z_8n, row);
-    po.pin(out, row);
+    c.pin(constants_8n, 6 * row);
+    c.pin(wires_8n, 9 * row);
+    c.pin(s_sigma_8n, 6 * row);
+    c.pin(plonk_z_8n, row);
+    c.pin(out, row);
     void *dc = nullptr, *dw = nullptr, *ds = nullptr, *dz = nullptr, *dout = nullptr;
     PLK_TRY(c.in(dc, constants_8n, 6 * row));
     PLK_TRY(c.in(dw, wires_8n, 9 * row));
@@ -718,13 +590,19 @@ int plk_plonk_evaluate_all_constraints(int field, size_t count, const uint64_t* 
 }
 
 // ---- MSM ----
+// Over a device group (plk_init_devices) a tabled precomputation of at least 2^PLK_MULTI_MIN_LOG_N generators is built on every
+// device (multi.hip); smaller ones, and table-free contexts (one-shot MSMs: latency, not throughput), stay on the caller's device.
+static bool fan_out_msm(size_t n, unsigned flags) {
+    return group_size() > 1 && !(flags & PLK_MSM_TABLE_FREE) && n >= ((size_t)1 << multi_min_log_n()) && n >= (size_t)group_size();
+}
 int plk_msm_precompute_dev_ex(int curve, size_t n, const void* d_bases_xy, const void* d_base_zero, unsigned window_bits, unsigned flags, void* stream,
                               plk_msm_ctx** out_ctx) {
+    if (fan_out_msm(n, flags) && d_bases_xy) return msm_precompute_multi(curve, n, d_bases_xy, d_base_zero, false, window_bits, as_stream(stream), out_ctx);
     return msm_precompute_dev_impl(curve, n, d_bases_xy, d_base_zero, window_bits, flags, as_stream(stream), out_ctx);
 }
 int plk_msm_precompute_dev(int curve, size_t n, const void* d_bases_xy, const void* d_base_zero, unsigned window_bits, void* stream,
                            plk_msm_ctx** out_ctx) {
-    return msm_precompute_dev_impl(curve, n, d_bases_xy, d_base_zero, window_bits, 0, as_stream(stream), out_ctx);
+    return plk_msm_precompute_dev_ex(curve, n, d_bases_xy, d_base_zero, window_bits, 0, stream, out_ctx);
 }
 
 int plk_msm_precompute_ex(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, unsigned window_bits, unsigned flags,
@@ -732,6 +610,10 @@ int plk_msm_precompute_ex(int curve, size_t n, const uint64_t* bases_xy, const u
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (n && !bases_xy) return set_error(PLK_ERR_INVALID_ARG, "null bases");
+    if (fan_out_msm(n, flags)) {
+        DeviceScope primary(0);
+        return msm_precompute_multi(curve, n, bases_xy, base_zero, true, window_bits, nullptr, out_ctx);
+    }
     HostLane* l = nullptr;
     PLK_TRY(lane_get(l));
     LaneBuf db, dz;
@@ -759,6 +641,13 @@ size_t plk_msm_ctx_len(const plk_msm_ctx* ctx) { return ctx ? msm_ctx_len(ctx) :
 unsigned plk_msm_ctx_window(const plk_msm_ctx* ctx) { return ctx ? msm_ctx_window(ctx) : 0; }
 
 int plk_msm_execute_dev(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, void* stream) {
+    if (msm_ctx_is_multi(ctx) && batch && d_scalars && n_scalars == msm_ctx_len(ctx)) {
+        // a context that lives on every device of the group: the vectors (memory of the caller's device) reach the other devices
+        // peer to peer, the results come back to the caller's device; asynchronous on `stream` like the one-device form
+        std::vector<const void*> vecs(batch);
+        for (unsigned b = 0; b < batch; ++b) vecs[b] = (const uint8_t*)d_scalars + (size_t)b * n_scalars * 32;
+        return msm_execute_multi(ctx, batch, vecs.data(), false, n_scalars, d_out_xy, d_out_zero, as_stream(stream));
+    }
     return msm_execute_dev_impl(ctx, batch, d_scalars, n_scalars, d_out_xy, d_out_zero, as_stream(stream));
 }
 
@@ -777,43 +666,48 @@ int plk_msm_execute_batch(plk_msm_ctx* ctx, unsigned batch, const uint64_t* cons
     if (!scalars || !out_xy || !out_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     for (unsigned b = 0; b < batch; ++b)
         if (n_scalars && !scalars[b]) return set_error(PLK_ERR_INVALID_ARG, "null scalars in batch slot %u", b);
-    HostLane* l = nullptr;
-    PLK_TRY(lane_get(l));
+    const bool multi = msm_ctx_is_multi(ctx);
+    DeviceScope primary(multi ? 0 : thread_logical_device());  // a group context's results are combined on its first device
     const size_t L = (size_t)curve_limbs(msm_ctx_curve(ctx));
     const size_t sb = n_scalars * 32;
-    LaneBuf ds, dxy, dz;
-    PLK_TRY(ds.alloc(sb * batch, l->stream));
-    PLK_TRY(dxy.alloc((size_t)batch * 2 * L * 8, l->stream));
-    PLK_TRY(dz.alloc(batch, l->stream));
-    std::vector<LaneOut> outs;
-    int rc = PLK_OK;
-    if (batch == 1 || sb < ((size_t)1 << 20)) {
-        for (unsigned b = 0; b < batch; ++b) PLK_TRY(lane_h2d(*l, (uint8_t*)ds.p + b * sb, scalars[b], sb));
-        rc = msm_execute_dev_impl(ctx, batch, ds.p, n_scalars, dxy.p, dz.p, l->stream);
+    LaneCall c;
+    PLK_TRY(c.begin());
+    HostLane* l = c.l;
+    void *dxy = nullptr, *dz = nullptr;
+    PLK_TRY(c.tmp(dxy, (size_t)batch * 2 * L * 8));
+    PLK_TRY(c.tmp(dz, batch));
+    if (multi) {
+        // every device uploads its own share over its own PCIe link (multi.hip); the vectors stay registered until this call's
+        // final synchronisation, which - through the events the caller's stream waits for - covers the workers' copies
+        for (unsigned b = 0; b < batch; ++b) c.pin(scalars[b], sb);
+        PLK_TRY(msm_execute_multi(ctx, batch, (const void* const*)scalars, true, n_scalars, dxy, dz, l->stream));
+    } else if (batch == 1 || sb < ((size_t)1 << 20)) {
+        void* ds = nullptr;
+        PLK_TRY(c.tmp(ds, sb * batch));
+        for (unsigned b = 0; b < batch; ++b) PLK_TRY(lane_h2d(*l, (uint8_t*)ds + b * sb, scalars[b], sb));
+        PLK_TRY(msm_execute_dev_impl(ctx, batch, ds, n_scalars, dxy, dz, l->stream));
     } else {
         // the scalar vectors of a batch (commit_polynomials, plonk_util.rs:215-231: nine 32 MiB vectors at 2^20) cross PCIe on a
         // second stream, vector b + 1 while vector b is being ordered and accumulated: one event per vector
-        std::vector<HostPin> pins(batch);
-        for (unsigned b = 0; b < batch; ++b) pins[b].pin(scalars[b], sb);
-        rc = lane_fork(*l);
-        while (rc == PLK_OK && l->ev_ready.size() < batch) {
+        void* ds = nullptr;
+        PLK_TRY(c.tmp(ds, sb * batch));
+        for (unsigned b = 0; b < batch; ++b) c.pin(scalars[b], sb);
+        PLK_TRY(lane_fork(*l));
+        while (l->ev_ready.size() < batch) {
             hipEvent_t e = nullptr;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = set_error(PLK_ERR_HIP, "hipEventCreate failed");
-            else l->ev_ready.push_back(e);
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return set_error(PLK_ERR_HIP, "hipEventCreate failed");
+            l->ev_ready.push_back(e);
         }
-        for (unsigned b = 0; b < batch && rc == PLK_OK; ++b) {
-            if (hipMemcpyAsync((uint8_t*)ds.p + b * sb, scalars[b], sb, hipMemcpyHostToDevice, l->aux[0]) != hipSuccess ||
+        for (unsigned b = 0; b < batch; ++b) {
+            if (hipMemcpyAsync((uint8_t*)ds + b * sb, scalars[b], sb, hipMemcpyHostToDevice, l->aux[0]) != hipSuccess ||
                 hipEventRecord(l->ev_ready[b], l->aux[0]) != hipSuccess)
-                rc = set_error(PLK_ERR_HIP, "upload of scalar vector %u failed", b);
+                return set_error(PLK_ERR_HIP, "upload of scalar vector %u failed", b);
         }
-        if (rc == PLK_OK) rc = msm_execute_dev_impl(ctx, batch, ds.p, n_scalars, dxy.p, dz.p, l->stream, l->ev_ready.data());
-        const int rj = lane_join(*l);  // before the registrations go
-        if (rc == PLK_OK) rc = rj;
+        PLK_TRY(msm_execute_dev_impl(ctx, batch, ds, n_scalars, dxy, dz, l->stream, l->ev_ready.data()));
     }
-    if (rc == PLK_OK) rc = lane_d2h(*l, outs, out_xy, dxy.p, (size_t)batch * 2 * L * 8);
-    if (rc == PLK_OK) rc = lane_d2h(*l, outs, out_zero, dz.p, batch);
-    const int rf = lane_finish(*l, outs);
-    return rc != PLK_OK ? rc : rf;
+    PLK_TRY(c.out(out_xy, dxy, (size_t)batch * 2 * L * 8));
+    PLK_TRY(c.out(out_zero, dz, batch));
+    return c.finish();
 }
 
 int plk_msm_execute(plk_msm_ctx* ctx, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xy, uint8_t* out_zero) {
@@ -871,8 +765,7 @@ int plk_msm_precompute_table(int curve, size_t n, const uint64_t* bases_xy, cons
     const size_t digits = (size_t)msm_table_digits(curve, w);
     LaneCall c;
     PLK_TRY(c.begin());
-    HostPin po;
-    po.pin(out_xy, n * digits * 2 * L * 8);
+    c.pin(out_xy, n * digits * 2 * L * 8);
     void *db = nullptr, *dz = nullptr, *dout = nullptr, *doz = nullptr;
     PLK_TRY(c.in(db, bases_xy, n * 2 * L * 8));
     if (base_zero) PLK_TRY(c.in(dz, base_zero, n));

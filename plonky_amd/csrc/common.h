@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <functional>
 #include <memory>
 #include <string>
 
@@ -30,9 +31,30 @@ int set_error(int code, const char* fmt, ...);
         if (_rc != PLK_OK) return _rc; \
     } while (0)
 
-// Makes sure a device is selected for the calling thread (plk_init may have been called on
-// another thread: hipSetDevice is per thread).
+// Makes sure the calling thread's device is selected (plk_init may have been called on another thread: hipSetDevice is per
+// thread): the physical device of the thread's logical device in the group (multi.hip).
 int ensure_device();
+
+// ---- the device group (multi.hip): logical device d of the process -> physical HIP device ----
+constexpr int PLK_MAX_DEVICES = 16;
+int group_size();                            // logical devices in use (1 unless plk_init_devices made it more)
+int group_phys(int logical);                 // physical HIP device of a logical device
+int thread_logical_device();                 // the logical device the calling thread's calls run on
+void set_thread_logical_device(int logical);
+int next_round_robin_device();               // single-unit calls from many host threads take the devices in turn
+unsigned multi_min_log_n();                  // size gate of the fan-out (PLK_MULTI_MIN_LOG_N)
+struct DeviceScope {                         // the calling thread works on logical device `logical` for the scope
+    int prev;
+    explicit DeviceScope(int logical);
+    ~DeviceScope();
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+int group_init_single(int device);           // plk_init
+int group_init(int n_devices);               // plk_init_devices
+void group_shutdown();
+// fn(d) on the worker thread of every logical device d < count, side by side; returns when all have; the first failure wins
+int run_on_devices(int count, const std::function<int(int)>& fn);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -236,6 +236,9 @@ struct plk_halo_ctx {
     uint8_t *ratios = nullptr, *rec = nullptr, *hu = nullptr;  // 2^virt_total fold scalars | two partial-sum records | [l, <a,b>] x 2
     size_t rec_bytes = 0;
     bool lr_done = false;
+    // a fold failed after the scalars were folded (scratch, launch): the vectors no longer belong to one round - every later
+    // call reports that instead of returning an L / R of a half-folded state
+    bool poisoned = false;
     std::mutex mu;
     ~plk_halo_ctx() {
         if (stream) (void)hipStreamSynchronize(stream);
@@ -336,7 +339,14 @@ int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, c
     c->n0 = c->n = n;
     c->stream = stream;
     c->endo = curve != PLK_CURVE_BLS12_377;  // the 2^r-to-1 fold runs along the endomorphism
-    if (const char* e = getenv("PLK_HALO_FREEZE_LOG")) freeze_log = (unsigned)atoi(e);
+    // tuning variables apply where the caller left the choice to the library (argument 0), and only with a sane value
+    auto env_uint = [](const char* name, unsigned lo, unsigned hi, unsigned& out) {
+        if (const char* e = getenv(name)) {
+            const long v = atol(e);
+            if (v >= (long)lo && v <= (long)hi) out = (unsigned)v;
+        }
+    };
+    if (freeze_log == 0) env_uint("PLK_HALO_FREEZE_LOG", 1, 40, freeze_log);
     c->freeze_log = freeze_log ? freeze_log : 14u;
     if (const char* e = getenv("PLK_HALO_STAGE")) c->stage_depth = (unsigned)atoi(e);
     if (c->stage_depth > 4) c->stage_depth = 4;
@@ -349,7 +359,7 @@ int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, c
         if (msm_ctx_curve(tables) != curve || msm_ctx_table_free(tables) || msm_ctx_len(tables) < n)
             return set_error(PLK_ERR_INVALID_ARG, "the tables handed to the argument must be a tabled context of this curve over at least %zu generators", n);
         unsigned lead = lead_rounds ? lead_rounds : 2u;
-        if (const char* e = getenv("PLK_HALO_LEAD")) lead = (unsigned)atoi(e);
+        if (lead_rounds == 0) env_uint("PLK_HALO_LEAD", 0, 4, lead);
         if (lead > 4) lead = 4;
         while (lead > 0 && (n >> lead) < fz) --lead;
         if (c->endo && lead) {
@@ -428,6 +438,7 @@ int halo_round_lr_impl(plk_halo_ctx* c, const uint64_t* l_blind, const uint64_t*
     if (!c || !l_blind || !r_blind || !lr_xy || !lr_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     PLK_TRY(ensure_device());
     std::lock_guard<std::mutex> lk(c->mu);
+    if (c->poisoned) return set_error(PLK_ERR_INVALID_ARG, "the argument's context is unusable: an earlier fold failed half way");
     if (c->n < 2) return set_error(PLK_ERR_INVALID_ARG, "the argument is finished (length %zu)", c->n);
     const size_t m = c->n / 2, pt = (size_t)2 * c->L * 8;
     const bool virt = c->virt_left > 0, lead = virt && c->lead_ctx;
@@ -496,9 +507,17 @@ int halo_round_fold_impl(plk_halo_ctx* c, const uint64_t* u_j, const uint64_t* u
     if (!c || !u_j || !u_j_inv) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     PLK_TRY(ensure_device());
     std::lock_guard<std::mutex> lk(c->mu);
+    if (c->poisoned) return set_error(PLK_ERR_INVALID_ARG, "the argument's context is unusable: an earlier fold failed half way");
     if (c->n < 2) return set_error(PLK_ERR_INVALID_ARG, "the argument is finished (length %zu)", c->n);
     const size_t m = c->n / 2, pt = (size_t)2 * c->L * 8;
     const bool virt = c->virt_left > 0;
+    struct Poison {  // armed while the scalars are folded and the generators are not
+        plk_halo_ctx* c;
+        bool armed;
+        ~Poison() {
+            if (armed) c->poisoned = true;
+        }
+    } poison{c, false};
     const size_t m0 = (c->frozen || virt) ? c->m0 : 0;
     const size_t work = m > m0 ? m : m0;
     HALO_FIELD_SWITCH(c->sfield, (k_halo_fold_scalars<P><<<(unsigned)((work + 255) / 256), 256, 0, c->stream>>>(
@@ -507,6 +526,7 @@ int halo_round_fold_impl(plk_halo_ctx* c, const uint64_t* u_j, const uint64_t* u
     PLK_HIP_TRY(hipGetLastError());
     c->n = m;
     c->lr_done = false;
+    poison.armed = true;
     if (virt) {
         HALO_FIELD_SWITCH(c->sfield, (k_halo_lead_ratios<P><<<1, 64, 0, c->stream>>>((uint4*)c->ratios, (int)(c->virt_total - c->virt_left), (const uint4*)c->dsc)));
         PLK_HIP_TRY(hipGetLastError());
@@ -530,6 +550,7 @@ int halo_round_fold_impl(plk_halo_ctx* c, const uint64_t* u_j, const uint64_t* u
             PLK_TRY(curve_fold_pairs_dev_impl(c->curve, m, c->g, c->gz, c->g + m * pt, c->gz + m, nullptr, nullptr, c->g, c->gz, c->stream, c->dsc, 1));
         PLK_TRY(halo_next_stage(c));
     }
+    poison.armed = false;
     return PLK_OK;
 }
 
@@ -542,6 +563,7 @@ int halo_read_impl(plk_halo_ctx* c, uint64_t* a, uint64_t* b, uint64_t* g_xy, ui
     if (!c) return set_error(PLK_ERR_INVALID_ARG, "null context");
     PLK_TRY(ensure_device());
     std::lock_guard<std::mutex> lk(c->mu);
+    if (c->poisoned) return set_error(PLK_ERR_INVALID_ARG, "the argument's context is unusable: an earlier fold failed half way");
     const size_t pt = (size_t)2 * c->L * 8;
     if (a) PLK_HIP_TRY(hipMemcpyAsync(a, c->a, c->n * 32, hipMemcpyDeviceToHost, c->stream));
     if (b) PLK_HIP_TRY(hipMemcpyAsync(b, c->b, c->n * 32, hipMemcpyDeviceToHost, c->stream));

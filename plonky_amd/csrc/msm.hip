@@ -729,10 +729,15 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
     head_live[lane] = (head || (parked && tid == 0)) ? 1 : 0;
 }
 #ifndef PLK_ACC_WAVES
-#define PLK_ACC_WAVES 1  // waves per SIMD the register allocation of the accumulation is held to (tuning builds: variants/)
+#define PLK_ACC_WAVES 1  // waves per SIMD the register allocation of the accumulation is held to (tuning builds: tools/acc_ab.sh)
+#endif
+#if PLK_ACC_WAVES > 0
+#define PLK_ACC_BOUNDS __launch_bounds__(ACC_THREADS, PLK_ACC_WAVES)
+#else
+#define PLK_ACC_BOUNDS __launch_bounds__(ACC_THREADS)  // round 2's form (A/B builds)
 #endif
 template <class C>
-__global__ void __launch_bounds__(ACC_THREADS, PLK_ACC_WAVES) k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
+__global__ void PLK_ACC_BOUNDS k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
                                                                 const uint32_t* __restrict__ off, uint4* __restrict__ p_start, uint4* __restrict__ p_head,
                                                                 uint8_t* __restrict__ head_live, uint32_t buckets, const uint32_t* __restrict__ dyn_chunk,
                                                                 int wshift, uint32_t n_sub, uint32_t tab_entries) {
@@ -1355,7 +1360,19 @@ struct plk_msm_ctx {
     static constexpr int N_STAGES = 7;  // order: count + scan | scatter | bins; accumulate; heavy + assemble + lines; planes; final
     std::vector<std::vector<hipEvent_t>> prof_sets;  // each N_STAGES + 1 events, recorded
     std::vector<std::vector<hipEvent_t>> prof_free;
+    // A context built while the library runs over several devices (plk_init_devices; multi.hip) owns one context with the full
+    // tables on every other logical device (peers[d - 1]) and, on every device d including this one, a context over that device's
+    // contiguous share of the generators with the window such a share deserves (shards[d]): whole vectors of a batch run on the
+    // full tables, a single MSM runs sharded by base range.
+    std::vector<plk_msm_ctx*> peers, shards;
     ~plk_msm_ctx() {
+        for (auto* v : {&peers, &shards})
+            for (plk_msm_ctx* sub : *v)
+                if (sub) {
+                    (void)hipSetDevice(sub->device);
+                    delete sub;
+                }
+        (void)hipSetDevice(device);
         if (tab && table_free) {
             // pooled: hand it back ordered after the last kernel that read it (several user streams: wait for them here)
             hipStream_t last = tab_stream;
@@ -1978,6 +1995,7 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
     if (batch == 0) return PLK_OK;
     if ((!parts && ctx->n && !d_scalars) || !d_out_xy || !d_out_zero) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
     PLK_TRY(ensure_device());
+    PLK_HIP_TRY(hipSetDevice(ctx->device));  // a context works on the device it was built on, whichever device the thread last used
     std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t L = (size_t)curve_limbs(ctx->curve);
     auto run_one = [&](unsigned b, MsmWork& w, hipStream_t st, int phases) -> int {
@@ -2156,7 +2174,15 @@ size_t msm_ctx_len(const plk_msm_ctx* ctx) { return ctx->n; }
 unsigned msm_ctx_window(const plk_msm_ctx* ctx) { return (unsigned)ctx->c; }
 int msm_ctx_curve(const plk_msm_ctx* ctx) { return ctx->curve; }
 int msm_ctx_table_free(const plk_msm_ctx* ctx) { return ctx->table_free ? 1 : 0; }
-void msm_ctx_delete(plk_msm_ctx* ctx) { delete ctx; }
+void msm_ctx_delete(plk_msm_ctx* ctx) {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    delete ctx;  // frees on the devices its parts live on
+    if (cur >= 0) (void)hipSetDevice(cur);
+}
+int msm_ctx_device(const plk_msm_ctx* ctx) { return ctx->device; }
+std::vector<plk_msm_ctx*>& msm_ctx_peers(plk_msm_ctx* ctx) { return ctx->peers; }
+std::vector<plk_msm_ctx*>& msm_ctx_shards(plk_msm_ctx* ctx) { return ctx->shards; }
 
 // msm_precompute with the reference's output (curve_msm.rs:27-52): powers_per_generator[i][j] = [2^(w j)] G_i, j < ceil(BITS / w)
 int msm_table_digits(int curve, unsigned w) { return w ? (scalar_bits(curve) + (int)w - 1) / (int)w : -1; }

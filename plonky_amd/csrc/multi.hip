@@ -1,0 +1,470 @@
+// multi.hip -- several GPUs behind the single-process C ABI (plk_init(n_devices), 8(e); section 5: PLK_NGPU).
+//
+// The reference's callers are ONE process with Rayon threads: commit_polynomials -> coeffs_vec_to_commitments
+// (plonk_util.rs:215-231, poly_commit.rs:52-66) commits the wire polynomials one msm_execute_parallel after the other, and
+// polynomials_to_values_padded / values_to_polynomials (plonk_util.rs:169-190) run nine transforms on nine threads.  With those
+// files untouched the library is entered from one process - so the split over the GPUs of a node has to happen HERE, below the
+// entry points:
+//   * a device group (plk_init_devices / PLK_NGPU): logical device d -> physical HIP device; PLK_VIRTUAL_DEVICES=k makes k
+//     logical devices out of ONE physical GPU (k contexts, k worker threads, k stream sets) so that the whole path runs in a
+//     one-GPU test suite;
+//   * one worker thread per logical device (hipSetDevice is per thread; a worker owns the lanes of its device): a fan-out call
+//     hands every worker its share, the workers ENQUEUE side by side and return, the caller's stream waits for their events;
+//   * msm_precompute builds, on every device, the full window tables (for whole vectors of a batch) and a context over the
+//     device's own contiguous share of the generators with the window such a share deserves (for a single sharded MSM);
+//   * msm_execute[_batch]: the batch plan of SURVEY 8(e) / DESIGN section 6 - floor(batch / N) WHOLE vectors per device (vector v
+//     belongs to device v mod N), the remaining batch mod N vectors SHARDED by contiguous base range, every device's partial
+//     results in one record (plk_msm_partials_bytes), the records copied peer to peer (xGMI; a device-to-device copy when the
+//     devices are virtual) into one buffer on the caller's device, k_combine_partials there.  Point addition is not a
+//     collective's reduction op and the payload is a few hundred bytes: N - 1 small peer writes are the whole exchange;
+//   * transforms are independent units: a batch is dealt out round-robin (no exchange), single-transform calls coming from
+//     many host threads take the devices in turn.
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+#include "host_lane.h"
+
+struct plk_msm_ctx;
+
+namespace plk {
+
+int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, unsigned flags, hipStream_t stream,
+                            plk_msm_ctx** out_ctx, const void* d_extra = nullptr, size_t n_extra = 0, const size_t* also_n = nullptr,
+                            int also_count = 0);
+struct MsmParts {
+    const uint64_t* first;
+    const uint64_t* count;
+    const void* const* scalars;
+};
+int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
+                         hipEvent_t* ready = nullptr, const MsmParts* parts = nullptr);
+int msm_combine_partials_dev_impl(int curve, unsigned world, unsigned batch, unsigned whole_per_rank, const void* d_gathered, void* d_out_xy, void* d_out_zero,
+                                  hipStream_t stream);
+size_t msm_partials_bytes(int curve, unsigned batch);
+size_t msm_ctx_len(const plk_msm_ctx* ctx);
+int msm_ctx_curve(const plk_msm_ctx* ctx);
+int msm_ctx_table_free(const plk_msm_ctx* ctx);
+void msm_ctx_delete(plk_msm_ctx* ctx);
+std::vector<plk_msm_ctx*>& msm_ctx_peers(plk_msm_ctx* ctx);
+std::vector<plk_msm_ctx*>& msm_ctx_shards(plk_msm_ctx* ctx);
+
+// ---- the device group ----
+static std::mutex g_group_mu;            // guards changes of the group and of the worker set
+static std::atomic<int> g_n{0};          // logical devices; 0: not initialised (the first call adopts the thread's current device)
+static int g_phys[PLK_MAX_DEVICES] = {};
+static thread_local int t_logical = 0;   // the logical device this thread's calls run on
+static std::atomic<unsigned> g_round_robin{0};
+
+int group_size() {
+    const int n = g_n.load(std::memory_order_acquire);
+    return n > 0 ? n : 1;
+}
+int group_phys(int logical) { return g_phys[logical >= 0 && logical < group_size() ? logical : 0]; }
+int thread_logical_device() { return t_logical < group_size() ? t_logical : 0; }
+void set_thread_logical_device(int logical) { t_logical = logical; }
+int next_round_robin_device() { return (int)(g_round_robin.fetch_add(1u, std::memory_order_relaxed) % (unsigned)group_size()); }
+
+unsigned multi_min_log_n() {
+    // below 2^this many scalars / elements a call stays on one device: a device's share must be worth the fixed latency of an
+    // MSM reduction (0.45 ms) resp. of a transform's three launches
+    static const unsigned v = [] {
+        const char* e = getenv("PLK_MULTI_MIN_LOG_N");
+        const int x = e ? atoi(e) : 17;
+        return x < 0 ? 0u : (unsigned)x;
+    }();
+    return v;
+}
+
+int ensure_device() {
+    int n = g_n.load(std::memory_order_acquire);
+    if (n == 0) {
+        std::lock_guard<std::mutex> lk(g_group_mu);
+        n = g_n.load(std::memory_order_acquire);
+        if (n == 0) {
+            int count = 0;
+            hipError_t e = hipGetDeviceCount(&count);
+            if (e != hipSuccess || count <= 0)
+                return set_error(PLK_ERR_NO_DEVICE, "no HIP device visible (%s); the HIP path has no CPU fallback", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+            int cur = 0;
+            if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+            g_phys[0] = cur;
+            g_n.store(1, std::memory_order_release);
+            n = 1;
+        }
+    }
+    const int l = t_logical < n ? t_logical : 0;
+    PLK_HIP_TRY(hipSetDevice(g_phys[l]));
+    return PLK_OK;
+}
+
+DeviceScope::DeviceScope(int logical) : prev(t_logical) { t_logical = logical; }
+DeviceScope::~DeviceScope() { t_logical = prev; }
+
+// ---- worker threads: one per logical device ----
+struct Worker {
+    int logical = 0;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    const std::function<int(int)>* job = nullptr;
+    bool pending = false, finished = false, stop = false;
+    int rc = PLK_OK;
+    std::string err;
+    hipEvent_t ev_done = nullptr;  // on this worker's device: "my share of the current fan-out call is enqueued up to here"
+};
+static std::vector<Worker*>* g_workers = nullptr;  // never destroyed at exit: detached threads may still wait on their condition variables
+static std::mutex g_dispatch_mu;                    // one fan-out call at a time (each uses every device anyway)
+
+static void worker_main(Worker* w) {
+    t_logical = w->logical;
+    std::unique_lock<std::mutex> lk(w->mu);
+    for (;;) {
+        w->cv.wait(lk, [&] { return w->pending || w->stop; });
+        if (w->stop) break;
+        const std::function<int(int)>* job = w->job;
+        w->pending = false;
+        lk.unlock();
+        int rc = ensure_device();
+        if (rc == PLK_OK) rc = (*job)(w->logical);
+        lk.lock();
+        w->rc = rc;
+        w->err = rc != PLK_OK ? last_error_ref() : std::string();
+        w->finished = true;
+        w->cv.notify_all();
+    }
+}
+
+static void workers_stop_locked() {
+    if (!g_workers) return;
+    for (Worker* w : *g_workers) {
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->stop = true;
+        }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+        if (w->ev_done) (void)hipEventDestroy(w->ev_done);
+        delete w;
+    }
+    g_workers->clear();
+}
+
+static int workers_ensure() {
+    std::lock_guard<std::mutex> lk(g_group_mu);
+    if (!g_workers) g_workers = new std::vector<Worker*>();
+    const int n = group_size();
+    if ((int)g_workers->size() == n) return PLK_OK;
+    workers_stop_locked();
+    for (int d = 0; d < n; ++d) {
+        Worker* w = new Worker();
+        w->logical = d;
+        PLK_HIP_TRY(hipSetDevice(g_phys[d]));
+        PLK_HIP_TRY(hipEventCreateWithFlags(&w->ev_done, hipEventDisableTiming));
+        w->th = std::thread(worker_main, w);
+        g_workers->push_back(w);
+    }
+    PLK_HIP_TRY(hipSetDevice(g_phys[thread_logical_device()]));
+    return PLK_OK;
+}
+
+// fn(d) on the worker thread of every logical device d < count, side by side; returns when all have returned.  The first
+// failure's code and text become the caller's.  The caller holds g_dispatch_mu.
+static int run_on_devices_locked(int count, const std::function<int(int)>& fn) {
+    PLK_TRY(workers_ensure());
+    std::vector<Worker*>& ws = *g_workers;
+    for (int d = 0; d < count; ++d) {
+        std::lock_guard<std::mutex> lk(ws[d]->mu);
+        ws[d]->job = &fn;
+        ws[d]->finished = false;
+        ws[d]->pending = true;
+    }
+    for (int d = 0; d < count; ++d) ws[d]->cv.notify_all();
+    int rc = PLK_OK;
+    for (int d = 0; d < count; ++d) {
+        std::unique_lock<std::mutex> lk(ws[d]->mu);
+        ws[d]->cv.wait(lk, [&] { return ws[d]->finished; });
+        if (ws[d]->rc != PLK_OK && rc == PLK_OK) {
+            rc = ws[d]->rc;
+            last_error_ref() = "device " + std::to_string(d) + ": " + ws[d]->err;
+        }
+    }
+    return rc;
+}
+int run_on_devices(int count, const std::function<int(int)>& fn) {
+    std::lock_guard<std::mutex> lk(g_dispatch_mu);
+    return run_on_devices_locked(count, fn);
+}
+
+static int check_gfx950(int device) {
+    hipDeviceProp_t prop;
+    PLK_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(PLK_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    return PLK_OK;
+}
+
+// plk_init: one device for this process
+int group_init_single(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return set_error(PLK_ERR_NO_DEVICE, "no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device == -1) {
+        const char* env = getenv("PLK_DEVICE");
+        device = env ? atoi(env) : 0;
+    }
+    if (device < 0 || device >= count) return set_error(PLK_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, count);
+    PLK_HIP_TRY(hipSetDevice(device));
+    PLK_TRY(check_gfx950(device));
+    std::lock_guard<std::mutex> dl(g_dispatch_mu);
+    std::lock_guard<std::mutex> lk(g_group_mu);
+    if (g_n.load() > 1) workers_stop_locked();
+    g_phys[0] = device;
+    g_n.store(1, std::memory_order_release);
+    return PLK_OK;
+}
+
+// plk_init_devices: n_devices > 0: that many; 0: PLK_NGPU, else every visible device.  PLK_VIRTUAL_DEVICES=k (k >= 2): k logical
+// devices on the ONE physical device PLK_DEVICE (default 0) - n_devices, when positive, overrides k.
+int group_init(int n_devices) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return set_error(PLK_ERR_NO_DEVICE, "no HIP device visible (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (n_devices < 0) return set_error(PLK_ERR_INVALID_ARG, "n_devices = %d", n_devices);
+    const char* venv = getenv("PLK_VIRTUAL_DEVICES");
+    const int virt = venv ? atoi(venv) : 0;
+    int phys[PLK_MAX_DEVICES];
+    int n = n_devices;
+    if (virt >= 2) {
+        if (n == 0) n = virt;
+        if (n > PLK_MAX_DEVICES) return set_error(PLK_ERR_INVALID_ARG, "%d virtual devices (at most %d)", n, PLK_MAX_DEVICES);
+        const char* denv = getenv("PLK_DEVICE");
+        const int base = denv ? atoi(denv) : 0;
+        if (base < 0 || base >= count) return set_error(PLK_ERR_INVALID_ARG, "PLK_DEVICE %d out of range (%d visible)", base, count);
+        for (int d = 0; d < n; ++d) phys[d] = base;
+    } else {
+        if (n == 0) {
+            const char* nenv = getenv("PLK_NGPU");
+            n = nenv ? atoi(nenv) : count;
+            if (n <= 0) n = count;
+        }
+        if (n > count) return set_error(PLK_ERR_INVALID_ARG, "%d devices asked for, %d visible", n, count);
+        if (n > PLK_MAX_DEVICES) return set_error(PLK_ERR_INVALID_ARG, "%d devices (at most %d)", n, PLK_MAX_DEVICES);
+        for (int d = 0; d < n; ++d) phys[d] = d;
+    }
+    for (int d = 0; d < n; ++d)
+        if (d == 0 || phys[d] != phys[d - 1]) PLK_TRY(check_gfx950(phys[d]));
+    // peer access both ways between every pair of distinct devices (xGMI): the exchange of partial results and the device-source
+    // forms copy straight from one HBM to another.  Where it cannot be enabled the runtime stages such copies through the host.
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) {
+            if (phys[a] == phys[b]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, phys[a], phys[b]) != hipSuccess || !can) continue;
+            PLK_HIP_TRY(hipSetDevice(phys[a]));
+            const hipError_t pe = hipDeviceEnablePeerAccess(phys[b], 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        }
+    PLK_HIP_TRY(hipSetDevice(phys[0]));
+    std::lock_guard<std::mutex> dl(g_dispatch_mu);
+    std::lock_guard<std::mutex> lk(g_group_mu);
+    bool same = g_n.load() == n;
+    for (int d = 0; d < n && same; ++d) same = g_phys[d] == phys[d];
+    if (!same) {
+        workers_stop_locked();
+        for (int d = 0; d < n; ++d) g_phys[d] = phys[d];
+        g_n.store(n, std::memory_order_release);
+    }
+    return PLK_OK;
+}
+
+void group_shutdown() {
+    std::lock_guard<std::mutex> dl(g_dispatch_mu);
+    std::lock_guard<std::mutex> lk(g_group_mu);
+    workers_stop_locked();
+    g_n.store(0, std::memory_order_release);
+}
+
+// ---- MSM over the group ----
+static inline size_t share_first(size_t n, int d, int world) { return (size_t)(((unsigned __int128)n * (unsigned)d) / (unsigned)world); }
+
+bool msm_ctx_is_multi(plk_msm_ctx* ctx) { return ctx && !msm_ctx_shards(ctx).empty(); }
+
+// msm_precompute on every device of the group.  `bases` / `zero`: host memory (host_src) or memory of the caller's device.
+// The caller's stream is synchronised on return (as msm_precompute_dev_impl does).
+int msm_precompute_multi(int curve, size_t n, const void* bases, const void* zero, bool host_src, unsigned window_bits, hipStream_t caller_stream,
+                         plk_msm_ctx** out_ctx) {
+    if (!out_ctx) return set_error(PLK_ERR_INVALID_ARG, "null out_ctx");
+    *out_ctx = nullptr;
+    const int L = curve_limbs(curve);
+    if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    const int world = group_size();
+    const size_t pt = (size_t)2 * L * 8;
+    PLK_TRY(ensure_device());
+    const int src_phys = group_phys(thread_logical_device());
+    std::lock_guard<std::mutex> dl(g_dispatch_mu);
+    PLK_TRY(workers_ensure());
+    if (!host_src) PLK_HIP_TRY(hipStreamSynchronize(caller_stream));  // the generators are complete before another device reads them
+    HostPin pin_b, pin_z;
+    if (host_src) {
+        pin_b.pin(bases, n * pt);
+        if (zero) pin_z.pin(zero, n);
+    }
+    std::vector<plk_msm_ctx*> full((size_t)world, nullptr), shard((size_t)world, nullptr);
+    auto job = [&](int d) -> int {
+        HostLane* l = nullptr;
+        PLK_TRY(lane_get(l));
+        const void* b = bases;
+        const void* z = zero;
+        LaneBuf db, dz;
+        if (host_src || group_phys(d) != src_phys) {
+            PLK_TRY(db.alloc(n * pt, l->stream));
+            PLK_HIP_TRY(hipMemcpyAsync(db.p, bases, n * pt, hipMemcpyDefault, l->stream));
+            b = db.p;
+            if (zero) {
+                PLK_TRY(dz.alloc(n, l->stream));
+                PLK_HIP_TRY(hipMemcpyAsync(dz.p, zero, n, hipMemcpyDefault, l->stream));
+                z = dz.p;
+            }
+        }
+        int rc = msm_precompute_dev_impl(curve, n, b, z, window_bits, 0, l->stream, &full[(size_t)d]);
+        if (rc == PLK_OK) {
+            const size_t f = share_first(n, d, world), e = share_first(n, d + 1, world);
+            rc = msm_precompute_dev_impl(curve, e - f, (const uint8_t*)b + f * pt, z ? (const uint8_t*)z + f : nullptr, 0, 0, l->stream, &shard[(size_t)d]);
+        }
+        const hipError_t se = hipStreamSynchronize(l->stream);
+        l->pin_used = 0;
+        if (rc == PLK_OK && se != hipSuccess) rc = set_error(PLK_ERR_HIP, "precompute on device %d failed: %s", d, hipGetErrorString(se));
+        return rc;
+    };
+    const int rc = run_on_devices_locked(world, job);
+    if (rc != PLK_OK) {
+        for (auto* v : {&full, &shard})
+            for (plk_msm_ctx* c : *v)
+                if (c) msm_ctx_delete(c);
+        (void)ensure_device();
+        return rc;
+    }
+    plk_msm_ctx* ctx = full[0];
+    for (int d = 1; d < world; ++d) msm_ctx_peers(ctx).push_back(full[(size_t)d]);
+    msm_ctx_shards(ctx) = shard;
+    *out_ctx = ctx;
+    return PLK_OK;
+}
+
+// `batch` scalar vectors (vecs[b]: n scalars of 32 bytes, host memory or memory of the caller's device) against a context built
+// by msm_precompute_multi.  Results: device memory of the caller's device, asynchronous on caller_stream (which also orders the
+// inputs of the device-source form).  The workers only enqueue; a host-source caller synchronises caller_stream before it lets
+// go of the vectors.
+int msm_execute_multi(plk_msm_ctx* ctx, unsigned batch, const void* const* vecs, bool host_src, size_t n, void* d_out_xy, void* d_out_zero,
+                      hipStream_t caller_stream) {
+    if (!ctx || !msm_ctx_is_multi(ctx)) return set_error(PLK_ERR_INVALID_ARG, "not a multi-device context");
+    if (n != msm_ctx_len(ctx))
+        return set_error(PLK_ERR_SIZE_MISMATCH, "scalars.len() = %zu but the precomputation holds %zu generators (curve_msm.rs:67)", n, msm_ctx_len(ctx));
+    if (batch == 0) return PLK_OK;
+    if (!vecs || !d_out_xy || !d_out_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    std::vector<plk_msm_ctx*>& peers = msm_ctx_peers(ctx);
+    std::vector<plk_msm_ctx*>& shards = msm_ctx_shards(ctx);
+    const int world = (int)shards.size();
+    if (world != group_size() || (int)peers.size() != world - 1)
+        return set_error(PLK_ERR_INVALID_ARG, "the context was built for %d devices, the library now runs %d", world, group_size());
+    const int curve = msm_ctx_curve(ctx);
+    const size_t L = (size_t)curve_limbs(curve);
+    const unsigned whole = batch / (unsigned)world, rem = batch - whole * (unsigned)world, slots = whole + rem;
+    const size_t rec = msm_partials_bytes(curve, slots);
+    PLK_TRY(ensure_device());
+    const int src_phys = group_phys(thread_logical_device());
+    std::lock_guard<std::mutex> dl(g_dispatch_mu);
+    PLK_TRY(workers_ensure());
+    uint8_t* gathered = (uint8_t*)scratch_acquire(rec * (size_t)world, caller_stream);
+    if (!gathered) return PLK_ERR_OOM;
+    struct Release {
+        void* p;
+        hipStream_t s;
+        ~Release() { scratch_release(p, s); }
+    } release_gathered{gathered, caller_stream};
+    // the workers' streams start after whatever the caller's stream holds now (device-resident inputs; the previous use of d_out)
+    static thread_local hipEvent_t t_ev_in = nullptr;
+    static thread_local int t_ev_in_dev = -1;
+    if (t_ev_in && t_ev_in_dev != src_phys) {
+        (void)hipEventDestroy(t_ev_in);
+        t_ev_in = nullptr;
+    }
+    if (!t_ev_in) {
+        PLK_HIP_TRY(hipEventCreateWithFlags(&t_ev_in, hipEventDisableTiming));
+        t_ev_in_dev = src_phys;
+    }
+    const hipEvent_t ev_in = t_ev_in;  // a plain copy for the workers: a thread_local named inside the lambda would be THEIR instance
+    PLK_HIP_TRY(hipEventRecord(ev_in, caller_stream));
+    auto job = [&](int d) -> int {
+        HostLane* l = nullptr;
+        PLK_TRY(lane_get(l));
+        PLK_HIP_TRY(hipStreamWaitEvent(l->stream, ev_in, 0));
+        PLK_TRY(lane_fork(*l));  // the copy stream starts after the main one, i.e. after the caller's inputs
+        while (l->ev_ready.size() < slots) {
+            hipEvent_t e = nullptr;
+            PLK_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            l->ev_ready.push_back(e);
+        }
+        // this device's slots: its whole vectors over all the generators, then its base range of every sharded vector
+        const size_t f = share_first(n, d, world), cnt = share_first(n, d + 1, world) - f;
+        const bool pure_shard = whole == 0;  // a single MSM (or fewer vectors than devices): the context over this device's own range
+        std::vector<uint64_t> first(slots), count(slots);
+        std::vector<const void*> ptr(slots);
+        size_t need = 0;
+        for (unsigned s = 0; s < slots; ++s) {
+            first[s] = s < whole ? 0 : f;
+            count[s] = s < whole ? n : cnt;
+            need += count[s];
+        }
+        const bool direct = !host_src && group_phys(d) == src_phys;  // the vectors already live on this device
+        LaneBuf sbuf, rbuf;
+        if (!direct) PLK_TRY(sbuf.alloc(need * 32, l->stream));
+        PLK_TRY(rbuf.alloc(rec, l->stream));
+        size_t off = 0;
+        for (unsigned s = 0; s < slots; ++s) {
+            const uint8_t* src = (const uint8_t*)vecs[s < whole ? s * (unsigned)world + (unsigned)d : whole * (unsigned)world + (s - whole)] + first[s] * 32;
+            if (direct) {
+                ptr[s] = src;
+            } else {
+                uint8_t* dst = (uint8_t*)sbuf.p + off * 32;
+                // host memory crosses this device's own PCIe link; memory of the caller's device crosses xGMI
+                PLK_HIP_TRY(hipMemcpyAsync(dst, src, count[s] * 32, hipMemcpyDefault, l->aux[0]));
+                ptr[s] = dst;
+                off += count[s];
+            }
+            PLK_HIP_TRY(hipEventRecord(l->ev_ready[s], l->aux[0]));
+            if (pure_shard) first[s] = 0;  // the shard context counts from its own first generator
+        }
+        MsmParts parts{first.data(), count.data(), ptr.data()};
+        plk_msm_ctx* c = pure_shard ? shards[(size_t)d] : (d == 0 ? ctx : peers[(size_t)d - 1]);
+        uint8_t* r = (uint8_t*)rbuf.p;
+        PLK_TRY(msm_execute_dev_impl(c, slots, nullptr, 0, r, r + (size_t)slots * 2 * L * 8, l->stream, l->ev_ready.data(), &parts));
+        PLK_HIP_TRY(hipMemcpyAsync(gathered + (size_t)d * rec, r, rec, hipMemcpyDefault, l->stream));
+        PLK_HIP_TRY(hipEventRecord((*g_workers)[(size_t)d]->ev_done, l->stream));
+        return PLK_OK;
+    };
+    const int rc = run_on_devices_locked(world, job);
+    if (rc != PLK_OK) {
+        // whatever was enqueued must not outlive the caller's vectors
+        auto drain = [&](int) -> int {
+            HostLane* l = nullptr;
+            if (lane_get(l) == PLK_OK) (void)lane_join(*l);
+            return PLK_OK;
+        };
+        const std::string keep = last_error_ref();
+        (void)run_on_devices_locked(world, drain);
+        last_error_ref() = keep;
+        (void)ensure_device();
+        return rc;
+    }
+    PLK_TRY(ensure_device());
+    for (int d = 0; d < world; ++d) PLK_HIP_TRY(hipStreamWaitEvent(caller_stream, (*g_workers)[(size_t)d]->ev_done, 0));
+    return msm_combine_partials_dev_impl(curve, (unsigned)world, batch, whole, gathered, d_out_xy, d_out_zero, caller_stream);
+}
+
+}  // namespace plk

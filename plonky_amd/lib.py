@@ -24,6 +24,9 @@ PLK_ERR_OOM = -7
 _vp, _i, _u, _sz, _u64, _cp = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_char_p
 SYMBOLS = [
     ("plk_init", _i, [_i]),
+    ("plk_init_devices", _i, [_i]),
+    ("plk_device_count", _i, []),
+    ("plk_set_thread_device", _i, [_i]),
     ("plk_shutdown", None, []),
     ("plk_last_error", _cp, []),
     ("plk_min_gpu_log_n", _u, []),
@@ -106,12 +109,35 @@ class PlonkyHipError(RuntimeError):
         self.code = code
 
 
+def _source_hash():
+    """sha256 over everything the two libraries are built from (sources, headers, Makefile)."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(f for f in os.listdir(_CSRC) if f.endswith((".hip", ".cuh", ".h")) or f == "Makefile")
+    for f in names + [os.path.join("..", "..", "include", "plonky_hip.h")]:
+        h.update(f.encode())
+        with open(os.path.join(_CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+_STAMP = os.path.join(_CSRC, ".build_stamp")
+
+
 def build(force=False):
-    """Compile libplonky_hip.so and its checked twin (-DPLK_CHECKED) for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    args = ["make", "-C", _CSRC, "-j8", "all", "checked"]
-    if force:
-        args.append("-B")
-    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    """Compile libplonky_hip.so and its checked twin (-DPLK_CHECKED) for gfx950 in-tree (hipcc cross-compiles without a GPU).
+    A stamp with the hash of the sources sits next to the libraries: a tree whose libraries were built from exactly these
+    sources (the snapshot on a GPU lease, which carries the .so files but not the objects) is left alone."""
+    want = _source_hash()
+    have = open(_STAMP).read().strip() if os.path.exists(_STAMP) else ""
+    libs = [os.path.join(_CSRC, "libplonky_hip.so"), os.path.join(_CSRC, "libplonky_hip_checked.so")]
+    if force or have != want or not all(os.path.exists(p) for p in libs):
+        args = ["make", "-C", _CSRC, "-j8", "all", "checked"]
+        if force:
+            args.append("-B")
+        subprocess.check_call(args, stdout=subprocess.DEVNULL)
+        with open(_STAMP, "w") as fh:
+            fh.write(want + "\n")
     build_host_harness()
     return SO_PATH
 

@@ -83,13 +83,15 @@ class PartialExchange:
     on the device (plk_msm_combine_partials_dev: whole vectors copied from their owner, sharded ones summed over the ranks).
     No packing, no allocation, no host round trip inside a step (except the host staging gloo needs for device tensors)."""
 
-    def __init__(self, curve, batch, device="cuda", whole_per_rank=0, world=None, rank=None):
+    def __init__(self, curve, batch, device="cuda", whole_per_rank=0, world=None, rank=None, solo=False):
+        """solo: this process works alone even though a process group exists (rank 0 timing the one-GPU form of a problem
+        inside a multi-rank run): no collective, the record is copied into its slot like an emulated rank's."""
         from . import lib as _lib
         from .api import _CURVE_LIMBS
         self.curve, self.batch, self.whole = curve, batch, whole_per_rank
         self.L = _CURVE_LIMBS[curve]
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
-        self.real_world = dist.get_world_size() if dist.is_initialized() else 1
+        self.real_world = 1 if solo else (dist.get_world_size() if dist.is_initialized() else 1)
         self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
         self.slots = whole_per_rank + (batch - whole_per_rank * self.world)
         assert 0 < self.slots <= batch
@@ -137,6 +139,40 @@ class PartialExchange:
         pts = self.slots * 2 * self.L * 8
         xy = rows[:, :pts].contiguous().view(torch.int64).view(self.world, self.slots, 2, self.L)
         return xy, rows[:, pts:pts + self.slots].contiguous()
+
+
+def ntt_batch_sharded(transform, inputs, n_out, gather=True):
+    """A batch of INDEPENDENT transforms over the ranks (plonk_util.rs:169-190: the nine iNTTs / LDEs of a proof):
+    transform b belongs to rank b mod world (round_robin); computing it needs no collective.
+    inputs: (batch, n, 4) tensor (a rank only touches its own rows); transform(rows (k, n, 4)) -> (k, n_out, 4) runs this rank's
+    rows in ONE batched call (device.ntt_dev / device.ntt_padded_dev on the GPUs, the oracle in the CPU test).
+    gather=False: the results stay where they were computed - returns (indices, results) of this rank; a downstream stage dealt
+    out the same way needs nothing else.  gather=True: ONE all-gather hands every rank all results in batch order, (batch, n_out, 4)
+    (equal-sized blocks of ceil(batch / world) rows: a rank with one row fewer sends a zero row that is dropped)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    batch = inputs.shape[0]
+    mine = round_robin(batch, rank, world)
+    out = transform(inputs[mine]) if mine else None
+    if not gather:
+        return mine, out
+    if world == 1:
+        return out
+    per = (batch + world - 1) // world
+    block = torch.zeros((per, n_out, inputs.shape[2]), dtype=inputs.dtype, device=inputs.device)
+    if out is not None:
+        block[:len(mine)] = out
+    staged = block.is_cuda and _backend() == "gloo"
+    src = block.cpu() if staged else block
+    recv = torch.empty((world * per, n_out, inputs.shape[2]), dtype=block.dtype, device=src.device)
+    dist.all_gather_into_tensor(recv.view(-1), src.view(-1))
+    recv = recv.to(inputs.device).view(world, per, n_out, inputs.shape[2])
+    res = torch.empty((batch, n_out, inputs.shape[2]), dtype=inputs.dtype, device=inputs.device)
+    for r in range(world):
+        idx = round_robin(batch, r, world)
+        if idx:
+            res[idx] = recv[r, :len(idx)]
+    return res
 
 
 def all_gather_points(xy, zero):

@@ -41,7 +41,100 @@ static void rand_elems(std::vector<uint64_t>& v, size_t n, uint64_t seed) {
     }
 }
 
-int main() {
+// `capi_host multi`: the same host program over a device group.  Nine 2^16 scalar vectors are committed against 2^16 generators
+// (coeffs_vec_to_commitments, poly_commit.rs:52-66) and nine polynomials transformed (polynomials_to_values_padded,
+// plonk_util.rs:179-190) first with ONE device (plk_init) and then with the group plk_init_devices(0) gives - PLK_NGPU real
+// devices, or PLK_VIRTUAL_DEVICES logical ones on a one-GPU box - through the very same calls; the results must agree bit for bit.
+static int run_multi() {
+    const int CURVE = PLK_CURVE_TWEEDLEDEE, BASE = PLK_FIELD_TWEEDLEDEE_BASE;
+    const unsigned LOG_N = 16, BATCH = 9;
+    const size_t n = (size_t)1 << LOG_N;
+    CHECK(plk_init(0));
+    const uint64_t p_minus_1[4] = {0x842cafd400000000ull, 0x038aa127696286c9ull, 0, 0x4000000000000000ull};
+    uint64_t canon[8] = {p_minus_1[0], p_minus_1[1], p_minus_1[2], p_minus_1[3], 2, 0, 0, 0}, g[8];
+    CHECK(plk_field_op(BASE, 7, canon, nullptr, g, 2));
+    const int digits = plk_msm_table_digits(CURVE, 1);
+    std::vector<uint64_t> tab((size_t)digits * 8);
+    std::vector<uint8_t> tab_zero(digits);
+    CHECK(plk_msm_precompute_table(CURVE, 1, g, nullptr, 1, tab.data(), tab_zero.data()));
+    const size_t m = (size_t)digits - 1, rounds = (n + m - 1) / m;
+    std::vector<uint64_t> bases(rounds * m * 8), ab;
+    std::vector<uint8_t> bz(rounds * m);
+    rand_elems(ab, 2 * rounds, 0xB45E5);
+    for (size_t r = 0; r < rounds; ++r)
+        CHECK(plk_curve_fold_pairs(CURVE, m, tab.data(), nullptr, tab.data() + 8, nullptr, ab.data() + 8 * r, ab.data() + 8 * r + 4, bases.data() + r * m * 8,
+                                   bz.data() + r * m));
+    std::vector<std::vector<uint64_t>> s(BATCH), x(BATCH);
+    std::vector<const uint64_t*> sp(BATCH), xp(BATCH);
+    std::vector<size_t> xl(BATCH);
+    for (unsigned b = 0; b < BATCH; ++b) {
+        rand_elems(s[b], n, 3000 + b);
+        rand_elems(x[b], n / 8, 4000 + b);
+        sp[b] = s[b].data();
+        xp[b] = x[b].data();
+        xl[b] = n / 8 - b;  // ragged lengths
+    }
+    struct Result {
+        std::vector<uint64_t> commit, single;
+        std::vector<uint8_t> cz;
+        std::vector<std::vector<uint64_t>> lde, ntt;
+        uint8_t sz = 0;
+    } one, grp;
+    auto run = [&](Result& r) -> int {
+        plk_msm_ctx* ctx = nullptr;
+        CHECK(plk_msm_precompute(CURVE, n, bases.data(), nullptr, 0, &ctx));
+        r.commit.assign(BATCH * 8, 0);
+        r.cz.assign(BATCH, 0);
+        CHECK(plk_msm_execute_batch(ctx, BATCH, sp.data(), n, r.commit.data(), r.cz.data()));
+        r.single.assign(8, 0);
+        CHECK(plk_msm_execute(ctx, sp[4], n, r.single.data(), &r.sz));
+        CHECK(plk_msm_free(ctx));
+        r.lde.assign(BATCH, std::vector<uint64_t>(n * 4));
+        r.ntt.assign(BATCH, std::vector<uint64_t>(n * 4));
+        std::vector<uint64_t*> lp(BATCH), np_(BATCH);
+        for (unsigned b = 0; b < BATCH; ++b) {
+            lp[b] = r.lde[b].data();
+            np_[b] = r.ntt[b].data();
+        }
+        CHECK(plk_ntt_padded_batch(BASE, LOG_N, BATCH, xp.data(), xl.data(), lp.data()));
+        CHECK(plk_ntt_batch(BASE, LOG_N, 0, BATCH, sp.data(), np_.data()));  // any 4-limb data below p is a polynomial
+        // nine host threads, one transform each - the reference's par_iter
+        std::vector<std::vector<uint64_t>> th_out(BATCH, std::vector<uint64_t>(n * 4));
+        std::vector<int> rc(BATCH, 0);
+        std::vector<std::thread> pool;
+        for (unsigned b = 0; b < BATCH; ++b) pool.emplace_back([&, b] { rc[b] = plk_ntt(BASE, LOG_N, 0, sp[b], th_out[b].data()); });
+        for (auto& t : pool) t.join();
+        for (unsigned b = 0; b < BATCH; ++b)
+            if (rc[b] != PLK_OK || th_out[b] != r.ntt[b]) {
+                std::fprintf(stderr, "multi: transform %u from its own thread differs (rc %d)\n", b, rc[b]);
+                return 1;
+            }
+        return 0;
+    };
+    if (run(one)) return 1;
+    plk_shutdown();
+    CHECK(plk_init_devices(0));
+    const int world = plk_device_count();
+    if (world < 2) {
+        std::fprintf(stderr, "multi: only %d device in the group (set PLK_VIRTUAL_DEVICES=2 on a one-GPU box)\n", world);
+        return 1;
+    }
+    if (run(grp)) return 1;
+    if (one.commit != grp.commit || one.cz != grp.cz || one.single != grp.single || one.sz != grp.sz || one.lde != grp.lde || one.ntt != grp.ntt) {
+        std::fprintf(stderr, "multi: the device group's results differ from one device's\n");
+        return 1;
+    }
+    if (std::memcmp(grp.single.data(), grp.commit.data() + 4 * 8, 64)) {
+        std::fprintf(stderr, "multi: the sharded single MSM differs from its slot of the batch\n");
+        return 1;
+    }
+    plk_shutdown();
+    std::printf("capi_host multi: OK (%d devices, nine 2^%u-scalar commitments, nine transforms, bit-identical to one device)\n", world, LOG_N);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && !std::strcmp(argv[1], "multi")) return run_multi();
     const int CURVE = PLK_CURVE_TWEEDLEDEE, BASE = PLK_FIELD_TWEEDLEDEE_BASE;
     const int SCALAR = plk_curve_scalar_field(CURVE);
     const unsigned THREADS = 9, LOG_N = 14;

@@ -81,7 +81,34 @@ def main():
         pbytes = np.array([[(1 if z else 0) | (2 if P[1] & 1 else 0)] + list(P[0].to_bytes(8 * L, "little")) for P, z in zip(pts, zero)], dtype=np.uint8)
         np.savez(os.path.join(OUT, "bytes_%s.npz" % c.name), curve=c.curve_id, field=f.field_id, elems=arr([f.to_mont(v) for v in vals], L), elem_bytes=fbytes,
                  points=np.stack([arr([f.to_mont(P[0]), f.to_mont(P[1])], L) for P in pts]), points_zero=np.array(zero, dtype=np.uint8), point_bytes=pbytes)
+    msm_seeded_generators()
     print("golden vectors written to", OUT)
+
+
+SEEDED_MSM = [(br.TWEEDLEDEE, 16), (br.TWEEDLEDEE, 18), (br.TWEEDLEDEE, 20), (br.BLS12_377, 16), (br.BLS12_377, 18)]
+
+
+def msm_seeded_generators():
+    """MSMs at production geometry over generators WITHOUT structure (curve_msm.rs:218-241 tests arbitrary generators): G_i = [h_i] G
+    for seeded h_i, seeded scalars s_i - the fixture holds only the seeds and the expected affine point [sum s_i h_i mod r] G, one
+    scalar multiplication on Python integers (the generators lie in the r-subgroup).  The tests rebuild
+    the generators from the seeds with the oracle's scalar multiplication (curve_multiplication.rs)."""
+    for c, log_n in SEEDED_MSM:
+        n = 1 << log_n
+        f, r = c.scalar, c.scalar.p
+        seed_h, seed_s = 0x601D6000 + 0x100 * c.curve_id + log_n, 0x601D7000 + 0x100 * c.curve_id + log_n
+        h = synth.rand_field(f.field_id, seed_h, n)
+        sv = synth.rand_field(f.field_id, seed_s, n)
+        hb, sb = h.tobytes(), sv.tobytes()
+        acc = 0
+        for i in range(n):  # Montgomery limbs as integers: (s R)(h R) summed, R^-2 taken off once
+            acc += int.from_bytes(sb[32 * i:32 * i + 32], "little") * int.from_bytes(hb[32 * i:32 * i + 32], "little")
+        rinv = pow(1 << 256, -1, r)
+        k = acc % r * rinv % r * rinv % r
+        P = br.ec_mul(c, k, (c.gx, c.gy))
+        L = c.base.n_limbs
+        np.savez(os.path.join(OUT, "seeded_msm_%s_2p%d.npz" % (c.name, log_n)), curve=c.curve_id, log_n=log_n, seed_h=seed_h, seed_s=seed_s,
+                 expected_xy=arr([c.base.to_mont(P[0]), c.base.to_mont(P[1])], L), expected_zero=0)
 
 
 if __name__ == "__main__":

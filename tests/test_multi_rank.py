@@ -179,3 +179,47 @@ def test_bench_without_gpus_fails_loudly():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
                          text=True, timeout=300)
     assert out.returncode == 3 and "needs 2 GPU(s), 0 visible" in out.stderr
+
+
+def _ntt_worker(rank, world, port, batch, log_n, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1 << log_n
+    polys = torch.from_numpy(np.stack([synth.rand_field(0, 0xF70020 + v, n) for v in range(batch)]).view(np.int64))
+    pre = ol.FftPrecomputation(0, n)
+    calls = []
+
+    def transform(rows):  # the oracle stands in for device.ntt_dev: one batched call per rank
+        calls.append(rows.shape[0])
+        return torch.from_numpy(np.stack([pre.fft_with_precomputation_power_of_2(r.numpy().view(np.uint64)) for r in rows]).view(np.int64))
+
+    gathered = parallel.ntt_batch_sharded(transform, polys, n, gather=True)
+    mine, local = parallel.ntt_batch_sharded(transform, polys, n, gather=False)
+    dist.barrier()
+    out_q.put((rank, calls, mine, local.numpy().view(np.uint64), gathered.numpy().view(np.uint64) if rank == 1 else None))
+    dist.destroy_process_group()
+
+
+def test_ntt_batch_sharded_world_size_2_gloo():
+    """The transform batch of a proof (plonk_util.rs:169-190) dealt out over two ranks: each rank transforms its own rows in one
+    batched call, one all-gather returns all nine in batch order on every rank; without the gather the rows stay with their rank."""
+    batch, world, log_n = 9, 2, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ntt_worker, args=(r, world, port, batch, log_n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = 1 << log_n
+    pre = ol.FftPrecomputation(0, n)
+    exp = np.stack([pre.fft_with_precomputation_power_of_2(synth.rand_field(0, 0xF70020 + v, n)) for v in range(batch)])
+    for rank, calls, mine, local, gathered in got:
+        assert mine == list(range(rank, batch, world)) and calls == [len(mine), len(mine)]
+        assert np.array_equal(local, exp[mine])
+        if gathered is not None:
+            assert np.array_equal(gathered, exp)
