@@ -241,6 +241,54 @@ def test_bench_spawns_its_ranks(flags):
     assert r["scaling"] == ("weak" if "both" in flags else "strong")
     if r["scaling"] == "strong":
         assert r["checks"]["msm_global_sum_closed_form"]
+    else:
+        # the driver's default form at N > 1 also carries BASELINE's strong-scaling configurations with their one-GPU times
+        # measured by rank 0 in the same run, and the number of ranks the communicator carried
+        m = r["components"]["multi_gpu"]
+        for case in ("commit9_strong", "bls12_377_2p22_shard"):
+            assert m[case + "_ms"] > 0 and m[case + "_one_gpu_ms"] > 0 and 0 < m[case + "_efficiency"] < 1.5, m
+            assert r["checks"][case + "_closed_form"] and r["checks"][case + "_one_gpu_closed_form"]
+        assert m["gloo_ranks"] == 2 and m["backend"] == "gloo"
+
+
+def test_bench_single_process_virtual_devices():
+    """`python bench.py --gpus 2 --single-process --virtual-devices`: the in-library device group (plk_init_devices) through the
+    host-pointer C ABI - nine commitments in one call, one sharded MSM, nine transforms - bit-identical to one device."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PLK_VIRTUAL_DEVICES")}
+    env["PLK_MULTI_MIN_LOG_N"] = "10"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-process", "--virtual-devices", "--log-n", "16", "--steps", "8"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    c = r["components"]
+    assert r["n_gpus"] == 2 and c["devices"] == 2 and c["virtual"] and c["bit_identical_to_one_device"]
+    for k in ("commit9_ms", "msm_single_ms", "ntt9_ms"):
+        assert c["one_device"][k] > 0 and c["group"][k] > 0
+
+
+def test_bench_nccl_every_visible_gpu():
+    """`python bench.py --gpus N` with N = every visible GPU over the nccl backend (RCCL): skips on a one-GPU box - the only
+    place where RCCL carries more than one rank (the driver's 8-GPU node, a developer's multi-GPU box)."""
+    torch = pytest.importorskip("torch")
+    import json
+    import subprocess
+    import sys
+    count = torch.cuda.device_count()
+    if count < 2:
+        pytest.skip("one GPU visible: RCCL with more than one rank needs a multi-GPU node")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(count), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--log-n", "18"],
+                         env=env, capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    m = r["components"]["multi_gpu"]
+    assert r["n_gpus"] == count and m["rccl_ranks"] == count and m["backend"] == "nccl" and all(r["checks"].values()), (m, r["checks"])
+    assert m["single_process"].get("bit_identical_to_one_device"), m["single_process"]
 
 
 def test_bench_emulated_rank():
