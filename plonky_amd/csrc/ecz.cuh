@@ -44,8 +44,20 @@ template <class FP> PLK_DNI XyzzZ<FP> xyzzz_mdbl(Fz<FP> x, Fz<FP> y) {
     return r;
 }
 
-// acc += (x2, y2); x2 < p canonical, y2 < 2p (a negated canonical y is 2p - y)
-template <class FP> PLK_DI void xyzzz_madd(XyzzZ<FP>& acc, const Fz<FP>& x2, const Fz<FP>& y2) {
+// ---- the mixed addition of the bucket accumulation ------------------------------------------------------------------------
+// Round 4 put it on an instruction diet (tools/madd_lab.hip; SQ_INSTS_VALU per addition 2446 -> ~2290):
+//   * the products lost their "+ q_k" additions (fz_mul / fz_sqr, fz.cuh);
+//   * Y may stay UNCARRIED between additions ("lazy Y": limbs <= 3 * 2^29 - 3 instead of < 2^29 + 8).  Inside an addition Y only
+//     meets a subtraction that borrows 2^31 per limb and a product with the exactly normalised PPP, both of which accept such
+//     limbs; xyzzz_settle() moves the carries before the point leaves the loop (a store, a full addition);
+//   * -y of a table entry is formed without a carry pass (limbs <= 2^30): it goes straight into the product with the exactly
+//     normalised ZZZ;
+//   * "P = 0 mod p" (equal or opposite points) is screened by ZZ3's lowest limb - for a non-zero ZZ3 < 2p it is 0 or p_0 = 1 with
+//     probability 2^-28 - before the full comparison.
+// acc: X < 8p, ZZ < 2p, ZZZ < 2p with limbs < 2^29 + 8 (ZZ, ZZZ exactly normalised after the first addition: they are products);
+// Y < 4p with limbs <= 3 * 2^29 - 3.  (x2, y2): x2 < 2p exactly normalised limbs; y2 < 2p, limbs <= 2^30.
+template <class FP> PLK_DI void xyzzz_madd_lazy(XyzzZ<FP>& acc, const Fz<FP>& x2, const Fz<FP>& y2) {
+    static_assert(3ull * (1ull << 29) <= FzLazyBound<FP>::MUL_LIMB_MAX, "a lazy Y must be a legal multiplicand of an exactly normalised operand");
     if (acc.inf) {
         acc.x = x2;
         acc.y = y2;
@@ -55,18 +67,21 @@ template <class FP> PLK_DI void xyzzz_madd(XyzzZ<FP>& acc, const Fz<FP>& x2, con
         return;
     }
     Fz<FP> u2 = fz_mul<FP>(x2, acc.zz);                      // < 2
-    Fz<FP> s2 = fz_mul<FP>(y2, acc.zzz);                     // < 2
+    Fz<FP> s2 = fz_mul<FP>(y2, acc.zzz);                     // < 2      (y2 limbs <= 2^30 against an exactly normalised ZZZ... or < 2^29 + 8: fz_mul's general bound)
     Fz<FP> p = fz_sub<FP, 4>(u2, acc.x);                     // < 2 + 16 = 18      (X < 8 <= 16 - margin)
-    Fz<FP> r = fz_sub<FP, 2>(s2, acc.y);                     // < 2 + 4 = 6        (Y < 3.4)
+    Fz<FP> r = fz_sub_nc<FP, 2, 31>(s2, acc.y);              // < 2 + 4 = 6        (Y < 3.6; its limbs <= 3 * 2^29 - 3 <= 2^31 - 4)
+    fz_carry<FP>(r);                                         // limbs <= 2^29 + 2^31 + 2^29 -> < 2^29 + 8
     Fz<FP> pp = fz_sqr<FP>(p);                               // < 18^2/128 + 1 < 3.6
     Fz<FP> ppp = fz_mul<FP>(p, pp);                          // < 18*3.6/128 + 1 < 1.6
     Fz<FP> q = fz_mul<FP>(acc.x, pp);                        // < 8*3.6/128 + 1 < 1.3
     Fz<FP> rr = fz_sqr<FP>(r);                               // < 36/128 + 1 < 1.3
     Fz<FP> zz3 = fz_mul<FP>(acc.zz, pp);                     // < 1.1
-    if (fz_is_zero_mod_p<FP>(zz3)) {
+    if (zz3.l[0] <= 1u && fz_is_zero_mod_p<FP>(zz3)) {
         // p = 0 mod p: the operands share x.  Same point -> double it; opposite points -> identity.
         if (fz_is_zero_mod_p<FP>(rr)) {
-            acc = xyzzz_mdbl<FP>(x2, y2);  // rare, out of line
+            Fz<FP> yc = y2;
+            fz_carry<FP>(yc);
+            acc = xyzzz_mdbl<FP>(x2, yc);  // rare, out of line
         } else {
             acc.inf = true;
         }
@@ -79,10 +94,29 @@ template <class FP> PLK_DI void xyzzz_madd(XyzzZ<FP>& acc, const Fz<FP>& x2, con
     Fz<FP> t;                                                           // < 1.3 + 8 = 9.3
     if constexpr (FzCfg<FP>::NZ <= 10) t = fz_sub_nc<FP, 3, 30>(q, x3);  // limbs <= 2^31 <= FzNcBound::MUL_LIMB_MAX
     else t = fz_sub<FP, 3>(q, x3);                                      // 14 limbs: the column sums have no room for it
-    acc.y = fz_sub<FP, 1>(fz_mul<FP>(r, t), fz_mul<FP>(acc.y, ppp));    // < (6*9.3/128 + 1) + 2 < 3.5 < 4
+    // Y3 = r t - Y1 PPP, both products exactly normalised: the difference keeps its carries (limbs <= 3 * 2^29 - 3)
+    acc.y = fz_sub_nc<FP, 1, 29>(fz_mul<FP>(r, t), fz_mul<FP>(acc.y, ppp));  // < (6*9.3/128 + 1) + 2 < 3.5 < 4
     acc.x = x3;
     acc.zz = zz3;
     acc.zzz = fz_mul<FP>(acc.zzz, ppp);                                 // < 1.1
+}
+// the carries of a lazy Y moved: the point is inside the invariant every other routine expects (limbs < 2^29 + 8)
+template <class FP> PLK_DI void xyzzz_settle(XyzzZ<FP>& acc) { fz_carry<FP>(acc.y); }
+
+// acc += (x2, y2); x2 < p canonical, y2 < 2p (a negated canonical y is 2p - y); limbs < 2^29 + 8 in and out
+template <class FP> PLK_DI void xyzzz_madd(XyzzZ<FP>& acc, const Fz<FP>& x2, const Fz<FP>& y2) {
+    xyzzz_madd_lazy<FP>(acc, x2, y2);
+    xyzzz_settle<FP>(acc);
+}
+// acc += +-(x, y) for a table entry in the interface form (R'-form words, canonical): conversion, conditional negation without a
+// carry pass (2p - y: limbs <= 2^30 - 2), lazy addition.  The caller settles acc before it leaves the loop.
+template <class FP> PLK_DI void xyzzz_madd_entry(XyzzZ<FP>& acc, const Fe<FP>& x, const Fe<FP>& y, bool negate) {
+    const Fz<FP> xz = fz_from_fe<FP>(x), yp = fz_from_fe<FP>(y);
+    const Fz<FP> yn = fz_sub_nc<FP, 1, 29>(fz_zero<FP>(), yp);
+    Fz<FP> yz;
+#pragma unroll
+    for (int i = 0; i < FzCfg<FP>::NZ; ++i) yz.l[i] = negate ? yn.l[i] : yp.l[i];
+    xyzzz_madd_lazy<FP>(acc, xz, yz);
 }
 
 // 2 * a, XYZZ operand within the accumulator invariant (EFD dbl-2008-s-1, a = 0)

@@ -69,6 +69,19 @@ PLK_DI uint32_t fz_opaque(uint32_t c) {
 #endif
     return c;
 }
+// Quotient digits without their own addition (round 4).  Column k < NZ of a Montgomery product needs q_k = -acc_k mod 2^29 and
+// then (acc_k + q_k) >> 29: the low 29 bits vanish, so that is (acc_k >> 29) + (1 if they were not zero), i.e. (acc_k + M) >> 29 with
+// M = 2^29 - 1.  The column adds the CONSTANT M (kept opaque in scalar registers: one v_lshl_add_u64, where "+ q_k" needed the
+// digit first) and with acc'_k = acc_k + M the digit is q_k = ~acc'_k & M (-x = ~x + 1 and M = -1 mod 2^29): one v_bitop3_b32
+// instead of a subtraction and a mask, no register copies around the 64-bit pair.  fz_mul 201 -> 184 VALU instructions per
+// product on gfx950, fz_sqr 173 -> 155 (tools/madd_lab.hip + tools/isa_count.py).  (Starting the column's multiply-add chain
+// from M through inline assembly was tried: the compiler still joins two chains with an addition - 183 - and pads with s_nop.)
+PLK_DI uint64_t fz_opaque64(uint64_t c) {
+#ifdef __HIPCC__
+    asm volatile("" : "+s"(c));
+#endif
+    return c;
+}
 template <class P> struct FzPow2Limb {
     // index of a modulus limb (j >= 1) that is a power of two, or -1
     static constexpr int index() {
@@ -173,6 +186,12 @@ template <class P> struct FzNcBound {
     static_assert(FzCfg<P>::NZ <= 10, "limb bound of the carry-free forms is derived for NZ <= 10");
     static constexpr uint32_t MUL_LIMB_MAX = 5u * (1u << 29) + 16u;  // 2.5 * 2^30 + 16
 };
+// The same bound for any limb count: the largest limb La of one operand of fz_mul whose other operand is exactly normalised
+// (< 2^29), from  NZ La 2^29 + NZ 2^58 + 2^37 <= 2^64:  La <= (2^35 - NZ 2^29 - 2^8) / NZ  (3.57 * 2^29 for the 14 limbs of
+// Bls12377Base, 6.1 * 2^29 for 9 limbs).  The lazy mixed addition (ecz.cuh) checks its unnormalised operands against it.
+template <class P> struct FzLazyBound {
+    static constexpr uint64_t MUL_LIMB_MAX = (((uint64_t)1 << 35) - (uint64_t)FzCfg<P>::NZ * ((uint64_t)1 << 29) - 256u) / (uint64_t)FzCfg<P>::NZ;
+};
 template <class P> PLK_DI Fz<P> fz_add_nc(const Fz<P>& a, const Fz<P>& b) {
     Fz<P> r;
 #pragma unroll
@@ -184,7 +203,7 @@ template <class P, int K, int B> PLK_DI Fz<P> fz_sub_nc(const Fz<P>& a, const Fz
     Fz<P> r;
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
-        // limb i of 2^K p, plus the 2^B lent by limb i + 1, minus the one lent to limb i - 1
+        // limb i of 2^K p, plus the 2^B lent by limb i + 1, minus the one lent to limb i - 1 (so: limbs of b <= 2^B - 2^(B - 29))
         const uint32_t c = FzCfg<P>::kp_limb(K, i) - (i == 0 ? (1u << 30) : i == NZ - 1 ? 0u - 2u : (1u << 30) - 2u);
         constexpr uint32_t lent = 1u << (B - 29);
         const uint32_t k = i == 0 ? c + (1u << B) : i == NZ - 1 ? c - lent : c + (1u << B) - lent;
@@ -202,10 +221,12 @@ template <class P> PLK_DI Fz<P> fz_mul(const Fz<P>& a, const Fz<P>& b) {
     static_assert(Mod29<P>::limb(0) == 1u, "needs p = 1 (mod 2^29)");
     uint32_t q[NZ];
     Fz<P> r;
+    const uint64_t m64 = fz_opaque64((uint64_t)M);
     uint64_t acc = 0;
     const uint32_t p_pow2 = FzPow2Limb<P>::index() >= 0 ? fz_opaque(FzCfg<P>::plimb(FzPow2Limb<P>::index() >= 0 ? FzPow2Limb<P>::index() : 0)) : 0u;
 #pragma unroll
     for (int k = 0; k <= 2 * NZ - 2; ++k) {
+        if (k < NZ) acc += m64;  // see fz_opaque64
 #pragma unroll
         for (int i = 0; i < NZ; ++i) {
             const int j = k - i;
@@ -217,12 +238,8 @@ template <class P> PLK_DI Fz<P> fz_mul(const Fz<P>& a, const Fz<P>& b) {
             if (i < k && j >= 1 && j < NZ && FzCfg<P>::plimb(j) != 0u)
                 acc = (uint64_t)q[i] * (j == FzPow2Limb<P>::index() ? p_pow2 : FzCfg<P>::plimb(j)) + acc;
         }
-        if (k < NZ) {
-            q[k] = (0u - (uint32_t)acc) & M;
-            acc += q[k];  // + q_k p_0 with p_0 = 1: the low 29 bits vanish
-        } else {
-            r.l[k - NZ] = (uint32_t)acc & M;
-        }
+        if (k < NZ) q[k] = ~(uint32_t)acc & M;  // + q_k p_0 (p_0 = 1) is what the M already in acc stands for
+        else r.l[k - NZ] = (uint32_t)acc & M;
         acc = fz_shr29(acc);
     }
     r.l[NZ - 1] = (uint32_t)acc;
@@ -237,10 +254,12 @@ template <class P> PLK_DI Fz<P> fz_sqr(const Fz<P>& a) {
 #pragma unroll
     for (int i = 0; i < NZ; ++i) a2[i] = a.l[i] << 1;
     Fz<P> r;
+    const uint64_t m64 = fz_opaque64((uint64_t)M);
     uint64_t acc = 0;
     const uint32_t p_pow2 = FzPow2Limb<P>::index() >= 0 ? fz_opaque(FzCfg<P>::plimb(FzPow2Limb<P>::index() >= 0 ? FzPow2Limb<P>::index() : 0)) : 0u;
 #pragma unroll
     for (int k = 0; k <= 2 * NZ - 2; ++k) {
+        if (k < NZ) acc += m64;
 #pragma unroll
         for (int i = 0; i < NZ; ++i) {
             const int j = k - i;
@@ -253,12 +272,8 @@ template <class P> PLK_DI Fz<P> fz_sqr(const Fz<P>& a) {
             if (i < k && j >= 1 && j < NZ && FzCfg<P>::plimb(j) != 0u)
                 acc = (uint64_t)q[i] * (j == FzPow2Limb<P>::index() ? p_pow2 : FzCfg<P>::plimb(j)) + acc;
         }
-        if (k < NZ) {
-            q[k] = (0u - (uint32_t)acc) & M;
-            acc += q[k];
-        } else {
-            r.l[k - NZ] = (uint32_t)acc & M;
-        }
+        if (k < NZ) q[k] = ~(uint32_t)acc & M;
+        else r.l[k - NZ] = (uint32_t)acc & M;
         acc = fz_shr29(acc);
     }
     r.l[NZ - 1] = (uint32_t)acc;

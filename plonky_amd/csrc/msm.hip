@@ -683,6 +683,7 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
         if (PLK_CHK((ent >> 1) - ent_sub < tab_entries, CHK_TABLE_INDEX)) ident = affine_load<FP>(tab + (size_t)((ent >> 1) - ent_sub) * 2 * W, x, y);
         for (uint32_t k = begin; k < end; ++k) {
             if (k == next) {  // entry k opens a new bucket: the piece of the old one is closed
+                xyzzz_settle<FP>(acc);  // the additions keep Y uncarried (ecz.cuh): move its carries before the piece is stored
                 if (head) {
                     xyzzz_store_raw<FP>(s_head + tid * RU, acc);
                     parked = true;
@@ -707,10 +708,9 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
                     ident = affine_load<FP>(tab + (size_t)((ent >> 1) - nsub) * 2 * W, x, y);
             }
             if (cident) continue;
-            Fz<FP> xz = fz_from_fe<FP>(cx), yz = fz_from_fe<FP>(cy);
-            if (cur & 1u) yz = fz_neg_canonical<FP>(yz);
-            xyzzz_madd<FP>(acc, xz, yz);
+            xyzzz_madd_entry<FP>(acc, cx, cy, (cur & 1u) != 0);
         }
+        xyzzz_settle<FP>(acc);
     }
     s_parked[tid] = parked ? 1 : 0;
     __syncthreads();

@@ -108,13 +108,20 @@ template <class P> static void ecz_sum(size_t n, const uint32_t* xs, const uint3
     XyzzZ<P> acc;
     acc.inf = true;
     acc.x = acc.y = acc.zz = acc.zzz = fz_zero<P>();
+    out[4 * P::NL] = 0;
     for (size_t i = 0; i < n; ++i) {
         Fe<P> x, y;
         for (int k = 0; k < P::NL; ++k) { x.v[k] = xs[i * P::NL + k]; y.v[k] = ys[i * P::NL + k]; }
-        Fz<P> xz = fz_from_fe<P>(x), yz = fz_from_fe<P>(y);
-        if (negs[i]) yz = fz_neg_canonical<P>(yz);
-        xyzzz_madd<P>(acc, xz, yz);
+        // the accumulation kernel's own step (k_msm_accumulate): the entry in interface words + its sign, Y left uncarried
+        // between additions; the carries are moved where a piece would be stored (here: every seventh entry) and at the end
+        xyzzz_madd_entry<P>(acc, x, y, negs[i] != 0);
+        for (int k = 0; k < FzCfg<P>::NZ; ++k)
+            if (acc.y.l[k] > 3u * (1u << 29)) out[4 * P::NL] |= 2u;  // the limb bound of a lazy Y (ecz.cuh)
+        if (i % 7 == 6) xyzzz_settle<P>(acc);
     }
+    xyzzz_settle<P>(acc);
+    for (int k = 0; k < FzCfg<P>::NZ; ++k)
+        if (acc.y.l[k] >= (1u << 29) + 8u) out[4 * P::NL] |= 4u;
     Fz<P> one = fz_one_rprime<P>();
     Fe<P> c[4];
     if (acc.inf) { for (auto& e : c) e = fe_zero<P>(); }
@@ -127,7 +134,7 @@ template <class P> static void ecz_sum(size_t n, const uint32_t* xs, const uint3
     }
     for (int j = 0; j < 4; ++j)
         for (int k = 0; k < P::NL; ++k) out[j * P::NL + k] = c[j].v[k];
-    out[4 * P::NL] = acc.inf ? 1u : 0u;
+    out[4 * P::NL] |= acc.inf ? 1u : 0u;  // bit 0: identity; bits 1, 2: a limb bound was exceeded (the test expects 0 / 1 only)
 }
 // Same sum, but as a balanced tree of full XYZZ additions (xyzzz_add / xyzzz_dbl): the reduction kernels' shape.
 template <class P> static void ecz_tree(size_t n, const uint32_t* xs, const uint32_t* ys, const uint8_t* negs, uint32_t* out) {

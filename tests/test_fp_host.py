@@ -152,6 +152,7 @@ def test_lazy_xyzz_accumulation_on_host(host_lib, c):
         out32 = np.zeros(4 * 2 * n + 2, dtype=np.uint32)
         assert getattr(host_lib, fn)(f.field_id, len(points), xs.ctypes.data, ys.ctypes.data, ng.ctypes.data, out32.ctypes.data) == 0
         inf = int(out32[4 * 2 * n])
+        assert inf in (0, 1), "a limb bound of the lazy accumulation was exceeded (flag %d)" % inf
         if inf:
             return None
         w = out32[: 4 * 2 * n].reshape(4, 2 * n)
