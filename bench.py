@@ -965,13 +965,21 @@ def run(args):
         multi["backend"] = dist.get_backend()
         # the in-library form of the same split: rank 0 alone drives all N GPUs from its one process through the host-pointer
         # C ABI (plk_init_devices) while the other ranks wait; skipped when the ranks share a GPU
-        if not gloo and rank == 0 and torch.cuda.device_count() >= world:
-            try:
-                multi["single_process"] = single_process_case(L, lib, world, args.log_n, max(2, args.steps // 4))
-                checks["single_process_bit_identical"] = multi["single_process"]["bit_identical_to_one_device"]
-            except Exception as e:  # noqa: BLE001 - the spawned-rank numbers above stand on their own
-                multi["single_process"] = {"error": str(e)[:300]}
-            dev.init(device_index)
+        if not gloo and torch.cuda.device_count() >= world:
+            # the other ranks wait on the process group's key-value store, on the CPU: a collective barrier would park an RCCL
+            # kernel on the very GPUs rank 0 is about to measure
+            store = dist.distributed_c10d._get_default_store()
+            sync()
+            if rank == 0:
+                try:
+                    multi["single_process"] = single_process_case(L, lib, world, args.log_n, max(2, args.steps // 4))
+                    checks["single_process_bit_identical"] = multi["single_process"]["bit_identical_to_one_device"]
+                except Exception as e:  # noqa: BLE001 - the spawned-rank numbers above stand on their own
+                    multi["single_process"] = {"error": str(e)[:300]}
+                dev.init(device_index)
+                store.set("plk_single_process_done", "1")
+            else:
+                store.wait(["plk_single_process_done"])
         sync()
         comp["multi_gpu"] = multi
 

@@ -54,6 +54,10 @@ template <class FP> PLK_DNI XyzzZ<FP> xyzzz_mdbl(Fz<FP> x, Fz<FP> y) {
 //     normalised ZZZ;
 //   * "P = 0 mod p" (equal or opposite points) is screened by ZZ3's lowest limb - for a non-zero ZZ3 < 2p it is 0 or p_0 = 1 with
 //     probability 2^-28 - before the full comparison.
+// (A branch-free form - the formulas run on an identity accumulator's stale coordinates and the result is selected - was built
+// and measured in the ISA: the register copies at the merge fall from 90 to 38 per iteration, but the entry must stay live to the
+// end: 198 registers, two waves per SIMD, or 55 scratch accesses in the loop when held to three.  The branch stays; the caller
+// marks a new bucket with acc.inf = true instead of clearing 36 registers.)
 // acc: X < 8p, ZZ < 2p, ZZZ < 2p with limbs < 2^29 + 8 (ZZ, ZZZ exactly normalised after the first addition: they are products);
 // Y < 4p with limbs <= 3 * 2^29 - 3.  (x2, y2): x2 < 2p exactly normalised limbs; y2 < 2p, limbs <= 2^30.
 template <class FP> PLK_DI void xyzzz_madd_lazy(XyzzZ<FP>& acc, const Fz<FP>& x2, const Fz<FP>& y2) {

@@ -691,7 +691,7 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
                     xyzzz_store_raw<FP>(p_start + (size_t)b * RU, acc);
                 }
                 head = false;
-                acc = xyzzz_identity<FP>();
+                acc.inf = true;  // the coordinates stay as they are (36 register clears less): the next addition overwrites them (ecz.cuh)
                 b = next_bucket(off, b, buckets, k);
                 next = off[b + 1];
             }

@@ -440,7 +440,7 @@ template <class P, int PASS>
 __global__ void __launch_bounds__(128, 2) k_vanishing_points(const uint4* __restrict__ constants, const uint4* __restrict__ wires, const uint4* __restrict__ s_sigma,
                                                              const uint4* __restrict__ z, const uint4* __restrict__ xs_lo_z, const uint4* __restrict__ xs_hi_z,
                                                              const uint4* __restrict__ l1, const uint4* __restrict__ small, PlonkScalars sc, int log_degree,
-                                                             uint32_t* __restrict__ part, uint4* __restrict__ out) {
+                                                             uint32_t* __restrict__ part, uint4* __restrict__ out, size_t first, size_t count) {
     static_assert(P::NL == 8, "256-bit scalar fields");
     using D = Lz<P, 16>;
     constexpr int MASK = PASS == 0 ? GATES_RESCUE_A : PASS == 1 ? GATES_RESCUE_B : PASS == 2 ? (GATES_ENDO | GATES_BASE4_ARITH)
@@ -448,8 +448,8 @@ __global__ void __launch_bounds__(128, 2) k_vanishing_points(const uint4* __rest
     __shared__ uint32_t s_sc[NUM_SCALARS][FzCfg<P>::NZ];
     stage_scalars<P>(sc, s_sc);
     const size_t n8 = (size_t)8 << log_degree;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n8) return;
+    const size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // this launch covers the points first .. first + count - 1
+    if (i >= first + count || i >= n8) return;
     const size_t i_right = (i + 8) & (n8 - 1), i_below = (i + 8 * GRID_WIDTH) & (n8 - 1);
     // the rows a gate reads from: local constants, local wires, the right gate's wires (loaded where they are used)
     const LazyRow<P> k{constants, n8, i}, l{wires, n8, i}, r{wires, n8, i_right};
@@ -534,16 +534,28 @@ static int vanishing_points_t(unsigned log_degree, const void* d_constants, cons
     const size_t n8 = (size_t)8 << log_degree;
     void* part = scratch_acquire(limb_bytes(n8, FzCfg<P>::NZ), stream);
     if (!part) return PLK_ERR_OOM;
-    const unsigned blocks = (unsigned)((n8 + 127) / 128);
+    // PLK_VANISH_SLAB_LOG=k: the five launches walk the domain in slabs of 2^k points, so that the rows a slab reads (29 x 32 B per
+    // point) are still in the 256 MiB Infinity Cache when the next launch of the slab re-reads them (round-3 review item 5;
+    // measured in DESIGN.md section 4c).  Default: the whole domain per launch.
+    static const int slab_log = [] {
+        const char* e = getenv("PLK_VANISH_SLAB_LOG");
+        const int v = e ? atoi(e) : 0;
+        return v >= 10 && v <= 40 ? v : 0;
+    }();
+    const size_t slab = slab_log ? ((size_t)1 << slab_log) : n8;
 #define PLK_VANISH(PASS)                                                                                                                                  \
     k_vanishing_points<P, PASS><<<blocks, 128, 0, stream>>>((const uint4*)d_constants, (const uint4*)d_wires, (const uint4*)d_s_sigma, (const uint4*)d_z, \
                                                             (const uint4*)t->xs_lo_z, (const uint4*)t->xs_hi_z, (const uint4*)t->l1, (const uint4*)t->small, sc, \
-                                                            (int)log_degree, (uint32_t*)part, (uint4*)d_out)
-    PLK_VANISH(0);
-    PLK_VANISH(1);
-    PLK_VANISH(2);
-    PLK_VANISH(3);
-    PLK_VANISH(4);
+                                                            (int)log_degree, (uint32_t*)part, (uint4*)d_out, first, cnt)
+    for (size_t first = 0; first < n8; first += slab) {
+        const size_t cnt = n8 - first < slab ? n8 - first : slab;
+        const unsigned blocks = (unsigned)((cnt + 127) / 128);
+        PLK_VANISH(0);
+        PLK_VANISH(1);
+        PLK_VANISH(2);
+        PLK_VANISH(3);
+        PLK_VANISH(4);
+    }
 #undef PLK_VANISH
     const hipError_t e = hipGetLastError();
     scratch_release(part, stream);

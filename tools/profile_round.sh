@@ -3,8 +3,8 @@
 # (separate runs, kernel trace only, as MI355X_MICROARCH.md prescribes), for the headline workload AND for --workload quotient
 # (the vanishing points and the generator fold), plus one SQ_INSTS_VALU pass (instructions per element of the NTT pass kernel and
 # per addition of the accumulation).  Run on the GPU box from the repo root; results land in gpurun_out/.
-# usage: tools/profile_round.sh [round tag, default r03]
-RN=${1:-r03}
+# usage: tools/profile_round.sh [round tag, default r04]
+RN=${1:-r04}
 export TMPDIR=/tmp; R="${GRAFT_REPO_ROOT:-$PWD}"; cd /tmp
 O=$R/gpurun_out
 rm -rf $O/prof_$RN $O/pmc_fetch $O/pmc_write $O/pmc_valu $O/prof_q $O/pmc_fetch_q $O/pmc_write_q
