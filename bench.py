@@ -378,7 +378,17 @@ def single_process_case(L, lib, n_devices, log_n, reps, virtual=False):
     L.plk_shutdown()
     same = (np.array_equal(r_one[0], r_grp[0]) and np.array_equal(r_one[1], r_grp[1]) and np.array_equal(r_one[2], r_grp[2]) and np.array_equal(r_one[3], r_grp[3])
             and all(np.array_equal(a, b) for a, b in zip(r_one[4], r_grp[4])) and np.array_equal(r_grp[2], r_grp[0][4]) and not r_grp[1].any())
+    # the same checks the spawned-rank form makes: every commitment against the closed form of the WHOLE problem
+    # (sum s_i (G + i D) = [sum s_i] G + [sum i s_i] D on Python integers), the transforms through an inverse transform on one device
+    from plonky_amd.selfcheck import closed_form_msm
+    closed = all((synth.from_mont(0, r_grp[0][v][0]), synth.from_mont(0, r_grp[0][v][1])) == closed_form_msm(0, vecs[v], G, D, first=0) for v in range(9))
+    lib.check(L.plk_init(0))
+    back = np.zeros_like(polys[0])
+    lib.check(L.plk_ntt(0, log_n, 1, vp(r_grp[4][8].ctypes.data), vp(back.ctypes.data)))
+    roundtrip = bool(np.array_equal(back, polys[8]))
+    L.plk_shutdown()
     out = {"devices": n_devices, "virtual": bool(virtual), "log_n": log_n, "one_device": one, "group": grp, "bit_identical_to_one_device": bool(same),
+           "msm_closed_form_bit_exact": bool(closed), "ntt_roundtrip_bit_exact": roundtrip,
            "note": "host-pointer C ABI (pageable numpy buffers, PCIe inside): plk_msm_execute_batch of nine 2^log_n vectors, one plk_msm_execute, "
                    "plk_ntt_batch of nine transforms; efficiency = T_one_device / (N T_group)"}
     for k in ("commit9_ms", "msm_single_ms", "ntt9_ms"):
@@ -403,9 +413,10 @@ def run_single_process(args):
               "config": {"workload": "single process, plk_init_devices(%d)%s: nine 2^%d-pair commitments per step through plk_msm_execute_batch (host pointers)"
                                      % (args.gpus, " on virtual devices of GPU 0" if virtual else "", args.log_n), "log_n": args.log_n, "curve": "tweedledee",
                          "gpu": gpu_identity(torch, 0)},
-              "components": r, "checks": {"bit_identical_to_one_device": r["bit_identical_to_one_device"]}}
+              "components": r, "checks": {"bit_identical_to_one_device": r["bit_identical_to_one_device"], "msm_closed_form_bit_exact": r["msm_closed_form_bit_exact"],
+                                         "ntt_roundtrip_bit_exact": r["ntt_roundtrip_bit_exact"]}}
     print(json.dumps(result), flush=True)
-    assert r["bit_identical_to_one_device"]
+    assert all(result["checks"].values()), "self-check failed: %r" % result["checks"]
 
 
 def run_quotient(args):
@@ -974,6 +985,7 @@ def run(args):
                 try:
                     multi["single_process"] = single_process_case(L, lib, world, args.log_n, max(2, args.steps // 4))
                     checks["single_process_bit_identical"] = multi["single_process"]["bit_identical_to_one_device"]
+                    checks["single_process_msm_closed_form"] = multi["single_process"]["msm_closed_form_bit_exact"]
                 except Exception as e:  # noqa: BLE001 - the spawned-rank numbers above stand on their own
                     multi["single_process"] = {"error": str(e)[:300]}
                 dev.init(device_index)

@@ -20,6 +20,7 @@
 //   * transforms are independent units: a batch is dealt out round-robin (no exchange), single-transform calls coming from
 //     many host threads take the devices in turn.
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -111,6 +112,7 @@ struct Worker {
     std::condition_variable cv;
     const std::function<int(int)>* job = nullptr;
     bool pending = false, finished = false, stop = false;
+    std::atomic<int> poke{0};  // bumped with every hand-over in either direction: lets the other side spin briefly instead of sleeping
     int rc = PLK_OK;
     std::string err;
     hipEvent_t ev_done = nullptr;  // on this worker's device: "my share of the current fan-out call is enqueued up to here"
@@ -118,10 +120,28 @@ struct Worker {
 static std::vector<Worker*>* g_workers = nullptr;  // never destroyed at exit: detached threads may still wait on their condition variables
 static std::mutex g_dispatch_mu;                    // one fan-out call at a time (each uses every device anyway)
 
+// A prover calls back to back: after a hand-over the other side is usually ready within microseconds, and a condition-variable
+// wake-up costs tens of them - a noticeable part of a single MSM sharded eight ways (0.5 ms per device).  Both sides therefore spin
+// on the hand-over counter for up to ~100 us before they go to sleep.
+static void spin_for_poke(const std::atomic<int>& poke, int seen) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (poke.load(std::memory_order_acquire) == seen) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) return;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
 static void worker_main(Worker* w) {
     t_logical = w->logical;
     std::unique_lock<std::mutex> lk(w->mu);
     for (;;) {
+        if (!w->pending && !w->stop) {
+            const int seen = w->poke.load(std::memory_order_acquire);
+            lk.unlock();
+            spin_for_poke(w->poke, seen);
+            lk.lock();
+        }
         w->cv.wait(lk, [&] { return w->pending || w->stop; });
         if (w->stop) break;
         const std::function<int(int)>* job = w->job;
@@ -133,6 +153,7 @@ static void worker_main(Worker* w) {
         w->rc = rc;
         w->err = rc != PLK_OK ? last_error_ref() : std::string();
         w->finished = true;
+        w->poke.fetch_add(1, std::memory_order_release);
         w->cv.notify_all();
     }
 }
@@ -180,11 +201,18 @@ static int run_on_devices_locked(int count, const std::function<int(int)>& fn) {
         ws[d]->job = &fn;
         ws[d]->finished = false;
         ws[d]->pending = true;
+        ws[d]->poke.fetch_add(1, std::memory_order_release);
     }
     for (int d = 0; d < count; ++d) ws[d]->cv.notify_all();
     int rc = PLK_OK;
     for (int d = 0; d < count; ++d) {
         std::unique_lock<std::mutex> lk(ws[d]->mu);
+        if (!ws[d]->finished) {
+            const int seen = ws[d]->poke.load(std::memory_order_acquire);
+            lk.unlock();
+            spin_for_poke(ws[d]->poke, seen);
+            lk.lock();
+        }
         ws[d]->cv.wait(lk, [&] { return ws[d]->finished; });
         if (ws[d]->rc != PLK_OK && rc == PLK_OK) {
             rc = ws[d]->rc;
