@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_scatter(const uint2
 // chunk goes to p_start[bucket], the piece of the bucket that was already running at the chunk's first entry goes to
 // p_head[lane].  bucket b = p_start[b] + sum of p_head[l] for the lanes l0 < l <= l1, l0 = off[b] / chunk,
 // l1 = (off[b+1] - 1) / chunk (k_msm_assemble).  Pieces are stored as they are (lazy 29-bit limbs, accumulator invariant of
-// ecz.cuh; the identity is all-zero): a store inside the loop must be cheap, because some lane of the wave has one almost every round.
+// ecz.cuh; the identity is ZZ = 0): a store inside the loop must be cheap, because some lane of the wave has one almost every round.
 template <class FP> constexpr int raw_u4() { return FzCfg<FP>::NZ; }  // uint4 per raw point: 4 NZ words
 
 template <class FP> PLK_DI void xyzzz_store_raw(uint4* dst, const XyzzZ<FP>& a) {
@@ -541,10 +541,12 @@ template <class FP> PLK_DI void xyzzz_store_raw(uint4* dst, const XyzzZ<FP>& a) 
     uint32_t w[4 * NZ];
 #pragma unroll
     for (int i = 0; i < NZ; ++i) {
-        w[i] = a.inf ? 0u : a.x.l[i];
-        w[NZ + i] = a.inf ? 0u : a.y.l[i];
+        // the identity is ZZ = 0 (xyzzz_load_raw); its other coordinates are never looked at, so only ZZ pays for a select - the
+        // store sits on the path that some lane of an accumulation wave takes almost every round
+        w[i] = a.x.l[i];
+        w[NZ + i] = a.y.l[i];
         w[2 * NZ + i] = a.inf ? 0u : a.zz.l[i];
-        w[3 * NZ + i] = a.inf ? 0u : a.zzz.l[i];
+        w[3 * NZ + i] = a.zzz.l[i];
     }
 #pragma unroll
     for (int i = 0; i < NZ; ++i) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
