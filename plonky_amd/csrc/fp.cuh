@@ -379,6 +379,17 @@ template <class P> PLK_DNI Fe<P> fe_inv_safegcd(const Fe<P>& a) {
             f[N - 1] = (int32_t)cf;
             g[N - 1] = (int32_t)cg;
         }
+        // ITER covers the worst case (590 / 886 division steps); a random element is done after 17-18 of the 20 (25-26 of the 30)
+        // iterations (measured on the host over 20 000 elements per field).  Once g = 0 further steps change nothing (g even: no
+        // swap, the matrix is 2^30 times the identity on d), so the loop may stop: lanes of a wave that are done wait for the
+        // others at no cost, and the one-lane inversion at the end of every MSM (k_msm_final) is ~12 % shorter.
+        int32_t gz = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) gz |= g[i];
+#ifdef PLK_INV_STATS
+        if (gz == 0) { ++plk_inv_stats[it]; }
+#endif
+        if (gz == 0) break;
     }
     // g = 0, f = +-1 and d = +-a^-1 in (-2p, p): fix the sign, bring into [0, p)
     {

@@ -11,6 +11,16 @@ from oracle import bigint_ref as br, oracle_lib as ol
 from tests.util import ints_to_array
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+# FUZZ_DEVICES=k: the same cases over a device group of k logical devices (virtual ones on a box with fewer GPUs): every tabled MSM of
+# at least k generators, every batch of transforms and every padded batch then runs through the fan-out of multi.hip - still against
+# the oracle, bit for bit
+if os.environ.get("FUZZ_DEVICES"):
+    _k = int(os.environ["FUZZ_DEVICES"])
+    import torch
+    if torch.cuda.device_count() < _k:
+        os.environ["PLK_VIRTUAL_DEVICES"] = str(_k)
+    os.environ.setdefault("PLK_MULTI_MIN_LOG_N", "0")
+    assert pa.init_devices(_k) == _k
 # Every case draws from its OWN generator, seeded from (FUZZ_SEED, case index): a failure names its case seed, and
 # FUZZ_CASE=<seed> replays exactly that case.  The summary keeps every 100th case seed and the first / last of every family.
 MASTER = int(os.environ.get("FUZZ_SEED", "12345"))
@@ -202,7 +212,7 @@ while time.time() < t_end:
     seeds[kind].append(case_seed)
     if REPLAY:
         break
-print("fuzz ok (FUZZ_SEED=%d, %d cases):" % (MASTER, case_idx), counts)
+print("fuzz ok (FUZZ_SEED=%d, %d cases%s):" % (MASTER, case_idx, ", device group of %s" % os.environ["FUZZ_DEVICES"] if os.environ.get("FUZZ_DEVICES") else ""), counts)
 for k, v in seeds.items():
     if v:
         print("  %-5s %6d cases  first %#x  last %#x  every 100th: %s" % (k, len(v), v[0], v[-1], " ".join("%#x" % x for x in v[::100][:40])))
