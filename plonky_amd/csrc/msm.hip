@@ -43,6 +43,15 @@
 
 namespace plk {
 
+// comb.hip: small fixed-base MSMs without buckets (a table of every multiple a signed 4-bit digit can ask for)
+struct CombPlan;
+int comb_build(int curve, size_t n, const void* d_base0, const void* d_chain, hipStream_t stream, CombPlan** out);
+void comb_free(CombPlan* p);
+int comb_execute(const CombPlan* p, unsigned batch, const void* const* d_scalars, const uint64_t* first, const uint64_t* count, void* d_out_xy, void* d_out_zero,
+                 hipStream_t stream);
+constexpr size_t COMB_MAX_N = (size_t)1 << 15;  // generators up to which a tabled context with an automatic window is a comb (1 GB of table at 2^15)
+constexpr int COMB_WINDOW = 4, COMB_WINDOWS = 64;
+
 // -DPLK_CHECKED (make checked -> libplonky_hip_checked.so; SURVEY.md section 5: the reference's debug assertions and overflow
 // checks have no equivalent in a release kernel): every index the ordering and accumulation kernels compute into sorted[],
 // tmp[], the tables and the bucket arrays is compared with its bound; a violation is counted per site and the access is
@@ -1367,7 +1376,12 @@ struct plk_msm_ctx {
     // contiguous share of the generators with the window such a share deserves (shards[d]): whole vectors of a batch run on the
     // full tables, a single MSM runs sharded by base range.
     std::vector<plk_msm_ctx*> peers, shards;
+    // With PLK_MSM_COMB=1 a tabled context over few generators (<= COMB_MAX_N, automatic window) is a COMB (comb.hip): no window tables,
+    // no workspaces, no bucket method - executions are mixed additions of table entries and a tree over the lanes' sums.
+    plk::CombPlan* comb = nullptr;
+    bool auto_window = false;
     ~plk_msm_ctx() {
+        if (comb) plk::comb_free(comb);
         for (auto* v : {&peers, &shards})
             for (plk_msm_ctx* sub : *v)
                 if (sub) {
@@ -1593,6 +1607,34 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
                             const size_t* also_n, int also_count) {
     using FP = typename C::FP;
     const size_t pt_bytes = (size_t)2 * FP::NL * 4;
+    // PLK_MSM_COMB=1 (read at every precompute): off by default - measured in round 4 (profiles/r04_comb_small_msm.txt): an execution
+    // is faster than the bucket method only up to ~2^12 generators (0.19 / 0.25 ms against 0.30 / 0.33 at 2^10 / 2^12; equal at 2^14,
+    // slower at 2^15: eight dependent gathers + additions per lane and two trees of full additions are latency too), its table costs
+    // 2-4 x the window tables to build, and the frozen generators of an opening argument (2^14 + 2) gain nothing.
+    const char* comb_env = getenv("PLK_MSM_COMB");
+    const bool want_comb = comb_env && atoi(comb_env) != 0;
+    if (!ctx->table_free && ctx->auto_window && ctx->n >= 1 && ctx->n <= COMB_MAX_N && want_comb) {
+        // the doubling chain [2^(4 j)] G_i on quads (window 0 affine in `base0`, the others raw in `raw`), then comb.hip turns every
+        // window's point into its multiples 1 .. 8
+        const size_t n = ctx->n;
+        constexpr size_t RAW = (size_t)raw_u4<FP>() * 16;
+        uint4* base0 = (uint4*)scratch_acquire(n * pt_bytes + 16, stream);
+        uint4* raw = (uint4*)scratch_acquire((size_t)(COMB_WINDOWS - 1) * n * RAW + 16, stream);
+        int rc = (base0 && raw) ? PLK_OK : PLK_ERR_OOM;
+        if (rc == PLK_OK) {
+            k_msm_table_chain<C><<<(unsigned)((4 * n + 63) / 64), 64, 0, stream>>>((const uint4*)d_bases, (const uint8_t*)d_zero, base0, raw, n, COMB_WINDOW,
+                                                                                 COMB_WINDOWS, n - n_extra, (const uint4*)d_extra);
+            if (hipGetLastError() != hipSuccess) rc = set_error(PLK_ERR_HIP, "comb chain launch failed");
+        }
+        if (rc == PLK_OK) rc = comb_build(ctx->curve, n, base0, raw, stream, &ctx->comb);
+        if (raw) scratch_release(raw, stream);
+        if (base0) scratch_release(base0, stream);
+        PLK_TRY(rc);
+        ctx->c = COMB_WINDOW;
+        ctx->windows = COMB_WINDOWS;
+        PLK_HIP_TRY(hipStreamSynchronize(stream));
+        return PLK_OK;
+    }
     ctx->ws.resize(1);
     size_t tab_min = 0;
     if (also_count > 0) {
@@ -1767,6 +1809,7 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
     PLK_HIP_TRY(hipGetDevice(&dev));
     auto* ctx = new plk_msm_ctx();
     ctx->device = dev;
+    ctx->auto_window = window_bits == 0 && also_count == 0;
     int rc = msm_configure(ctx, curve, n, window_bits, (flags & PLK_MSM_TABLE_FREE) != 0);
     if (rc == PLK_OK) switch (curve) {
         case PLK_CURVE_TWEEDLEDEE: rc = msm_precompute_t<TweedledeeCurve>(ctx, d_bases, d_zero, d_extra, n_extra, stream, also_n, also_count); break;
@@ -2000,6 +2043,18 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
     PLK_HIP_TRY(hipSetDevice(ctx->device));  // a context works on the device it was built on, whichever device the thread last used
     std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t L = (size_t)curve_limbs(ctx->curve);
+    if (ctx->comb) {
+        // few generators: additions of table entries and a tree, two launches for the whole batch (comb.hip)
+        std::vector<const void*> ptr(batch);
+        std::vector<uint64_t> first(batch), count(batch);
+        for (unsigned b = 0; b < batch; ++b) {
+            if (ready) PLK_HIP_TRY(hipStreamWaitEvent(stream, ready[b], 0));
+            ptr[b] = parts ? parts->scalars[b] : (const void*)((const uint8_t*)d_scalars + (size_t)b * ctx->n * 32);
+            first[b] = parts ? parts->first[b] : 0;
+            count[b] = parts ? parts->count[b] : ctx->n;
+        }
+        return comb_execute(ctx->comb, batch, ptr.data(), first.data(), count.data(), d_out_xy, d_out_zero, stream);
+    }
     auto run_one = [&](unsigned b, MsmWork& w, hipStream_t st, int phases) -> int {
         if (ready && (phases & PH_ORDER)) PLK_HIP_TRY(hipStreamWaitEvent(st, ready[b], 0));
         const uint8_t* sc = parts ? (const uint8_t*)parts->scalars[b] : (const uint8_t*)d_scalars + (size_t)b * ctx->n * 32;
@@ -2148,7 +2203,7 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
 int msm_set_profiling_impl(plk_msm_ctx* ctx, int enable) {
     if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->profiling = enable != 0;
+    ctx->profiling = enable != 0 && !ctx->comb;  // a comb has no stages to time: two launches
     return PLK_OK;
 }
 // sum_ms[7]: digits, partition (counts), bucket scan + final scatter, accumulate, bucket sums, planes, final -- summed over `calls` executions since the last read
@@ -2296,6 +2351,7 @@ int msm_reserve_workspaces_impl(plk_msm_ctx* ctx, unsigned count, hipStream_t st
     if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
     PLK_TRY(ensure_device());
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->comb) return PLK_OK;  // nothing to reserve
     if (count > (unsigned)TAIL_MAX) count = TAIL_MAX;
     while (ctx->ws.size() < count) {
         ctx->ws.emplace_back();

@@ -436,8 +436,11 @@ template <class P> PLK_DI Lz<P, 16> scalar_at(const uint32_t (*s_sc)[FzCfg<P>::N
 //   Constant   PASS 4: the permutation argument, L_1 and reduce_with_powers -> out
 // The sum over the gates and the powers of alpha commute (ReducedSink), every value is exact: same result as one loop.
 constexpr int VANISH_PASSES = 5;
+#ifndef PLK_VANISH_WAVES
+#define PLK_VANISH_WAVES 2  // waves per SIMD the register allocation is held to (3 was measured in round 4: tools/gpu/r04_vanish_waves.sh)
+#endif
 template <class P, int PASS>
-__global__ void __launch_bounds__(128, 2) k_vanishing_points(const uint4* __restrict__ constants, const uint4* __restrict__ wires, const uint4* __restrict__ s_sigma,
+__global__ void __launch_bounds__(128, PLK_VANISH_WAVES) k_vanishing_points(const uint4* __restrict__ constants, const uint4* __restrict__ wires, const uint4* __restrict__ s_sigma,
                                                              const uint4* __restrict__ z, const uint4* __restrict__ xs_lo_z, const uint4* __restrict__ xs_hi_z,
                                                              const uint4* __restrict__ l1, const uint4* __restrict__ small, PlonkScalars sc, int log_degree,
                                                              uint32_t* __restrict__ part, uint4* __restrict__ out, size_t first, size_t count) {

@@ -4,6 +4,8 @@ Bit-exact on integer limbs everywhere.  The tests read like the reference's own 
 (src/fft.rs:164-232, src/curve/curve_msm.rs:186-241, src/curve/curve_summations.rs:164-184,
 src/field/field.rs:618-780) with the reference call replaced by the plonky_amd mirror.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -766,3 +768,71 @@ def test_fft_precompute_table_2p20_spot_layers():
         assert np.array_equal(layers[i], pre.layer(i)), i
     with pytest.raises(AssertionError):
         api.fft_precompute_table(5, 1 << 33)  # beyond VestaBase's 2-adicity (field.rs:430)
+
+
+# ---------------- small fixed-base MSMs without buckets (comb.hip) ----------------
+@pytest.mark.parametrize("c", [br.TWEEDLEDEE, br.BLS12_377, br.PALLAS], ids=lambda c: c.name)
+def test_msm_comb_small_contexts(c):
+    """With PLK_MSM_COMB=1 a tabled context over <= 2^15 generators with an automatic window is a COMB (comb.hip: a table of the multiples 1 .. 8 of
+    every window's point, executions = mixed additions + a tree): against the oracle and against the bucket method (explicit
+    window) - sizes around the lane / block geometry, identity generators, duplicate and opposite generators, edge scalars, batches
+    larger than one launch pair takes, sub-ranges of the generators."""
+    torch = pytest.importorskip("torch")
+    from plonky_amd import device as dev
+    G = (c.gx, c.gy)
+    D = br.ec_mul(c, 0xC0FFEE, G)
+    L = c.base.n_limbs
+    r = c.scalar.p
+    os.environ["PLK_MSM_COMB"] = "1"  # read at every precompute; the bucket contexts below name their window and are unaffected
+    try:
+        _comb_cases(c, G, D, L, r, torch, dev)
+    finally:
+        del os.environ["PLK_MSM_COMB"]
+
+
+def _comb_cases(c, G, D, L, r, torch, dev):
+    for n in (1, 2, 3, 31, 32, 33, 257, 2050):
+        bases = ol.gen_bases(c.curve_id, n, _bases(c, [G])[0], _bases(c, [D])[0]).reshape(n, 2, L)
+        zero = np.zeros(n, dtype=np.uint8)
+        scalars = synth.rand_field(c.scalar.field_id, 0xC0B + n, n)
+        if n >= 31:
+            zero[3] = 1                                                    # AffinePoint::ZERO among the generators
+            bases[7] = bases[6]                                            # the doubling branch inside the tree
+            scalars[7] = scalars[6]
+            bases[9] = np.array([c.base.mont_limbs(G[0]), c.base.mont_limbs(c.base.p - G[1])], dtype=np.uint64)  # -G next to G: cancels
+            bases[8] = np.array([c.base.mont_limbs(G[0]), c.base.mont_limbs(G[1])], dtype=np.uint64)
+            scalars[9] = scalars[8]
+            for k, v in enumerate([0, 1, r - 1, 8, 9, 16, (1 << 252) + 8, r // 2]):
+                scalars[10 + k] = mont_arr(c.scalar, [v])[0]
+        opre = ol.MsmPrecomputation(c.curve_id, bases, 8, zero=zero, threads=8)
+        exp, ez = opre.execute(scalars, parallel=True, threads=8)
+        pre = pa.msm_precompute(c.curve_id, bases, 8, zero=zero)          # automatic window: the comb
+        assert pre.window == 4
+        got, gz = pa.msm_execute_parallel(pre, scalars)
+        assert gz == ez and (ez or np.array_equal(got, exp)), (c.name, n)
+        buck = pa.msm_precompute(c.curve_id, bases, 8, zero=zero, device_window=7)  # the bucket method on the same data
+        b_xy, b_z = pa.msm_execute_parallel(buck, scalars)
+        assert b_z == gz and (gz or np.array_equal(b_xy, got)), (c.name, n)
+        # a batch of 19 vectors (more than one launch pair of the comb takes), among them an all-zero one
+        vecs = np.stack([synth.rand_field(c.scalar.field_id, 0xBA7 + v, n) for v in range(19)])
+        vecs[4] = 0
+        vecs[11] = scalars
+        bxy, bz = pa.msm_execute_batch(pre, vecs)
+        assert bz[4] == 1 and int(bz[11]) == ez and (ez or np.array_equal(bxy[11], exp))
+        for v in (0, 18):
+            e2, z2 = opre.execute(vecs[v], parallel=True, threads=8)
+            assert int(bz[v]) == z2 and (z2 or np.array_equal(bxy[v], e2)), (c.name, n, v)
+        if n >= 33:
+            # sub-ranges of the generators (plk_msm_execute_parts_dev) over a device-resident comb context
+            dpre = dev.msm_precompute_dev(c.curve_id, dev.to_device(bases), zero=torch.from_numpy(zero).cuda())
+            sd = dev.to_device(scalars)
+            parts = [(0, sd), (5, sd[5:n - 2].contiguous()), (n - 1, sd[n - 1:].contiguous()), (12, sd[12:12].contiguous())]
+            pxy, pz = dev.msm_execute_parts_dev(dpre, parts)
+            torch.cuda.synchronize()
+            pxy, pz = dev.to_host(pxy).reshape(4, 2, L), pz.cpu().numpy()
+            for k, (f, cnt) in enumerate([(0, n), (5, n - 7), (n - 1, 1), (12, 0)]):
+                e3, z3 = ol.MsmPrecomputation(c.curve_id, bases[f:f + cnt], 8, zero=zero[f:f + cnt], threads=8).execute(scalars[f:f + cnt], parallel=True, threads=8) if cnt else (None, 1)
+                assert int(pz[k]) == z3 and (z3 or np.array_equal(pxy[k], e3)), (c.name, n, k)
+            dpre.free()
+        pre.free()
+        buck.free()
