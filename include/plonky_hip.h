@@ -75,6 +75,11 @@ int plk_init(int device);
  * the whole multi-device path (tests).  Call before creating contexts; contexts do not survive a change of the device group. */
 int plk_init_devices(int n_devices);
 int plk_device_count(void);                    /* logical devices in use (1 after plk_init) */
+/* The plan the fan-out follows, as pure arithmetic (no device needed): slot s < *slots of `device` among `world` devices computes
+ * vector vec[s] of a batch of `batch` vectors over n generators, over the generators first[s] .. first[s] + count[s] - 1 - whole
+ * vectors first (vector s * world + device, all n generators), then its contiguous share of every sharded vector.  vec / first /
+ * count: arrays of at least batch entries, or all three NULL to ask for *slots only. */
+int plk_multi_plan(unsigned world, unsigned batch, size_t n, unsigned device, unsigned* slots, unsigned* vec, uint64_t* first, uint64_t* count);
 int plk_set_thread_device(int logical_device); /* the _dev entry points of the calling thread run on this logical device */
 void plk_shutdown(void);
 /* Size gate for the binding: problems below 2^plk_min_gpu_log_n() elements / pairs stay on the reference's

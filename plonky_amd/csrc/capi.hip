@@ -69,6 +69,7 @@ unsigned msm_ctx_window(const plk_msm_ctx* ctx);
 int msm_ctx_curve(const plk_msm_ctx* ctx);
 void msm_ctx_delete(plk_msm_ctx* ctx);
 // multi.hip
+void multi_plan_slot(int world, unsigned batch, size_t n, int d, unsigned slot, unsigned* vec, size_t* first, size_t* count);
 bool msm_ctx_is_multi(plk_msm_ctx* ctx);
 int msm_precompute_multi(int curve, size_t n, const void* bases, const void* zero, bool host_src, unsigned window_bits, hipStream_t caller_stream,
                          plk_msm_ctx** out_ctx);
@@ -303,6 +304,19 @@ int plk_set_thread_device(int logical_device) {
         return set_error(PLK_ERR_INVALID_ARG, "logical device %d out of range (%d in use)", logical_device, group_size());
     set_thread_logical_device(logical_device);
     return ensure_device();
+}
+
+int plk_multi_plan(unsigned world, unsigned batch, size_t n, unsigned device, unsigned* slots, unsigned* vec, uint64_t* first, uint64_t* count) {
+    if (world == 0 || device >= world || !slots) return set_error(PLK_ERR_INVALID_ARG, "bad world / device");
+    const unsigned whole = batch / world, total = whole + (batch - whole * world);
+    *slots = total;
+    for (unsigned s = 0; s < total && vec && first && count; ++s) {
+        size_t f = 0, c = 0;
+        multi_plan_slot((int)world, batch, n, (int)device, s, &vec[s], &f, &c);
+        first[s] = f;
+        count[s] = c;
+    }
+    return PLK_OK;
 }
 
 void plk_shutdown(void) {

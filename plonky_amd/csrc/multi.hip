@@ -318,9 +318,31 @@ void group_shutdown() {
 }
 
 // ---- MSM over the group ----
-static inline size_t share_first(size_t n, int d, int world) { return (size_t)(((unsigned __int128)n * (unsigned)d) / (unsigned)world); }
+// first generator of device d's contiguous share: balanced, sizes differ by at most one, the larger shares first - the same split
+// as parallel.shard_bounds of the one-process-per-GPU form
+static inline size_t share_first(size_t n, int d, int world) {
+    const size_t base = n / (size_t)world, rem = n % (size_t)world, dd = (size_t)d;
+    return dd * base + (dd < rem ? dd : rem);
+}
 
 bool msm_ctx_is_multi(plk_msm_ctx* ctx) { return ctx && !msm_ctx_shards(ctx).empty(); }
+
+// The batch plan, in one place (pure arithmetic; also behind plk_multi_plan for hosts and tests): `batch` vectors of n scalars over
+// `world` devices.  whole = floor(batch / world) vectors go to every device WHOLE - vector s * world + d is slot s of device d - and
+// the remaining batch - whole * world vectors are SHARDED by contiguous base range: vector whole * world + j is slot whole + j of
+// every device, which reduces the generators [n d / world, n (d + 1) / world) of it.
+void multi_plan_slot(int world, unsigned batch, size_t n, int d, unsigned slot, unsigned* vec, size_t* first, size_t* count) {
+    const unsigned whole = batch / (unsigned)world;
+    if (slot < whole) {
+        *vec = slot * (unsigned)world + (unsigned)d;
+        *first = 0;
+        *count = n;
+    } else {
+        *vec = whole * (unsigned)world + (slot - whole);
+        *first = share_first(n, d, world);
+        *count = share_first(n, d + 1, world) - *first;
+    }
+}
 
 // msm_precompute on every device of the group.  `bases` / `zero`: host memory (host_src) or memory of the caller's device.
 // The caller's stream is synchronised on return (as msm_precompute_dev_impl does).
@@ -439,15 +461,17 @@ int msm_execute_multi(plk_msm_ctx* ctx, unsigned batch, const void* const* vecs,
             l->ev_ready.push_back(e);
         }
         // this device's slots: its whole vectors over all the generators, then its base range of every sharded vector
-        const size_t f = share_first(n, d, world), cnt = share_first(n, d + 1, world) - f;
         const bool pure_shard = whole == 0;  // a single MSM (or fewer vectors than devices): the context over this device's own range
         std::vector<uint64_t> first(slots), count(slots);
+        std::vector<unsigned> vec(slots);
         std::vector<const void*> ptr(slots);
         size_t need = 0;
         for (unsigned s = 0; s < slots; ++s) {
-            first[s] = s < whole ? 0 : f;
-            count[s] = s < whole ? n : cnt;
-            need += count[s];
+            size_t f = 0, c = 0;
+            multi_plan_slot(world, batch, n, d, s, &vec[s], &f, &c);
+            first[s] = f;
+            count[s] = c;
+            need += c;
         }
         const bool direct = !host_src && group_phys(d) == src_phys;  // the vectors already live on this device
         LaneBuf sbuf, rbuf;
@@ -455,7 +479,7 @@ int msm_execute_multi(plk_msm_ctx* ctx, unsigned batch, const void* const* vecs,
         PLK_TRY(rbuf.alloc(rec, l->stream));
         size_t off = 0;
         for (unsigned s = 0; s < slots; ++s) {
-            const uint8_t* src = (const uint8_t*)vecs[s < whole ? s * (unsigned)world + (unsigned)d : whole * (unsigned)world + (s - whole)] + first[s] * 32;
+            const uint8_t* src = (const uint8_t*)vecs[vec[s]] + first[s] * 32;
             if (direct) {
                 ptr[s] = src;
             } else {

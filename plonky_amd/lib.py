@@ -27,6 +27,7 @@ SYMBOLS = [
     ("plk_init_devices", _i, [_i]),
     ("plk_device_count", _i, []),
     ("plk_set_thread_device", _i, [_i]),
+    ("plk_multi_plan", _i, [_u, _u, _sz, _u, _vp, _vp, _vp, _vp]),
     ("plk_shutdown", None, []),
     ("plk_last_error", _cp, []),
     ("plk_min_gpu_log_n", _u, []),

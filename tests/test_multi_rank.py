@@ -223,3 +223,38 @@ def test_ntt_batch_sharded_world_size_2_gloo():
         assert np.array_equal(local, exp[mine])
         if gathered is not None:
             assert np.array_equal(gathered, exp)
+
+
+def test_library_plan_equals_batch_plan():
+    """plk_multi_plan - the plan the in-library fan-out over a device group follows (multi.hip, pure arithmetic: runs without a GPU) -
+    against parallel.BatchPlan, the plan of the one-process-per-GPU form: the same vectors whole, the same base ranges, and every
+    (vector, generator) pair exactly once over the devices."""
+    import ctypes
+    from plonky_amd import lib
+    L = lib.load()
+    for batch, world, n in ((9, 8, 1 << 20), (9, 4, 50), (9, 2, 33), (1, 4, 40), (3, 3, 17), (5, 8, 16), (16, 3, 1000), (2, 7, 7), (0, 4, 10)):
+        seen = np.zeros((max(batch, 1), n), dtype=np.int64) if n <= 4096 else None
+        pairs = 0
+        for d in range(world):
+            slots = ctypes.c_uint(0)
+            vec = (ctypes.c_uint * max(batch, 1))()
+            first = (ctypes.c_uint64 * max(batch, 1))()
+            count = (ctypes.c_uint64 * max(batch, 1))()
+            assert L.plk_multi_plan(world, batch, n, d, ctypes.byref(slots), vec, first, count) == 0
+            plan = parallel.BatchPlan(batch, world, d, n)
+            assert slots.value == plan.slots
+            for s in range(slots.value):
+                if s < plan.whole:
+                    assert (vec[s], first[s], count[s]) == (plan.own[s], 0, n)
+                else:
+                    assert (vec[s], first[s], count[s]) == (plan.rem[s - plan.whole], plan.lo, plan.hi - plan.lo)
+                pairs += count[s]
+                if seen is not None:
+                    seen[vec[s], first[s]:first[s] + count[s]] += 1
+        assert pairs == batch * n
+        if seen is not None and batch:
+            assert (seen == 1).all(), (batch, world, n)
+    slots = ctypes.c_uint(0)
+    assert L.plk_multi_plan(0, 1, 1, 0, ctypes.byref(slots), None, None, None) != 0      # no devices
+    assert L.plk_multi_plan(4, 9, 100, 4, ctypes.byref(slots), None, None, None) != 0    # device out of range
+    assert L.plk_multi_plan(4, 9, 100, 1, ctypes.byref(slots), None, None, None) == 0 and slots.value == 3  # the count alone
