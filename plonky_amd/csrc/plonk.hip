@@ -263,6 +263,7 @@ template <int GATE, class P, int B> PLK_DI void add_product(Term<P>& u, const Lz
     u.v = fz_add<P>(u.v, product.v);
 }
 template <class P> struct TermSink {
+    static constexpr bool kReduced = false;
     Term<P> (&u)[NUM_TERMS];
     template <int GATE, int T, class F> PLK_DI void put(const F&) {}
     template <int GATE, int T, class F, class C0, class... Cs> PLK_DI void put(const F& f, const C0& c0, const Cs&... cs) {
@@ -277,12 +278,32 @@ template <class P> struct TermSink {
 };
 template <class A, class C0> PLK_DI auto lz_horner(const A&, const C0& c0) { return c0; }
 template <class A, class C0, class... Cs> PLK_DI auto lz_horner(const A& alpha, const C0& c0, const Cs&... cs) { return c0 + lz_horner(alpha, cs...) * alpha; }
+// The weights of a launch (k_plonk_weights): what depends on alpha / beta / k_is only, so that a point does not recompute it.
+//   [0..3]  W_c  = sum_i alpha^(2 i + 1) / (4 + i - c): RescueStepA's share of reduce_with_powers that is linear in its state wire 4 + c
+//           (its constraints 2 i + 1 are rows of the MDS matrix, mds.rs:63-77 - sixteen products by matrix entries become four by W_c);
+//   [4..7]  W'_c = sum_i alpha^i / (4 + i - c): the same for RescueStepB (constraint i is MDS row i over the fifth powers);
+//   [8..13] beta k_is[j] (plonk.rs:431: beta * k_i * x is one product per wire instead of two).
+constexpr int NUM_WEIGHTS = 8 + NUM_ROUTED_WIRES;
 template <class P> struct ReducedSink {
+    static constexpr bool kReduced = true;
     Lz<P, 16> alpha;
     Term<P> total;
+    const uint32_t (*weights)[FzCfg<P>::NZ];  // staged in LDS, read where a gate uses them
+    PLK_DI Lz<P, 16> weight(int w) const {
+        Lz<P, 16> r;
+#pragma unroll
+        for (int i = 0; i < FzCfg<P>::NZ; ++i) r.v.l[i] = weights[w][i];
+        return r;
+    }
     template <int GATE, class F, class... Cs> PLK_DI void gate(const F& f, const Cs&... cs) {
         gate_fence();
         add_product<GATE>(total, f * lz_horner(alpha, cs...));
+        gate_fence();
+    }
+    // filter * (c_0 + alpha c_1 + ... + extra): `extra` is the part of the gate's sum that was folded into the launch's weights
+    template <int GATE, class F, class E, class... Cs> PLK_DI void gate_extra(const F& f, const E& extra, const Cs&... cs) {
+        gate_fence();
+        add_product<GATE>(total, f * (lz_horner(alpha, cs...) + extra));
         gate_fence();
     }
 };
@@ -322,16 +343,31 @@ PLK_DI void all_constraints(const K& k, const LW& l, const RW& r, const D& b2, c
 #define PLK_MDS_ROW(i, v0, v1, v2, v3) (k[2 + i] + (mds[3 + i] * v0 + mds[2 + i] * v1 + mds[1 + i] * v2 + mds[i] * v3) - r[i])
         if constexpr ((MASK & GATES_RESCUE_A) != 0) {
             const D l4 = l[4], l5 = l[5], l6 = l[6], l7 = l[7];
-            sink.template gate<7>(nk0 * (one - k1),                                           //
-                                  l4.pow5() - l[0], PLK_MDS_ROW(0, l4, l5, l6, l7),           //
-                                  l5.pow5() - l[1], PLK_MDS_ROW(1, l4, l5, l6, l7),           //
-                                  l6.pow5() - l[2], PLK_MDS_ROW(2, l4, l5, l6, l7),           //
-                                  l7.pow5() - l[3], PLK_MDS_ROW(3, l4, l5, l6, l7));
+            if constexpr (Sink::kReduced) {
+                // sum_t alpha^t c_t with the matrix part of the odd constraints taken out: sum_c l_(4 + c) W_c (weights 0..3)
+                const auto folded = l4 * sink.weight(0) + l5 * sink.weight(1) + l6 * sink.weight(2) + l7 * sink.weight(3);
+                sink.template gate_extra<7>(nk0 * (one - k1), folded,                 //
+                                            l4.pow5() - l[0], k[2] - r[0],            //
+                                            l5.pow5() - l[1], k[3] - r[1],            //
+                                            l6.pow5() - l[2], k[4] - r[2],            //
+                                            l7.pow5() - l[3], k[5] - r[3]);
+            } else {
+                sink.template gate<7>(nk0 * (one - k1),                                           //
+                                      l4.pow5() - l[0], PLK_MDS_ROW(0, l4, l5, l6, l7),           //
+                                      l5.pow5() - l[1], PLK_MDS_ROW(1, l4, l5, l6, l7),           //
+                                      l6.pow5() - l[2], PLK_MDS_ROW(2, l4, l5, l6, l7),           //
+                                      l7.pow5() - l[3], PLK_MDS_ROW(3, l4, l5, l6, l7));
+            }
         }
         if constexpr ((MASK & GATES_RESCUE_B) != 0) {
             const auto e0 = l[0].pow5(), e1 = l[1].pow5(), e2 = l[2].pow5(), e3 = l[3].pow5();
-            sink.template gate<8>(nk0 * k1, PLK_MDS_ROW(0, e0, e1, e2, e3), PLK_MDS_ROW(1, e0, e1, e2, e3), PLK_MDS_ROW(2, e0, e1, e2, e3),
-                                  PLK_MDS_ROW(3, e0, e1, e2, e3));
+            if constexpr (Sink::kReduced) {
+                const auto folded = e0 * sink.weight(4) + e1 * sink.weight(5) + e2 * sink.weight(6) + e3 * sink.weight(7);
+                sink.template gate_extra<8>(nk0 * k1, folded, k[2] - r[0], k[3] - r[1], k[4] - r[2], k[5] - r[3]);
+            } else {
+                sink.template gate<8>(nk0 * k1, PLK_MDS_ROW(0, e0, e1, e2, e3), PLK_MDS_ROW(1, e0, e1, e2, e3), PLK_MDS_ROW(2, e0, e1, e2, e3),
+                                      PLK_MDS_ROW(3, e0, e1, e2, e3));
+            }
         }
 #undef PLK_MDS_ROW
     }
@@ -353,23 +389,30 @@ PLK_DI void all_constraints(const K& k, const LW& l, const RW& r, const D& b2, c
     const auto p10 = k[0] * (one - k[1]);
     if constexpr ((MASK & GATES_BASE4_ARITH) != 0) {
         const auto p100 = p10 * (one - k[2]);
+        // the two filters below p100 share one product: p100 (1 - k3) = p100 - p100 k3
+        const auto f_arith = p100 * k[3];
+        const auto f_base4 = p100 - f_arith;
+        // ArithmeticGate 1001, arithmetic.rs:30-46
+        sink.template gate<6>(f_arith, k[4] * l[0] * l[1] + k[5] * l[2] - l[3]);
         {  // Base4SumGate 1000, base_4_sum.rs:34-63: 7 limbs in wires 2..8
             const auto two = one.dbl();
-            const auto three = two + one;
-            // (limb - 0) (limb - 1) (limb - 2) (limb - 3), times ONE in the reference
-            auto b4 = [&](const D& limb) { return limb * (limb - one) * (limb - two) * (limb - three); };
+            // (limb - 0) (limb - 1) (limb - 2) (limb - 3), times ONE in the reference: with t = limb^2 - 3 limb = limb (limb - 3) it is
+            // t (t + 2) - a squaring and a product instead of three products
+            auto b4 = [&](const D& limb) {
+                const auto t = limb.sq() - (limb.dbl() + limb);
+                return t * (t + two);
+            };
 #define PLK_B4(i) b4(l[2 + i])
-            sink.template gate<3>(p100 * (one - k[3]), (base4_chain<0>(l[0], l) - l[1]).rs(), PLK_B4(0), PLK_B4(1), PLK_B4(2), PLK_B4(3), PLK_B4(4), PLK_B4(5),
-                                  PLK_B4(6));
+            sink.template gate<3>(f_base4, (base4_chain<0>(l[0], l) - l[1]).rs(), PLK_B4(0), PLK_B4(1), PLK_B4(2), PLK_B4(3), PLK_B4(4), PLK_B4(5), PLK_B4(6));
 #undef PLK_B4
         }
-        // ArithmeticGate 1001, arithmetic.rs:30-46
-        sink.template gate<6>(p100 * k[3], k[4] * l[0] * l[1] + k[5] * l[2] - l[3]);
     }
     if constexpr ((MASK & (GATES_ADD_PUBLIC | GATES_DBL_CONST)) == 0) return;
     const auto p101 = p10 * k[2];
     if constexpr ((MASK & GATES_ADD_PUBLIC) != 0) {
         const auto p1010 = p101 * (one - k[3]);
+        const auto f_add = p1010 * k[4];        // p1010 (1 - k4) = p1010 - p1010 k4: the two filters below p1010 share one product
+        const auto f_not_add = p1010 - f_add;
         {  // CurveAddGate 10101, curve_add.rs:60-101
             const D &x1 = l[0], &y1 = l[1], &x4 = r[0], &y4 = r[1], &acc_old = l[2], &acc_new = l[3], &x2 = l[4], &y2 = l[5], &bit = l[6], &inverse = l[7],
                     &lambda = l[8];
@@ -377,16 +420,21 @@ PLK_DI void all_constraints(const K& k, const LW& l, const RW& r, const D& b2, c
             const auto x3 = lambda.sq() - x1 - x2;
             const auto y3 = lambda * (x1 - x4) - y1;
             const auto not_bit = one - bit;
-            const auto computed_x4 = bit * x3 + not_bit * x1;
-            const auto computed_y4 = bit * y3 + not_bit * y1;
-            sink.template gate<0>(p1010 * k[4], computed_lambda - lambda, computed_x4 - x4, computed_y4 - y4, acc_new - (acc_old.dbl() + bit), bit * not_bit,
+            // bit x3 + (1 - bit) x1 = x1 + bit (x3 - x1): one product each instead of two
+            const auto computed_x4 = x1 + bit * (x3 - x1);
+            const auto computed_y4 = y1 + bit * (y3 - y1);
+            sink.template gate<0>(f_add, computed_lambda - lambda, computed_x4 - x4, computed_y4 - y4, acc_new - (acc_old.dbl() + bit), bit * not_bit,
                                   inverse * (x1 - x2) - one);
         }
         // PublicInputGate 101001, public_input.rs:26-37: advice wires 6..8 against the right gate's wires 0..2
-        sink.template gate<4>(p1010 * (one - k[4]) * k[5], l[6] - r[0], l[7] - r[1], l[8] - r[2]);
+        sink.template gate<4>(f_not_add * k[5], l[6] - r[0], l[7] - r[1], l[8] - r[2]);
     }
     if constexpr ((MASK & GATES_DBL_CONST) != 0) {
         const auto p1011 = p101 * k[3];
+        const auto f_dbl = p1011 * k[4];
+        const auto f_const = p1011 - f_dbl;
+        // ConstantGate 10110, constant.rs:28-39
+        sink.template gate<5>(f_const, k[5] - l[0]);
         {  // CurveDblGate 10111, curve_dbl.rs:42-68
             const D &x_old = l[0], &y_old = l[1], &x_new = l[2], &y_new = l[3], &inverse = l[4], &lambda = l[5];
             const auto xx = x_old.sq();
@@ -394,10 +442,8 @@ PLK_DI void all_constraints(const K& k, const LW& l, const RW& r, const D& b2, c
             const auto computed_lambda = numerator * inverse;
             const auto computed_x_new = lambda.sq() - x_old.dbl();
             const auto computed_y_new = lambda * (x_old - x_new) - y_old;
-            sink.template gate<1>(p1011 * k[4], computed_lambda - lambda, computed_x_new - x_new, computed_y_new - y_new, y_old.dbl() * inverse - one);
+            sink.template gate<1>(f_dbl, computed_lambda - lambda, computed_x_new - x_new, computed_y_new - y_new, y_old.dbl() * inverse - one);
         }
-        // ConstantGate 10110, constant.rs:28-39
-        sink.template gate<5>(p1011 * (one - k[4]), k[5] - l[0]);
     }
 }
 
@@ -407,8 +453,13 @@ struct PlonkScalars {
 };
 // the scalars of a launch in the working form, converted once per workgroup: [0..5] k_is, 6 alpha, 7 beta, 8 gamma, 9 zeta, 10 a
 constexpr int NUM_SCALARS = NUM_ROUTED_WIRES + 5;
-template <class P> PLK_DI void stage_scalars(const PlonkScalars& sc, uint32_t (*s_sc)[FzCfg<P>::NZ]) {
+// rows NUM_SCALARS .. NUM_SCALARS + NUM_WEIGHTS - 1: the weights of the launch (k_plonk_weights; limb form already), when there are any
+template <class P> PLK_DI void stage_scalars(const PlonkScalars& sc, uint32_t (*s_sc)[FzCfg<P>::NZ], const uint32_t* __restrict__ weights = nullptr) {
     const int t = threadIdx.x;
+    if (weights && t >= NUM_SCALARS && t < NUM_SCALARS + NUM_WEIGHTS) {
+#pragma unroll
+        for (int i = 0; i < FzCfg<P>::NZ; ++i) s_sc[t][i] = weights[(t - NUM_SCALARS) * FzCfg<P>::NZ + i];
+    }
     if (t < NUM_SCALARS) {
         const uint32_t* w = t < NUM_ROUTED_WIRES ? sc.k_is[t] : t == 6 ? sc.alpha : t == 7 ? sc.beta : t == 8 ? sc.gamma : t == 9 ? sc.zeta : sc.a;
         Fe<P> x;
@@ -427,6 +478,38 @@ template <class P> PLK_DI Lz<P, 16> scalar_at(const uint32_t (*s_sc)[FzCfg<P>::N
     return r;
 }
 
+// The weights of a call (ReducedSink), one lane each; alpha^e by repeated products - fourteen lanes, once per call.
+template <class P> __global__ void __launch_bounds__(64) k_plonk_weights(const uint4* __restrict__ small, PlonkScalars sc, uint32_t* __restrict__ out) {
+    using D = Lz<P, 16>;
+    const int t = threadIdx.x;
+    if (t >= NUM_WEIGHTS) return;
+    auto load = [](const uint32_t (&w)[8]) {
+        Fe<P> x;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x.v[i] = w[i];
+        return lz_from_rform<P>(x);
+    };
+    D res;
+    if (t < 8) {
+        const D alpha = load(sc.alpha);
+        const int c = t & 3;
+        const bool step_b = t >= 4;
+        // RescueStepA: exponents 1, 3, 5, 7 (its matrix rows are the odd constraints); RescueStepB: 0, 1, 2, 3
+        D pw = step_b ? lz_one<P>().template widen<16>() : alpha;
+        const D step = step_b ? alpha : (alpha * alpha).template widen<16>();
+        D acc{fz_zero<P>()};
+        for (int i = 0; i < 4; ++i) {
+            acc = (acc + pw * lz_table<P>(small, 3 + i - c)).rs();  // MDS entry (i, c) = 1 / (4 + i - c), mds.rs:63-77
+            pw = (pw * step).template widen<16>();
+        }
+        res = acc;
+    } else {
+        res = (load(sc.beta) * load(sc.k_is[t - 8])).template widen<16>();
+    }
+#pragma unroll
+    for (int i = 0; i < FzCfg<P>::NZ; ++i) out[t * FzCfg<P>::NZ + i] = res.v.l[i];
+}
+
 // plonk.rs:392-453, one lane per point of the 8n domain, in FIVE launches.  The ten gates, the permutation argument and their
 // inputs (21 + 10 elements per point) are several register files wide; evaluated in one piece the kernel spills to scratch
 // and, at one wave per SIMD, waits out every reload.  A launch evaluates a group of gates and hands the running sum on (limb
@@ -443,13 +526,15 @@ template <class P, int PASS>
 __global__ void __launch_bounds__(128, PLK_VANISH_WAVES) k_vanishing_points(const uint4* __restrict__ constants, const uint4* __restrict__ wires, const uint4* __restrict__ s_sigma,
                                                              const uint4* __restrict__ z, const uint4* __restrict__ xs_lo_z, const uint4* __restrict__ xs_hi_z,
                                                              const uint4* __restrict__ l1, const uint4* __restrict__ small, PlonkScalars sc, int log_degree,
-                                                             uint32_t* __restrict__ part, uint4* __restrict__ out, size_t first, size_t count) {
+                                                             uint32_t* __restrict__ part, uint4* __restrict__ out, size_t first, size_t count,
+                                                             const uint32_t* __restrict__ weights) {
     static_assert(P::NL == 8, "256-bit scalar fields");
     using D = Lz<P, 16>;
     constexpr int MASK = PASS == 0 ? GATES_RESCUE_A : PASS == 1 ? GATES_RESCUE_B : PASS == 2 ? (GATES_ENDO | GATES_BASE4_ARITH)
                          : PASS == 3 ? (GATES_ADD_PUBLIC | GATES_DBL_CONST) : 0;
-    __shared__ uint32_t s_sc[NUM_SCALARS][FzCfg<P>::NZ];
-    stage_scalars<P>(sc, s_sc);
+    static_assert(NUM_SCALARS + NUM_WEIGHTS <= 128, "one lane of the workgroup stages one row");
+    __shared__ uint32_t s_sc[NUM_SCALARS + NUM_WEIGHTS][FzCfg<P>::NZ];
+    stage_scalars<P>(sc, s_sc, weights);
     const size_t n8 = (size_t)8 << log_degree;
     const size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // this launch covers the points first .. first + count - 1
     if (i >= first + count || i >= n8) return;
@@ -463,7 +548,7 @@ __global__ void __launch_bounds__(128, PLK_VANISH_WAVES) k_vanishing_points(cons
             b2 = lz_load<P>(wires, (size_t)2 * n8 + i_below);
             b3 = lz_load<P>(wires, (size_t)3 * n8 + i_below);
         }
-        ReducedSink<P> sink{alpha, Term<P>{fz_zero<P>()}};
+        ReducedSink<P> sink{alpha, Term<P>{fz_zero<P>()}, s_sc + NUM_SCALARS};
         all_constraints<P, D, MASK>(k, l, r, b2, b3, scalar_at<P>(s_sc, 9), scalar_at<P>(s_sc, 10), small, sink);
         if constexpr (PASS == 0) {
             limbs_store<P>(part, i, sink.total.v);  // one gate: < 1.25p
@@ -482,10 +567,10 @@ __global__ void __launch_bounds__(128, PLK_VANISH_WAVES) k_vanishing_points(cons
         Lz<P, 9> f_prime = one.template widen<9>(), g_prime = f_prime;
 #pragma unroll
         for (int j = 0; j < NUM_ROUTED_WIRES; ++j) {  // plonk.rs:428-437
-            const auto s_id = scalar_at<P>(s_sc, j) * x;
+            const auto beta_s_id = scalar_at<P>(s_sc, NUM_SCALARS + 8 + j) * x;  // beta * (k_is[j] * x), plonk.rs:430-431: beta k_is[j] is a weight of the call
             const D s_sig = lz_load<P>(s_sigma, (size_t)j * n8 + i);
             const D lj = l[j];
-            f_prime = f_prime * (lj + beta * s_id + gamma);
+            f_prime = f_prime * (lj + beta_s_id + gamma);
             g_prime = g_prime * (lj + beta * s_sig + gamma);
         }
         const auto v_shift_term = f_prime * z_x - g_prime * z_gz;  // plonk.rs:438
@@ -537,6 +622,12 @@ static int vanishing_points_t(unsigned log_degree, const void* d_constants, cons
     const size_t n8 = (size_t)8 << log_degree;
     void* part = scratch_acquire(limb_bytes(n8, FzCfg<P>::NZ), stream);
     if (!part) return PLK_ERR_OOM;
+    uint32_t* weights = (uint32_t*)scratch_acquire((size_t)NUM_WEIGHTS * FzCfg<P>::NZ * 4, stream);
+    if (!weights) {
+        scratch_release(part, stream);
+        return PLK_ERR_OOM;
+    }
+    k_plonk_weights<P><<<1, 64, 0, stream>>>((const uint4*)t->small, sc, weights);
     // PLK_VANISH_SLAB_LOG=k: the five launches walk the domain in slabs of 2^k points, so that the rows a slab reads (29 x 32 B per
     // point) are still in the 256 MiB Infinity Cache when the next launch of the slab re-reads them (round-3 review item 5;
     // measured in DESIGN.md section 4c).  Default: the whole domain per launch.
@@ -549,7 +640,7 @@ static int vanishing_points_t(unsigned log_degree, const void* d_constants, cons
 #define PLK_VANISH(PASS)                                                                                                                                  \
     k_vanishing_points<P, PASS><<<blocks, 128, 0, stream>>>((const uint4*)d_constants, (const uint4*)d_wires, (const uint4*)d_s_sigma, (const uint4*)d_z, \
                                                             (const uint4*)t->xs_lo_z, (const uint4*)t->xs_hi_z, (const uint4*)t->l1, (const uint4*)t->small, sc, \
-                                                            (int)log_degree, (uint32_t*)part, (uint4*)d_out, first, cnt)
+                                                            (int)log_degree, (uint32_t*)part, (uint4*)d_out, first, cnt, weights)
     for (size_t first = 0; first < n8; first += slab) {
         const size_t cnt = n8 - first < slab ? n8 - first : slab;
         const unsigned blocks = (unsigned)((cnt + 127) / 128);
@@ -561,6 +652,7 @@ static int vanishing_points_t(unsigned log_degree, const void* d_constants, cons
     }
 #undef PLK_VANISH
     const hipError_t e = hipGetLastError();
+    scratch_release(weights, stream);
     scratch_release(part, stream);
     if (e != hipSuccess) return set_error(PLK_ERR_HIP, "vanishing points launch failed: %s", hipGetErrorString(e));
     // the tables stay alive in the cache (plk_ntt_clear_cache / plk_shutdown drop them after a device synchronisation)

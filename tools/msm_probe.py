@@ -21,7 +21,7 @@ for curve, log_n in [(int(a.split(":")[0]), int(a.split(":")[1])) for a in sys.a
     s = dev.to_device(s_host)
     t0 = time.perf_counter(); pre = dev.msm_precompute_dev(curve, bases); torch.cuda.synchronize(); t_pre = time.perf_counter() - t0
     oxy, oz = dev.msm_execute_dev(pre, s); torch.cuda.synchronize()
-    K = 5
+    K = int(os.environ.get("PROBE_ITERS", "5"))
     t0 = time.perf_counter()
     for _ in range(K): dev.msm_execute_dev(pre, s, oxy, oz)
     torch.cuda.synchronize(); t = (time.perf_counter() - t0) / K
