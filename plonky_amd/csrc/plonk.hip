@@ -110,7 +110,58 @@ template <class P> PLK_DI Lz<P, 16> lz_from_rform(const Fe<P>& x) {
     }
     return {fz_reduce_small<P>(r)};
 }
-template <class P> PLK_DI Lz<P, 16> lz_load(const uint4* p, size_t i) { return lz_from_rform<P>(fe_load<P>(p + i * 2)); }
+// The same conversion for the rows a point reads (~110 loads per point of the quotient numerator), without the reduction: cut the
+// word X < p at bit s = floor(log2 p) - 5, X = t 2^s + X_low.  Then 32 X = 32 X_low + t 2^(s + 5) with 32 X_low < 2^(s + 5) <= p, and
+// (t 2^(s + 5)) mod p is a table of p / 2^s + 1 <= 38 plain integers in 29-bit limbs (LZ_TOP_ROWS rows, staged in LDS by
+// the kernels; built with the circuit-size tables): nine limb additions instead of a quotient estimate and a multiply-subtract per
+// limb.  Value below 2p; limbs below 2^30 - 1 (two exact limbs added, no carry pass) - what fz_sub accepts of a subtrahend
+// (fz.cuh) and what a product accepts of BOTH operands: 9 (2^30)^2 + 9 2^58 + 2^36 < 2^64.
+constexpr int LZ_TOP_ROWS = 64, LZ_TOP_STRIDE = 12;
+template <class P> struct LzSplit {
+    static constexpr int top_bit() {
+        for (int b = 32 * P::NL - 1; b >= 0; --b)
+            if ((P::MOD[b >> 5] >> (b & 31)) & 1u) return b;
+        return 0;
+    }
+    static constexpr int S = top_bit() - 5;  // X_low = X mod 2^S
+    static_assert(S >= 29 * (FzCfg<P>::NZ - 1) - 5 && S >= 32 * (P::NL - 1), "the cut must lie in the top limb and the top word");
+};
+// LDS copy of the table: a row is read with three 16-byte accesses (a limb-major copy read word by word - no two rows in one bank -
+// was measured too: 10.44-10.51 ms against 10.27-10.28 for this layout, profiles/r04_quotient_diet.txt)
+template <class P> using LzTop = uint32_t[LZ_TOP_ROWS][LZ_TOP_STRIDE];
+template <class P> PLK_DI Lz<P, 16> lz_from_rform(const Fe<P>& x, const LzTop<P>& top) {
+    constexpr int NZ = FzCfg<P>::NZ, SH = 29 * NZ - 32 * P::NL, S = LzSplit<P>::S;
+    static_assert(SH > 0 && SH < 29 && NZ <= LZ_TOP_STRIDE, "R' / R must be a shift by less than a limb");
+    // t <= (p - 1) >> S for a canonical word; the clamp keeps a non-canonical one inside the table (any row is a valid residue)
+    const uint32_t t = min(x.v[P::NL - 1] >> (S - 32 * (P::NL - 1)), (uint32_t)LZ_TOP_ROWS - 1u);
+    const uint4 t0 = *reinterpret_cast<const uint4*>(&top[t][0]), t1 = *reinterpret_cast<const uint4*>(&top[t][4]),
+                t2 = *reinterpret_cast<const uint4*>(&top[t][8]);
+    const uint32_t tl[12] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w};
+    Fz<P> r;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+        const int off = 29 * i - SH;
+        uint32_t v;
+        if (off < 0) v = x.v[0] << (-off);
+        else {
+            const int w = off >> 5, sh = off & 31;
+            if (sh == 0) v = x.v[w];
+            else if (sh + 29 <= 32 || w + 1 >= P::NL) v = x.v[w] >> sh;
+            else v = (x.v[w] >> sh) | (x.v[w + 1] << (32 - sh));
+        }
+        // the top limb ends at the cut: bits 29 (NZ - 1) - SH .. S - 1 of X
+        const uint32_t mask = i == NZ - 1 ? (1u << (S - (29 * (NZ - 1) - SH))) - 1u : FzCfg<P>::M;
+        r.l[i] = (v & mask) + tl[i];
+    }
+    return {r};
+}
+template <class P> PLK_DI Lz<P, 16> lz_load(const uint4* p, size_t i) { return lz_from_rform<P>(fe_load<P>(p + i * 2)); }  // k_all_constraints: no table staged
+template <class P> PLK_DI Lz<P, 16> lz_load(const uint4* p, size_t i, const LzTop<P>& top) { return lz_from_rform<P>(fe_load<P>(p + i * 2), top); }
+// the table (LZ_TOP_ROWS rows of LZ_TOP_STRIDE words) into LDS; the caller's next barrier publishes it
+template <class P> PLK_DI void stage_top_table(const uint32_t* __restrict__ top_global, LzTop<P>& s_top) {
+    for (int k = threadIdx.x; k < LZ_TOP_ROWS * LZ_TOP_STRIDE / 4; k += blockDim.x)
+        reinterpret_cast<uint4*>(&s_top[0][0])[k] = reinterpret_cast<const uint4*>(top_global)[k];
+}
 // table entries are stored in R'-form, canonical
 template <class P> PLK_DI Lz<P, 8> lz_table(const uint4* p, size_t i) { return {fz_from_fe<P>(fe_load<P>(p + i * 2))}; }
 template <class P> PLK_DI Lz<P, 8> lz_one() { return {fz_one_rprime<P>()}; }
@@ -128,8 +179,9 @@ struct PlonkTables {
     void* xs_hi_z = nullptr;
     void* l1 = nullptr;       // L_1(g^i), i < 8n  (plonk_util.rs:14-24), R'-form
     void* small = nullptr;    // [0..7]: 1/1 .. 1/7 then unused, R'-form; MDS entry (r, c) = 1 / (4 + r - c)  (mds.rs:63-77)
+    void* top = nullptr;      // (t 2^(S + 5)) mod p, t < LZ_TOP_ROWS, plain integers in 29-bit limbs (lz_from_rform)
     ~PlonkTables() {
-        for (void* p : {xs_lo, xs_hi, xs_lo_z, xs_hi_z, l1, small})
+        for (void* p : {xs_lo, xs_hi, xs_lo_z, xs_hi_z, l1, small, top})
             if (p) (void)hipFree(p);
     }
 };
@@ -143,7 +195,7 @@ int plonk_clear_cache_impl() {
 }
 
 template <class P> __global__ void k_plonk_xs(const uint4* __restrict__ pw, int log_t, int log_n8, uint4* __restrict__ lo, uint4* __restrict__ hi,
-                                              uint4* __restrict__ lo_z, uint4* __restrict__ hi_z, uint4* __restrict__ small) {
+                                              uint4* __restrict__ lo_z, uint4* __restrict__ hi_z, uint4* __restrict__ small, uint32_t* __restrict__ top) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n_lo = (size_t)1 << XS_LO_LOG;
     const size_t n_hi = log_n8 > XS_LO_LOG ? (size_t)1 << (log_n8 - XS_LO_LOG) : 1;
@@ -163,6 +215,17 @@ template <class P> __global__ void k_plonk_xs(const uint4* __restrict__ pw, int 
         Fe<P> c = fe_zero<P>();
         c.v[0] = v;
         fe_store<P>(small + (v - 1) * 2, to_rprime<P>(fe_inv_safegcd<P>(fe_from_canonical<P>(c))));
+    } else if (idx < n_lo + n_hi + 7 + LZ_TOP_ROWS) {
+        // (t 2^(S + 5)) mod p as a plain integer: the product of the two numbers in Montgomery form, brought back
+        const uint32_t tt = (uint32_t)(idx - n_lo - n_hi - 7);
+        constexpr int E = LzSplit<P>::S + 5;  // 2^E <= p
+        Fe<P> a = fe_zero<P>(), b = fe_zero<P>();
+        a.v[0] = tt;
+        b.v[E >> 5] = 1u << (E & 31);
+        const Fe<P> prod = fe_to_canonical<P>(fe_mul<P>(fe_from_canonical<P>(a), fe_from_canonical<P>(b)));
+        const Fz<P> z = fz_from_fe<P>(prod);
+#pragma unroll
+        for (int i = 0; i < LZ_TOP_STRIDE; ++i) top[tt * LZ_TOP_STRIDE + i] = i < FzCfg<P>::NZ ? z.l[i] : 0u;
     }
 }
 template <class P> PLK_DI Fe<P> plonk_x(const uint4* lo, const uint4* hi, size_t i) {
@@ -228,9 +291,10 @@ template <class P> static int get_plonk_tables(int log_degree, hipStream_t strea
     PLK_HIP_TRY(hipMalloc(&t->xs_hi_z, n_hi * 32));
     PLK_HIP_TRY(hipMalloc(&t->small, 8 * 32));
     PLK_HIP_TRY(hipMalloc(&t->l1, n8 * 32));
-    const size_t cnt = n_lo + n_hi + 7;
+    PLK_HIP_TRY(hipMalloc(&t->top, (size_t)LZ_TOP_ROWS * LZ_TOP_STRIDE * 4));
+    const size_t cnt = n_lo + n_hi + 7 + LZ_TOP_ROWS;
     k_plonk_xs<P><<<(unsigned)((cnt + 127) / 128), 128, 0, stream>>>((const uint4*)pw, log_t, log_n8, (uint4*)t->xs_lo, (uint4*)t->xs_hi, (uint4*)t->xs_lo_z,
-                                                                     (uint4*)t->xs_hi_z, (uint4*)t->small);
+                                                                     (uint4*)t->xs_hi_z, (uint4*)t->small, (uint32_t*)t->top);
     const size_t lanes = (n8 + L1_PER_LANE - 1) / L1_PER_LANE;
     k_plonk_l1<P><<<(unsigned)((lanes + 63) / 64), 64, 0, stream>>>((const uint4*)t->xs_lo, (const uint4*)t->xs_hi, log_degree, (uint4*)t->l1);
     PLK_HIP_TRY(hipGetLastError());
@@ -248,8 +312,10 @@ template <class P> static int get_plonk_tables(int log_degree, hipStream_t strea
 //  * ReducedSink: total += filter * (c_0 + alpha c_1 + alpha^2 c_2 + ..), the gate's share of reduce_with_powers over the unified
 //    terms (plonk_util.rs:27-33; the sum over the gates and the powers of alpha commute) - one running value instead of eight,
 //    and one product by the filter per gate instead of one per constraint.
-// Ten gates, each adds at most once to a term / to the total, every summand a product (below 1.25p): the sums stay below 12.5p.
-template <class P> using Term = Lz<P, 100>;
+// Ten gates, each adds at most once to a term / to the total, every summand a product (below LZ_SUMMAND_MAX / 8 p = 2p - a filter that is
+// a difference of two prefix products and a sum of constraints can both be a few p): the sums stay below 20p.
+constexpr int LZ_SUMMAND_MAX = 16;
+template <class P> using Term = Lz<P, 10 * LZ_SUMMAND_MAX>;
 // Between two gates: the instruction scheduler must not interleave them (left alone it overlaps all ten gates for
 // instruction-level parallelism and the kernel needs several times the register file).
 PLK_DI void gate_fence() {
@@ -259,7 +325,7 @@ PLK_DI void gate_fence() {
 }
 template <int GATE, class P, int B> PLK_DI void add_product(Term<P>& u, const Lz<P, B>& product) {
     static_assert(GATE >= 0 && GATE < 10, "ten gates");
-    static_assert(B <= 10, "a summand must be a product");
+    static_assert(B <= LZ_SUMMAND_MAX, "a summand must be a product");
     u.v = fz_add<P>(u.v, product.v);
 }
 template <class P> struct TermSink {
@@ -327,7 +393,8 @@ constexpr int GATES_RESCUE = GATES_RESCUE_A | GATES_RESCUE_B;
 template <class P> struct LazyRow {
     const uint4* base;
     size_t stride, i;
-    PLK_DI Lz<P, 16> operator[](int j) const { return lz_load<P>(base, (size_t)j * stride + i); }
+    const LzTop<P>& top;
+    PLK_DI Lz<P, 16> operator[](int j) const { return lz_load<P>(base, (size_t)j * stride + i, top); }
 };
 template <class P, class D, int MASK, class K, class LW, class RW, class Sink>
 PLK_DI void all_constraints(const K& k, const LW& l, const RW& r, const D& b2, const D& b3, const D& zeta, const D& a_coeff,
@@ -336,6 +403,13 @@ PLK_DI void all_constraints(const K& k, const LW& l, const RW& r, const D& b2, c
     if constexpr ((MASK & GATES_RESCUE) != 0) {  // RescueStepAGate 00, rescue_a.rs:38-69, and RescueStepBGate 01, rescue_b.rs:30-58
         const auto nk0 = one - k[0];
         const D k1 = k[1];
+        // both steps in one launch: (1 - k0) (1 - k1) = (1 - k0) - (1 - k0) k1, one product for the two filters
+        constexpr bool BOTH_STEPS = (MASK & GATES_RESCUE) == GATES_RESCUE;
+        const auto f_step_b = nk0 * k1;
+        auto filter_a = [&] {
+            if constexpr (BOTH_STEPS) return nk0 - f_step_b;
+            else return nk0 * (one - k1);
+        };
         Lz<P, 8> mds[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) mds[i] = lz_table<P>(small, i);  // mds[v - 1] = 1 / v; entry (r, c) = 1 / (4 + r - c), mds.rs:63-77
@@ -346,13 +420,13 @@ PLK_DI void all_constraints(const K& k, const LW& l, const RW& r, const D& b2, c
             if constexpr (Sink::kReduced) {
                 // sum_t alpha^t c_t with the matrix part of the odd constraints taken out: sum_c l_(4 + c) W_c (weights 0..3)
                 const auto folded = l4 * sink.weight(0) + l5 * sink.weight(1) + l6 * sink.weight(2) + l7 * sink.weight(3);
-                sink.template gate_extra<7>(nk0 * (one - k1), folded,                 //
+                sink.template gate_extra<7>(filter_a(), folded,                      //
                                             l4.pow5() - l[0], k[2] - r[0],            //
                                             l5.pow5() - l[1], k[3] - r[1],            //
                                             l6.pow5() - l[2], k[4] - r[2],            //
                                             l7.pow5() - l[3], k[5] - r[3]);
             } else {
-                sink.template gate<7>(nk0 * (one - k1),                                           //
+                sink.template gate<7>(filter_a(),                                                //
                                       l4.pow5() - l[0], PLK_MDS_ROW(0, l4, l5, l6, l7),           //
                                       l5.pow5() - l[1], PLK_MDS_ROW(1, l4, l5, l6, l7),           //
                                       l6.pow5() - l[2], PLK_MDS_ROW(2, l4, l5, l6, l7),           //
@@ -363,14 +437,15 @@ PLK_DI void all_constraints(const K& k, const LW& l, const RW& r, const D& b2, c
             const auto e0 = l[0].pow5(), e1 = l[1].pow5(), e2 = l[2].pow5(), e3 = l[3].pow5();
             if constexpr (Sink::kReduced) {
                 const auto folded = e0 * sink.weight(4) + e1 * sink.weight(5) + e2 * sink.weight(6) + e3 * sink.weight(7);
-                sink.template gate_extra<8>(nk0 * k1, folded, k[2] - r[0], k[3] - r[1], k[4] - r[2], k[5] - r[3]);
+                sink.template gate_extra<8>(f_step_b, folded, k[2] - r[0], k[3] - r[1], k[4] - r[2], k[5] - r[3]);
             } else {
-                sink.template gate<8>(nk0 * k1, PLK_MDS_ROW(0, e0, e1, e2, e3), PLK_MDS_ROW(1, e0, e1, e2, e3), PLK_MDS_ROW(2, e0, e1, e2, e3),
+                sink.template gate<8>(f_step_b, PLK_MDS_ROW(0, e0, e1, e2, e3), PLK_MDS_ROW(1, e0, e1, e2, e3), PLK_MDS_ROW(2, e0, e1, e2, e3),
                                       PLK_MDS_ROW(3, e0, e1, e2, e3));
             }
         }
 #undef PLK_MDS_ROW
     }
+    [[maybe_unused]] Lz<P, lz_mul_bound(16, 16)> f_endo{fz_zero<P>()};  // k0 k1; the prefix 10 below is k0 - k0 k1 when both are evaluated here
     if constexpr ((MASK & GATES_ENDO) != 0) {  // CurveEndoGate 11, curve_endo.rs:96-141
         const D &x1 = l[0], &y1 = l[1], &x_in = l[4], &y_in = l[5], &x3 = r[0], &y3 = r[1];
         const D &unsigned_old = l[2], &unsigned_new = b2, &signed_old = l[3], &signed_new = b3, &bit0 = l[6], &bit1 = l[7], &inverse = l[8];
@@ -382,11 +457,15 @@ PLK_DI void all_constraints(const K& k, const LW& l, const RW& r, const D& b2, c
         const auto computed_x3 = lambda.sq() - x1 - x2;
         const auto computed_y3 = lambda * (x1 - x3) - y1;
         const auto signed_limb = sgn * mult;
-        sink.template gate<2>(k[0] * k[1], computed_x3 - x3, computed_y3 - y3, unsigned_new - (unsigned_old.quad() + bit1.dbl() + bit0).rs(),
+        f_endo = k[0] * k[1];
+        sink.template gate<2>(f_endo, computed_x3 - x3, computed_y3 - y3, unsigned_new - (unsigned_old.quad() + bit1.dbl() + bit0).rs(),
                               signed_new - (signed_old.dbl() + signed_limb), bit0 * (bit0 - one), bit1 * (bit1 - one), inverse * (x1 - x2) - one);
     }
     if constexpr ((MASK & (GATES_BASE4_ARITH | GATES_ADD_PUBLIC | GATES_DBL_CONST)) == 0) return;
-    const auto p10 = k[0] * (one - k[1]);
+    const auto p10 = [&] {
+        if constexpr ((MASK & GATES_ENDO) != 0) return k[0] - f_endo;
+        else return k[0] * (one - k[1]);
+    }();
     if constexpr ((MASK & GATES_BASE4_ARITH) != 0) {
         const auto p100 = p10 * (one - k[2]);
         // the two filters below p100 share one product: p100 (1 - k3) = p100 - p100 k3
@@ -519,6 +598,9 @@ template <class P> __global__ void __launch_bounds__(64) k_plonk_weights(const u
 //   Constant   PASS 4: the permutation argument, L_1 and reduce_with_powers -> out
 // The sum over the gates and the powers of alpha commute (ReducedSink), every value is exact: same result as one loop.
 constexpr int VANISH_PASSES = 5;
+#ifndef PLK_VANISH_MERGE_RESCUE
+#define PLK_VANISH_MERGE_RESCUE 1  // 1: the two Rescue gates in one launch (PASS 1 is not launched); 0: a launch each (measured 3 % slower, round 4)
+#endif
 #ifndef PLK_VANISH_WAVES
 #define PLK_VANISH_WAVES 2  // waves per SIMD the register allocation is held to (3 was measured in round 4: tools/gpu/r04_vanish_waves.sh)
 #endif
@@ -527,48 +609,50 @@ __global__ void __launch_bounds__(128, PLK_VANISH_WAVES) k_vanishing_points(cons
                                                              const uint4* __restrict__ z, const uint4* __restrict__ xs_lo_z, const uint4* __restrict__ xs_hi_z,
                                                              const uint4* __restrict__ l1, const uint4* __restrict__ small, PlonkScalars sc, int log_degree,
                                                              uint32_t* __restrict__ part, uint4* __restrict__ out, size_t first, size_t count,
-                                                             const uint32_t* __restrict__ weights) {
+                                                             const uint32_t* __restrict__ weights, const uint32_t* __restrict__ top_table) {
     static_assert(P::NL == 8, "256-bit scalar fields");
     using D = Lz<P, 16>;
-    constexpr int MASK = PASS == 0 ? GATES_RESCUE_A : PASS == 1 ? GATES_RESCUE_B : PASS == 2 ? (GATES_ENDO | GATES_BASE4_ARITH)
-                         : PASS == 3 ? (GATES_ADD_PUBLIC | GATES_DBL_CONST) : 0;
+    constexpr int MASK = PASS == 0 ? (PLK_VANISH_MERGE_RESCUE ? GATES_RESCUE : GATES_RESCUE_A) : PASS == 1 ? GATES_RESCUE_B
+                         : PASS == 2 ? (GATES_ENDO | GATES_BASE4_ARITH) : PASS == 3 ? (GATES_ADD_PUBLIC | GATES_DBL_CONST) : 0;
     static_assert(NUM_SCALARS + NUM_WEIGHTS <= 128, "one lane of the workgroup stages one row");
     __shared__ uint32_t s_sc[NUM_SCALARS + NUM_WEIGHTS][FzCfg<P>::NZ];
-    stage_scalars<P>(sc, s_sc, weights);
+    __shared__ __attribute__((aligned(16))) LzTop<P> s_top;
+    stage_top_table<P>(top_table, s_top);
+    stage_scalars<P>(sc, s_sc, weights);  // ends with the barrier that publishes both
     const size_t n8 = (size_t)8 << log_degree;
     const size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // this launch covers the points first .. first + count - 1
     if (i >= first + count || i >= n8) return;
     const size_t i_right = (i + 8) & (n8 - 1), i_below = (i + 8 * GRID_WIDTH) & (n8 - 1);
     // the rows a gate reads from: local constants, local wires, the right gate's wires (loaded where they are used)
-    const LazyRow<P> k{constants, n8, i}, l{wires, n8, i}, r{wires, n8, i_right};
+    const LazyRow<P> k{constants, n8, i, s_top}, l{wires, n8, i, s_top}, r{wires, n8, i_right, s_top};
     const D alpha = scalar_at<P>(s_sc, 6);
     if constexpr (PASS < 4) {
         D b2{fz_zero<P>()}, b3{fz_zero<P>()};
         if constexpr ((MASK & GATES_ENDO) != 0) {
-            b2 = lz_load<P>(wires, (size_t)2 * n8 + i_below);
-            b3 = lz_load<P>(wires, (size_t)3 * n8 + i_below);
+            b2 = lz_load<P>(wires, (size_t)2 * n8 + i_below, s_top);
+            b3 = lz_load<P>(wires, (size_t)3 * n8 + i_below, s_top);
         }
         ReducedSink<P> sink{alpha, Term<P>{fz_zero<P>()}, s_sc + NUM_SCALARS};
         all_constraints<P, D, MASK>(k, l, r, b2, b3, scalar_at<P>(s_sc, 9), scalar_at<P>(s_sc, 10), small, sink);
         if constexpr (PASS == 0) {
-            limbs_store<P>(part, i, sink.total.v);  // one gate: < 1.25p
+            limbs_store<P>(part, i, sink.total.v);  // one or two gates, below 2p each
         } else {
-            // gates so far: 1 (PASS 1), 2 (PASS 2), 5 (PASS 3), each below 1.25p
-            const Lz<P, PASS == 1 ? 10 : PASS == 2 ? 20 : 50> before{limbs_load<P>(part, i)};
+            // gates so far: 1 (PASS 1), 2 (PASS 2), 5 (PASS 3), each below 2p
+            const Lz<P, LZ_SUMMAND_MAX * (PASS == 1 ? 1 : PASS == 2 ? 2 : 5)> before{limbs_load<P>(part, i)};
             limbs_store<P>(part, i, (before + sink.total).v);
         }
     } else {
-        const Lz<P, 90> total{limbs_load<P>(part, i)};  // nine gates with constraints: < 11.25p
+        const Lz<P, 9 * LZ_SUMMAND_MAX> total{limbs_load<P>(part, i)};  // nine gates with constraints: < 18p
         const auto one = lz_one<P>();
         const auto x = lz_table<P>(xs_lo_z, i & (((size_t)1 << XS_LO_LOG) - 1)) * lz_table<P>(xs_hi_z, i >> XS_LO_LOG);  // hi[0] = 1
-        const D z_x = lz_load<P>(z, i), z_gz = lz_load<P>(z, i_right);
+        const D z_x = lz_load<P>(z, i, s_top), z_gz = lz_load<P>(z, i_right, s_top);
         const auto z_1_term = lz_table<P>(l1, i) * (z_x - one);  // plonk.rs:425
         const D beta = scalar_at<P>(s_sc, 7), gamma = scalar_at<P>(s_sc, 8);
         Lz<P, 9> f_prime = one.template widen<9>(), g_prime = f_prime;
 #pragma unroll
         for (int j = 0; j < NUM_ROUTED_WIRES; ++j) {  // plonk.rs:428-437
             const auto beta_s_id = scalar_at<P>(s_sc, NUM_SCALARS + 8 + j) * x;  // beta * (k_is[j] * x), plonk.rs:430-431: beta k_is[j] is a weight of the call
-            const D s_sig = lz_load<P>(s_sigma, (size_t)j * n8 + i);
+            const D s_sig = lz_load<P>(s_sigma, (size_t)j * n8 + i, s_top);
             const D lj = l[j];
             f_prime = f_prime * (lj + beta_s_id + gamma);
             g_prime = g_prime * (lj + beta * s_sig + gamma);
@@ -604,7 +688,7 @@ __global__ void __launch_bounds__(128) k_all_constraints(const uint4* __restrict
     all_constraints<P, D, GATES_ALL>(k, l, r, lz_load<P>(below, i * NUM_WIRES + 2), lz_load<P>(below, i * NUM_WIRES + 3), scalar_at<P>(s_sc, 9),
                                      scalar_at<P>(s_sc, 10), small, sink);
 #pragma unroll
-    for (int t = 0; t < NUM_TERMS; ++t) fe_store<P>(out + (i * NUM_TERMS + t) * 2, lz_to_rform<P>(u[t]));
+    for (int t = 0; t < NUM_TERMS; ++t) fe_store<P>(out + (i * NUM_TERMS + t) * 2, lz_to_rform<P>(u[t].rs()));
 }
 
 static void put_words(uint32_t (&dst)[8], const uint64_t* src) {
@@ -640,12 +724,12 @@ static int vanishing_points_t(unsigned log_degree, const void* d_constants, cons
 #define PLK_VANISH(PASS)                                                                                                                                  \
     k_vanishing_points<P, PASS><<<blocks, 128, 0, stream>>>((const uint4*)d_constants, (const uint4*)d_wires, (const uint4*)d_s_sigma, (const uint4*)d_z, \
                                                             (const uint4*)t->xs_lo_z, (const uint4*)t->xs_hi_z, (const uint4*)t->l1, (const uint4*)t->small, sc, \
-                                                            (int)log_degree, (uint32_t*)part, (uint4*)d_out, first, cnt, weights)
+                                                            (int)log_degree, (uint32_t*)part, (uint4*)d_out, first, cnt, weights, (const uint32_t*)t->top)
     for (size_t first = 0; first < n8; first += slab) {
         const size_t cnt = n8 - first < slab ? n8 - first : slab;
         const unsigned blocks = (unsigned)((cnt + 127) / 128);
         PLK_VANISH(0);
-        PLK_VANISH(1);
+        if (!PLK_VANISH_MERGE_RESCUE) PLK_VANISH(1);
         PLK_VANISH(2);
         PLK_VANISH(3);
         PLK_VANISH(4);

@@ -45,6 +45,26 @@ def test_vanishing_points_match_oracle(f, degree):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("f", FIELDS, ids=lambda f: f.name)
+def test_vanishing_points_extreme_words(f):
+    """The same comparison with half of every table (and then the challenges) replaced by words at the edges of the input conversion
+    and of the lazy limb arithmetic: largest limbs, zero operands, every row of the top-part table (tests/test_oracle_plonk.py pins
+    the oracle to the big-integer restatement on such tables)."""
+    from tests.test_oracle_plonk import extreme_tables
+    degree = 64
+    (consts, wires, sigma, z, k_is, alpha, beta, gamma, zeta, a), ext = extreme_tables(f, degree, 0xE47)
+    rng = np.random.default_rng(7)
+    for round_ in range(3):
+        if round_ == 1:
+            alpha, beta, gamma = ext[-1].copy(), ext[-2].copy(), ext[0].copy()  # p - 1, p - 2, 0
+        if round_ == 2:
+            k_is = ext[rng.integers(0, len(ext), 6)].copy()
+            zeta, a = ext[-1].copy(), ext[-1].copy()
+        got = api.vanishing_points(f.field_id, degree, consts, wires, sigma, z, k_is, alpha, beta, gamma, zeta, a)
+        exp = ol.vanishing_points(f.field_id, degree, consts, wires, sigma, z, k_is, alpha, beta, gamma, zeta, a, threads=16)
+        assert np.array_equal(got, exp), round_
+
+
 def honest_tables(f, degree, seed):
     """A satisfied circuit of `degree` gates cycling through Arithmetic / Constant / Base4Sum / Buffer / CurveDbl gates with
     the identity wiring (s_sigma_j = k_j x, hence Z = 1): selector and wire columns on the n-subgroup, Montgomery limbs."""

@@ -180,6 +180,44 @@ def test_vanishing_points_match_bigint_restatement(f, degree):
     assert got == exp
 
 
+def extreme_words(f):
+    """Stored (Montgomery) words at the edges of a 256-bit word and of the device's input conversion (it cuts a word at bit
+    s = floor(log2 p) - 5, plonk.hip lz_from_rform): 0, 1, p - 1, all-ones low parts, every cut boundary +- 1."""
+    p = f.p
+    s = p.bit_length() - 1 - 5
+    vals = {0, 1, 2, p - 1, p - 2, (p - 1) // 2, (1 << s) - 1, 1 << s, (1 << s) + 1, ((p - 1) >> s) << s, (((p - 1) >> s) << s) - 1, (1 << 29) - 1, 1 << 29,
+            (1 << 232) - 1, 1 << 232, (1 << 227) - 1, 1 << 227}
+    for t in range(1, ((p - 1) >> s) + 1):
+        vals.update({t << s, (t << s) - 1, (t << s) | ((1 << 29) - 1)})
+    return sorted(v for v in vals if 0 <= v < p)
+
+
+def extreme_tables(f, degree, seed):
+    """_random_tables with half of every table replaced by extreme_words; returns the tables and the word list (as arrays)."""
+    consts, wires, sigma, z, k_is, alpha, beta, gamma, zeta, a = _random_tables(f, degree, seed)
+    ext = ints_to_array(extreme_words(f), 4)
+    rng = np.random.default_rng(seed + f.field_id)
+    for t in (consts, wires, sigma, z):
+        flat = t.reshape(-1, 4)
+        idx = rng.random(flat.shape[0]) < 0.5
+        flat[idx] = ext[rng.integers(0, len(ext), int(idx.sum()))]
+    return (consts, wires, sigma, z, k_is, alpha, beta, gamma, zeta, a), ext
+
+
+@pytest.mark.parametrize("f", FIELDS, ids=lambda f: f.name)
+def test_vanishing_points_extreme_words_match_bigint_restatement(f):
+    """The oracle itself at the edge words (the GPU test of the same name compares the device with the oracle there)."""
+    degree = 4
+    (consts, wires, sigma, z, k_is, alpha, beta, gamma, zeta, a), ext = extreme_tables(f, degree, 0xE47)
+    alpha, beta, gamma = ext[-1].copy(), ext[-2].copy(), ext[0].copy()  # p - 1, p - 2, 0
+    got = unmont(f, ol.vanishing_points(f.field_id, degree, consts, wires, sigma, z, k_is, alpha, beta, gamma, zeta, a, threads=4))
+    rows = lambda t: [unmont(f, t[j]) for j in range(t.shape[0])]
+    one = lambda v: unmont(f, v.reshape(1, 4))[0]
+    exp = br.plonk_vanishing_points(f, degree, rows(consts), rows(wires), rows(sigma), unmont(f, z), unmont(f, k_is), one(alpha), one(beta),
+                                    one(gamma), one(zeta), one(a))
+    assert got == exp
+
+
 @pytest.mark.parametrize("gate", range(N_GATES), ids=[g[0] for g in br.PLONK_GATES])
 def test_gate_low_degree(gate):
     """test_gate_low_degree! (gates/mod.rs:336-443) at n = 16 instead of 256: random degree < n constant and wire
