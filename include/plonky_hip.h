@@ -386,7 +386,7 @@ int plk_msm_get_timings(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls);
 /* Element-wise field ops on host arrays of `count` elements: op 0 add, 1 sub, 2 mul, 3 neg(a),
  * 4 square(a), 5 inverse(a) by Fermat (0 -> 0), 6 to_canonical(a), 7 from_canonical(a), 8 inverse by the
  * reference's binary Euclid (bigint_inverse.rs:6-55), 9 inverse by division steps (the one the kernels
- * use).  b ignored for unary. */
+ * use), 10 the same in its data-dependent one-lane form (the normalisation at the end of an MSM).  b ignored for unary. */
 int plk_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count);
 /* Synthetic generators B_i = G0 + (first + i) * D, i < n, affine, written to DEVICE memory
  * (n * 2L limbs).  g0_xy / d_xy are host pointers (2L limbs each). */

@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(COMB_RED_THREADS) k_comb_reduce(const uint4* _
         acc = tid < COMB_RED_THREADS / 64 ? xyzzz_load_packed<FP>(s_pts + tid * 4 * W) : xyzzz_identity<FP>();
 #pragma unroll 1
         for (int m = 1; m < COMB_RED_THREADS / 64; m <<= 1) acc = xyzzz_add<FP>(acc, xyzzz_shfl_xor<FP>(acc, m));
-        if (tid == 0) emit_affine<FP>(acc, cv.out_xy, cv.out_zero);
+        if (tid == 0) emit_affine<FP, true>(acc, cv.out_xy, cv.out_zero);
     }
 }
 

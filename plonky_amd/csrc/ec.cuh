@@ -172,7 +172,9 @@ template <class FP, bool SINGLE_LANE = false> PLK_DI bool xyzz_to_affine(const X
         y = fe_zero<FP>();
         return true;
     }
-    Fe<FP> i3 = fe_inv_safegcd<FP>(p.zzz);
+    Fe<FP> i3;
+    if constexpr (SINGLE_LANE) i3 = fe_inv_safegcd_var<FP>(p.zzz);  // one lane: runs of division steps at once (fp.cuh)
+    else i3 = fe_inv_safegcd<FP>(p.zzz);
     Fe<FP> iz = fe_mul<FP>(p.zz, i3);
     Fe<FP> izz = fe_sqr<FP>(iz);
     x = fe_mul<FP>(p.x, izz);

@@ -226,7 +226,8 @@ template <class FP> PLK_DI XyzzZ<FP> xyzzz_load_packed_volatile(const uint4* src
     return r;
 }
 // back to the reference's form, then ProjectivePoint::to_affine (curve.rs:206-214)
-template <class FP> PLK_DI void emit_affine(const XyzzZ<FP>& acc, uint4* out_xy, uint8_t* out_zero) {
+// ONE_LANE: the caller is a single lane (the end of an MSM) - the inversion takes its data-dependent form (fp.cuh)
+template <class FP, bool ONE_LANE = false> PLK_DI void emit_affine(const XyzzZ<FP>& acc, uint4* out_xy, uint8_t* out_zero) {
     constexpr int W = FP::NL / 4;
     Xyzz<FP> r = xyzz_identity<FP>();
     if (!acc.inf) {
@@ -237,7 +238,7 @@ template <class FP> PLK_DI void emit_affine(const XyzzZ<FP>& acc, uint4* out_xy,
         r.zzz = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zzz, back));
     }
     Fe<FP> x, y;
-    bool ident = xyzz_to_affine<FP, true>(r, x, y);
+    bool ident = xyzz_to_affine<FP, ONE_LANE>(r, x, y);
     fe_store<FP>(out_xy, x);
     fe_store<FP>(out_xy + W, y);
     *out_zero = ident ? 1 : 0;

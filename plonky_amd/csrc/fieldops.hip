@@ -22,7 +22,8 @@ template <class P> __global__ void k_field_op(int op, const uint4* a, const uint
         case 6: r = fe_to_canonical<P>(x); break;
         case 7: r = fe_from_canonical<P>(x); break;
         case 8: r = fe_inv_eea<P>(x); break;       // the reference's Euclid (bigint_inverse.rs:6-55)
-        default: r = fe_inv_safegcd<P>(x); break;  // what the kernels use
+        case 10: r = fe_inv_safegcd_var<P>(x); break;  // its one-lane form (the end of an MSM)
+        default: r = fe_inv_safegcd<P>(x); break;      // what the kernels use
     }
     fe_store<P>(out + i * W, r);
 }
@@ -297,7 +298,7 @@ int field_fold_slices_dev_impl(int field, const void* d_lo, const void* d_hi, co
 }
 
 int field_op_impl(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count) {
-    if (op < 0 || op > 9) return set_error(PLK_ERR_INVALID_ARG, "bad field op %d", op);
+    if (op < 0 || op > 10) return set_error(PLK_ERR_INVALID_ARG, "bad field op %d", op);
     if (!a || !out || (op <= 2 && !b)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     PLK_TRY(ensure_device());
     switch (field) {

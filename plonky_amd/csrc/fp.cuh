@@ -292,10 +292,17 @@ template <class P> PLK_DNI Fe<P> fe_inv_eea(const Fe<P>& a) {
 // (the organisation of libsecp256k1's modinv32, restated for these moduli: p = 1 mod 2^32, so p^-1 mod 2^30 = 1).
 // About a tenth of the instructions of the bit-by-bit Euclid above and branch-free, so a wave stays converged.
 // Same contract as fe_inv_eea: Montgomery in, Montgomery out (monty.rs:162-166), 0 -> 0.
-template <class P> PLK_DNI Fe<P> fe_inv_safegcd(const Fe<P>& a) {
+//
+// VAR: the data-dependent form for ONE lane (the normalisation at the end of an MSM): the plain division steps (delta starts at 1),
+// runs of them taken at once - the zeros at the bottom of g by a count, then up to six bits of g cancelled by one multiple
+// w = -g / f mod 2^k of f (f^-1 = f (2 - f^2) mod 2^6 for odd f), as long as no swap falls due inside the run (k <= eta + 1).
+// About a third of the instructions of the fixed-length loop; the matrix and its application to (d, e), (f, g) are the same.
+// A wave whose lanes all invert (the fold kernels) keeps the branch-free form: there the longest lane is what everyone pays.
+template <class P, bool VAR> PLK_DNI Fe<P> fe_inv_safegcd_impl(const Fe<P>& a) {
     constexpr int NL = P::NL;
     constexpr int N = (NL * 32 + 29) / 30;          // 9 limbs for 256 bits, 13 for 384
-    constexpr int ITER = NL == 8 ? 20 : 30;         // 590 steps suffice below 2^256, 886 below 2^384
+    // fixed form (half-delta steps): 590 steps suffice below 2^256, 886 below 2^384; plain steps (VAR): 741 / 1103 at most
+    constexpr int ITER = VAR ? (NL == 8 ? 25 : 37) : (NL == 8 ? 20 : 30);
     constexpr int32_t M30 = (int32_t)(0xffffffffu >> 2);
     if (fe_is_zero<P>(a)) return a;
     int32_t m[N], f[N], g[N], d[N], e[N];
@@ -319,6 +326,32 @@ template <class P> PLK_DNI Fe<P> fe_inv_safegcd(const Fe<P>& a) {
     for (int it = 0; it < ITER; ++it) {
         // 30 division steps on the low words; (u v; q r) is 2^30 times the transition matrix
         uint32_t u = 1, v = 0, q = 0, r = 1, fl = (uint32_t)f[0], gl = (uint32_t)g[0];
+        if constexpr (VAR) {
+            // here zeta is eta = -delta of the plain steps (same start: -1)
+            int left = 30;
+            for (;;) {
+                const int zeros = __builtin_ctz(gl | (0xffffffffu << left));  // at most `left`
+                gl >>= zeros;
+                u <<= zeros;
+                v <<= zeros;
+                zeta -= zeros;
+                left -= zeros;
+                if (left == 0) break;
+                if (zeta < 0) {  // g odd, delta > 0: (f, g) <- (g, -f), and the matrix rows with them
+                    zeta = -zeta;
+                    uint32_t t = fl; fl = gl; gl = 0u - t;
+                    t = u; u = q; q = 0u - t;
+                    t = v; v = r; r = 0u - t;
+                }
+                // up to min(eta + 1, left, 6) steps without a swap: g += w f clears that many low bits
+                const int limit = zeta + 1 > left ? left : zeta + 1;
+                const uint32_t mask = (0xffffffffu >> (32 - limit)) & 63u;
+                const uint32_t w = (fl * gl * (fl * fl - 2u)) & mask;
+                gl += fl * w;
+                q += u * w;
+                r += v * w;
+            }
+        } else
         for (int i = 0; i < 30; ++i) {
             uint32_t c1 = (uint32_t)(zeta >> 31);           // zeta < 0
             const uint32_t c2 = (uint32_t)0 - (gl & 1u);     // g odd
@@ -424,6 +457,9 @@ template <class P> PLK_DNI Fe<P> fe_inv_safegcd(const Fe<P>& a) {
     }
     return fe_mul<P>(r, r3);
 }
+
+template <class P> PLK_DI Fe<P> fe_inv_safegcd(const Fe<P>& a) { return fe_inv_safegcd_impl<P, false>(a); }
+template <class P> PLK_DI Fe<P> fe_inv_safegcd_var(const Fe<P>& a) { return fe_inv_safegcd_impl<P, true>(a); }
 
 // x/2 mod p for Montgomery or canonical x alike (used to build n^-1 = 2^-log n)
 template <class P> PLK_DI Fe<P> fe_half(const Fe<P>& a) {

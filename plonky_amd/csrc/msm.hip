@@ -1080,7 +1080,7 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int w
         const int shift = pair_shift < 0 ? win * window_bits : (win >> 1) * window_bits + (win & 1) * pair_shift;
         for (int k = 0; k < shift; ++k) acc = xyzzz_dbl_q<FP>(acc, ql);
         if (windows == 1) {
-            if (tid == 0) emit_affine<FP>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
+            if (tid == 0) emit_affine<FP, true>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
         } else {
             uint4* win_pts = tb.s[slot].win_pts;
             if (tid == 0) xyzzz_store_packed<FP>(win_pts + (size_t)win * 4 * W, acc);
@@ -1098,7 +1098,7 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int w
                         if (o != win) acc = xyzzz_add_q<FP>(acc, xyzzz_load_packed_volatile<FP>(win_pts + (size_t)o * 4 * W), ql);
                     if (tid == 0) {
                         *tb.s[slot].final_done = 0;
-                        emit_affine<FP>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
+                        emit_affine<FP, true>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
                     }
                 }
             }
@@ -1124,7 +1124,7 @@ __global__ void __launch_bounds__(COMBINE_THREADS) k_msm_combine(TailBatch tb, i
     if (tid < 64) {
         acc = item < COMBINE_THREADS / 64 ? xyzzz_load_packed<FP>(s_pts + item * 4 * W) : xyzzz_identity<FP>();
         acc = wave_sum_q<FP>(acc, COMBINE_THREADS / 64, ql);
-        if (tid == 0) emit_affine<FP>(acc, out_xy, out_zero);
+        if (tid == 0) emit_affine<FP, true>(acc, out_xy, out_zero);
     }
 }
 

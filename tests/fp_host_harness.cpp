@@ -22,6 +22,7 @@ template <class P> static void run(int op, const uint32_t* a, const uint32_t* b,
             case 6: r = fe_half<P>(x); break;
             case 8: r = fe_inv_eea<P>(x); break;
             case 18: r = fe_inv_safegcd<P>(x); break;
+            case 28: r = fe_inv_safegcd_var<P>(x); break;
             // ---- lazy 29-bit-limb arithmetic (fz.cuh): results brought back to canonical words ----
             case 10: r = fz_to_fe_canonical<P>(fz_from_fe<P>(x)); break;
             case 11: r = fz_to_fe_canonical<P>(fz_mul<P>(fz_from_fe<P>(x), fz_from_fe<P>(y))); break;

@@ -75,6 +75,11 @@ def test_device_header_arithmetic_on_host(host_lib, f):
     edge = [v for v in edge if v % p]
     assert run(host_lib, f, 18, ints_to_array(nz + edge, n)) == [pow(v * Rinv % p, -1, p) * f.R % p for v in nz + edge]
     assert run(host_lib, f, 18, ints_to_array([0], n)) == [0]
+    # its data-dependent form for one lane (fe_inv_safegcd_var: runs of division steps at once): every input of this test + powers of two
+    allv = [v for v in inputs if v % p] + edge + [(1 << k) % p for k in range(0, 32 * n, 7)] + [(p - (1 << k)) % p for k in range(0, 32 * n - 2, 11)]
+    allv = [v for v in allv if v % p]
+    assert run(host_lib, f, 28, ints_to_array(allv, n)) == [pow(v * Rinv % p, -1, p) * f.R % p for v in allv]
+    assert run(host_lib, f, 28, ints_to_array([0], n)) == [0]
 
 
 @pytest.mark.parametrize("f", FIELDS, ids=lambda f: f.name)

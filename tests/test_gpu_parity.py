@@ -53,6 +53,7 @@ def test_device_field_inverse_and_random(f):
         want = ol.field_unop(f.field_id, "inverse", arr)
         assert np.array_equal(api.field_op(f.field_id, "inverse_euclid", arr), want)
         assert np.array_equal(api.field_op(f.field_id, "inverse_divsteps", arr), want)
+        assert np.array_equal(api.field_op(f.field_id, "inverse_divsteps_var", arr), want)
 
 
 # ---------------- NTT ----------------
