@@ -528,8 +528,10 @@ def run_quotient(args):
                         "algorithmic_bytes_per_launch": alg_bytes}, "note": note}
 
     rooflines = {
-        "vanishing_points": entry("k_vanishing_points", 170.0, n8, v_ms, 30.0 * 32 * n8,
-                                  "five launches per call (launch_ms = the call); ~170 field multiplications per point (DESIGN.md 4c); algorithmic bytes: "
+        "vanishing_points": entry("k_vanishing_points", 151.0, n8, v_ms, 30.0 * 32 * n8,
+                                  "four launches per call (launch_ms = the call); 151 multiplication-equivalents per point = the 19 003 multiplier "
+                                  "instructions of a point / 126 per product (a squaring counts 0.74; round 3 quoted ~170 for what was 200 by this "
+                                  "count; DESIGN.md 4c); algorithmic bytes: "
                                   "29 elements read + 1 written per point"),
         "fold_pairs": entry("k_fold_pairs_glv", 2570.0, m, f_ms, 3.0 * 64 * m,
                             "G' = [u^-1] G_lo + [u] G_hi along the endomorphism (plk_curve_fold_pairs_dev): ~130 doublings (6M + 3S) + ~130 mixed additions "
