@@ -398,6 +398,31 @@ def single_process_case(L, lib, n_devices, log_n, reps, virtual=False):
     return out
 
 
+def single_process_child(n_devices, log_n, steps, timeout_s=900, extra=()):
+    """single_process_case in a process of its own (no launcher variables in its environment), its JSON line parsed; a time-out, a
+    crash or a failed self-check comes back as {"error": ...} - never as an exception, never as a hang of the caller."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
+                        "ROLE_WORLD_SIZE", "ROLE_NAME") and not k.startswith("TORCHELASTIC") and not k.startswith("TORCH_NCCL")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n_devices), "--single-process", "--log-n", str(log_n), "--steps", str(steps)] + list(extra)
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "no result within %d s (child stopped)" % timeout_s}
+    except OSError as e:
+        return {"error": "could not start: %s" % e}
+    for line in reversed(p.stdout.splitlines()):
+        if line.startswith("{"):
+            try:
+                r = json.loads(line)["components"]
+                r["exit_code"] = p.returncode
+                return r
+            except (ValueError, KeyError):
+                break
+    return {"error": "exit code %d, no JSON line; stderr tail: %s" % (p.returncode, p.stderr[-300:])}
+
+
 def run_single_process(args):
     """python bench.py --gpus N --single-process [--virtual-devices]: ONE JSON line for the in-library multi-GPU path."""
     import torch
@@ -986,13 +1011,13 @@ def run(args):
             store = dist.distributed_c10d._get_default_store()
             sync()
             if rank == 0:
-                try:
-                    multi["single_process"] = single_process_case(L, lib, world, args.log_n, max(2, args.steps // 4))
+                # in a CHILD process with a time limit (`bench.py --gpus N --single-process`, the form the GPU suite runs on virtual
+                # devices): this path has never met a real multi-GPU node, and neither a hang nor a crash in it may take the
+                # spawned-rank numbers above with it
+                multi["single_process"] = single_process_child(world, args.log_n, args.steps)
+                if "error" not in multi["single_process"]:
                     checks["single_process_bit_identical"] = multi["single_process"]["bit_identical_to_one_device"]
                     checks["single_process_msm_closed_form"] = multi["single_process"]["msm_closed_form_bit_exact"]
-                except Exception as e:  # noqa: BLE001 - the spawned-rank numbers above stand on their own
-                    multi["single_process"] = {"error": str(e)[:300]}
-                dev.init(device_index)
                 store.set("plk_single_process_done", "1")
             else:
                 store.wait(["plk_single_process_done"])

@@ -270,6 +270,28 @@ def test_bench_single_process_virtual_devices():
         assert c["one_device"][k] > 0 and c["group"][k] > 0
 
 
+def test_bench_single_process_child_form():
+    """The same case the way the driver's N > 1 line runs it: bench.single_process_child (a child process with a time limit,
+    launcher variables stripped), here on two virtual devices."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    saved = {k: os.environ.get(k) for k in ("RANK", "WORLD_SIZE", "PLK_MULTI_MIN_LOG_N")}
+    os.environ.update({"RANK": "0", "WORLD_SIZE": "2", "PLK_MULTI_MIN_LOG_N": "10"})
+    try:
+        c = bench.single_process_child(2, 16, 8, extra=["--virtual-devices"])
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert "error" not in c, c
+    assert c["exit_code"] == 0 and c["devices"] == 2 and c["virtual"] and c["bit_identical_to_one_device"] and c["msm_closed_form_bit_exact"], c
+
+
 def test_bench_nccl_every_visible_gpu():
     """`python bench.py --gpus N` with N = every visible GPU over the nccl backend (RCCL): skips on a one-GPU box - the only
     place where RCCL carries more than one rank (the driver's 8-GPU node, a developer's multi-GPU box)."""

@@ -181,6 +181,26 @@ def test_bench_without_gpus_fails_loudly():
     assert out.returncode == 3 and "needs 2 GPU(s), 0 visible" in out.stderr
 
 
+def test_bench_single_process_child_never_raises():
+    """bench.py runs the in-library multi-GPU case of the driver's N > 1 line in a child process with a time limit: a child that
+    cannot run (no GPU here), one that is cut off by the limit - both come back as {"error": ...}, neither as an exception."""
+    import importlib.util
+    if torch.cuda.is_available():
+        return
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "2"  # what a launcher leaves behind must not reach the child
+    try:
+        r = bench.single_process_child(2, 10, 4, timeout_s=300)
+        assert "error" in r and "no JSON line" in r["error"] and "there is no CPU path" in r["error"], r
+        r = bench.single_process_child(2, 10, 4, timeout_s=0.05)
+        assert "error" in r and "child stopped" in r["error"], r
+    finally:
+        del os.environ["RANK"], os.environ["WORLD_SIZE"]
+
+
 def _ntt_worker(rank, world, port, batch, log_n, out_q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
