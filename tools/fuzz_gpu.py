@@ -169,6 +169,19 @@ def one_case(rng):
         mk = lambda rows, k: ol.rand_field(f.field_id, seed + k, rows * n8).reshape(rows, n8, 4)
         sc = ol.rand_field(f.field_id, seed + 9, 11)
         args = (mk(6, 1), mk(9, 2), mk(6, 3), mk(1, 4)[0], sc[:6], sc[6], sc[7], sc[8], sc[9], sc[10])
+        if rng.random() < 0.5:
+            # half of every table (sometimes the challenges too) replaced by words at the edges of the device's input conversion
+            # and lazy limbs: 0, 1, p - 1, every cut boundary +- 1 (tests/test_oracle_plonk.py extreme_words)
+            from tests.test_oracle_plonk import extreme_words
+            ext = ints_to_array(extreme_words(f), 4)
+            nrng = np.random.default_rng(seed)
+            for t in args[:4]:
+                flat = t.reshape(-1, 4)
+                idx = nrng.random(flat.shape[0]) < 0.5
+                flat[idx] = ext[nrng.integers(0, len(ext), int(idx.sum()))]
+            if rng.random() < 0.5:
+                idx = nrng.random(11) < 0.5
+                sc[idx] = ext[nrng.integers(0, len(ext), int(idx.sum()))]
         assert np.array_equal(pa.api.vanishing_points(f.field_id, degree, *args), ol.vanishing_points(f.field_id, degree, *args, threads=8)), ("plonk", f.name, degree)
     elif kind == "misc":
         # batch inversion with zeros, byte encodings round trip
