@@ -159,7 +159,9 @@ int plk_poly_mul_dev(int field, const void* d_a, size_t la, const void* d_b, siz
  * ChaCha8 output: an input here), the challenges alpha, beta, gamma, and the two constants through which InnerC enters the
  * gates, InnerC::ZETA (curve_endo.rs:119) and InnerC::A (curve_dbl.rs:57).  d_out: n8 elements; the closing
  * Polynomial::from_evaluations (plonk.rs:455) is plk_ntt_dev(inverse = 1) on it.  Asynchronous on `stream`; the first call
- * for a (field, log_degree) builds and caches the circuit-size tables (L_1 over the domain, powers of g, MDS entries). */
+ * for a (field, log_degree) builds and caches the circuit-size tables (L_1 over the domain, powers of g, MDS entries).
+ * Table elements are the reference's field elements as stored: Montgomery form, CANONICAL (below p - what every Field value is,
+ * field.rs / monty.rs); the kernels convert a row element through a table indexed by its top bits, so a word >= p is outside the contract. */
 int plk_plonk_vanishing_points_dev(int field, unsigned log_degree, const void* d_constants_8n, const void* d_wires_8n, const void* d_s_sigma_8n,
                                    const void* d_plonk_z_8n, const uint64_t* k_is, const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma,
                                    const uint64_t* inner_zeta, const uint64_t* inner_a, void* d_out, void* stream);
