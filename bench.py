@@ -447,7 +447,7 @@ def run_single_process(args):
 
 
 def run_quotient(args):
-    """--workload quotient: k_vanishing_points (five launches per call), k_fold_pairs_glv and the 4-to-1 fold k_fold_multi_glv, timed with HIP events on the launch
+    """--workload quotient: k_vanishing_points (four launches per call), k_fold_pairs_glv and the 4-to-1 fold k_fold_multi_glv, timed with HIP events on the launch
     stream, priced against the same ceilings as the headline kernels.  One GPU; correctness of both is the GPU suite's business
     (tests/test_gpu_plonk.py, tests/test_gpu_halo.py) - here the fold is checked by its closed form, the numerator by determinism."""
     import numpy as np

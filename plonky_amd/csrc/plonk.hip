@@ -589,15 +589,14 @@ template <class P> __global__ void __launch_bounds__(64) k_plonk_weights(const u
     for (int i = 0; i < FzCfg<P>::NZ; ++i) out[t * FzCfg<P>::NZ + i] = res.v.l[i];
 }
 
-// plonk.rs:392-453, one lane per point of the 8n domain, in FIVE launches.  The ten gates, the permutation argument and their
+// plonk.rs:392-453, one lane per point of the 8n domain, in FOUR launches.  The ten gates, the permutation argument and their
 // inputs (21 + 10 elements per point) are several register files wide; evaluated in one piece the kernel spills to scratch
 // and, at one wave per SIMD, waits out every reload.  A launch evaluates a group of gates and hands the running sum on (limb
 // form, 48 B per point, in `part`); its inputs are read where a gate uses them (LazyRow), so a launch fits the 256
 // registers of two waves per SIMD:
-//   PASS 0: RescueStepA   PASS 1: RescueStepB   PASS 2: CurveEndo, Base4Sum, Arithmetic   PASS 3: CurveAdd, PublicInput, CurveDbl,
-//   Constant   PASS 4: the permutation argument, L_1 and reduce_with_powers -> out
+//   PASS 0: RescueStepA + RescueStepB (PASS 1 is RescueStepB alone when PLK_VANISH_MERGE_RESCUE is 0)   PASS 2: CurveEndo, Base4Sum,
+//   Arithmetic   PASS 3: CurveAdd, PublicInput, CurveDbl, Constant   PASS 4: the permutation argument, L_1 and reduce_with_powers -> out
 // The sum over the gates and the powers of alpha commute (ReducedSink), every value is exact: same result as one loop.
-constexpr int VANISH_PASSES = 5;
 #ifndef PLK_VANISH_MERGE_RESCUE
 #define PLK_VANISH_MERGE_RESCUE 1  // 1: the two Rescue gates in one launch (PASS 1 is not launched); 0: a launch each (measured 3 % slower, round 4)
 #endif
@@ -712,7 +711,7 @@ static int vanishing_points_t(unsigned log_degree, const void* d_constants, cons
         return PLK_ERR_OOM;
     }
     k_plonk_weights<P><<<1, 64, 0, stream>>>((const uint4*)t->small, sc, weights);
-    // PLK_VANISH_SLAB_LOG=k: the five launches walk the domain in slabs of 2^k points, so that the rows a slab reads (29 x 32 B per
+    // PLK_VANISH_SLAB_LOG=k: the launches walk the domain in slabs of 2^k points, so that the rows a slab reads (29 x 32 B per
     // point) are still in the 256 MiB Infinity Cache when the next launch of the slab re-reads them (round-3 review item 5;
     // measured in DESIGN.md section 4c).  Default: the whole domain per launch.
     static const int slab_log = [] {
