@@ -4,7 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r4r; mkdir -p $O
 (rocm-smi --showuniqueid 2>/dev/null | grep "^GPU\[") > $O/box.txt
-( timeout 1500 python -m pytest tests/test_gpu_plonk.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -3 ) | tee $O/tests.txt
+( timeout 1500 python -m pytest tests/test_gpu_plonk.py tests/test_gpu_fullsize.py -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 ) | tee $O/tests.txt
 bash tools/profile_round.sh r04 > $O/profile_round.log 2>&1; tail -4 $O/profile_round.log | cut -c1-200
 cp gpurun_out/r04_pmc_traffic.json gpurun_out/r04_pmc_traffic_quotient.json profiles/
 timeout 1500 python bench.py > $O/r04_bench.json 2> $O/r04_bench.err
