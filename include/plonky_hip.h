@@ -75,6 +75,15 @@ int plk_init(int device);
  * the whole multi-device path (tests).  Call before creating contexts; contexts do not survive a change of the device group. */
 int plk_init_devices(int n_devices);
 int plk_device_count(void);                    /* logical devices in use (1 after plk_init) */
+/* Copies between two devices of the group since the library was loaded: `peer_copies` went as one hipMemcpyAsync (same physical
+ * device, or peer access over xGMI), `staged_copies` through a pinned host buffer (no peer access between the pair, or PLK_PEER_MODE=host,
+ * which forces that path for every pair - also between the logical devices of PLK_VIRTUAL_DEVICES).  Either pointer may be NULL.
+ * PLK_VERBOSE=1 makes plk_init_devices print how many device pairs have peer access. */
+int plk_group_copy_stats(unsigned long long* peer_copies, unsigned long long* staged_copies);
+/* The calling thread's current HIP device as THIS library's HIP runtime sees it (>= 0; negative: error); set_to >= 0 selects that device
+ * first.  Every other entry point leaves the calling thread's HIP device as it found it - except plk_init, plk_init_devices and
+ * plk_set_thread_device, which select the device they were asked for.  For hosts and tests that want to check exactly that. */
+int plk_thread_hip_device(int set_to);
 /* The plan the fan-out follows, as pure arithmetic (no device needed): slot s < *slots of `device` among `world` devices computes
  * vector vec[s] of a batch of `batch` vectors over n generators, over the generators first[s] .. first[s] + count[s] - 1 - whole
  * vectors first (vector s * world + device, all n generators), then its contiguous share of every sharded vector.  vec / first /
@@ -390,6 +399,20 @@ int plk_msm_get_timings(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls);
  * reference's binary Euclid (bigint_inverse.rs:6-55), 9 inverse by division steps (the one the kernels
  * use), 10 the same in its data-dependent one-lane form (the normalisation at the end of an MSM).  b ignored for unary. */
 int plk_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count);
+/* The integer-ALU ceilings of the GPU the calling thread runs on, measured now (~60 ms; G operations per second over the whole GPU):
+ * out[0] v_mad_u64_u32 lane-operations (8 waves per SIMD, 8 independent chains per lane) - the raw issue rate of the instruction a
+ * modular multiplication is made of (126 per 9-limb product, 294 per 14-limb product): the hardware-referenced roofline of every
+ * kernel here; out[1], out[2] this build's Montgomery product at 4 waves per SIMD on the 9-limb / 14-limb fields; out[3], out[4] the
+ * lazy mixed addition of the accumulation (8 M + 2 S, no memory) at the occupancy k_msm_accumulate has on those fields (3 / 2 waves).
+ * n_out >= 5.  There is nothing to replace in the reference: bench.py prices its rooflines with it. */
+int plk_bench_ceilings(double* out, unsigned n_out);
+/* The digit recoding of the MSM's ordering kernels on its own (replaces to_digits, curve_msm.rs:159-180; the device never stores
+ * digits, it recomputes them where they are used).  scalars: n * 4 limbs, Montgomery form in the curve's SCALAR field, host memory.
+ * *n_digits = ceil((BITS + 1) / window_bits) digits per scalar; digits (may be NULL to query n_digits only): n * *n_digits signed
+ * values d_j in [-2^(w-1), 2^(w-1)], least significant window first, sum_j d_j 2^(w j) = the canonical scalar.  The reference's
+ * unsigned digits are u_j = d_j - carry_j + 2^w carry_(j+1) with carry_(j+1) = [d_j - carry_j < 0], carry_0 = 0
+ * (tests/test_gpu_parity.py pins them to the vector of curve_msm.rs:186-216). */
+int plk_msm_debug_digits(int curve, unsigned window_bits, size_t n, const uint64_t* scalars, int32_t* digits, unsigned* n_digits);
 /* Synthetic generators B_i = G0 + (first + i) * D, i < n, affine, written to DEVICE memory
  * (n * 2L limbs).  g0_xy / d_xy are host pointers (2L limbs each). */
 int plk_curve_gen_bases_dev(int curve, size_t n, uint64_t first, const uint64_t* g0_xy, const uint64_t* d_xy, void* d_out_xy, void* stream);

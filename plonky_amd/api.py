@@ -378,6 +378,27 @@ def field_op(field, op, a, b=None):
     return out
 
 
+def msm_debug_digits(curve, scalars, window_bits):
+    """The MSM's digit recoding on its own (to_digits, curve_msm.rs:159-180): scalars (n, 4) Montgomery limbs in the curve's scalar field
+    -> (n, ceil((BITS + 1) / w)) signed digits as the ordering kernels form them, and the reference's unsigned digits rebuilt from them
+    (u_j = d_j - carry_j + 2^w carry_(j+1), carry_(j+1) = [d_j - carry_j < 0]), and the carry out of the top window (always 0: it has room)."""
+    import ctypes
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    nd = ctypes.c_uint()
+    _lib.check(_lib.load().plk_msm_debug_digits(curve, window_bits, 0, None, None, ctypes.byref(nd)))
+    d = np.zeros((s.shape[0], nd.value), dtype=np.int32)
+    _lib.check(_lib.load().plk_msm_debug_digits(curve, window_bits, s.shape[0], _ptr(s), _ptr(d), ctypes.byref(nd)))
+    # carry_(j+1) = [d_j - carry_j < 0]: a negative digit borrowed from the next window, and so did a ZERO digit that stands for
+    # 2^w - 1 + carry_j = 2^w (the device has no entry for it: magnitude 0, carry out)
+    unsigned = np.zeros(d.shape, dtype=np.int64)
+    carry = np.zeros(s.shape[0], dtype=np.int64)
+    for j in range(nd.value):
+        v = d[:, j].astype(np.int64) - carry
+        carry = (v < 0).astype(np.int64)
+        unsigned[:, j] = v + (carry << window_bits)
+    return d, unsigned, carry
+
+
 # ---- the Plonk quotient numerator (plonk.rs:375-456, gates/) ----
 NUM_WIRES, NUM_ROUTED_WIRES, NUM_CONSTANTS, GRID_WIDTH = 9, 6, 6, 65  # plonk.rs:21-25
 

@@ -1,10 +1,12 @@
 // capi.hip -- the extern "C" surface declared in include/plonky_hip.h.
 // Thin: argument validation, host<->device staging for the host-pointer variants, dispatch.
 #include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -44,6 +46,9 @@ int curve_gen_bases_dev_impl(int curve, size_t n, uint64_t first, const void* d_
 size_t msm_partials_bytes(int curve, unsigned batch);
 int checked_build_impl();
 int checked_failures_impl(unsigned* counts);
+int msm_debug_digits_impl(int curve, unsigned window_bits, size_t n, const void* d_scalars, void* d_digits, hipStream_t stream);
+int msm_debug_digit_count(int curve, unsigned window_bits);
+int bench_ceilings_impl(double* out, unsigned n_out);
 int msm_combine_partials_dev_impl(int curve, unsigned world, unsigned batch, unsigned whole_per_rank, const void* d_gathered, void* d_out_xy, void* d_out_zero,
                                   hipStream_t stream);
 int curve_fold_pairs_dev_impl(int curve, size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero,
@@ -71,6 +76,8 @@ void msm_ctx_delete(plk_msm_ctx* ctx);
 // multi.hip
 void multi_plan_slot(int world, unsigned batch, size_t n, int d, unsigned slot, unsigned* vec, size_t* first, size_t* count);
 bool msm_ctx_is_multi(plk_msm_ctx* ctx);
+void group_copy_stats(unsigned long long* peer, unsigned long long* staged);
+int msm_ctx_device(const plk_msm_ctx* ctx);
 int msm_precompute_multi(int curve, size_t n, const void* bases, const void* zero, bool host_src, unsigned window_bits, hipStream_t caller_stream,
                          plk_msm_ctx** out_ctx);
 int msm_execute_multi(plk_msm_ctx* ctx, unsigned batch, const void* const* vecs, bool host_src, size_t n, void* d_out_xy, void* d_out_zero,
@@ -227,35 +234,124 @@ int lane_get(HostLane*& out) {
     return PLK_OK;
 }
 
+// Registered caller ranges: NON-OVERLAPPING intervals, each with the threads that hold it (host_lane.h).  A request inside a
+// registered interval shares it; a request that extends or partly overlaps one never leaves a half-registered range behind (HIP
+// resolves a pointer to the registered object it starts in - an asynchronous copy longer than that object is rejected, and the
+// first holder's release would unregister pages under the second caller's DMA):
+//  * held by OTHER threads: wait until they have released it (they do not depend on us), then register the union;
+//  * held by the calling thread alone (two overlapping buffers of one batched call, an in-place padded transform): every device
+//    of the group is synchronised - the thread's own copies over the old interval are complete - and the interval is re-registered
+//    as the union, the thread's holds carried over.
 struct PinEntry {
     size_t bytes;
-    unsigned refs;
+    std::map<std::thread::id, unsigned> holders;
+    unsigned refs() const {
+        unsigned r = 0;
+        for (const auto& h : holders) r += h.second;
+        return r;
+    }
 };
 static std::mutex g_pin_mu;
-static std::map<const void*, PinEntry> g_pins;
+static std::condition_variable g_pin_cv;
+static std::map<const uint8_t*, PinEntry> g_pins;  // by start address; intervals never overlap
+
+static void pin_sync_all_devices() {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < group_size(); ++d) {
+        if (d && group_phys(d) == group_phys(d - 1)) continue;
+        (void)hipSetDevice(group_phys(d));
+        (void)hipDeviceSynchronize();
+    }
+    if (cur >= 0) (void)hipSetDevice(cur);
+}
 bool pin_registry_acquire(const void* ptr, size_t bytes) {
-    std::lock_guard<std::mutex> lk(g_pin_mu);
-    auto it = g_pins.find(ptr);
-    if (it != g_pins.end()) {
-        if (it->second.bytes < bytes) return false;  // a longer range from the same start: not covered, copy synchronously
-        ++it->second.refs;
+    if (!ptr || !bytes) return false;
+    const uint8_t* lo = (const uint8_t*)ptr;
+    const uint8_t* hi = lo + bytes;
+    const std::thread::id me = std::this_thread::get_id();
+    std::unique_lock<std::mutex> lk(g_pin_mu);
+    for (;;) {
+        // the registered intervals that touch [lo, hi)
+        std::vector<std::map<const uint8_t*, PinEntry>::iterator> hit;
+        auto it = g_pins.upper_bound(lo);
+        if (it != g_pins.begin()) --it;
+        for (; it != g_pins.end() && it->first < hi; ++it)
+            if (it->first + it->second.bytes > lo) hit.push_back(it);
+        if (hit.empty()) {
+            if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterPortable) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;  // exotic memory: the copies block the caller instead
+            }
+            PinEntry e{bytes, {}};
+            e.holders[me] = 1;
+            g_pins[lo] = e;
+            return true;
+        }
+        if (hit.size() == 1 && hit[0]->first <= lo && hit[0]->first + hit[0]->second.bytes >= hi) {
+            ++hit[0]->second.holders[me];
+            return true;
+        }
+        bool others = false;
+        for (auto& h : hit)
+            for (const auto& who : h->second.holders)
+                if (who.first != me && who.second) others = true;
+        if (others) {
+            g_pin_cv.wait(lk);  // a release wakes us; then look again
+            continue;
+        }
+        // every interval in the way is held by this thread alone: replace them by their union with the request
+        const uint8_t* ulo = lo;
+        const uint8_t* uhi = hi;
+        unsigned mine = 1;
+        for (auto& h : hit) {
+            if (h->first < ulo) ulo = h->first;
+            if (h->first + h->second.bytes > uhi) uhi = h->first + h->second.bytes;
+            mine += h->second.refs();
+        }
+        lk.unlock();
+        pin_sync_all_devices();  // this thread's copies over the old intervals are complete
+        lk.lock();
+        // nobody else can have taken a hold meanwhile without waiting for us?  They can (a request INSIDE one of our intervals):
+        // look again in that case
+        bool changed = false;
+        for (auto& h : hit)
+            for (const auto& who : h->second.holders)
+                if (who.first != me && who.second) changed = true;
+        if (changed) continue;
+        for (auto& h : hit) {
+            (void)hipHostUnregister(const_cast<uint8_t*>(h->first));
+            g_pins.erase(h);
+        }
+        if (hipHostRegister(const_cast<uint8_t*>(ulo), (size_t)(uhi - ulo), hipHostRegisterPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            // nothing of the union is registered now: this thread's earlier holds are gone with it (its copies become blocking
+            // ones, which is correct), and releases of them find no interval and do nothing
+            g_pin_cv.notify_all();
+            return false;
+        }
+        PinEntry e{(size_t)(uhi - ulo), {}};
+        e.holders[me] = mine;
+        g_pins[ulo] = e;
         return true;
     }
-    if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterPortable) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    g_pins[ptr] = PinEntry{bytes, 1u};
-    return true;
 }
+// ptr: any address a successful acquire was made with (it lies inside exactly one interval)
 void pin_registry_release(const void* ptr) {
+    const uint8_t* p = (const uint8_t*)ptr;
     std::lock_guard<std::mutex> lk(g_pin_mu);
-    auto it = g_pins.find(ptr);
-    if (it == g_pins.end()) return;
-    if (--it->second.refs == 0) {
-        (void)hipHostUnregister(const_cast<void*>(ptr));
+    auto it = g_pins.upper_bound(p);
+    if (it == g_pins.begin()) return;
+    --it;
+    if (p >= it->first + it->second.bytes) return;
+    auto h = it->second.holders.find(std::this_thread::get_id());
+    if (h == it->second.holders.end()) return;  // not ours: a hold is released by the thread that took it (HostPin lives in one call object)
+    if (h->second && --h->second == 0) it->second.holders.erase(h);
+    if (it->second.refs() == 0) {
+        (void)hipHostUnregister(const_cast<uint8_t*>(it->first));
         g_pins.erase(it);
     }
+    g_pin_cv.notify_all();
 }
 
 int field_limbs(int field) {
@@ -306,6 +402,17 @@ int plk_set_thread_device(int logical_device) {
     return ensure_device();
 }
 
+int plk_thread_hip_device(int set_to) {
+    if (set_to >= 0) PLK_HIP_TRY(hipSetDevice(set_to));
+    int cur = -1;
+    PLK_HIP_TRY(hipGetDevice(&cur));
+    return cur;
+}
+int plk_group_copy_stats(unsigned long long* peer_copies, unsigned long long* staged_copies) {
+    group_copy_stats(peer_copies, staged_copies);
+    return PLK_OK;
+}
+
 int plk_multi_plan(unsigned world, unsigned batch, size_t n, unsigned device, unsigned* slots, unsigned* vec, uint64_t* first, uint64_t* count) {
     if (world == 0 || device >= world || !slots) return set_error(PLK_ERR_INVALID_ARG, "bad world / device");
     const unsigned whole = batch / world, total = whole + (batch - whole * world);
@@ -338,8 +445,9 @@ int plk_curve_limbs(int curve) { return curve_limbs(curve); }
 int plk_curve_scalar_field(int curve) { return curve_scalar_field(curve); }
 
 // ---- NTT ----
-int plk_ntt_precompute(int field, unsigned log_n) { return ntt_precompute_impl(field, log_n); }
+int plk_ntt_precompute(int field, unsigned log_n) { PLK_API; return ntt_precompute_impl(field, log_n); }
 int plk_ntt_clear_cache(void) {
+    PLK_API;
     (void)plonk_clear_cache_impl();
     (void)poly_clear_cache_impl();
     const int rc = ntt_clear_cache_impl();
@@ -348,9 +456,11 @@ int plk_ntt_clear_cache(void) {
 }
 
 int plk_ntt_precompute_table_dev(int field, unsigned log_n, void* d_out, void* stream) {
+    PLK_API;
     return ntt_reference_table_dev_impl(field, log_n, d_out, as_stream(stream));
 }
 int plk_ntt_precompute_table(int field, unsigned log_n, uint64_t* out) {
+    PLK_API;
     if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
     if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
     if (!out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
@@ -366,6 +476,7 @@ int plk_ntt_precompute_table(int field, unsigned log_n, uint64_t* out) {
 }
 
 int plk_ntt_dev(int field, unsigned log_n, int inverse, unsigned batch, const void* d_in, void* d_out, void* stream) {
+    PLK_API;
     return ntt_dev_impl(field, log_n, inverse, batch, d_in, d_out, as_stream(stream));
 }
 
@@ -418,6 +529,7 @@ static int deal_units(unsigned log_n, unsigned batch, const std::function<int(un
 }
 
 int plk_ntt_batch(int field, unsigned log_n, int inverse, unsigned batch, const uint64_t* const* in, uint64_t* const* out) {
+    PLK_API;
     if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
     if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
     if (batch == 0) return PLK_OK;
@@ -437,11 +549,13 @@ int plk_ntt_batch(int field, unsigned log_n, int inverse, unsigned batch, const 
 }
 
 int plk_ntt(int field, unsigned log_n, int inverse, const uint64_t* in, uint64_t* out) {
+    PLK_API;
     return plk_ntt_batch(field, log_n, inverse, 1, &in, &out);
 }
 
 int plk_ntt_padded_dev(int field, unsigned log_n, unsigned batch, const void* d_in, size_t in_len, size_t in_stride, void* d_out,
                        void* stream) {
+    PLK_API;
     if (batch == 0) return PLK_OK;
     return ntt_padded_dev_impl(field, log_n, batch, d_in, in_len, in_stride, d_out, as_stream(stream));
 }
@@ -459,20 +573,22 @@ static int ntt_padded_batch_local(int field, unsigned log_n, unsigned batch, con
     PLK_TRY(c.tmp(dout, n * 32 * batch));
     for (unsigned b = 0; b < batch; ++b) {
         uint8_t* slot = (uint8_t*)din + (size_t)b * max_in * 32;
-        c.pin(in[b], n_in[b] * 32);
+        // in place (out[b] == in[b]): ONE registration of the larger range, made here
+        c.pin(in[b], (const void*)out[b] == (const void*)in[b] && n > n_in[b] ? n * 32 : n_in[b] * 32);
         PLK_TRY(lane_h2d(*c.l, slot, in[b], n_in[b] * 32));
         // shorter polynomials of the batch: F::ZERO is all-zero limbs in Montgomery form too
         if (n_in[b] < max_in) PLK_HIP_TRY(hipMemsetAsync(slot + n_in[b] * 32, 0, (max_in - n_in[b]) * 32, c.stream()));
     }
     PLK_TRY(ntt_padded_dev_impl(field, log_n, batch, din, max_in, max_in, dout, c.stream()));
     for (unsigned b = 0; b < batch; ++b) {
-        c.pin(out[b], n * 32);
+        c.pin(out[b], n * 32);  // in place: inside the registration made above
         PLK_TRY(c.out(out[b], (uint8_t*)dout + (size_t)b * n * 32, n * 32));
     }
     return c.finish();
 }
 
 int plk_ntt_padded_batch(int field, unsigned log_n, unsigned batch, const uint64_t* const* in, const size_t* n_in, uint64_t* const* out) {
+    PLK_API;
     if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
     if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
     if (batch == 0) return PLK_OK;
@@ -497,6 +613,7 @@ int plk_ntt_padded_batch(int field, unsigned log_n, unsigned batch, const uint64
 }
 
 int plk_ntt_padded(int field, unsigned log_n, const uint64_t* in, size_t n_in, uint64_t* out) {
+    PLK_API;
     return plk_ntt_padded_batch(field, log_n, 1, &in, &n_in, &out);
 }
 
@@ -509,10 +626,12 @@ static size_t pow2_ceil_sz(size_t v) {
 
 int plk_poly_divide_by_z_h_dev(int field, const void* d_coeffs, size_t len, size_t n, void* d_out, size_t out_cap, size_t* out_len,
                                void* stream) {
+    PLK_API;
     return poly_divide_by_z_h_dev_impl(field, d_coeffs, len, n, d_out, out_cap, out_len, as_stream(stream));
 }
 
 int plk_poly_divide_by_z_h(int field, const uint64_t* coeffs, size_t len, size_t n, uint64_t* out, size_t out_cap, size_t* out_len) {
+    PLK_API;
     if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
     if (!out_len || (len && !coeffs)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     const size_t cap = len > pow2_ceil_sz(len) ? len : pow2_ceil_sz(len);
@@ -532,10 +651,12 @@ int plk_poly_divide_by_z_h(int field, const uint64_t* coeffs, size_t len, size_t
 
 int plk_poly_mul_dev(int field, const void* d_a, size_t la, const void* d_b, size_t lb, void* d_out, size_t out_cap, size_t* out_len,
                      void* stream) {
+    PLK_API;
     return poly_mul_dev_impl(field, d_a, la, d_b, lb, d_out, out_cap, out_len, as_stream(stream));
 }
 
 int plk_poly_mul(int field, const uint64_t* a, size_t la, const uint64_t* b, size_t lb, uint64_t* out, size_t out_cap, size_t* out_len) {
+    PLK_API;
     if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
     if (!out_len || (la && !a) || (lb && !b)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     const size_t cap = pow2_ceil_sz(la + lb);
@@ -558,12 +679,14 @@ int plk_poly_mul(int field, const uint64_t* a, size_t la, const uint64_t* b, siz
 int plk_plonk_vanishing_points_dev(int field, unsigned log_degree, const void* d_constants_8n, const void* d_wires_8n, const void* d_s_sigma_8n,
                                    const void* d_plonk_z_8n, const uint64_t* k_is, const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma,
                                    const uint64_t* inner_zeta, const uint64_t* inner_a, void* d_out, void* stream) {
+    PLK_API;
     return plonk_vanishing_points_dev_impl(field, log_degree, d_constants_8n, d_wires_8n, d_s_sigma_8n, d_plonk_z_8n, k_is, alpha, beta, gamma, inner_zeta,
                                            inner_a, d_out, as_stream(stream));
 }
 int plk_plonk_vanishing_points(int field, unsigned log_degree, const uint64_t* constants_8n, const uint64_t* wires_8n, const uint64_t* s_sigma_8n,
                                const uint64_t* plonk_z_8n, const uint64_t* k_is, const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma,
                                const uint64_t* inner_zeta, const uint64_t* inner_a, uint64_t* out) {
+    PLK_API;
     if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d is not a circuit scalar field", field);
     if (log_degree + 3 > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_degree %u too large", log_degree);
     if (!constants_8n || !wires_8n || !s_sigma_8n || !plonk_z_8n || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
@@ -587,6 +710,7 @@ int plk_plonk_vanishing_points(int field, unsigned log_degree, const uint64_t* c
 }
 int plk_plonk_evaluate_all_constraints(int field, size_t count, const uint64_t* constants, const uint64_t* local_wires, const uint64_t* right_wires,
                                        const uint64_t* below_wires, const uint64_t* inner_zeta, const uint64_t* inner_a, uint64_t* out) {
+    PLK_API;
     if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d is not a circuit scalar field", field);
     if (count == 0) return PLK_OK;
     if (!constants || !local_wires || !right_wires || !below_wires || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
@@ -611,16 +735,19 @@ static bool fan_out_msm(size_t n, unsigned flags) {
 }
 int plk_msm_precompute_dev_ex(int curve, size_t n, const void* d_bases_xy, const void* d_base_zero, unsigned window_bits, unsigned flags, void* stream,
                               plk_msm_ctx** out_ctx) {
+    PLK_API;
     if (fan_out_msm(n, flags) && d_bases_xy) return msm_precompute_multi(curve, n, d_bases_xy, d_base_zero, false, window_bits, as_stream(stream), out_ctx);
     return msm_precompute_dev_impl(curve, n, d_bases_xy, d_base_zero, window_bits, flags, as_stream(stream), out_ctx);
 }
 int plk_msm_precompute_dev(int curve, size_t n, const void* d_bases_xy, const void* d_base_zero, unsigned window_bits, void* stream,
                            plk_msm_ctx** out_ctx) {
+    PLK_API;
     return plk_msm_precompute_dev_ex(curve, n, d_bases_xy, d_base_zero, window_bits, 0, stream, out_ctx);
 }
 
 int plk_msm_precompute_ex(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, unsigned window_bits, unsigned flags,
                           plk_msm_ctx** out_ctx) {
+    PLK_API;
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (n && !bases_xy) return set_error(PLK_ERR_INVALID_ARG, "null bases");
@@ -643,10 +770,12 @@ int plk_msm_precompute_ex(int curve, size_t n, const uint64_t* bases_xy, const u
     return rc;
 }
 int plk_msm_precompute(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, unsigned window_bits, plk_msm_ctx** out_ctx) {
+    PLK_API;
     return plk_msm_precompute_ex(curve, n, bases_xy, base_zero, window_bits, 0, out_ctx);
 }
 
 int plk_msm_free(plk_msm_ctx* ctx) {
+    PLK_API;
     if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
     msm_ctx_delete(ctx);
     return PLK_OK;
@@ -655,6 +784,7 @@ size_t plk_msm_ctx_len(const plk_msm_ctx* ctx) { return ctx ? msm_ctx_len(ctx) :
 unsigned plk_msm_ctx_window(const plk_msm_ctx* ctx) { return ctx ? msm_ctx_window(ctx) : 0; }
 
 int plk_msm_execute_dev(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, void* stream) {
+    PLK_API;
     if (msm_ctx_is_multi(ctx) && batch && d_scalars && n_scalars == msm_ctx_len(ctx)) {
         // a context that lives on every device of the group: the vectors (memory of the caller's device) reach the other devices
         // peer to peer, the results come back to the caller's device; asynchronous on `stream` like the one-device form
@@ -667,11 +797,13 @@ int plk_msm_execute_dev(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars,
 
 int plk_msm_execute_parts_dev(plk_msm_ctx* ctx, unsigned batch, const uint64_t* first, const uint64_t* count, const void* const* d_scalars, void* d_out_xy,
                               void* d_out_zero, void* stream) {
+    PLK_API;
     MsmParts parts{first, count, d_scalars};
     return msm_execute_dev_impl(ctx, batch, nullptr, 0, d_out_xy, d_out_zero, as_stream(stream), nullptr, &parts);
 }
 
 int plk_msm_execute_batch(plk_msm_ctx* ctx, unsigned batch, const uint64_t* const* scalars, size_t n_scalars, uint64_t* out_xy, uint8_t* out_zero) {
+    PLK_API;
     if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
     if (n_scalars != msm_ctx_len(ctx))
         return set_error(PLK_ERR_SIZE_MISMATCH, "scalars.len() = %zu but the precomputation holds %zu generators (curve_msm.rs:67)", n_scalars,
@@ -725,10 +857,12 @@ int plk_msm_execute_batch(plk_msm_ctx* ctx, unsigned batch, const uint64_t* cons
 }
 
 int plk_msm_execute(plk_msm_ctx* ctx, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xy, uint8_t* out_zero) {
+    PLK_API;
     return plk_msm_execute_batch(ctx, 1, &scalars, n_scalars, out_xy, out_zero);
 }
 
 int plk_msm(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, const uint64_t* scalars, uint64_t* out_xy, uint8_t* out_zero) {
+    PLK_API;
     plk_msm_ctx* ctx = nullptr;
     // generators used once: no window tables (their construction costs ~30 executions)
     PLK_TRY(plk_msm_precompute_ex(curve, n, bases_xy, base_zero, 0, PLK_MSM_TABLE_FREE, &ctx));
@@ -738,6 +872,7 @@ int plk_msm(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_z
 }
 
 int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint8_t* pts_zero, uint64_t* out_xy, uint8_t* out_zero) {
+    PLK_API;
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if ((k && !pts_xy) || !out_xy || !out_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
@@ -758,6 +893,7 @@ int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint
 size_t plk_msm_partials_bytes(int curve, unsigned slots) { return msm_partials_bytes(curve, slots); }
 int plk_msm_combine_partials_dev(int curve, unsigned world, unsigned batch, unsigned whole_per_rank, const void* d_gathered, void* d_out_xy,
                                  void* d_out_zero, void* stream) {
+    PLK_API;
     return msm_combine_partials_dev_impl(curve, world, batch, whole_per_rank, d_gathered, d_out_xy, d_out_zero, as_stream(stream));
 }
 
@@ -768,9 +904,11 @@ int plk_msm_table_digits(int curve, unsigned w) {
 }
 int plk_msm_precompute_table_dev(int curve, size_t n, const void* d_bases_xy, const void* d_base_zero, unsigned w, void* d_out_xy, void* d_out_zero,
                                  void* stream) {
+    PLK_API;
     return msm_reference_table_dev_impl(curve, n, d_bases_xy, d_base_zero, w, d_out_xy, d_out_zero, as_stream(stream));
 }
 int plk_msm_precompute_table(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, unsigned w, uint64_t* out_xy, uint8_t* out_zero) {
+    PLK_API;
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (w < 1 || w > 64) return set_error(PLK_ERR_INVALID_ARG, "window size %u outside [1, 64]", w);
@@ -794,11 +932,13 @@ int plk_msm_precompute_table(int curve, size_t n, const uint64_t* bases_xy, cons
 // ---- IPA generator fold ----
 int plk_curve_fold_pairs_dev(int curve, size_t m, const void* d_lo_xy, const void* d_lo_zero, const void* d_hi_xy, const void* d_hi_zero,
                              const uint64_t* scalar_lo, const uint64_t* scalar_hi, void* d_out_xy, void* d_out_zero, void* stream) {
+    PLK_API;
     return curve_fold_pairs_dev_impl(curve, m, d_lo_xy, d_lo_zero, d_hi_xy, d_hi_zero, scalar_lo, scalar_hi, d_out_xy, d_out_zero, as_stream(stream));
 }
 
 int plk_curve_fold_pairs(int curve, size_t m, const uint64_t* lo_xy, const uint8_t* lo_zero, const uint64_t* hi_xy, const uint8_t* hi_zero,
                          const uint64_t* scalar_lo, const uint64_t* scalar_hi, uint64_t* out_xy, uint8_t* out_zero) {
+    PLK_API;
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (m && (!lo_xy || !hi_xy || !out_xy || !out_zero)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
@@ -822,6 +962,7 @@ int plk_curve_fold_pairs(int curve, size_t m, const uint64_t* lo_xy, const uint8
 
 // ---- batch inversion ----
 int plk_field_batch_inverse_dev(int field, const void* d_x, void* d_out, void* d_is_none, size_t count, void* stream) {
+    PLK_API;
     if (field_limbs(field) < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
     return field_batch_inverse_dev_impl(field, d_x, d_out, d_is_none, nullptr, count, as_stream(stream));
 }
@@ -849,15 +990,18 @@ static int batch_inverse_host(int field, const uint64_t* x, uint64_t* out, uint8
     if (is_none) PLK_TRY(c.out(is_none, dz, count));
     return c.finish();
 }
-int plk_field_batch_inverse(int field, const uint64_t* x, uint64_t* out, size_t count) { return batch_inverse_host(field, x, out, nullptr, count, true); }
+int plk_field_batch_inverse(int field, const uint64_t* x, uint64_t* out, size_t count) { PLK_API; return batch_inverse_host(field, x, out, nullptr, count, true); }
 int plk_field_batch_inverse_opt(int field, const uint64_t* x, uint64_t* out, uint8_t* is_none, size_t count) {
+    PLK_API;
     if (count && !is_none) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     return batch_inverse_host(field, x, out, is_none, count, false);
 }
 int plk_curve_batch_to_affine_dev(int curve, size_t count, const void* d_proj_xyz, const void* d_proj_zero, void* d_out_xy, void* d_out_zero, void* stream) {
+    PLK_API;
     return curve_batch_to_affine_dev_impl(curve, count, d_proj_xyz, d_proj_zero, d_out_xy, d_out_zero, as_stream(stream));
 }
 int plk_curve_batch_to_affine(int curve, size_t count, const uint64_t* proj_xyz, const uint8_t* proj_zero, uint64_t* out_xy, uint8_t* out_zero) {
+    PLK_API;
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (count == 0) return PLK_OK;
@@ -877,6 +1021,7 @@ int plk_curve_batch_to_affine(int curve, size_t count, const uint64_t* proj_xyz,
 
 // ---- canonical byte encodings ----
 int plk_field_to_bytes(int field, const uint64_t* x, size_t count, uint8_t* out_bytes) {
+    PLK_API;
     const int L = field_limbs(field);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
     if (count == 0) return PLK_OK;
@@ -891,6 +1036,7 @@ int plk_field_to_bytes(int field, const uint64_t* x, size_t count, uint8_t* out_
     return c.finish();
 }
 int plk_field_from_bytes(int field, const uint8_t* bytes, size_t count, uint64_t* out) {
+    PLK_API;
     const int L = field_limbs(field);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
     if (count == 0) return PLK_OK;
@@ -911,6 +1057,7 @@ int plk_field_from_bytes(int field, const uint8_t* bytes, size_t count, uint64_t
     return PLK_OK;
 }
 int plk_curve_point_to_bytes(int curve, const uint64_t* xy, const uint8_t* zero, size_t count, uint8_t* out_bytes) {
+    PLK_API;
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (count == 0) return PLK_OK;
@@ -927,6 +1074,7 @@ int plk_curve_point_to_bytes(int curve, const uint64_t* xy, const uint8_t* zero,
     return c.finish();
 }
 int plk_curve_point_from_bytes(int curve, const uint8_t* bytes, size_t count, uint64_t* out_xy, uint8_t* out_zero, uint8_t* status) {
+    PLK_API;
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (count == 0) return PLK_OK;
@@ -958,31 +1106,45 @@ int plk_curve_point_from_bytes(int curve, const uint8_t* bytes, size_t count, ui
 
 // ---- scalar side of an IPA round ----
 int plk_field_inner_product_dev(int field, const void* d_a, const void* d_b, size_t count, void* d_out, void* stream) {
+    PLK_API;
     return field_inner_product_dev_impl(field, d_a, d_b, count, d_out, as_stream(stream));
 }
 int plk_field_fold_slices_dev(int field, const void* d_lo, const void* d_hi, const uint64_t* scalar_lo, const uint64_t* scalar_hi, size_t count,
                               void* d_out, void* stream) {
+    PLK_API;
     return field_fold_slices_dev_impl(field, d_lo, d_hi, scalar_lo, scalar_hi, count, d_out, as_stream(stream));
 }
 
 // ---- one inner-product argument ----
 int plk_halo_begin_dev(int curve, size_t n, const void* d_halo_a, const void* d_halo_b, const void* d_halo_g_xy, const void* d_halo_g_zero,
                        const uint64_t* pedersen_h_xy, const uint64_t* u_prime_xy, unsigned freeze_log, void* stream, plk_halo_ctx** out_ctx) {
+    PLK_API;
     return halo_begin_dev_impl(curve, n, d_halo_a, d_halo_b, d_halo_g_xy, d_halo_g_zero, pedersen_h_xy, u_prime_xy, freeze_log, as_stream(stream), out_ctx);
 }
 int plk_halo_begin_tabled_dev(int curve, size_t n, const void* d_halo_a, const void* d_halo_b, const void* d_halo_g_xy, const void* d_halo_g_zero,
                               plk_msm_ctx* pedersen_g_tables, const uint64_t* pedersen_h_xy, const uint64_t* u_prime_xy, size_t h_index, size_t u_index,
                               const uint64_t* u_prime_scalar, unsigned freeze_log, unsigned lead_rounds, void* stream, plk_halo_ctx** out_ctx) {
+    PLK_API;
     if (!pedersen_g_tables) return set_error(PLK_ERR_INVALID_ARG, "null tables");
+    // the argument runs on the calling thread's device, on `stream`; the tables must live there too.  A device-group context
+    // (plk_init_devices) is kept on logical device 0 whatever thread built it: open over it from a thread on that device
+    PLK_TRY(ensure_device());
+    int cur = -1;
+    PLK_HIP_TRY(hipGetDevice(&cur));
+    if (cur != msm_ctx_device(pedersen_g_tables))
+        return set_error(PLK_ERR_INVALID_ARG, "the commitment tables live on HIP device %d but the calling thread works on device %d%s", msm_ctx_device(pedersen_g_tables),
+                         cur, msm_ctx_is_multi(pedersen_g_tables) ? " (a device-group context is kept on logical device 0: plk_set_thread_device(0))" : "");
     return halo_begin_dev_impl(curve, n, d_halo_a, d_halo_b, d_halo_g_xy, d_halo_g_zero, pedersen_h_xy, u_prime_xy, freeze_log, as_stream(stream), out_ctx,
                                pedersen_g_tables, lead_rounds, h_index, u_index, u_prime_scalar);
 }
 int plk_curve_fold_multi_dev(int curve, size_t n_out, unsigned log_inputs, const void* d_g_xy, const void* d_g_zero, const void* d_scalars, void* d_out_xy,
                              void* d_out_zero, void* stream) {
+    PLK_API;
     return curve_fold_multi_dev_impl(curve, n_out, (int)log_inputs, d_g_xy, d_g_zero, d_scalars, d_out_xy, d_out_zero, as_stream(stream));
 }
 int plk_halo_begin(int curve, size_t n, const uint64_t* halo_a, const uint64_t* halo_b, const uint64_t* halo_g_xy, const uint8_t* halo_g_zero,
                    const uint64_t* pedersen_h_xy, const uint64_t* u_prime_xy, unsigned freeze_log, plk_halo_ctx** out_ctx) {
+    PLK_API;
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (!halo_a || !halo_b || !halo_g_xy) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
@@ -1006,15 +1168,18 @@ int plk_halo_begin(int curve, size_t n, const uint64_t* halo_a, const uint64_t* 
     return rc;
 }
 int plk_halo_round_lr(plk_halo_ctx* ctx, const uint64_t* l_blinding, const uint64_t* r_blinding, uint64_t* lr_xy, uint8_t* lr_zero) {
+    PLK_API;
     return halo_round_lr_impl(ctx, l_blinding, r_blinding, lr_xy, lr_zero);
 }
-int plk_halo_round_fold(plk_halo_ctx* ctx, const uint64_t* u_j, const uint64_t* u_j_inv) { return halo_round_fold_impl(ctx, u_j, u_j_inv); }
+int plk_halo_round_fold(plk_halo_ctx* ctx, const uint64_t* u_j, const uint64_t* u_j_inv) { PLK_API; return halo_round_fold_impl(ctx, u_j, u_j_inv); }
 size_t plk_halo_len(const plk_halo_ctx* ctx) { return halo_len_impl(ctx); }
 int plk_halo_frozen(const plk_halo_ctx* ctx) { return halo_frozen_impl(ctx); }
 int plk_halo_read(plk_halo_ctx* ctx, uint64_t* halo_a, uint64_t* halo_b, uint64_t* halo_g_xy, uint8_t* halo_g_zero) {
+    PLK_API;
     return halo_read_impl(ctx, halo_a, halo_b, halo_g_xy, halo_g_zero);
 }
 int plk_halo_free(plk_halo_ctx* ctx) {
+    PLK_API;
     if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
     halo_delete(ctx);
     return PLK_OK;
@@ -1022,6 +1187,7 @@ int plk_halo_free(plk_halo_ctx* ctx) {
 
 // ---- self-test ----
 int plk_selftest_quad(int curve, const uint64_t* pts_xy, size_t n, unsigned quads, unsigned* mismatches) {
+    PLK_API;
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (!pts_xy || !mismatches || n == 0 || n > 0xffffffffu) return set_error(PLK_ERR_INVALID_ARG, "bad argument");
@@ -1034,20 +1200,56 @@ int plk_selftest_quad(int curve, const uint64_t* pts_xy, size_t n, unsigned quad
 
 // ---- checked build ----
 int plk_checked_build(void) { return checked_build_impl(); }
-int plk_checked_failures(unsigned* counts) { return checked_failures_impl(counts); }
+int plk_checked_failures(unsigned* counts) { PLK_API; return checked_failures_impl(counts); }
 
 // ---- measurement hooks ----
 int plk_ntt_set_profiling(int enable) { return ntt_set_profiling_impl(enable); }
-int plk_ntt_get_timings(double* sum_ms, unsigned* launches) { return ntt_get_timings_impl(sum_ms, launches); }
-int plk_msm_set_profiling(plk_msm_ctx* ctx, int enable) { return msm_set_profiling_impl(ctx, enable); }
-int plk_msm_get_timings(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls) { return msm_get_timings_impl(ctx, sum_ms, calls); }
+int plk_ntt_get_timings(double* sum_ms, unsigned* launches) { PLK_API; return ntt_get_timings_impl(sum_ms, launches); }
+// A device-group context runs its executions on its per-device parts (full tables on every device, a share context per device):
+// the handle's own stage events would stay empty - refused instead of returning stale or empty numbers.
+static int refuse_group_profiling(plk_msm_ctx* ctx) {
+    if (msm_ctx_is_multi(ctx))
+        return set_error(PLK_ERR_INVALID_ARG, "per-stage timings are collected on one-device contexts only: a device-group context executes on its per-device parts");
+    return PLK_OK;
+}
+int plk_msm_set_profiling(plk_msm_ctx* ctx, int enable) {
+    if (enable) PLK_TRY(refuse_group_profiling(ctx));
+    return msm_set_profiling_impl(ctx, enable);
+}
+int plk_msm_get_timings(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls) {
+    PLK_API;
+    PLK_TRY(refuse_group_profiling(ctx));
+    return msm_get_timings_impl(ctx, sum_ms, calls);
+}
 
 // ---- utilities ----
+int plk_msm_debug_digits(int curve, unsigned window_bits, size_t n, const uint64_t* scalars, int32_t* digits, unsigned* n_digits) {
+    PLK_API;
+    const int nd = msm_debug_digit_count(curve, window_bits);
+    if (nd < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d or window of %u bits", curve, window_bits);
+    if (n_digits) *n_digits = (unsigned)nd;
+    if (!digits || !n) return PLK_OK;
+    if (!scalars) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    PLK_TRY(ensure_device());
+    DevBuf ds, dd;
+    PLK_TRY(ds.alloc(n * 32));
+    PLK_TRY(dd.alloc(n * (size_t)nd * 4));
+    PLK_HIP_TRY(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
+    PLK_TRY(msm_debug_digits_impl(curve, window_bits, n, ds.p, dd.p, nullptr));
+    PLK_HIP_TRY(hipDeviceSynchronize());
+    PLK_HIP_TRY(hipMemcpy(digits, dd.p, n * (size_t)nd * 4, hipMemcpyDeviceToHost));
+    return PLK_OK;
+}
+
+int plk_bench_ceilings(double* out, unsigned n_out) { PLK_API; return bench_ceilings_impl(out, n_out); }
+
 int plk_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count) {
+    PLK_API;
     return field_op_impl(field, op, a, b, out, count);
 }
 
 int plk_curve_gen_bases_dev(int curve, size_t n, uint64_t first, const uint64_t* g0_xy, const uint64_t* d_xy, void* d_out_xy, void* stream) {
+    PLK_API;
     const int L = curve_limbs(curve);
     if (L < 0) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
     if (!g0_xy || !d_xy || (n && !d_out_xy)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");

@@ -43,13 +43,27 @@ int thread_logical_device();                 // the logical device the calling t
 void set_thread_logical_device(int logical);
 int next_round_robin_device();               // single-unit calls from many host threads take the devices in turn
 unsigned multi_min_log_n();                  // size gate of the fan-out (PLK_MULTI_MIN_LOG_N)
-struct DeviceScope {                         // the calling thread works on logical device `logical` for the scope
-    int prev;
+struct DeviceScope {                         // the calling thread works on logical device `logical` for the scope; on exit the
+    int prev;                                // thread's logical device AND its current HIP device are what they were
+    int prev_hip;
     explicit DeviceScope(int logical);
     ~DeviceScope();
     DeviceScope(const DeviceScope&) = delete;
     DeviceScope& operator=(const DeviceScope&) = delete;
 };
+// Every public entry point (capi.hip: PLK_API) leaves the calling thread's current HIP device as it found it: the library selects
+// devices freely inside a call (the thread's logical device, a context's device, the devices of a group taken in turn), and a host
+// shim or torch that allocates on "the current device" afterwards must not land on another GPU.  Nested calls
+// (plk_ntt -> plk_ntt_batch) restore once, at the outermost level.
+struct ApiGuard {
+    int dev = -1;
+    bool outer;
+    ApiGuard();
+    ~ApiGuard();
+    ApiGuard(const ApiGuard&) = delete;
+    ApiGuard& operator=(const ApiGuard&) = delete;
+};
+#define PLK_API plk::ApiGuard plk_api_guard_
 int group_init_single(int device);           // plk_init
 int group_init(int n_devices);               // plk_init_devices
 void group_shutdown();

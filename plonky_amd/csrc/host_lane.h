@@ -80,12 +80,13 @@ inline int lane_join(HostLane& l) {
     return PLK_OK;
 }
 
-// Caller buffers registered with the HIP runtime so that copies from / to them are asynchronous: a process-wide, refcounted
-// registry of exact (pointer, size) ranges.  Two threads that pass the same read-only buffer at the same time (the Rayon-style
-// callers the lanes are built for) share ONE registration, released by whoever finishes last - the second thread used to fail
-// to register, copy "as pageable", and have the pages unregistered under its DMA by the first thread's return.  Registration can
-// still fail (a range that overlaps a different registered range, exotic memory): the copies then block the calling thread -
-// same result.  Registered as portable: every device of the group may copy from it.
+// Caller buffers registered with the HIP runtime so that copies from / to them are asynchronous: a process-wide registry of
+// NON-OVERLAPPING intervals, each with a hold count per thread (capi.hip).  Two threads that pass the same read-only buffer at the
+// same time (the Rayon-style callers the lanes are built for) share ONE registration, released by whoever finishes last.  A request
+// that extends or partly overlaps a registered interval never leaves a half-registered range: it waits for other threads' holds to
+// end, or - the calling thread's own holds - re-registers the union after synchronising the devices.  Registration can still fail
+// (exotic memory): the copies then block the calling thread - same result.  Registered as portable: every device of the group may
+// copy from it.  A hold is released by the thread that took it, with the address it was taken with.
 bool pin_registry_acquire(const void* ptr, size_t bytes);  // true: registered (by this call or an earlier one), must be released
 void pin_registry_release(const void* ptr);
 

@@ -34,9 +34,7 @@
 #include <type_traits>
 #include <vector>
 
-#include "common.h"
-#include "ec.cuh"
-#include "ecz.cuh"
+#include "msm_dev.cuh"
 #include "glv.cuh"
 #include "ecz_coop.cuh"
 #include "tables.cuh"
@@ -49,25 +47,20 @@ int comb_build(int curve, size_t n, const void* d_base0, const void* d_chain, hi
 void comb_free(CombPlan* p);
 int comb_execute(const CombPlan* p, unsigned batch, const void* const* d_scalars, const uint64_t* first, const uint64_t* count, void* d_out_xy, void* d_out_zero,
                  hipStream_t stream);
+// msm_acc.hip: the bucket accumulation kernel (its own translation unit)
+template <class C> int msm_accumulate_blocks_per_cu();
+template <class C>
+void msm_launch_accumulate(unsigned blocks, hipStream_t stream, const void* tab, const void* sorted, const void* off, void* p_start, void* p_head,
+                           void* head_live, uint32_t buckets, const uint32_t* dyn_chunk, int wshift, uint32_t n_sub, uint32_t tab_entries);
+// msm_order.hip: digits + the two-level bucket ordering; msm_tail.hip: the reduction
+template <class C> int msm_launch_glv_split(const void* d_scalars, size_t n, void* halves, hipStream_t stream);
+template <class C> int msm_launch_order_stage(int stage, const OrdCfg& o, const OrdBuffers& b, hipStream_t stream);
+template <class C> int msm_launch_digits(const void* d_scalars, size_t n, const OrdCfg& o, void* d_digits, hipStream_t stream);
+template <class C> int msm_launch_reduce_stage(int stage, const TailGeom& g, const TailBatch& tb, hipStream_t stream);
 constexpr size_t COMB_MAX_N = (size_t)1 << 15;  // generators up to which a tabled context with an automatic window is a comb (1 GB of table at 2^15)
 constexpr int COMB_WINDOW = 4, COMB_WINDOWS = 64;
 
-// -DPLK_CHECKED (make checked -> libplonky_hip_checked.so; SURVEY.md section 5: the reference's debug assertions and overflow
-// checks have no equivalent in a release kernel): every index the ordering and accumulation kernels compute into sorted[],
-// tmp[], the tables and the bucket arrays is compared with its bound; a violation is counted per site and the access is
-// skipped.  plk_checked_failures() reads the counters.  In the normal build the guards compile to nothing.
-#ifdef PLK_CHECKED
-__device__ unsigned g_plk_chk[8];
-#define PLK_CHK(cond, site) (!(cond) ? (atomicAdd(&g_plk_chk[site], 1u), false) : true)
-#else
-#define PLK_CHK(cond, site) (true)
-#endif
-enum { CHK_TMP_INDEX = 0, CHK_TILE_STAGE = 1, CHK_SORTED_INDEX = 2, CHK_SEG_STAGE = 3, CHK_TABLE_INDEX = 4, CHK_BUCKET = 5, CHK_ENTRY_RANGE = 6 };
 
-constexpr int MSM_MAX_PLANE_PARTS = 16;  // blocks per bit-plane in the reduction (planes * parts quads must fit the final block)
-constexpr int MSM_TF_MAX_WINDOW = 16;  // table-free mode: every window has its own 2^(c-1) buckets
-constexpr int MSM_MAX_WINDOW = 21;   // c - 1 <= 10 coarse + 11 fine bits in the partition (ORD_MAX_BINS, ORD_MAX_FINE)
-constexpr uint32_t CODE_INVALID = 0xFFFFFFFFu;
 
 // ---------------------------------------------------------------------------------------------
 // table construction: tab[j*n + i] = [2^(c j)] G_i, affine  (curve_msm.rs:40-52)
@@ -147,441 +140,6 @@ __global__ void __launch_bounds__(256) k_msm_table_export(const uint4* __restric
     out_zero[e] = ident ? 1 : 0;
 }
 
-// ---------------------------------------------------------------------------------------------
-// scalars -> signed window digits  (curve_msm.rs:159-180), computed where they are consumed
-// ---------------------------------------------------------------------------------------------
-// Digits are never stored: the two kernels of the first partition level recompute them from the scalars
-// (one Montgomery -> canonical conversion per scalar and kernel, ~10 instructions per digit), which replaces
-// a 4-byte write and two 4-byte reads per (scalar, window) by two extra reads of the 32-byte scalar.
-// The canonical limbs are parked in LDS (limb-major: conflict-free) so that the window loop can index them.
-constexpr int ORD_THREADS = 256;
-constexpr int ORD_TILE = 4096;      // entries staged per tile of the level-1 scatter
-constexpr int ORD_MAX_BINS = 1024;  // coarse bins
-constexpr int ORD_MAX_FINE = 11;    // fine bits: buckets per coarse bin <= 2048
-constexpr int ORD_BIN_THREADS = 512;
-constexpr uint32_t ORD_SEG = 8192;  // entries per level-2 workgroup
-// k_ord_bin_scatter stages a whole segment in LDS (3 fine-bit tables + the staged entries): ~74 KB, above the 64 KB a workgroup
-// gets on gfx90a / gfx942 - this library is built for gfx950 (160 KB of LDS per CU) only, plk_init refuses other devices
-static_assert(3 * (4u << ORD_MAX_FINE) + 4 * ORD_BIN_THREADS + 6 * ORD_SEG <= 160 * 1024, "k_ord_bin_scatter's LDS tile must fit a gfx950 CU");
-
-struct OrdCfg {
-    int c;                   // window bits
-    int windows;             // digits per scalar
-    uint32_t window_buckets; // table-free mode: 2^(c-1) (every window has its own bucket range), else 0
-    int fine_bits;           // bucket id = [coarse bin | fine]
-    int nbins;               // coarse bins in use
-    uint32_t spt;            // scalars per sub-tile (<= ORD_THREADS, spt * windows <= ORD_TILE)
-    uint32_t sub;            // sub-tiles per tile (one block walks them in turn)
-    uint32_t nt1;            // tiles
-    int raw_signed;          // 1: the "scalars" are half scalars of a GLV split: canonical magnitude, sign in bit 255 (glv.cuh)
-    uint32_t entries_cap;    // n_eff * windows: size of tmp[] / sorted[] and of the table (checked build)
-    uint32_t ent_stride;     // entry id of (window j, scalar i) = j * ent_stride + ent_first + i: the table index.  ent_stride = n_eff of the
-    uint32_t ent_first;      // context; ent_first > 0 when the scalars belong to generators first .. first + n - 1 only (plk_msm_execute_parts_dev)
-};
-
-template <class SP> PLK_DI void ord_park_scalar(const uint4* __restrict__ scalars, size_t i, uint32_t* s_lim, int tid, bool raw_signed) {
-    static_assert(SP::NL == 8, "scalar fields are 256-bit");
-    const uint4 lo = scalars[i * 2], hi = scalars[i * 2 + 1];
-    Fe<SP> s;
-    s.v[0] = lo.x; s.v[1] = lo.y; s.v[2] = lo.z; s.v[3] = lo.w;
-    s.v[4] = hi.x; s.v[5] = hi.y; s.v[6] = hi.z; s.v[7] = hi.w;
-    // Montgomery -> canonical in the SCALAR field (to_canonical_u64_vec, curve_msm.rs:164); half scalars are canonical already
-    if (!raw_signed) s = fe_to_canonical<SP>(s);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s_lim[k * ORD_THREADS + tid] = s.v[k];
-}
-// digit j of the parked scalar: signed c-bit window by carry-based integer recoding (never s -> r - s, so it is valid on
-// BLS12-377 G1 whose cofactor is even).  Returns (bucket << 1) | negative, or CODE_INVALID for a zero digit.
-PLK_DI uint32_t ord_digit(const uint32_t* s_lim, int tid, int j, const OrdCfg& cfg, uint32_t& carry) {
-    const int c = cfg.c;
-    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
-    const int bp = j * c, li = bp >> 5, sh = bp & 31;
-    uint64_t two = li < 8 ? s_lim[li * ORD_THREADS + tid] : 0u;
-    if (li + 1 < 8) two |= (uint64_t)s_lim[(li + 1) * ORD_THREADS + tid] << 32;
-    const uint32_t v = ((uint32_t)(two >> sh) & mask) + carry;
-    // v in [0, 2^c]; v > 2^(c-1) becomes v - 2^c with a carry into the next window
-    const uint32_t neg = v > half ? 1u : 0u;
-    const uint32_t mag = neg ? (1u << c) - v : v;
-    carry = neg;
-    if (mag == 0) return CODE_INVALID;
-    // a negative half scalar (sign parked in bit 255, far above its windows) flips every digit
-    const uint32_t flip = cfg.raw_signed ? s_lim[7 * ORD_THREADS + tid] >> 31 : 0u;
-    return ((mag - 1u + (uint32_t)j * cfg.window_buckets) << 1) | (neg ^ flip);
-}
-
-// exclusive prefix of `v` over the threads of the block (blockDim.x a multiple of 64, <= 1024); *total (optional) = the block sum.
-// Shuffles inside a wave, one LDS word per wave across: two barriers instead of two per doubling step.  s_tmp: >= 16 words,
-// free again when the call returns.
-PLK_DI uint32_t block_excl_prefix(uint32_t v, uint32_t* s_tmp, uint32_t* total = nullptr) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t u = __shfl_up(inc, d);
-        if (lane >= d) inc += u;
-    }
-    if (lane == 63) s_tmp[wave] = inc;
-    __syncthreads();
-    uint32_t base = 0, all = 0;
-    for (int w = 0; w < nw; ++w) {
-        const uint32_t x = s_tmp[w];
-        if (w < wave) base += x;
-        all += x;
-    }
-    if (total) *total = all;
-    __syncthreads();
-    return base + inc - v;
-}
-// exclusive scan of s_data[0..count) in place (count <= 4 * blockDim.x); s_tmp: 16 words.  The caller's writes to s_data must be
-// visible (a barrier before the call); ends with a barrier.
-PLK_DI void block_excl_scan4(uint32_t* s_data, int count, uint32_t* s_tmp) {
-    const int t = threadIdx.x;
-    uint32_t v[4], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = t * 4 + k;
-        v[k] = idx < count ? s_data[idx] : 0u;
-        sum += v[k];
-    }
-    uint32_t run = block_excl_prefix(sum, s_tmp);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = t * 4 + k;
-        if (idx < count) s_data[idx] = run;
-        run += v[k];
-    }
-    __syncthreads();
-}
-
-// ---------------------------------------------------------------------------------------------
-// entries -> bucket order  (replaces the reference's serial digit_occurrences scatter, curve_msm.rs:117-126)
-// ---------------------------------------------------------------------------------------------
-// Every (scalar i, window j) with a non-zero digit is an entry (id j * n + i = its table index) that goes to bucket
-// |d| - 1.  A bucket id is [coarse bin | fine].  Level 1 moves the entries to their coarse bin (per-tile LDS histogram ->
-// global [bin][tile] counts -> scan -> staged, run-wise writes); level 2 is one workgroup per coarse bin that counts,
-// scans and scatters its bin by the fine bits, producing the bucket offsets on the way.  Only LDS atomics; counts,
-// not capacities, drive the layout, so any digit distribution works.
-
-// GLV split of the scalars of a table-free MSM (glv.cuh): half[i] = k1_i, half[n + i] = k2_i (magnitude, sign in bit 255);
-// the ordering kernels then see 2n "scalars" of GLV_BITS bits over the points [G_0 .. G_(n-1), phi(G_0) .. phi(G_(n-1))].
-template <class C>
-__global__ void __launch_bounds__(256) k_glv_split(const uint4* __restrict__ scalars, size_t n, uint4* __restrict__ half) {
-    using SP = typename C::SP;
-    if constexpr (C::Glv::ENABLED) {
-        const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (i >= n) return;
-        const uint4 lo = scalars[i * 2], hi = scalars[i * 2 + 1];
-        Fe<SP> s;
-        s.v[0] = lo.x; s.v[1] = lo.y; s.v[2] = lo.z; s.v[3] = lo.w;
-        s.v[4] = hi.x; s.v[5] = hi.y; s.v[6] = hi.z; s.v[7] = hi.w;
-        s = fe_to_canonical<SP>(s);
-        uint32_t k1[8], k2[8];
-        glv_split<typename C::Glv>(s.v, k1, k2);
-        half[i * 2] = make_uint4(k1[0], k1[1], k1[2], k1[3]);
-        half[i * 2 + 1] = make_uint4(k1[4], k1[5], k1[6], k1[7]);
-        half[(n + i) * 2] = make_uint4(k2[0], k2[1], k2[2], k2[3]);
-        half[(n + i) * 2 + 1] = make_uint4(k2[4], k2[5], k2[6], k2[7]);
-    }
-}
-
-// level 1, step 1: cnt1[bin * nt1 + tile].  A tile is `sub` consecutive sub-tiles of spt scalars, walked by one block.
-template <class C>
-__global__ void __launch_bounds__(ORD_THREADS) k_ord_count(const uint4* __restrict__ scalars, size_t n, OrdCfg cfg, uint32_t* __restrict__ cnt1) {
-    using SP = typename C::SP;
-    __shared__ uint32_t s_lim[8 * ORD_THREADS];
-    __shared__ uint32_t s_hist[ORD_MAX_BINS];
-    const int tid = threadIdx.x;
-    const uint32_t tile = blockIdx.x;
-    for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_hist[k] = 0;
-    for (uint32_t st = 0; st < cfg.sub; ++st) {
-        const size_t i = ((size_t)tile * cfg.sub + st) * cfg.spt + tid;
-        const bool live = (uint32_t)tid < cfg.spt && i < n;
-        __syncthreads();
-        if (live) ord_park_scalar<SP>(scalars, i, s_lim, tid, cfg.raw_signed != 0);
-        __syncthreads();
-        if (live) {
-            uint32_t carry = 0;
-            for (int j = 0; j < cfg.windows; ++j) {
-                const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
-                if (code != CODE_INVALID) atomicAdd(&s_hist[code >> (cfg.fine_bits + 1)], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    for (int k = tid; k < cfg.nbins; k += ORD_THREADS) cnt1[(size_t)k * cfg.nt1 + tile] = s_hist[k];
-}
-
-// level 1, step 2: one block per bin row: in-place exclusive scan over the tiles; the block that finishes last turns the
-// bin totals into the bin offsets bin_base[0..nbins] (exclusive scan; bin_base[nbins] = number of entries) and into the
-// level-2 segment table seg_base[0..nbins] (a bin of t entries has ceil(t / ORD_SEG) segments).
-// It also fixes the accumulation's chunk length for THIS execution from the number of entries actually present (dyn_chunk[0]):
-// the lanes the context was laid out for share them, so a sparse vector (a slice of a sharded commitment, a zero-padded
-// quotient chunk, Z = 1) runs short chains on all lanes instead of full-length chains on a few - the accumulation of a
-// lane is a dependency chain, its length is the kernel's duration.
-__global__ void __launch_bounds__(256) k_ord_scan1(uint32_t* __restrict__ cnt1, uint32_t nt1, int nbins, uint32_t* __restrict__ bin_total,
-                                                   uint32_t* __restrict__ bin_base, uint32_t* __restrict__ seg_base, uint32_t* __restrict__ done_counter,
-                                                   uint32_t* __restrict__ dyn_chunk, uint32_t chunk_cfg, uint32_t lanes_cfg, uint32_t* __restrict__ off_direct) {
-    __shared__ uint32_t s_sum[256];
-    __shared__ uint32_t s_bins[ORD_MAX_BINS];
-    __shared__ bool s_last;
-    uint32_t* row = cnt1 + (size_t)blockIdx.x * nt1;
-    const uint32_t per = (nt1 + 255) / 256;
-    const uint32_t lo = min(nt1, threadIdx.x * per), hi = min(nt1, lo + per);
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += row[i];
-    uint32_t row_total = 0;
-    uint32_t run = block_excl_prefix(sum, s_sum, &row_total);
-    for (uint32_t i = lo; i < hi; ++i) {
-        uint32_t v = row[i];
-        row[i] = run;
-        run += v;
-    }
-    if (threadIdx.x == 255) {
-        bin_total[blockIdx.x] = row_total;
-        __threadfence();
-        s_last = atomicAdd(done_counter, 1u) == (uint32_t)nbins - 1u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    const volatile uint32_t* vt = bin_total;
-    for (int k = threadIdx.x; k < nbins; k += 256) s_bins[k] = vt[k];
-    __syncthreads();
-    const uint32_t last_total = s_bins[nbins - 1];
-    block_excl_scan4(s_bins, nbins, s_sum);
-    for (int k = threadIdx.x; k < nbins; k += 256) {
-        bin_base[k] = s_bins[k];
-        if (off_direct) off_direct[k] = s_bins[k];  // one-level ordering: the bins are the buckets
-    }
-    if (threadIdx.x == 0) {
-        const uint32_t total = s_bins[nbins - 1] + last_total;
-        bin_base[nbins] = total;
-        if (off_direct) off_direct[nbins] = total;
-        uint32_t ch = lanes_cfg ? (total + lanes_cfg - 1) / lanes_cfg : chunk_cfg;
-        if (ch < 8u) ch = 8u;
-        if (ch > chunk_cfg) ch = chunk_cfg;
-        dyn_chunk[0] = ch;
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < nbins; k += 256) s_bins[k] = (vt[k] + ORD_SEG - 1) / ORD_SEG;
-    __syncthreads();
-    const uint32_t last_segs = s_bins[nbins - 1];
-    block_excl_scan4(s_bins, nbins, s_sum);
-    for (int k = threadIdx.x; k < nbins; k += 256) seg_base[k] = s_bins[k];
-    if (threadIdx.x == 0) {
-        seg_base[nbins] = s_bins[nbins - 1] + last_segs;
-        *done_counter = 0;  // ready for the next execution
-    }
-}
-
-// level 1, step 3: (code, entry id) to its coarse bin; every sub-tile is ordered by bin inside LDS first, so that consecutive
-// lanes store to consecutive slots of the same (tile, bin) run
-template <class C>
-__global__ void __launch_bounds__(ORD_THREADS) k_ord_scatter(const uint4* __restrict__ scalars, size_t n, OrdCfg cfg, const uint32_t* __restrict__ cnt1,
-                                                             const uint32_t* __restrict__ bin_base, uint2* __restrict__ tmp,
-                                                             uint32_t* __restrict__ sorted_direct) {
-    using SP = typename C::SP;
-    __shared__ uint32_t s_lim[8 * ORD_THREADS];
-    __shared__ uint32_t s_cnt[ORD_MAX_BINS], s_base[ORD_MAX_BINS], s_gbase[ORD_MAX_BINS];
-    __shared__ uint32_t s_tmp[ORD_THREADS];
-    __shared__ uint2 s_ent[ORD_TILE];
-    __shared__ uint16_t s_rank[ORD_TILE];  // [window][scalar of the sub-tile]: spt * windows <= ORD_TILE
-    const int tid = threadIdx.x;
-    const uint32_t tile = blockIdx.x;
-    for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_gbase[k] = bin_base[k] + cnt1[(size_t)k * cfg.nt1 + tile];
-    for (uint32_t st = 0; st < cfg.sub; ++st) {
-        const size_t i = ((size_t)tile * cfg.sub + st) * cfg.spt + tid;
-        const bool live = (uint32_t)tid < cfg.spt && i < n;
-        __syncthreads();  // the previous sub-tile has been written out
-        for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_cnt[k] = 0;
-        if (live) ord_park_scalar<SP>(scalars, i, s_lim, tid, cfg.raw_signed != 0);
-        __syncthreads();
-        if (live) {
-            // one atomic per entry: its return value is the entry's rank inside its bin, kept for the placement below
-            uint32_t carry = 0;
-            for (int j = 0; j < cfg.windows; ++j) {
-                const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
-                if (code != CODE_INVALID) s_rank[j * cfg.spt + tid] = (uint16_t)atomicAdd(&s_cnt[code >> (cfg.fine_bits + 1)], 1u);
-            }
-        }
-        __syncthreads();
-        for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_base[k] = s_cnt[k];
-        __syncthreads();
-        block_excl_scan4(s_base, cfg.nbins, s_tmp);
-        if (live) {
-            uint32_t carry = 0;
-            for (int j = 0; j < cfg.windows; ++j) {
-                const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
-                if (code != CODE_INVALID) {
-                    const uint32_t slot = s_base[code >> (cfg.fine_bits + 1)] + s_rank[j * cfg.spt + tid];
-                    if (PLK_CHK(slot < (uint32_t)ORD_TILE, CHK_TILE_STAGE)) s_ent[slot] = make_uint2(code, (uint32_t)((size_t)j * cfg.ent_stride + cfg.ent_first + i));
-                }
-            }
-        }
-        __syncthreads();
-        const uint32_t total = s_base[cfg.nbins - 1] + s_cnt[cfg.nbins - 1];
-        for (uint32_t sidx = tid; sidx < total; sidx += ORD_THREADS) {
-            const uint2 e = s_ent[sidx];
-            const uint32_t bin = e.x >> (cfg.fine_bits + 1);
-            const uint32_t at = s_gbase[bin] + (sidx - s_base[bin]);
-            if (PLK_CHK(at < cfg.entries_cap, CHK_TMP_INDEX)) {
-                if (sorted_direct) sorted_direct[at] = (e.y << 1) | (e.x & 1u);  // one-level ordering: this IS the bucket order
-                else tmp[at] = e;
-            }
-        }
-        __syncthreads();
-        for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_gbase[k] += s_cnt[k];  // this sub-tile's entries of bin k
-    }
-}
-
-// level 2: a coarse bin is cut into segments of <= ORD_SEG entries, one workgroup each (a hot bin - short top window, skewed
-// witness - is shared by many workgroups).  Block -> (bin, segment) by a search in seg_base.
-PLK_DI bool ord_segment(const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ bin_base, int nbins, uint32_t blk, uint32_t& bin,
-                        uint32_t& seg, uint32_t& lo, uint32_t& hi) {
-    if (blk >= seg_base[nbins]) return false;
-    uint32_t a = 0, b = (uint32_t)nbins;  // seg_base[a] <= blk < seg_base[b]
-    while (b - a > 1) {
-        const uint32_t m = (a + b) >> 1;
-        if (seg_base[m] <= blk) a = m; else b = m;
-    }
-    bin = a;
-    seg = blk - seg_base[a];
-    lo = bin_base[a] + seg * ORD_SEG;
-    hi = min(bin_base[a + 1], lo + ORD_SEG);
-    return true;
-}
-// step 1: cnt2[segment][fine]
-__global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_count(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bin_base,
-                                                                   const uint32_t* __restrict__ seg_base, int fine_bits, int nbins,
-                                                                   uint32_t* __restrict__ cnt2) {
-    __shared__ uint32_t s_hist[1 << ORD_MAX_FINE];
-    const int tid = threadIdx.x;
-    uint32_t bin, seg, lo, hi;
-    if (!ord_segment(seg_base, bin_base, nbins, blockIdx.x, bin, seg, lo, hi)) return;
-    const int nf = 1 << fine_bits;
-    const uint32_t fmask = (uint32_t)nf - 1u;
-    for (int k = tid; k < nf; k += ORD_BIN_THREADS) s_hist[k] = 0;
-    __syncthreads();
-    for (uint32_t p = lo + tid; p < hi; p += ORD_BIN_THREADS) atomicAdd(&s_hist[(tmp[p].x >> 1) & fmask], 1u);
-    __syncthreads();
-    for (int k = tid; k < nf; k += ORD_BIN_THREADS) cnt2[((size_t)blockIdx.x << fine_bits) + k] = s_hist[k];
-}
-// step 2: bucket offsets of the bin (sum over its segments, scanned), this segment's start inside every bucket, scatter.
-// The segment is ordered by bucket inside LDS first: its entries of one bucket leave as one run.
-__global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_scatter(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bin_base,
-                                                                     const uint32_t* __restrict__ seg_base, int fine_bits, int nbins, uint32_t buckets,
-                                                                     const uint32_t* __restrict__ cnt2, uint32_t* __restrict__ off,
-                                                                     uint32_t* __restrict__ sorted, uint32_t entries_cap) {
-    __shared__ uint32_t s_glob[1 << ORD_MAX_FINE], s_loc[1 << ORD_MAX_FINE], s_cur[1 << ORD_MAX_FINE];
-    __shared__ uint32_t s_tmp[ORD_BIN_THREADS];
-    __shared__ uint32_t s_out[ORD_SEG];
-    __shared__ uint16_t s_fine[ORD_SEG];
-    const int tid = threadIdx.x;
-    uint32_t bin, seg, lo, hi;
-    if (!ord_segment(seg_base, bin_base, nbins, blockIdx.x, bin, seg, lo, hi)) {
-        // bins without entries still own bucket offsets: written by the blocks past the last segment, one bin each
-        // (the grid has at least nbins blocks past the segments; see the launch)
-        const uint32_t extra = blockIdx.x - seg_base[nbins];
-        if (extra < (uint32_t)nbins && bin_base[extra + 1] == bin_base[extra]) {
-            const int nf = 1 << fine_bits;
-            for (int k = tid; k < nf; k += ORD_BIN_THREADS) off[((size_t)extra << fine_bits) + k] = bin_base[extra];
-        }
-        if (extra == 0 && tid == 0) off[buckets] = bin_base[nbins];
-        return;
-    }
-    const int nf = 1 << fine_bits;
-    const uint32_t fmask = (uint32_t)nf - 1u;
-    const uint32_t s0 = seg_base[bin], s1 = seg_base[bin + 1];
-    for (int k = tid; k < nf; k += ORD_BIN_THREADS) {
-        uint32_t tot = 0, before = 0, own = 0;
-        for (uint32_t sg = s0; sg < s1; ++sg) {
-            const uint32_t v = cnt2[((size_t)sg << fine_bits) + k];
-            if (sg - s0 < seg) before += v;
-            if (sg - s0 == seg) own = v;
-            tot += v;
-        }
-        s_glob[k] = tot;
-        s_cur[k] = before;
-        s_loc[k] = own;
-    }
-    __syncthreads();
-    block_excl_scan4(s_glob, nf, s_tmp);
-    block_excl_scan4(s_loc, nf, s_tmp);
-    const uint32_t bb = bin_base[bin];
-    for (int k = tid; k < nf; k += ORD_BIN_THREADS) {
-        const uint32_t o = bb + s_glob[k];
-        if (seg == 0) off[((size_t)bin << fine_bits) + k] = o;
-        s_glob[k] = o + s_cur[k];  // where this segment's entries of bucket k start
-        s_cur[k] = s_loc[k];       // LDS cursor
-    }
-    __syncthreads();
-    for (uint32_t p = lo + tid; p < hi; p += ORD_BIN_THREADS) {
-        const uint2 e = tmp[p];
-        const uint32_t f = (e.x >> 1) & fmask;
-        const uint32_t idx = atomicAdd(&s_cur[f], 1u);
-        if (PLK_CHK(idx < ORD_SEG, CHK_SEG_STAGE)) {
-            s_out[idx] = (e.y << 1) | (e.x & 1u);
-            s_fine[idx] = (uint16_t)f;
-        }
-    }
-    __syncthreads();
-    const uint32_t count = hi - lo;
-    for (uint32_t i = tid; i < count; i += ORD_BIN_THREADS) {
-        const uint32_t f = s_fine[i];
-        const uint32_t at = s_glob[f] + (i - s_loc[f]);
-        if (PLK_CHK(at < entries_cap, CHK_SORTED_INDEX)) sorted[at] = s_out[i];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// bucket accumulation: every lane adds exactly `chunk` consecutive sorted entries
-// ---------------------------------------------------------------------------------------------
-// The sorted entry list is cut into chunks of `chunk` entries regardless of the bucket boundaries, one lane per chunk:
-// perfectly balanced whatever the digit distribution and whatever the bucket sizes (26 entries on average at c = 20).  A
-// lane that crosses a bucket boundary stores what it has and starts over: the piece of the bucket that STARTS inside the
-// chunk goes to p_start[bucket], the piece of the bucket that was already running at the chunk's first entry goes to
-// p_head[lane].  bucket b = p_start[b] + sum of p_head[l] for the lanes l0 < l <= l1, l0 = off[b] / chunk,
-// l1 = (off[b+1] - 1) / chunk (k_msm_assemble).  Pieces are stored as they are (lazy 29-bit limbs, accumulator invariant of
-// ecz.cuh; the identity is ZZ = 0): a store inside the loop must be cheap, because some lane of the wave has one almost every round.
-template <class FP> constexpr int raw_u4() { return FzCfg<FP>::NZ; }  // uint4 per raw point: 4 NZ words
-
-template <class FP> PLK_DI void xyzzz_store_raw(uint4* dst, const XyzzZ<FP>& a) {
-    constexpr int NZ = FzCfg<FP>::NZ;
-    uint32_t w[4 * NZ];
-#pragma unroll
-    for (int i = 0; i < NZ; ++i) {
-        // the identity is ZZ = 0 (xyzzz_load_raw); its other coordinates are never looked at, so only ZZ pays for a select - the
-        // store sits on the path that some lane of an accumulation wave takes almost every round
-        w[i] = a.x.l[i];
-        w[NZ + i] = a.y.l[i];
-        w[2 * NZ + i] = a.inf ? 0u : a.zz.l[i];
-        w[3 * NZ + i] = a.zzz.l[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NZ; ++i) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-}
-template <class FP> PLK_DI XyzzZ<FP> xyzzz_load_raw(const uint4* src) {
-    constexpr int NZ = FzCfg<FP>::NZ;
-    uint32_t w[4 * NZ];
-#pragma unroll
-    for (int i = 0; i < NZ; ++i) {
-        const uint4 v = src[i];
-        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-    }
-    XyzzZ<FP> r;
-    uint32_t any = 0;
-#pragma unroll
-    for (int i = 0; i < NZ; ++i) {
-        r.x.l[i] = w[i];
-        r.y.l[i] = w[NZ + i];
-        r.zz.l[i] = w[2 * NZ + i];
-        r.zzz.l[i] = w[3 * NZ + i];
-        any |= w[2 * NZ + i];
-    }
-    r.inf = any == 0;  // a live accumulator never has ZZ = 0 (that case is caught as the identity in ecz.cuh)
-    return r;
-}
-
 // Short generator lists (the frozen generators of an inner-product argument: 2^14 + 2 points): one lane per generator is a
 // dependency chain, and in k_msm_table a quarter of it is the inversion that brings every window back to affine before the next
 // c doublings.  Here the chain only doubles - c (windows - 1) doublings without a normalisation in between, every window's
@@ -636,497 +194,6 @@ __global__ void __launch_bounds__(64) k_msm_table_norm(const uint4* __restrict__
     affine_store<FP>(tab + (n + t) * 2 * W, xr, yr, p.inf);   // entry (j, i) of the table sits at j n + i = n + t
 }
 
-// Head pieces are mostly short-lived: the head piece of lane l (closed at l's first bucket boundary) belongs to the last
-// bucket of lane l - 1, whose piece is still in registers when the loop ends.  Lanes therefore park a closed head piece in
-// LDS and their predecessor in the block adds it to its last piece before storing it: at c = 20 (26 entries per bucket,
-// 24 per lane) almost every bucket leaves the kernel whole, and k_msm_assemble only finds the head pieces of the first lane
-// of a block and of lanes that lie entirely inside one bucket (head_live[lane] = 1).
-constexpr int ACC_THREADS = 128;
-// the bucket of sorted position pos, known to lie after bucket b: usually b + 1; a search when empty buckets follow (sparse
-// scalar vectors - Z = 1, zero-padded quotient chunks - leave most buckets empty: a linear walk would cost a load per bucket)
-PLK_DI uint32_t next_bucket(const uint32_t* __restrict__ off, uint32_t b, uint32_t buckets, uint32_t pos) {
-    uint32_t lo = b + 1;
-    if (off[lo + 1] > pos) return lo;
-    uint32_t hi = buckets;  // off[lo] <= pos < off[hi]
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (off[mid] <= pos) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-template <class C>
-PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ off,
-                                uint4* __restrict__ p_start, uint4* __restrict__ p_head, uint8_t* __restrict__ head_live, uint32_t buckets,
-                                const uint32_t* __restrict__ dyn_chunk, int wshift, uint32_t n_sub, uint4* s_head, uint8_t* s_parked, uint32_t tab_entries) {
-    using FP = typename C::FP;
-    constexpr int W = FP::NL / 4;
-    constexpr int RU = raw_u4<FP>();
-    const int tid = threadIdx.x;
-    const uint32_t lane = blockIdx.x * blockDim.x + tid;
-    const uint32_t total = off[buckets];
-    const uint32_t chunk = dyn_chunk[0];
-    const uint64_t begin64 = (uint64_t)lane * chunk;
-    const bool active = begin64 < total;
-    XyzzZ<FP> acc = xyzzz_identity<FP>();
-    bool head = false, parked = false;
-    uint32_t b = 0;
-    if (active) {
-        const uint32_t begin = (uint32_t)begin64;
-        const uint32_t end = (uint32_t)min((uint64_t)total, begin64 + chunk);
-        // bucket of the first entry: largest b with off[b] <= begin (empty buckets share an offset with their successor)
-        uint32_t lo = 0, hi = buckets;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (off[mid] <= begin) lo = mid; else hi = mid;
-        }
-        b = lo;
-        uint32_t next = off[b + 1];
-        head = off[b] < begin;  // the bucket was already running: this lane's first piece is a head piece
-        // entry ids are window * n + generator; with tables that is the table index, without (table-free mode:
-        // n_sub = n, buckets of window w are [w << wshift, (w + 1) << wshift)) the window part is taken off
-        const uint32_t ent_sub = (b >> wshift) * n_sub;
-        // Software pipeline: the table gather for entry k+1 (two dependent loads: index, then a random
-        // 64/96-byte point) is issued before the ~10^4-cycle addition of entry k.
-        (void)PLK_CHK(b < buckets && end <= total, CHK_ENTRY_RANGE);
-        uint32_t ent = sorted[begin];
-        Fe<FP> x, y;
-        bool ident = true;
-        if (PLK_CHK((ent >> 1) - ent_sub < tab_entries, CHK_TABLE_INDEX)) ident = affine_load<FP>(tab + (size_t)((ent >> 1) - ent_sub) * 2 * W, x, y);
-        for (uint32_t k = begin; k < end; ++k) {
-            if (k == next) {  // entry k opens a new bucket: the piece of the old one is closed
-                xyzzz_settle<FP>(acc);  // the additions keep Y uncarried (ecz.cuh): move its carries before the piece is stored
-                if (head) {
-                    xyzzz_store_raw<FP>(s_head + tid * RU, acc);
-                    parked = true;
-                } else if (PLK_CHK(b < buckets, CHK_BUCKET)) {
-                    xyzzz_store_raw<FP>(p_start + (size_t)b * RU, acc);
-                }
-                head = false;
-                acc.inf = true;  // the coordinates stay as they are (36 register clears less): the next addition overwrites them (ecz.cuh)
-                b = next_bucket(off, b, buckets, k);
-                next = off[b + 1];
-            }
-            const uint32_t cur = ent;
-            const Fe<FP> cx = x, cy = y;
-            const bool cident = ident;
-            if (k + 1 < end) {
-                // the next entry may belong to a later bucket (another window in table-free mode): its bucket is known here
-                const uint32_t nb = k + 1 == next ? next_bucket(off, b, buckets, k + 1) : b;
-                const uint32_t nsub = (nb >> wshift) * n_sub;
-                ent = sorted[k + 1];
-                ident = true;
-                if (PLK_CHK((ent >> 1) - nsub < tab_entries && nb < buckets, CHK_TABLE_INDEX))
-                    ident = affine_load<FP>(tab + (size_t)((ent >> 1) - nsub) * 2 * W, x, y);
-            }
-            if (cident) continue;
-            xyzzz_madd_entry<FP>(acc, cx, cy, (cur & 1u) != 0);
-        }
-        xyzzz_settle<FP>(acc);
-    }
-    s_parked[tid] = parked ? 1 : 0;
-    __syncthreads();
-    if (!active) return;
-    // the successor's closed head piece continues this lane's last bucket
-    if (tid + 1 < ACC_THREADS && s_parked[tid + 1]) acc = xyzzz_add<FP>(acc, xyzzz_load_raw<FP>(s_head + (tid + 1) * RU));
-    if (head) {
-        xyzzz_store_raw<FP>(p_head + (size_t)lane * RU, acc);  // the whole chunk lies inside one bucket
-    } else {
-        xyzzz_store_raw<FP>(p_start + (size_t)b * RU, acc);
-        if (parked && tid == 0) {  // no predecessor in this block: the head piece stays a head piece
-            const XyzzZ<FP> h = xyzzz_load_raw<FP>(s_head);
-            xyzzz_store_raw<FP>(p_head + (size_t)lane * RU, h);
-        }
-    }
-    head_live[lane] = (head || (parked && tid == 0)) ? 1 : 0;
-}
-#ifndef PLK_ACC_WAVES
-#define PLK_ACC_WAVES 1  // waves per SIMD the register allocation of the accumulation is held to (tuning builds: tools/acc_ab.sh)
-#endif
-#if PLK_ACC_WAVES > 0
-#define PLK_ACC_BOUNDS __launch_bounds__(ACC_THREADS, PLK_ACC_WAVES)
-#else
-#define PLK_ACC_BOUNDS __launch_bounds__(ACC_THREADS)  // round 2's form (A/B builds)
-#endif
-template <class C>
-__global__ void PLK_ACC_BOUNDS k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
-                                                                const uint32_t* __restrict__ off, uint4* __restrict__ p_start, uint4* __restrict__ p_head,
-                                                                uint8_t* __restrict__ head_live, uint32_t buckets, const uint32_t* __restrict__ dyn_chunk,
-                                                                int wshift, uint32_t n_sub, uint32_t tab_entries) {
-    __shared__ uint4 s_head[ACC_THREADS * raw_u4<typename C::FP>()];
-    __shared__ uint8_t s_parked[ACC_THREADS];
-    msm_accumulate_body<C>(tab, sorted, off, p_start, p_head, head_live, buckets, dyn_chunk, wshift, n_sub, s_head, s_parked, tab_entries);
-}
-
-// ---------------------------------------------------------------------------------------------
-// reduction  sum_d d * bucket_d   (replaces the serial Yao tail of curve_msm.rs:149-154)
-// ---------------------------------------------------------------------------------------------
-// Steps (all batched over the MSMs of a group: blockIdx.y / a factor of blockIdx.z picks the MSM's slot):
-//  * buckets with very many head pieces (a hot digit of a skewed witness) are summed by whole workgroups (k_msm_heavy_*);
-//  * k_msm_assemble: bucket = start piece + head pieces;
-//  * two-level weighting (tabled mode, many buckets): with b = hi 2^L + lo, sum_b (b + 1) B_b =
-//    2^L sum_hi hi R_hi + sum_lo (lo + 1) C_lo, R_hi / C_lo the row / column sums of the 2^H x 2^L bucket grid:
-//    2 additions per bucket at one lane each (k_msm_gsum: groups of G serially; k_msm_lsum: the rest by wave shuffles),
-//    which leaves two weighted sums over 2^H and 2^L points;
-//  * those (or, with few buckets and in table-free mode, the buckets themselves) go through bit-plane tree sums on quads,
-//    sum_d d P_d = sum_p 2^p sum_{d: bit p} P_d, are doubled into place and added (k_msm_planes, k_msm_final, k_msm_combine),
-//    then normalised (to_affine, curve.rs:206-214).
-template <class FP> PLK_DI XyzzZ<FP> wave_sum(XyzzZ<FP> v, int width) {
-    for (int m = 1; m < width; m <<= 1) v = xyzzz_add<FP>(v, xyzzz_shfl_xor<FP>(v, m));
-    return v;
-}
-
-constexpr int TAIL_MAX = 16;
-struct TailSlot {
-    const uint32_t* off;  // bucket offsets off[buckets + 1]
-    uint4* p_start;       // raw, one per bucket (becomes the assembled bucket)
-    const uint4* p_head;  // raw, one per accumulation lane
-    const uint8_t* head_live;  // 1: p_head[lane] holds a piece that is not part of a start piece yet
-    uint4* bucket;        // packed points: the operands of the plane sums
-    uint32_t* heavy;
-    uint4* heavy_part;    // raw
-    uint4* line_part;     // raw: row partials then column partials
-    uint4* plane_part;
-    uint4* win_pts;
-    uint32_t* final_done;  // windows finished by k_msm_final (the last one adds them up); zero between executions
-    const uint32_t* dyn_chunk;  // entries per accumulation lane of this execution (k_ord_scan1)
-    uint4* out_xy;
-    uint8_t* out_zero;
-};
-struct TailBatch {
-    int count;
-    TailSlot s[TAIL_MAX];
-};
-
-constexpr uint32_t HEAVY_HEADS = 32;   // more head pieces than this PER LANE of k_msm_assemble (2^lpb_log lanes per bucket): the bucket is summed by workgroups
-constexpr uint32_t HEAVY_CHUNK = 2048;
-
-// head pieces of bucket b: lanes first .. first + count - 1
-PLK_DI bool bucket_heads(const uint32_t* __restrict__ off, uint32_t b, uint32_t chunk, uint32_t& first, uint32_t& count) {
-    const uint32_t o0 = off[b], o1 = off[b + 1];
-    first = 0;
-    count = 0;
-    if (o1 == o0) return false;
-    const uint32_t l0 = o0 / chunk, l1 = (o1 - 1) / chunk;
-    first = l0 + 1;
-    count = l1 - l0;
-    return true;
-}
-
-// heavy[0] = number of work items, heavy[1] = number of heavy buckets;
-// items at heavy[2 + 2k] = bucket, heavy[3 + 2k] = chunk index; heavy bucket ids at heavy[2 + 2 cap + k]
-__global__ void __launch_bounds__(256) k_msm_heavy_list(TailBatch tb, uint32_t buckets, uint32_t cap, int lpb_log) {
-    const uint32_t* __restrict__ off = tb.s[blockIdx.y].off;
-    const uint32_t chunk = tb.s[blockIdx.y].dyn_chunk[0];
-    uint32_t* __restrict__ heavy = tb.s[blockIdx.y].heavy;
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= buckets) return;
-    uint32_t first, ns;
-    bucket_heads(off, b, chunk, first, ns);
-    // (a small MSM - an IPA round over frozen generators: 2^10 buckets of ~190 entries, 8-entry chunks - has 24-48 head pieces in
-    // EVERY bucket; k_msm_assemble takes up to 32 per lane, so with 8 lanes per bucket nothing there is heavy)
-    if (ns <= (HEAVY_HEADS << lpb_log)) return;
-    const uint32_t chunks = (ns + HEAVY_CHUNK - 1) / HEAVY_CHUNK;
-    const uint32_t at = atomicAdd(&heavy[0], chunks);
-    const uint32_t hb = atomicAdd(&heavy[1], 1u);
-    if (hb < cap) heavy[2 + 2 * cap + hb] = b;
-    for (uint32_t k = 0; k < chunks; ++k)
-        if (at + k < cap) {
-            heavy[2 + 2 * (at + k)] = b;
-            heavy[3 + 2 * (at + k)] = k;
-        }
-}
-
-template <class FP> PLK_DI XyzzZ<FP> block256_sum(XyzzZ<FP> acc, uint4* s_pts) {
-    constexpr int RU = raw_u4<FP>();
-    acc = wave_sum<FP>(acc, 64);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) xyzzz_store_raw<FP>(s_pts + wave * RU, acc);
-    __syncthreads();
-    acc = (wave == 0 && lane < 4) ? xyzzz_load_raw<FP>(s_pts + lane * RU) : xyzzz_identity<FP>();
-    if (wave == 0) acc = wave_sum<FP>(acc, 4);
-    __syncthreads();
-    return acc;  // valid in thread 0
-}
-
-// one workgroup per (bucket, chunk) item: chunk partial -> heavy_part[item]
-template <class C>
-__global__ void __launch_bounds__(256) k_msm_heavy_chunks(TailBatch tb, uint32_t cap) {
-    using FP = typename C::FP;
-    constexpr int RU = raw_u4<FP>();
-    __shared__ uint4 s_pts[4 * RU];
-    const uint32_t chunk = tb.s[blockIdx.y].dyn_chunk[0];
-    const uint4* __restrict__ p_head = tb.s[blockIdx.y].p_head;
-    const uint32_t* __restrict__ off = tb.s[blockIdx.y].off;
-    const uint32_t* __restrict__ heavy = tb.s[blockIdx.y].heavy;
-    uint4* __restrict__ heavy_part = tb.s[blockIdx.y].heavy_part;
-    const uint32_t items = min(heavy[0], cap);
-    for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
-        const uint32_t b = heavy[2 + 2 * it], k = heavy[3 + 2 * it];
-        uint32_t first, ns;
-        bucket_heads(off, b, chunk, first, ns);
-        const uint32_t s0 = first + k * HEAVY_CHUNK, s1 = min(first + ns, s0 + HEAVY_CHUNK);
-        XyzzZ<FP> acc = xyzzz_identity<FP>();
-        for (uint32_t s = s0 + threadIdx.x; s < s1; s += 256)
-            if (tb.s[blockIdx.y].head_live[s]) acc = xyzzz_add<FP>(acc, xyzzz_load_raw<FP>(p_head + (size_t)s * RU));
-        acc = block256_sum<FP>(acc, s_pts);
-        if (threadIdx.x == 0) xyzzz_store_raw<FP>(heavy_part + (size_t)it * RU, acc);
-    }
-}
-// one workgroup per heavy bucket: its start piece + the sum of its chunk partials -> p_start[b] (the whole bucket)
-template <class C>
-__global__ void __launch_bounds__(256) k_msm_heavy_final(TailBatch tb, uint32_t cap) {
-    using FP = typename C::FP;
-    constexpr int RU = raw_u4<FP>();
-    __shared__ uint4 s_pts[4 * RU];
-    const uint32_t* __restrict__ heavy = tb.s[blockIdx.y].heavy;
-    const uint4* __restrict__ heavy_part = tb.s[blockIdx.y].heavy_part;
-    uint4* __restrict__ p_start = tb.s[blockIdx.y].p_start;
-    const uint32_t items = min(heavy[0], cap), nb = min(heavy[1], cap);
-    for (uint32_t hb = blockIdx.x; hb < nb; hb += gridDim.x) {
-        const uint32_t b = heavy[2 + 2 * cap + hb];
-        XyzzZ<FP> acc = threadIdx.x == 0 ? xyzzz_load_raw<FP>(p_start + (size_t)b * RU) : xyzzz_identity<FP>();
-        for (uint32_t it = threadIdx.x; it < items; it += 256)
-            if (heavy[2 + 2 * it] == b) acc = xyzzz_add<FP>(acc, xyzzz_load_raw<FP>(heavy_part + (size_t)it * RU));
-        acc = block256_sum<FP>(acc, s_pts);
-        if (threadIdx.x == 0) xyzzz_store_raw<FP>(p_start + (size_t)b * RU, acc);
-    }
-}
-
-// bucket = start piece + the head pieces that are still live, 2^lpb_log adjacent lanes per bucket (each takes every
-// 2^lpb_log-th head, shuffles combine).  PACKED: the result goes to bucket[] in the packed exchange format (operand of the
-// plane sums); else it stays in p_start[] raw, which is only rewritten when something was added (or the bucket is empty).
-template <class C, bool PACKED>
-__global__ void __launch_bounds__(256) k_msm_assemble(TailBatch tb, uint32_t buckets, int lpb_log) {
-    using FP = typename C::FP;
-    constexpr int W = FP::NL / 4;
-    constexpr int RU = raw_u4<FP>();
-    const TailSlot& sl = tb.s[blockIdx.y];
-    const uint32_t chunk = sl.dyn_chunk[0];
-    if (blockIdx.x == 0 && threadIdx.x < 2) sl.heavy[threadIdx.x] = 0;  // the counters of k_msm_heavy_list are free again
-    if (blockIdx.x == 0 && threadIdx.x == 2) *sl.final_done = 0;        // and so is k_msm_final's (left at zero by its last block anyway)
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t b = gid >> lpb_log, part = gid & ((1u << lpb_log) - 1u);
-    XyzzZ<FP> acc = xyzzz_identity<FP>();
-    bool nonempty = false, touched = false;
-    if (b < buckets) {
-        uint32_t first, ns;
-        nonempty = bucket_heads(sl.off, b, chunk, first, ns);
-        uint32_t live = 0;
-        if (ns <= (HEAVY_HEADS << lpb_log))  // heavier buckets are already whole (k_msm_heavy_final)
-            for (uint32_t h = part; h < ns; h += 1u << lpb_log) live |= sl.head_live[first + h] ? (1u << (h >> lpb_log)) : 0u;  // ns <= 32
-        touched = live != 0;
-        if (lpb_log > 0 || PACKED || touched) {
-            if (nonempty && part == 0) acc = xyzzz_load_raw<FP>(sl.p_start + (size_t)b * RU);
-            for (uint32_t h = part, k = 0; h < ns && live; h += 1u << lpb_log, ++k)
-                if ((live >> k) & 1u) acc = xyzzz_add<FP>(acc, xyzzz_load_raw<FP>(sl.p_head + (size_t)(first + h) * RU));
-        }
-    }
-    if (lpb_log > 0) acc = wave_sum<FP>(acc, 1 << lpb_log);  // the lanes of a bucket are adjacent; every lane takes part in the shuffles
-    if (b < buckets && part == 0) {
-        if constexpr (PACKED) xyzzz_store_packed<FP>(sl.bucket + (size_t)b * 4 * W, acc);
-        else if (lpb_log > 0 || touched || !nonempty) xyzzz_store_raw<FP>(sl.p_start + (size_t)b * RU, acc);
-    }
-}
-
-// Two-level weighting, step 1: partial row and column sums over groups of G = 2^g_log buckets, one lane per group.
-// lanes [0, NB / G): row hi, group g: buckets (hi << L) + g G + k;   lanes [NB / G, 2 NB / G): column lo, group g:
-// buckets ((g G + k) << L) + lo (adjacent lanes = adjacent columns = adjacent addresses).
-template <class C>
-__global__ void __launch_bounds__(128) k_msm_gsum(TailBatch tb, int L, int H, int g_log) {
-    using FP = typename C::FP;
-    constexpr int RU = raw_u4<FP>();
-    const TailSlot& sl = tb.s[blockIdx.y];
-    const uint32_t nbg = (1u << (L + H)) >> g_log;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * nbg) return;
-    // table-free mode: blockIdx.z is the window, every window its own 2^H x 2^L grid of buckets and its own partials
-    const uint32_t wbase = blockIdx.z << (L + H);
-    uint4* part = sl.line_part + (size_t)blockIdx.z * 2 * nbg * RU;
-    const uint32_t G = 1u << g_log;
-    uint32_t b0, bstep;  // first bucket, distance between consecutive buckets of the group
-    uint4* dst;
-    if (t < nbg) {
-        const uint32_t pr = (1u << L) >> g_log;  // groups per row
-        const uint32_t hi = t / pr, g = t % pr;
-        b0 = wbase + (hi << L) + (g << g_log);
-        bstep = 1;
-        dst = part + (size_t)t * RU;
-    } else {
-        const uint32_t u = t - nbg;
-        const uint32_t lo = u & ((1u << L) - 1u), g = u >> L;
-        const uint32_t pc = (1u << H) >> g_log;  // groups per column
-        b0 = wbase + ((g << g_log) << L) + lo;
-        bstep = 1u << L;
-        dst = part + ((size_t)nbg + (size_t)lo * pc + g) * RU;
-    }
-    // the load of element k + 1 is in flight while element k is added
-    XyzzZ<FP> acc = xyzzz_identity<FP>();
-    XyzzZ<FP> nxt = xyzzz_load_raw<FP>(sl.p_start + (size_t)b0 * RU);
-    for (uint32_t k = 0; k < G; ++k) {
-        XyzzZ<FP> cur = nxt;
-        const uint32_t b = b0 + k * bstep;
-        if (k + 1 < G) nxt = xyzzz_load_raw<FP>(sl.p_start + (size_t)(b + bstep) * RU);
-        acc = xyzzz_add<FP>(acc, cur);
-    }
-    xyzzz_store_raw<FP>(dst, acc);
-}
-
-// step 2: the lines.  Output slot s of 2 * wb (wb = 2^H): window 0 holds the column sums C_lo at index lo (weight lo + 1),
-// window 1 the row sums R_hi at index hi - 1 (weight hi; R_0 has weight 0 and is dropped); the rest is the identity.
-// A chain of additions on few points, i.e. latency: it runs on quads (ecz_coop.cuh), 2^qpl_log adjacent quads per line (<= 16):
-// each sums its share of the line's partials, quad-wide shuffles combine.
-template <class C>
-__global__ void __launch_bounds__(256) k_msm_lsum(TailBatch tb, int L, int H, int g_log, int qpl_log) {
-    using FP = typename C::FP;
-    constexpr int W = FP::NL / 4;
-    constexpr int RU = raw_u4<FP>();
-    const TailSlot& sl = tb.s[blockIdx.y];
-    const uint32_t wb = 1u << H;
-    const uint32_t nbg = (1u << (L + H)) >> g_log;
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ql = threadIdx.x & 3;
-    const uint32_t quad = gid >> 2;
-    const uint32_t slot = quad >> qpl_log, part = quad & ((1u << qpl_log) - 1u);
-    XyzzZ<FP> acc = xyzzz_identity<FP>();
-    const uint4* lines = sl.line_part + (size_t)blockIdx.z * 2 * nbg * RU;  // blockIdx.z: the window (table-free mode)
-    if (slot < 2 * wb) {
-        const uint32_t win = slot >> H, idx = slot & (wb - 1u);
-        const uint4* src = nullptr;
-        uint32_t cnt = 0;
-        if (win == 0 && idx < (1u << L)) {
-            cnt = (1u << H) >> g_log;
-            src = lines + ((size_t)nbg + (size_t)idx * cnt) * RU;
-        } else if (win == 1 && idx + 1 < wb) {
-            cnt = (1u << L) >> g_log;
-            src = lines + (size_t)(idx + 1) * cnt * RU;
-        }
-        for (uint32_t k = part; k < cnt; k += 1u << qpl_log) acc = xyzzz_add_q<FP>(acc, xyzzz_load_raw<FP>(src + (size_t)k * RU), ql);
-    }
-    acc = wave_sum_q<FP>(acc, 1 << qpl_log, ql);
-    if (slot < 2 * wb && part == 0 && ql == 0) xyzzz_store_packed<FP>(sl.bucket + ((size_t)blockIdx.z * 2 * wb + slot) * 4 * W, acc);
-}
-
-// The planes and the final kernel run on quads (ecz_coop.cuh): four lanes per point, a doubling is 3
-// multiplication latencies deep instead of 9, an addition 4 instead of 14.
-//
-// plane p of window z: tree-sum of { bucket_b : bit p of (b + 1) } over the window's buckets.
-// grid = (parts, planes, windows), 128 quads per block.
-constexpr int PLANE_THREADS = 512;
-template <class C>
-__global__ void __launch_bounds__(PLANE_THREADS) k_msm_planes(TailBatch tb, int windows, uint32_t wbuckets) {
-    using FP = typename C::FP;
-    constexpr int W = FP::NL / 4;
-    __shared__ uint4 s_pts[(PLANE_THREADS / 64) * 4 * W];  // one packed point per wave
-    const int ql = threadIdx.x & 3, quad = threadIdx.x >> 2;
-    const int plane = blockIdx.y;
-    const int slot = blockIdx.z / windows, win = blockIdx.z % windows;
-    uint4* __restrict__ plane_part = tb.s[slot].plane_part;
-    const uint4* wb = tb.s[slot].bucket + (size_t)win * wbuckets * 4 * W;
-    XyzzZ<FP> acc = xyzzz_identity<FP>();
-    for (uint32_t b = blockIdx.x * (PLANE_THREADS / 4) + quad; b < wbuckets; b += gridDim.x * (PLANE_THREADS / 4)) {
-        if (((b + 1u) >> plane) & 1u) acc = xyzzz_add_q<FP>(acc, xyzzz_load_packed<FP>(wb + (size_t)b * 4 * W), ql);
-    }
-    acc = wave_sum_q<FP>(acc, 16, ql);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) xyzzz_store_packed<FP>(s_pts + wave * 4 * W, acc);
-    __syncthreads();
-    if (wave == 0) {
-        acc = (lane >> 2) < PLANE_THREADS / 64 ? xyzzz_load_packed<FP>(s_pts + (lane >> 2) * 4 * W) : xyzzz_identity<FP>();
-        acc = wave_sum_q<FP>(acc, PLANE_THREADS / 64, ql);
-        if (lane == 0)
-            xyzzz_store_packed<FP>(plane_part + (((size_t)win * gridDim.y + plane) * gridDim.x + blockIdx.x) * 4 * W, acc);
-    }
-}
-
-// One block per window: sum_p 2^p (sum of the parts of plane p), one quad per (plane, part); parts a power of
-// two <= 16, planes <= 32, planes * parts <= 256.  With one window (tables) the block also normalises the result; with several
-// (table-free mode) it doubles its window into place, 2^(c * window), and k_msm_combine adds the windows.
-constexpr int FINAL_FUSE_WINDOWS = 4;  // up to this many tail windows are added by the last block of k_msm_final itself
-constexpr int FINAL_THREADS = 512;  // <= 8 waves, so the compiler may use 256 VGPRs: the point arithmetic must not spill
-// (256-thread workgroups - one wave per SIMD - were measured for the planes and this kernel: the same 66 / 139 us at c = 20, and the
-// one-shot MSM with its 2 x 13 tail windows went from 2.8 to 4.4 ms)
-template <class C>
-__global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int windows, int parts, int planes, int window_bits, int pair_shift) {
-    using FP = typename C::FP;
-    constexpr int W = FP::NL / 4;
-    __shared__ uint4 s_pts[33 * 4 * W];
-    const int tid = threadIdx.x, ql = tid & 3, item = tid >> 2;
-    const int slot = blockIdx.x / windows;
-    const uint4* __restrict__ plane_part = tb.s[slot].plane_part;
-    // a quad takes two parts when there are several (then 4 * planes * parts / 2 <= FINAL_THREADS), else one
-    const int ipq = parts > 1 ? 2 : 1, qpp = parts / ipq;  // quads per plane
-    const int plane = item / qpp, sub = item % qpp;
-    const int win = blockIdx.x % windows;
-    const bool live = plane < planes;
-    const uint4* src = plane_part + ((size_t)(win * planes + plane) * parts + sub * ipq) * 4 * W;
-    XyzzZ<FP> acc = live ? xyzzz_load_packed<FP>(src) : xyzzz_identity<FP>();
-    if (ipq == 2) acc = xyzzz_add_q<FP>(acc, live ? xyzzz_load_packed<FP>(src + 4 * W) : xyzzz_identity<FP>(), ql);
-    acc = wave_sum_q<FP>(acc, qpp, ql);  // the quads of a plane are adjacent in one wave
-    if (live && sub == 0) {
-        for (int k = 0; k < plane; ++k) acc = xyzzz_dbl_q<FP>(acc, ql);
-        if (ql == 0) xyzzz_store_packed<FP>(s_pts + plane * 4 * W, acc);
-    }
-    __syncthreads();
-    if (tid < 128) {  // the planes: 32 quads, two waves
-        acc = item < planes ? xyzzz_load_packed<FP>(s_pts + item * 4 * W) : xyzzz_identity<FP>();
-        acc = wave_sum_q<FP>(acc, 16, ql);
-        if (tid == 64) xyzzz_store_packed<FP>(s_pts + 32 * 4 * W, acc);
-    }
-    __syncthreads();
-    if (tid < 4) {
-        if (planes > 16) acc = xyzzz_add_q<FP>(acc, xyzzz_load_packed<FP>(s_pts + 32 * 4 * W), ql);
-        // pair_shift < 0: window `win` weighs 2^(win * window_bits).  Two-level tail: the windows come in pairs (column sums,
-        // row sums) of real window win / 2, the row sums shifted by pair_shift = L more
-        const int shift = pair_shift < 0 ? win * window_bits : (win >> 1) * window_bits + (win & 1) * pair_shift;
-        for (int k = 0; k < shift; ++k) acc = xyzzz_dbl_q<FP>(acc, ql);
-        if (windows == 1) {
-            if (tid == 0) emit_affine<FP, true>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
-        } else {
-            uint4* win_pts = tb.s[slot].win_pts;
-            if (tid == 0) xyzzz_store_packed<FP>(win_pts + (size_t)win * 4 * W, acc);
-            if (windows <= FINAL_FUSE_WINDOWS) {
-                // few windows (two in the two-level mode): the block that finishes last adds them up - no launch of its own
-                uint32_t seen = 0;
-                if (tid == 0) {
-                    __threadfence();
-                    seen = atomicAdd(tb.s[slot].final_done, 1u);
-                }
-                seen = __shfl(seen, 0, 4);
-                if (seen == (uint32_t)windows - 1u) {
-                    __threadfence();
-                    for (int o = 0; o < windows; ++o)
-                        if (o != win) acc = xyzzz_add_q<FP>(acc, xyzzz_load_packed_volatile<FP>(win_pts + (size_t)o * 4 * W), ql);
-                    if (tid == 0) {
-                        *tb.s[slot].final_done = 0;
-                        emit_affine<FP, true>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
-                    }
-                }
-            }
-        }
-    }
-}
-
-// table-free mode: the sum of the windows (<= 128 points, already doubled into place), normalised
-constexpr int COMBINE_THREADS = 512;
-template <class C>
-__global__ void __launch_bounds__(COMBINE_THREADS) k_msm_combine(TailBatch tb, int windows) {
-    using FP = typename C::FP;
-    constexpr int W = FP::NL / 4;
-    __shared__ uint4 s_pts[(COMBINE_THREADS / 64) * 4 * W];
-    const uint4* __restrict__ win_pts = tb.s[blockIdx.x].win_pts;
-    uint4* __restrict__ out_xy = tb.s[blockIdx.x].out_xy;
-    uint8_t* __restrict__ out_zero = tb.s[blockIdx.x].out_zero;
-    const int tid = threadIdx.x, ql = tid & 3, item = tid >> 2;
-    XyzzZ<FP> acc = item < windows ? xyzzz_load_packed<FP>(win_pts + (size_t)item * 4 * W) : xyzzz_identity<FP>();
-    acc = wave_sum_q<FP>(acc, 16, ql);
-    if ((tid & 63) == 0) xyzzz_store_packed<FP>(s_pts + (tid >> 6) * 4 * W, acc);
-    __syncthreads();
-    if (tid < 64) {
-        acc = item < COMBINE_THREADS / 64 ? xyzzz_load_packed<FP>(s_pts + item * 4 * W) : xyzzz_identity<FP>();
-        acc = wave_sum_q<FP>(acc, COMBINE_THREADS / 64, ql);
-        if (tid == 0) emit_affine<FP, true>(acc, out_xy, out_zero);
-    }
-}
 
 template <class FP> PLK_DI Xyzz<FP> block_sum(Xyzz<FP> v, uint4* s_pts) {
     constexpr int W = FP::NL / 4;
@@ -1182,11 +249,22 @@ __global__ void __launch_bounds__(64) k_combine_partials(const uint8_t* __restri
     const unsigned slot = is_whole ? v / world : whole + (v - whole * world);
     const unsigned r0 = is_whole ? v % world : 0, r1 = is_whole ? r0 + 1 : world;
     Xyzz<FP> acc = xyzz_identity<FP>();
+    // The records were written by OTHER devices (peer copies over xGMI, multi.hip), by RCCL or through the host, into a buffer this
+    // device may have read before (the scratch pool hands it out again): every word is read at SYSTEM scope, past this device's
+    // caches - a few hundred bytes per rank, so the price is nothing, and the hand-over does not depend on what a kernel boundary
+    // invalidates (each XCD has its own L2; MI355X_MICROARCH.md).  Records are 16-byte aligned (msm_partials_bytes).
+    auto word = [](const uint8_t* p) { return __hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
     for (unsigned r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
         const uint8_t* rec = gathered + (size_t)r * rec_bytes;
-        if (rec[(size_t)slots * 2 * W * 16 + slot]) continue;
-        const uint4* pt = (const uint4*)(rec + (size_t)slot * 2 * W * 16);
-        Fe<FP> x = fe_load<FP>(pt), y = fe_load<FP>(pt + W);
+        const size_t flag_at = (size_t)slots * 2 * W * 16 + slot;
+        if ((word(rec + (flag_at & ~(size_t)3)) >> (8 * (flag_at & 3))) & 0xffu) continue;
+        const uint8_t* pt = rec + (size_t)slot * 2 * W * 16;
+        Fe<FP> x, y;
+#pragma unroll
+        for (int i = 0; i < FP::NL; ++i) {
+            x.v[i] = word(pt + 4 * i);
+            y.v[i] = word(pt + 4 * (FP::NL + i));
+        }
         xyzz_madd<FP>(acc, x, y);
     }
     acc = block_sum<FP>(acc, s_pts);
@@ -1482,7 +560,7 @@ template <class C> static size_t accumulate_slots() {
     if (s == 0) {
         int per_cu = 0, cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_accumulate<C>, ACC_THREADS, 0) != hipSuccess || per_cu <= 0) per_cu = 6;
+        per_cu = msm_accumulate_blocks_per_cu<C>();
         s = (size_t)per_cu * ACC_THREADS * (size_t)cus;
     }
     return s;
@@ -1863,40 +941,18 @@ static TailSlot tail_slot(const plk_msm_ctx* ctx, const MsmWork& w, void* d_out_
     return t;
 }
 
-// pieces -> buckets -> (row / column sums ->) bit-plane sums -> result, for the tb.count MSMs of a batch at once
+// pieces -> buckets -> (row / column sums ->) bit-plane sums -> result, for the tb.count MSMs of a batch at once (msm_tail.hip)
 template <class C, class Mark>
-static int msm_reduce_t(plk_msm_ctx* ctx, TailBatch tb, hipStream_t stream, Mark&& mark) {
-    const uint32_t buckets = ctx->buckets;
-    const unsigned cnt = (unsigned)tb.count;
-    // hot buckets of a skewed scalar distribution (none for uniform scalars: the three launches then exit at once)
-    k_msm_heavy_list<<<dim3((buckets + 255) / 256, cnt), 256, 0, stream>>>(tb, buckets, ctx->heavy_cap, ctx->lpb_log);
-    k_msm_heavy_chunks<C><<<dim3(256, cnt), 256, 0, stream>>>(tb, ctx->heavy_cap);
-    k_msm_heavy_final<C><<<dim3(64, cnt), 256, 0, stream>>>(tb, ctx->heavy_cap);
-    const unsigned ab = (unsigned)((((size_t)buckets << ctx->lpb_log) + 255) / 256);
-    if (ctx->two_level) {
-        const uint32_t nbg = (1u << (ctx->L + ctx->H)) >> ctx->g_log;  // groups per window (rows; as many for the columns)
-        const unsigned wins = ctx->table_free ? (unsigned)ctx->windows : 1u;
-        // (Reading the pieces directly in the row / column sums - no k_msm_assemble pass - was built and measured in round 3: the merge of
-        // the rare live head pieces, inlined or out of line, takes k_msm_gsum from ~100 to 226-232 registers, and the tail went from
-        // 0.228 to 0.259 ms.  The separate 44 us pass stays.)
-        k_msm_assemble<C, false><<<dim3(ab, cnt), 256, 0, stream>>>(tb, buckets, ctx->lpb_log);
-        k_msm_gsum<C><<<dim3((2 * nbg + 127) / 128, cnt, wins), 128, 0, stream>>>(tb, ctx->L, ctx->H, ctx->g_log);
-        const size_t lanes = ((size_t)2 << ctx->H) << (ctx->lpl_log + 2);
-        k_msm_lsum<C><<<dim3((unsigned)((lanes + 255) / 256), cnt, wins), 256, 0, stream>>>(tb, ctx->L, ctx->H, ctx->g_log, ctx->lpl_log);
-    } else {
-        k_msm_assemble<C, true><<<dim3(ab, cnt), 256, 0, stream>>>(tb, buckets, ctx->lpb_log);
+static int msm_reduce_t(plk_msm_ctx* ctx, const TailBatch& tb, hipStream_t stream, Mark&& mark) {
+    TailGeom g;
+    g.buckets = ctx->buckets; g.heavy_cap = ctx->heavy_cap; g.tail_wbuckets = ctx->tail_wbuckets;
+    g.lpb_log = ctx->lpb_log; g.two_level = ctx->two_level ? 1 : 0; g.L = ctx->L; g.H = ctx->H; g.g_log = ctx->g_log; g.lpl_log = ctx->lpl_log;
+    g.table_free = ctx->table_free ? 1 : 0; g.windows = ctx->windows; g.tail_windows = ctx->tail_windows; g.plane_blocks = ctx->plane_blocks;
+    g.planes = ctx->planes; g.tail_shift = ctx->tail_shift;
+    for (int stage = 0; stage < 3; ++stage) {
+        PLK_TRY(msm_launch_reduce_stage<C>(stage, g, tb, stream));
+        mark();
     }
-    PLK_HIP_TRY(hipGetLastError());
-    mark();
-    const int tw = ctx->tail_windows;
-    dim3 pg(ctx->plane_blocks, ctx->planes, tw * cnt);
-    k_msm_planes<C><<<pg, PLANE_THREADS, 0, stream>>>(tb, tw, ctx->tail_wbuckets);
-    PLK_HIP_TRY(hipGetLastError());
-    mark();
-    k_msm_final<C><<<tw * cnt, FINAL_THREADS, 0, stream>>>(tb, tw, ctx->plane_blocks, ctx->planes, ctx->tail_shift, ctx->two_level ? ctx->L : -1);
-    if (tw > FINAL_FUSE_WINDOWS) k_msm_combine<C><<<cnt, COMBINE_THREADS, 0, stream>>>(tb, tw);
-    PLK_HIP_TRY(hipGetLastError());
-    mark();
     return PLK_OK;
 }
 
@@ -1951,7 +1007,7 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
             // the two half scalars of every scalar (stream-ordered scratch: handed back once the ordering kernels are enqueued)
             halves = scratch_acquire(n * 32, stream);
             if (!halves) return PLK_ERR_OOM;
-            k_glv_split<C><<<(unsigned)((ctx->n + 255) / 256), 256, 0, stream>>>((const uint4*)d_scalars, ctx->n, (uint4*)halves);
+            PLK_TRY(msm_launch_glv_split<C>(d_scalars, ctx->n, halves, stream));
             d_scalars = halves;
         }
         // the pooled buffers of this call go back on every path out of it
@@ -1967,24 +1023,15 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
                 if (!ev.empty()) ctx->prof_free.push_back(ev);
             }
         } guard{halves, ev, ctx, stream};
-        k_ord_count<C><<<o.nt1, ORD_THREADS, 0, stream>>>((const uint4*)d_scalars, n, o, (uint32_t*)w.cnt1);
-        const bool one_level = o.fine_bits == 0;
-        k_ord_scan1<<<o.nbins, 256, 0, stream>>>((uint32_t*)w.cnt1, o.nt1, o.nbins, bin_total, bin_base, seg_base, done_counter, done_counter + 2,
-                                                 ctx->chunk, (uint32_t)(ctx->max_lanes > 2 ? ctx->max_lanes - 2 : 1), one_level ? off : nullptr);
-        PLK_HIP_TRY(hipGetLastError());
+        OrdBuffers ob;
+        ob.scalars = d_scalars; ob.n = n; ob.cnt1 = w.cnt1; ob.tmp = w.tmp; ob.sorted = w.sorted; ob.cnt2 = w.cnt2; ob.off = off;
+        ob.bin_total = bin_total; ob.bin_base = bin_base; ob.seg_base = seg_base; ob.done_counter = done_counter;
+        ob.chunk = ctx->chunk; ob.lanes = (uint32_t)(ctx->max_lanes > 2 ? ctx->max_lanes - 2 : 1); ob.buckets = buckets;
+        PLK_TRY(msm_launch_order_stage<C>(0, o, ob, stream));
         mark();
-        k_ord_scatter<C><<<o.nt1, ORD_THREADS, 0, stream>>>((const uint4*)d_scalars, n, o, (const uint32_t*)w.cnt1, bin_base, (uint2*)w.tmp,
-                                                            one_level ? (uint32_t*)w.sorted : nullptr);
-        PLK_HIP_TRY(hipGetLastError());
+        PLK_TRY(msm_launch_order_stage<C>(1, o, ob, stream));
         mark();
-        if (!one_level) {
-            // the number of segments is only known on the device: launch for the upper bound (+ nbins blocks that write the
-            // offsets of the empty bins), blocks past the end exit
-            const unsigned segs = (unsigned)(n * (size_t)o.windows / ORD_SEG + o.nbins + 1);
-            k_ord_bin_count<<<segs, ORD_BIN_THREADS, 0, stream>>>((const uint2*)w.tmp, bin_base, seg_base, o.fine_bits, o.nbins, (uint32_t*)w.cnt2);
-            k_ord_bin_scatter<<<segs + o.nbins, ORD_BIN_THREADS, 0, stream>>>((const uint2*)w.tmp, bin_base, seg_base, o.fine_bits, o.nbins, buckets,
-                                                                              (const uint32_t*)w.cnt2, off, (uint32_t*)w.sorted, o.entries_cap);
-        }
+        PLK_TRY(msm_launch_order_stage<C>(2, o, ob, stream));
         PLK_HIP_TRY(hipGetLastError());
         guard.armed = false;
         if (halves) scratch_release(halves, stream);
@@ -1995,11 +1042,10 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
     if (phases & PH_ACC) {
         // the entry count is only known on the device: launch for the upper bound, lanes past it exit
         const unsigned ablocks = (unsigned)((ctx->max_lanes + ACC_THREADS - 1) / ACC_THREADS);
-        k_msm_accumulate<C><<<ablocks, ACC_THREADS, 0, stream>>>((const uint4*)ctx->tab, (const uint32_t*)w.sorted, off, (uint4*)w.p_start, (uint4*)w.p_head,
-                                                                 (uint8_t*)w.head_live, buckets, done_counter + 2, ctx->table_free ? ctx->c - 1 : 31,
-                                                                 ctx->table_free ? (uint32_t)n : 0u,
-                                                                 // tabled: sorted[] entries index the table; table-free: the table holds the n_eff points, sorted[] the entries
-                                                                 ctx->table_free ? (uint32_t)ctx->n_eff : o.entries_cap);
+        msm_launch_accumulate<C>(ablocks, stream, ctx->tab, w.sorted, off, w.p_start, w.p_head, w.head_live, buckets, done_counter + 2,
+                                 ctx->table_free ? ctx->c - 1 : 31, ctx->table_free ? (uint32_t)n : 0u,
+                                 // tabled: sorted[] entries index the table; table-free: the table holds the n_eff points, sorted[] the entries
+                                 ctx->table_free ? (uint32_t)ctx->n_eff : o.entries_cap);
         PLK_HIP_TRY(hipGetLastError());
     }
     mark();
@@ -2327,23 +1373,27 @@ int msm_combine_partials_dev_impl(int curve, unsigned world, unsigned batch, uns
     return PLK_OK;
 }
 
-int checked_build_impl() {
-#ifdef PLK_CHECKED
-    return 1;
-#else
-    return 0;
-#endif
-}
-// counts[8]: violations per guarded site since the library was loaded (all zero in the normal build, which has no guards)
-int checked_failures_impl(unsigned* counts) {
-    if (!counts) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
-    for (int k = 0; k < 8; ++k) counts[k] = 0;
-#ifdef PLK_CHECKED
+// the device's digit recoding on its own (plk_msm_debug_digits): d_digits = n * windows int32, windows = ceil((BITS + 1) / window_bits)
+int msm_debug_digits_impl(int curve, unsigned window_bits, size_t n, const void* d_scalars, void* d_digits, hipStream_t stream) {
+    if (window_bits < 2 || window_bits > (unsigned)MSM_MAX_WINDOW) return set_error(PLK_ERR_INVALID_ARG, "window of %u bits (2..%d)", window_bits, MSM_MAX_WINDOW);
+    if (curve < 0 || curve > PLK_CURVE_VESTA) return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    if (!n) return PLK_OK;
+    if (!d_scalars || !d_digits) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
     PLK_TRY(ensure_device());
-    PLK_HIP_TRY(hipDeviceSynchronize());
-    PLK_HIP_TRY(hipMemcpyFromSymbol(counts, HIP_SYMBOL(g_plk_chk), 8 * sizeof(unsigned)));
-#endif
-    return PLK_OK;
+    OrdCfg o{};
+    o.c = (int)window_bits;
+    o.windows = (scalar_bits(curve) + 1 + o.c - 1) / o.c;
+    switch (curve) {
+        case PLK_CURVE_TWEEDLEDEE: return msm_launch_digits<TweedledeeCurve>(d_scalars, n, o, d_digits, stream);
+        case PLK_CURVE_TWEEDLEDUM: return msm_launch_digits<TweedledumCurve>(d_scalars, n, o, d_digits, stream);
+        case PLK_CURVE_PALLAS: return msm_launch_digits<PallasCurve>(d_scalars, n, o, d_digits, stream);
+        case PLK_CURVE_VESTA: return msm_launch_digits<VestaCurve>(d_scalars, n, o, d_digits, stream);
+        default: return msm_launch_digits<Bls12377Curve>(d_scalars, n, o, d_digits, stream);
+    }
+}
+int msm_debug_digit_count(int curve, unsigned window_bits) {
+    if (curve < 0 || curve > PLK_CURVE_VESTA || window_bits < 2 || window_bits > (unsigned)MSM_MAX_WINDOW) return -1;
+    return (scalar_bits(curve) + 1 + (int)window_bits - 1) / (int)window_bits;
 }
 
 // workspaces for batches of up to `count` vectors, allocated ahead of the first batched execution

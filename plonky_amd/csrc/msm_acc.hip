@@ -1,0 +1,220 @@
+// msm_acc.hip -- the bucket accumulation of the MSM (replaces curve_msm.rs:131-145 + affine_multisummation_*, curve_summations.rs:24-158).
+// Split from msm.hip in round 5: this kernel is the one the MSM spends 60 % of its time in and the one that is tuned most.
+#include "msm_dev.cuh"
+
+namespace plk {
+
+// ---------------------------------------------------------------------------------------------
+// bucket accumulation: every lane adds exactly `chunk` consecutive sorted entries
+// ---------------------------------------------------------------------------------------------
+// The sorted entry list is cut into chunks of `chunk` entries regardless of the bucket boundaries, one lane per chunk:
+// perfectly balanced whatever the digit distribution and whatever the bucket sizes (26 entries on average at c = 20).  A
+// lane that crosses a bucket boundary stores what it has and starts over: the piece of the bucket that STARTS inside the
+// chunk goes to p_start[bucket], the piece of the bucket that was already running at the chunk's first entry goes to
+// p_head[lane].  bucket b = p_start[b] + sum of p_head[l] for the lanes l0 < l <= l1, l0 = off[b] / chunk,
+// l1 = (off[b+1] - 1) / chunk (k_msm_assemble).  Pieces are stored as they are (lazy 29-bit limbs, accumulator invariant of
+// ecz.cuh; the identity is ZZ = 0): a store inside the loop must be cheap, because some lane of the wave has one almost every round.
+// Head pieces are mostly short-lived: the head piece of lane l (closed at l's first bucket boundary) belongs to the last
+// bucket of lane l - 1, whose piece is still in registers when the loop ends.  Lanes therefore park a closed head piece in
+// LDS and their predecessor in the block adds it to its last piece before storing it: at c = 20 (26 entries per bucket,
+// 24 per lane) almost every bucket leaves the kernel whole, and k_msm_assemble only finds the head pieces of the first lane
+// of a block and of lanes that lie entirely inside one bucket (head_live[lane] = 1).
+// Memory discipline of the loop (round 5).  Until round 4 an iteration that closed a bucket made up to four DEPENDENT round trips
+// behind `s_waitcnt vmcnt(0)` - off[b + 2] (is the next bucket empty?) right after the ten stores of the piece, off[b + 1] again,
+// off[] once more for the bucket of the prefetched entry, then sorted[k + 1] before the table gather could even be issued - and
+// some lane of a wave closes a bucket in 92 % of the iterations (26 entries per bucket, 64 lanes): 27.5 % of the wave cycles
+// were parked (profiles/r04_rocprofv3_pmc_sq_wave_cycles.txt).  Now nothing in the common path waits for a load issued in the
+// same iteration:
+//  * `next2` = off[b + 2] is fetched when bucket b OPENS and first looked at when it closes (~26 iterations later): the new
+//    bucket is b + 1 unless next2 says it is empty, and only then a search runs;
+//  * the entry ids run two ahead of the additions (ent1 = sorted[k + 1] is in a register when iteration k starts), so the table
+//    gather of entry k + 1 is issued with no wait in front of it and has the whole addition of entry k to arrive.
+// largest bucket lo' >= lo with off[lo'] <= pos, given off[lo] <= pos (empty buckets share an offset with their successor)
+PLK_DI uint32_t bucket_search(const uint32_t* __restrict__ off, uint32_t lo, uint32_t buckets, uint32_t pos) {
+    uint32_t hi = buckets;  // off[lo] <= pos < off[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+// the loaded values are materialised HERE (an empty asm the compiler must feed with registers)
+template <class FP> PLK_DI void acc_pin(Fe<FP>& x, Fe<FP>& y, uint32_t& a, uint32_t& b) {
+#pragma unroll
+    for (int i = 0; i < FP::NL; ++i) asm volatile("" : "+v"(x.v[i]), "+v"(y.v[i]));
+    asm volatile("" : "+v"(a), "+v"(b) : : "memory");
+}
+template <class FP> PLK_DI void acc_gather(const uint4* src, Fe<FP>& x, Fe<FP>& y) {
+    x = fe_load<FP>(src);
+    y = fe_load<FP>(src + FP::NL / 4);
+}
+template <class C>
+PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ off,
+                                uint4* __restrict__ p_start, uint4* __restrict__ p_head, uint8_t* __restrict__ head_live, uint32_t buckets,
+                                const uint32_t* __restrict__ dyn_chunk, int wshift, uint32_t n_sub, uint4* s_head, uint8_t* s_parked, uint32_t tab_entries) {
+    using FP = typename C::FP;
+    constexpr int W = FP::NL / 4;
+    constexpr int RU = raw_u4<FP>();
+    const int tid = threadIdx.x;
+    const uint32_t lane = blockIdx.x * blockDim.x + tid;
+    const uint32_t total = off[buckets];
+    const uint32_t chunk = dyn_chunk[0];
+    const uint64_t begin64 = (uint64_t)lane * chunk;
+    const bool active = begin64 < total;
+    XyzzZ<FP> acc = xyzzz_identity<FP>();
+    bool head = false, parked = false;
+    uint32_t b = 0;
+    if (active) {
+        const uint32_t begin = (uint32_t)begin64;
+        const uint32_t end = (uint32_t)min((uint64_t)total, begin64 + chunk);
+        // bucket of the first entry: largest b with off[b] <= begin
+        b = bucket_search(off, 0, buckets, begin);
+        uint32_t next = off[b + 1];
+        uint32_t next2 = off[min(b + 2, buckets)];  // looked at when bucket b closes
+        head = off[b] < begin;  // the bucket was already running: this lane's first piece is a head piece
+        // entry ids are window * n + generator; with tables that is the table index, without (table-free mode:
+        // n_sub = n, buckets of window w are [w << wshift, (w + 1) << wshift)) the window part is taken off
+        const uint32_t ent_sub = (b >> wshift) * n_sub;
+        (void)PLK_CHK(b < buckets && end <= total, CHK_ENTRY_RANGE);
+        uint32_t ent = sorted[begin];
+        uint32_t ent1 = sorted[min(begin + 1, end - 1)];
+        // the table point of the entry in flight, as loaded: the identity flag rides in y's top word (affine_store, ec.cuh) and is
+        // only looked at when the point is consumed - testing it here would wait for the gather that was just issued
+        Fe<FP> x = fe_zero<FP>(), y = fe_zero<FP>();
+        y.v[FP::NL - 1] = AFF_IDENTITY_BIT;
+        if (PLK_CHK((ent >> 1) - ent_sub < tab_entries, CHK_TABLE_INDEX)) acc_gather<FP>(tab + (size_t)((ent >> 1) - ent_sub) * 2 * W, x, y);
+        for (uint32_t k = begin; k < end; ++k) {
+            // (1) everything this iteration reads from memory was requested at least one addition ago: entry k's table point, the id
+            // of entry k + 1, off[b + 2].  The ONE wait of the iteration sits here (acc_pin keeps the compiler from sinking it below
+            // the stores of a closed piece: the memory counter of gfx950 is in order, a wait behind them would wait for them too).
+            const uint32_t cur = ent;
+            Fe<FP> cx = x, cy = y;
+            uint32_t e1 = ent1, n2 = next2;
+            acc_pin<FP>(cx, cy, e1, n2);
+            const bool cident = (cy.v[FP::NL - 1] & AFF_IDENTITY_BIT) != 0;
+            cy.v[FP::NL - 1] &= ~AFF_IDENTITY_BIT;
+            if (k == next) {  // (2) entry k opens a new bucket: the piece of the old one is closed
+                xyzzz_settle<FP>(acc);  // the additions keep Y uncarried (ecz.cuh): move its carries before the piece is stored
+                if (head) {
+                    xyzzz_store_raw<FP>(s_head + tid * RU, acc);
+                    parked = true;
+                } else if (PLK_CHK(b < buckets, CHK_BUCKET)) {
+                    xyzzz_store_raw<FP>(p_start + (size_t)b * RU, acc);
+                }
+                head = false;
+                acc.inf = true;  // the coordinates stay as they are (36 register clears less): the next addition overwrites them (ecz.cuh)
+                uint32_t nb = b + 1, nn = n2;
+                if (n2 <= k) {  // bucket b + 1 is empty (e^-26 of the buckets at c = 20; the rule for sparse vectors)
+                    nb = bucket_search(off, b + 1, buckets, k);
+                    nn = off[nb + 1];
+                }
+                b = nb;
+                next = nn;
+                next2 = off[min(b + 2, buckets)];
+            }
+            if (k + 1 < end) {  // (3) request entry k + 1's table point and the id of entry k + 2
+                uint32_t nsub = 0;
+                if (n_sub) {
+                    // table-free mode: the next entry may belong to a later bucket in another window; its bucket is known here
+                    uint32_t nb = b;
+                    if (k + 1 == next) nb = next2 > k + 1 ? b + 1 : bucket_search(off, b + 1, buckets, k + 1);
+                    (void)PLK_CHK(nb < buckets, CHK_BUCKET);
+                    nsub = (nb >> wshift) * n_sub;
+                }
+                ent = e1;
+                ent1 = sorted[min(k + 2, end - 1)];
+#ifdef PLK_CHECKED
+                y.v[FP::NL - 1] = AFF_IDENTITY_BIT;  // a guarded (skipped) gather leaves the identity behind
+#endif
+                if (PLK_CHK((ent >> 1) - nsub < tab_entries, CHK_TABLE_INDEX)) acc_gather<FP>(tab + (size_t)((ent >> 1) - nsub) * 2 * W, x, y);
+            }
+            if (cident) continue;
+            xyzzz_madd_entry<FP>(acc, cx, cy, (cur & 1u) != 0);  // (4)
+        }
+        xyzzz_settle<FP>(acc);
+    }
+    s_parked[tid] = parked ? 1 : 0;
+    __syncthreads();
+    if (!active) return;
+    // the successor's closed head piece continues this lane's last bucket
+    if (tid + 1 < ACC_THREADS && s_parked[tid + 1]) acc = xyzzz_add<FP>(acc, xyzzz_load_raw<FP>(s_head + (tid + 1) * RU));
+    if (head) {
+        xyzzz_store_raw<FP>(p_head + (size_t)lane * RU, acc);  // the whole chunk lies inside one bucket
+    } else {
+        xyzzz_store_raw<FP>(p_start + (size_t)b * RU, acc);
+        if (parked && tid == 0) {  // no predecessor in this block: the head piece stays a head piece
+            const XyzzZ<FP> h = xyzzz_load_raw<FP>(s_head);
+            xyzzz_store_raw<FP>(p_head + (size_t)lane * RU, h);
+        }
+    }
+    head_live[lane] = (head || (parked && tid == 0)) ? 1 : 0;
+}
+#ifndef PLK_ACC_WAVES
+#define PLK_ACC_WAVES 1  // waves per SIMD the register allocation of the accumulation is held to (tuning builds: tools/acc_ab.sh)
+#endif
+#if PLK_ACC_WAVES > 0
+#define PLK_ACC_BOUNDS __launch_bounds__(ACC_THREADS, PLK_ACC_WAVES)
+#else
+#define PLK_ACC_BOUNDS __launch_bounds__(ACC_THREADS)  // round 2's form (A/B builds)
+#endif
+template <class C>
+__global__ void PLK_ACC_BOUNDS k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
+                                                                const uint32_t* __restrict__ off, uint4* __restrict__ p_start, uint4* __restrict__ p_head,
+                                                                uint8_t* __restrict__ head_live, uint32_t buckets, const uint32_t* __restrict__ dyn_chunk,
+                                                                int wshift, uint32_t n_sub, uint32_t tab_entries) {
+    __shared__ uint4 s_head[ACC_THREADS * raw_u4<typename C::FP>()];
+    __shared__ uint8_t s_parked[ACC_THREADS];
+    msm_accumulate_body<C>(tab, sorted, off, p_start, p_head, head_live, buckets, dyn_chunk, wshift, n_sub, s_head, s_parked, tab_entries);
+}
+
+// ---- host side: what msm.hip sees of this file ----------------------------------------------------------------------------
+// workgroups of the accumulation a CU holds at once (registers and LDS of THIS build of the kernel: the chunk length is sized from it)
+template <class C> int msm_accumulate_blocks_per_cu() {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msm_accumulate<C>, ACC_THREADS, 0) != hipSuccess || per_cu <= 0) per_cu = 6;
+    return per_cu;
+}
+template <class C>
+void msm_launch_accumulate(unsigned blocks, hipStream_t stream, const void* tab, const void* sorted, const void* off, void* p_start, void* p_head,
+                           void* head_live, uint32_t buckets, const uint32_t* dyn_chunk, int wshift, uint32_t n_sub, uint32_t tab_entries) {
+    k_msm_accumulate<C><<<blocks, ACC_THREADS, 0, stream>>>((const uint4*)tab, (const uint32_t*)sorted, (const uint32_t*)off, (uint4*)p_start, (uint4*)p_head,
+                                                            (uint8_t*)head_live, buckets, dyn_chunk, wshift, n_sub, tab_entries);
+}
+#define PLK_ACC_INSTANTIATE(C)                                                                                                          \
+    template int msm_accumulate_blocks_per_cu<C>();                                                                                    \
+    template void msm_launch_accumulate<C>(unsigned, hipStream_t, const void*, const void*, const void*, void*, void*, void*, uint32_t, \
+                                           const uint32_t*, int, uint32_t, uint32_t);
+PLK_ACC_INSTANTIATE(TweedledeeCurve)
+PLK_ACC_INSTANTIATE(TweedledumCurve)
+PLK_ACC_INSTANTIATE(Bls12377Curve)
+PLK_ACC_INSTANTIATE(PallasCurve)
+PLK_ACC_INSTANTIATE(VestaCurve)
+#undef PLK_ACC_INSTANTIATE
+
+// ---- the checked build (-DPLK_CHECKED: msm_acc_checked.o + msm_order_checked.o; include/plonky_hip.h) ----
+int msm_order_checked_failures(unsigned* counts);  // msm_order.hip
+PLK_CHK_READER(msm_acc_checked_failures)
+int checked_build_impl() {
+#ifdef PLK_CHECKED
+    return 1;
+#else
+    return 0;
+#endif
+}
+// counts[8]: violations per guarded site since the library was loaded (all zero in the normal build, which has no guards)
+int checked_failures_impl(unsigned* counts) {
+    if (!counts) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    for (int k = 0; k < 8; ++k) counts[k] = 0;
+#ifdef PLK_CHECKED
+    PLK_TRY(ensure_device());
+    PLK_HIP_TRY(hipDeviceSynchronize());
+    unsigned part[8];
+    PLK_TRY(msm_acc_checked_failures(part));    // the accumulation kernel's guards
+    for (int k = 0; k < 8; ++k) counts[k] += part[k];
+    PLK_TRY(msm_order_checked_failures(part));  // the ordering kernels' guards
+    for (int k = 0; k < 8; ++k) counts[k] += part[k];
+#endif
+    return PLK_OK;
+}
+
+}  // namespace plk

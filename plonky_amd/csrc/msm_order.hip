@@ -1,0 +1,438 @@
+// msm_order.hip -- the bucket ordering of the MSM: digits (to_digits, curve_msm.rs:159-180) and the two-level LDS partition that
+// replaces the reference's serial digit_occurrences scatter (curve_msm.rs:117-126).  Split from msm.hip in round 5 (build time).
+#include "msm_dev.cuh"
+#include "glv.cuh"
+
+namespace plk {
+
+// ---------------------------------------------------------------------------------------------
+// scalars -> signed window digits  (curve_msm.rs:159-180), computed where they are consumed
+// ---------------------------------------------------------------------------------------------
+// Digits are never stored: the two kernels of the first partition level recompute them from the scalars
+// (one Montgomery -> canonical conversion per scalar and kernel, ~10 instructions per digit), which replaces
+// a 4-byte write and two 4-byte reads per (scalar, window) by two extra reads of the 32-byte scalar.
+// The canonical limbs are parked in LDS (limb-major: conflict-free) so that the window loop can index them.
+
+template <class SP> PLK_DI void ord_park_scalar(const uint4* __restrict__ scalars, size_t i, uint32_t* s_lim, int tid, bool raw_signed) {
+    static_assert(SP::NL == 8, "scalar fields are 256-bit");
+    const uint4 lo = scalars[i * 2], hi = scalars[i * 2 + 1];
+    Fe<SP> s;
+    s.v[0] = lo.x; s.v[1] = lo.y; s.v[2] = lo.z; s.v[3] = lo.w;
+    s.v[4] = hi.x; s.v[5] = hi.y; s.v[6] = hi.z; s.v[7] = hi.w;
+    // Montgomery -> canonical in the SCALAR field (to_canonical_u64_vec, curve_msm.rs:164); half scalars are canonical already
+    if (!raw_signed) s = fe_to_canonical<SP>(s);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_lim[k * ORD_THREADS + tid] = s.v[k];
+}
+// digit j of the parked scalar: signed c-bit window by carry-based integer recoding (never s -> r - s, so it is valid on
+// BLS12-377 G1 whose cofactor is even).  Returns (bucket << 1) | negative, or CODE_INVALID for a zero digit.
+PLK_DI uint32_t ord_digit(const uint32_t* s_lim, int tid, int j, const OrdCfg& cfg, uint32_t& carry) {
+    const int c = cfg.c;
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    const int bp = j * c, li = bp >> 5, sh = bp & 31;
+    uint64_t two = li < 8 ? s_lim[li * ORD_THREADS + tid] : 0u;
+    if (li + 1 < 8) two |= (uint64_t)s_lim[(li + 1) * ORD_THREADS + tid] << 32;
+    const uint32_t v = ((uint32_t)(two >> sh) & mask) + carry;
+    // v in [0, 2^c]; v > 2^(c-1) becomes v - 2^c with a carry into the next window
+    const uint32_t neg = v > half ? 1u : 0u;
+    const uint32_t mag = neg ? (1u << c) - v : v;
+    carry = neg;
+    if (mag == 0) return CODE_INVALID;
+    // a negative half scalar (sign parked in bit 255, far above its windows) flips every digit
+    const uint32_t flip = cfg.raw_signed ? s_lim[7 * ORD_THREADS + tid] >> 31 : 0u;
+    return ((mag - 1u + (uint32_t)j * cfg.window_buckets) << 1) | (neg ^ flip);
+}
+
+// exclusive prefix of `v` over the threads of the block (blockDim.x a multiple of 64, <= 1024); *total (optional) = the block sum.
+// Shuffles inside a wave, one LDS word per wave across: two barriers instead of two per doubling step.  s_tmp: >= 16 words,
+// free again when the call returns.
+PLK_DI uint32_t block_excl_prefix(uint32_t v, uint32_t* s_tmp, uint32_t* total = nullptr) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t u = __shfl_up(inc, d);
+        if (lane >= d) inc += u;
+    }
+    if (lane == 63) s_tmp[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+    for (int w = 0; w < nw; ++w) {
+        const uint32_t x = s_tmp[w];
+        if (w < wave) base += x;
+        all += x;
+    }
+    if (total) *total = all;
+    __syncthreads();
+    return base + inc - v;
+}
+// exclusive scan of s_data[0..count) in place (count <= 4 * blockDim.x); s_tmp: 16 words.  The caller's writes to s_data must be
+// visible (a barrier before the call); ends with a barrier.
+PLK_DI void block_excl_scan4(uint32_t* s_data, int count, uint32_t* s_tmp) {
+    const int t = threadIdx.x;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = t * 4 + k;
+        v[k] = idx < count ? s_data[idx] : 0u;
+        sum += v[k];
+    }
+    uint32_t run = block_excl_prefix(sum, s_tmp);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = t * 4 + k;
+        if (idx < count) s_data[idx] = run;
+        run += v[k];
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// entries -> bucket order  (replaces the reference's serial digit_occurrences scatter, curve_msm.rs:117-126)
+// ---------------------------------------------------------------------------------------------
+// Every (scalar i, window j) with a non-zero digit is an entry (id j * n + i = its table index) that goes to bucket
+// |d| - 1.  A bucket id is [coarse bin | fine].  Level 1 moves the entries to their coarse bin (per-tile LDS histogram ->
+// global [bin][tile] counts -> scan -> staged, run-wise writes); level 2 is one workgroup per coarse bin that counts,
+// scans and scatters its bin by the fine bits, producing the bucket offsets on the way.  Only LDS atomics; counts,
+// not capacities, drive the layout, so any digit distribution works.
+
+// GLV split of the scalars of a table-free MSM (glv.cuh): half[i] = k1_i, half[n + i] = k2_i (magnitude, sign in bit 255);
+// the ordering kernels then see 2n "scalars" of GLV_BITS bits over the points [G_0 .. G_(n-1), phi(G_0) .. phi(G_(n-1))].
+template <class C>
+__global__ void __launch_bounds__(256) k_glv_split(const uint4* __restrict__ scalars, size_t n, uint4* __restrict__ half) {
+    using SP = typename C::SP;
+    if constexpr (C::Glv::ENABLED) {
+        const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= n) return;
+        const uint4 lo = scalars[i * 2], hi = scalars[i * 2 + 1];
+        Fe<SP> s;
+        s.v[0] = lo.x; s.v[1] = lo.y; s.v[2] = lo.z; s.v[3] = lo.w;
+        s.v[4] = hi.x; s.v[5] = hi.y; s.v[6] = hi.z; s.v[7] = hi.w;
+        s = fe_to_canonical<SP>(s);
+        uint32_t k1[8], k2[8];
+        glv_split<typename C::Glv>(s.v, k1, k2);
+        half[i * 2] = make_uint4(k1[0], k1[1], k1[2], k1[3]);
+        half[i * 2 + 1] = make_uint4(k1[4], k1[5], k1[6], k1[7]);
+        half[(n + i) * 2] = make_uint4(k2[0], k2[1], k2[2], k2[3]);
+        half[(n + i) * 2 + 1] = make_uint4(k2[4], k2[5], k2[6], k2[7]);
+    }
+}
+
+// level 1, step 1: cnt1[bin * nt1 + tile].  A tile is `sub` consecutive sub-tiles of spt scalars, walked by one block.
+template <class C>
+__global__ void __launch_bounds__(ORD_THREADS) k_ord_count(const uint4* __restrict__ scalars, size_t n, OrdCfg cfg, uint32_t* __restrict__ cnt1) {
+    using SP = typename C::SP;
+    __shared__ uint32_t s_lim[8 * ORD_THREADS];
+    __shared__ uint32_t s_hist[ORD_MAX_BINS];
+    const int tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_hist[k] = 0;
+    for (uint32_t st = 0; st < cfg.sub; ++st) {
+        const size_t i = ((size_t)tile * cfg.sub + st) * cfg.spt + tid;
+        const bool live = (uint32_t)tid < cfg.spt && i < n;
+        __syncthreads();
+        if (live) ord_park_scalar<SP>(scalars, i, s_lim, tid, cfg.raw_signed != 0);
+        __syncthreads();
+        if (live) {
+            uint32_t carry = 0;
+            for (int j = 0; j < cfg.windows; ++j) {
+                const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
+                if (code != CODE_INVALID) atomicAdd(&s_hist[code >> (cfg.fine_bits + 1)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < cfg.nbins; k += ORD_THREADS) cnt1[(size_t)k * cfg.nt1 + tile] = s_hist[k];
+}
+
+// The signed digits exactly as the ordering kernels form them (same ord_park_scalar / ord_digit), written out: digits[i * windows + j]
+// in [-2^(c-1), 2^(c-1)], 0 for an absent entry.  Debug / parity only (plk_msm_debug_digits): the device never stores digits, so
+// this is what pins its recoding to the reference's to_digits vector (curve_msm.rs:186-216) through the identity
+// u_j = d_j - carry_in + 2^c carry_out, carry_out = [d_j - carry_in < 0] (a zero digit with a carry in of 1 may stand for 2^c).
+template <class C>
+__global__ void __launch_bounds__(ORD_THREADS) k_ord_digits(const uint4* __restrict__ scalars, size_t n, OrdCfg cfg, int32_t* __restrict__ digits) {
+    using SP = typename C::SP;
+    __shared__ uint32_t s_lim[8 * ORD_THREADS];
+    const int tid = threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * ORD_THREADS + tid;
+    const bool live = i < n;
+    if (live) ord_park_scalar<SP>(scalars, i, s_lim, tid, false);
+    __syncthreads();
+    if (!live) return;
+    uint32_t carry = 0;
+    for (int j = 0; j < cfg.windows; ++j) {
+        const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
+        const int32_t mag = code == CODE_INVALID ? 0 : (int32_t)(code >> 1) + 1;
+        digits[i * (size_t)cfg.windows + j] = (code != CODE_INVALID && (code & 1u)) ? -mag : mag;
+    }
+}
+
+// level 1, step 2: one block per bin row: in-place exclusive scan over the tiles; the block that finishes last turns the
+// bin totals into the bin offsets bin_base[0..nbins] (exclusive scan; bin_base[nbins] = number of entries) and into the
+// level-2 segment table seg_base[0..nbins] (a bin of t entries has ceil(t / ORD_SEG) segments).
+// It also fixes the accumulation's chunk length for THIS execution from the number of entries actually present (dyn_chunk[0]):
+// the lanes the context was laid out for share them, so a sparse vector (a slice of a sharded commitment, a zero-padded
+// quotient chunk, Z = 1) runs short chains on all lanes instead of full-length chains on a few - the accumulation of a
+// lane is a dependency chain, its length is the kernel's duration.
+__global__ void __launch_bounds__(256) k_ord_scan1(uint32_t* __restrict__ cnt1, uint32_t nt1, int nbins, uint32_t* __restrict__ bin_total,
+                                                   uint32_t* __restrict__ bin_base, uint32_t* __restrict__ seg_base, uint32_t* __restrict__ done_counter,
+                                                   uint32_t* __restrict__ dyn_chunk, uint32_t chunk_cfg, uint32_t lanes_cfg, uint32_t* __restrict__ off_direct) {
+    __shared__ uint32_t s_sum[256];
+    __shared__ uint32_t s_bins[ORD_MAX_BINS];
+    __shared__ bool s_last;
+    uint32_t* row = cnt1 + (size_t)blockIdx.x * nt1;
+    const uint32_t per = (nt1 + 255) / 256;
+    const uint32_t lo = min(nt1, threadIdx.x * per), hi = min(nt1, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += row[i];
+    uint32_t row_total = 0;
+    uint32_t run = block_excl_prefix(sum, s_sum, &row_total);
+    for (uint32_t i = lo; i < hi; ++i) {
+        uint32_t v = row[i];
+        row[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 255) {
+        bin_total[blockIdx.x] = row_total;
+        __threadfence();
+        s_last = atomicAdd(done_counter, 1u) == (uint32_t)nbins - 1u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const volatile uint32_t* vt = bin_total;
+    for (int k = threadIdx.x; k < nbins; k += 256) s_bins[k] = vt[k];
+    __syncthreads();
+    const uint32_t last_total = s_bins[nbins - 1];
+    block_excl_scan4(s_bins, nbins, s_sum);
+    for (int k = threadIdx.x; k < nbins; k += 256) {
+        bin_base[k] = s_bins[k];
+        if (off_direct) off_direct[k] = s_bins[k];  // one-level ordering: the bins are the buckets
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t total = s_bins[nbins - 1] + last_total;
+        bin_base[nbins] = total;
+        if (off_direct) off_direct[nbins] = total;
+        uint32_t ch = lanes_cfg ? (total + lanes_cfg - 1) / lanes_cfg : chunk_cfg;
+        if (ch < 8u) ch = 8u;
+        if (ch > chunk_cfg) ch = chunk_cfg;
+        dyn_chunk[0] = ch;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nbins; k += 256) s_bins[k] = (vt[k] + ORD_SEG - 1) / ORD_SEG;
+    __syncthreads();
+    const uint32_t last_segs = s_bins[nbins - 1];
+    block_excl_scan4(s_bins, nbins, s_sum);
+    for (int k = threadIdx.x; k < nbins; k += 256) seg_base[k] = s_bins[k];
+    if (threadIdx.x == 0) {
+        seg_base[nbins] = s_bins[nbins - 1] + last_segs;
+        *done_counter = 0;  // ready for the next execution
+    }
+}
+
+// level 1, step 3: (code, entry id) to its coarse bin; every sub-tile is ordered by bin inside LDS first, so that consecutive
+// lanes store to consecutive slots of the same (tile, bin) run
+template <class C>
+__global__ void __launch_bounds__(ORD_THREADS) k_ord_scatter(const uint4* __restrict__ scalars, size_t n, OrdCfg cfg, const uint32_t* __restrict__ cnt1,
+                                                             const uint32_t* __restrict__ bin_base, uint2* __restrict__ tmp,
+                                                             uint32_t* __restrict__ sorted_direct) {
+    using SP = typename C::SP;
+    __shared__ uint32_t s_lim[8 * ORD_THREADS];
+    __shared__ uint32_t s_cnt[ORD_MAX_BINS], s_base[ORD_MAX_BINS], s_gbase[ORD_MAX_BINS];
+    __shared__ uint32_t s_tmp[ORD_THREADS];
+    __shared__ uint2 s_ent[ORD_TILE];
+    __shared__ uint16_t s_rank[ORD_TILE];  // [window][scalar of the sub-tile]: spt * windows <= ORD_TILE
+    const int tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_gbase[k] = bin_base[k] + cnt1[(size_t)k * cfg.nt1 + tile];
+    for (uint32_t st = 0; st < cfg.sub; ++st) {
+        const size_t i = ((size_t)tile * cfg.sub + st) * cfg.spt + tid;
+        const bool live = (uint32_t)tid < cfg.spt && i < n;
+        __syncthreads();  // the previous sub-tile has been written out
+        for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_cnt[k] = 0;
+        if (live) ord_park_scalar<SP>(scalars, i, s_lim, tid, cfg.raw_signed != 0);
+        __syncthreads();
+        if (live) {
+            // one atomic per entry: its return value is the entry's rank inside its bin, kept for the placement below
+            uint32_t carry = 0;
+            for (int j = 0; j < cfg.windows; ++j) {
+                const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
+                if (code != CODE_INVALID) s_rank[j * cfg.spt + tid] = (uint16_t)atomicAdd(&s_cnt[code >> (cfg.fine_bits + 1)], 1u);
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_base[k] = s_cnt[k];
+        __syncthreads();
+        block_excl_scan4(s_base, cfg.nbins, s_tmp);
+        if (live) {
+            uint32_t carry = 0;
+            for (int j = 0; j < cfg.windows; ++j) {
+                const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
+                if (code != CODE_INVALID) {
+                    const uint32_t slot = s_base[code >> (cfg.fine_bits + 1)] + s_rank[j * cfg.spt + tid];
+                    if (PLK_CHK(slot < (uint32_t)ORD_TILE, CHK_TILE_STAGE)) s_ent[slot] = make_uint2(code, (uint32_t)((size_t)j * cfg.ent_stride + cfg.ent_first + i));
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t total = s_base[cfg.nbins - 1] + s_cnt[cfg.nbins - 1];
+        for (uint32_t sidx = tid; sidx < total; sidx += ORD_THREADS) {
+            const uint2 e = s_ent[sidx];
+            const uint32_t bin = e.x >> (cfg.fine_bits + 1);
+            const uint32_t at = s_gbase[bin] + (sidx - s_base[bin]);
+            if (PLK_CHK(at < cfg.entries_cap, CHK_TMP_INDEX)) {
+                if (sorted_direct) sorted_direct[at] = (e.y << 1) | (e.x & 1u);  // one-level ordering: this IS the bucket order
+                else tmp[at] = e;
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_gbase[k] += s_cnt[k];  // this sub-tile's entries of bin k
+    }
+}
+
+// level 2: a coarse bin is cut into segments of <= ORD_SEG entries, one workgroup each (a hot bin - short top window, skewed
+// witness - is shared by many workgroups).  Block -> (bin, segment) by a search in seg_base.
+PLK_DI bool ord_segment(const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ bin_base, int nbins, uint32_t blk, uint32_t& bin,
+                        uint32_t& seg, uint32_t& lo, uint32_t& hi) {
+    if (blk >= seg_base[nbins]) return false;
+    uint32_t a = 0, b = (uint32_t)nbins;  // seg_base[a] <= blk < seg_base[b]
+    while (b - a > 1) {
+        const uint32_t m = (a + b) >> 1;
+        if (seg_base[m] <= blk) a = m; else b = m;
+    }
+    bin = a;
+    seg = blk - seg_base[a];
+    lo = bin_base[a] + seg * ORD_SEG;
+    hi = min(bin_base[a + 1], lo + ORD_SEG);
+    return true;
+}
+// step 1: cnt2[segment][fine]
+__global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_count(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bin_base,
+                                                                   const uint32_t* __restrict__ seg_base, int fine_bits, int nbins,
+                                                                   uint32_t* __restrict__ cnt2) {
+    __shared__ uint32_t s_hist[1 << ORD_MAX_FINE];
+    const int tid = threadIdx.x;
+    uint32_t bin, seg, lo, hi;
+    if (!ord_segment(seg_base, bin_base, nbins, blockIdx.x, bin, seg, lo, hi)) return;
+    const int nf = 1 << fine_bits;
+    const uint32_t fmask = (uint32_t)nf - 1u;
+    for (int k = tid; k < nf; k += ORD_BIN_THREADS) s_hist[k] = 0;
+    __syncthreads();
+    for (uint32_t p = lo + tid; p < hi; p += ORD_BIN_THREADS) atomicAdd(&s_hist[(tmp[p].x >> 1) & fmask], 1u);
+    __syncthreads();
+    for (int k = tid; k < nf; k += ORD_BIN_THREADS) cnt2[((size_t)blockIdx.x << fine_bits) + k] = s_hist[k];
+}
+// step 2: bucket offsets of the bin (sum over its segments, scanned), this segment's start inside every bucket, scatter.
+// The segment is ordered by bucket inside LDS first: its entries of one bucket leave as one run.
+__global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_scatter(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bin_base,
+                                                                     const uint32_t* __restrict__ seg_base, int fine_bits, int nbins, uint32_t buckets,
+                                                                     const uint32_t* __restrict__ cnt2, uint32_t* __restrict__ off,
+                                                                     uint32_t* __restrict__ sorted, uint32_t entries_cap) {
+    __shared__ uint32_t s_glob[1 << ORD_MAX_FINE], s_loc[1 << ORD_MAX_FINE], s_cur[1 << ORD_MAX_FINE];
+    __shared__ uint32_t s_tmp[ORD_BIN_THREADS];
+    __shared__ uint32_t s_out[ORD_SEG];
+    __shared__ uint16_t s_fine[ORD_SEG];
+    const int tid = threadIdx.x;
+    uint32_t bin, seg, lo, hi;
+    if (!ord_segment(seg_base, bin_base, nbins, blockIdx.x, bin, seg, lo, hi)) {
+        // bins without entries still own bucket offsets: written by the blocks past the last segment, one bin each
+        // (the grid has at least nbins blocks past the segments; see the launch)
+        const uint32_t extra = blockIdx.x - seg_base[nbins];
+        if (extra < (uint32_t)nbins && bin_base[extra + 1] == bin_base[extra]) {
+            const int nf = 1 << fine_bits;
+            for (int k = tid; k < nf; k += ORD_BIN_THREADS) off[((size_t)extra << fine_bits) + k] = bin_base[extra];
+        }
+        if (extra == 0 && tid == 0) off[buckets] = bin_base[nbins];
+        return;
+    }
+    const int nf = 1 << fine_bits;
+    const uint32_t fmask = (uint32_t)nf - 1u;
+    const uint32_t s0 = seg_base[bin], s1 = seg_base[bin + 1];
+    for (int k = tid; k < nf; k += ORD_BIN_THREADS) {
+        uint32_t tot = 0, before = 0, own = 0;
+        for (uint32_t sg = s0; sg < s1; ++sg) {
+            const uint32_t v = cnt2[((size_t)sg << fine_bits) + k];
+            if (sg - s0 < seg) before += v;
+            if (sg - s0 == seg) own = v;
+            tot += v;
+        }
+        s_glob[k] = tot;
+        s_cur[k] = before;
+        s_loc[k] = own;
+    }
+    __syncthreads();
+    block_excl_scan4(s_glob, nf, s_tmp);
+    block_excl_scan4(s_loc, nf, s_tmp);
+    const uint32_t bb = bin_base[bin];
+    for (int k = tid; k < nf; k += ORD_BIN_THREADS) {
+        const uint32_t o = bb + s_glob[k];
+        if (seg == 0) off[((size_t)bin << fine_bits) + k] = o;
+        s_glob[k] = o + s_cur[k];  // where this segment's entries of bucket k start
+        s_cur[k] = s_loc[k];       // LDS cursor
+    }
+    __syncthreads();
+    for (uint32_t p = lo + tid; p < hi; p += ORD_BIN_THREADS) {
+        const uint2 e = tmp[p];
+        const uint32_t f = (e.x >> 1) & fmask;
+        const uint32_t idx = atomicAdd(&s_cur[f], 1u);
+        if (PLK_CHK(idx < ORD_SEG, CHK_SEG_STAGE)) {
+            s_out[idx] = (e.y << 1) | (e.x & 1u);
+            s_fine[idx] = (uint16_t)f;
+        }
+    }
+    __syncthreads();
+    const uint32_t count = hi - lo;
+    for (uint32_t i = tid; i < count; i += ORD_BIN_THREADS) {
+        const uint32_t f = s_fine[i];
+        const uint32_t at = s_glob[f] + (i - s_loc[f]);
+        if (PLK_CHK(at < entries_cap, CHK_SORTED_INDEX)) sorted[at] = s_out[i];
+    }
+}
+
+
+// ---- host side: what msm.hip sees of this file ----------------------------------------------------------------------------
+template <class C> int msm_launch_glv_split(const void* d_scalars, size_t n, void* halves, hipStream_t stream) {
+    k_glv_split<C><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const uint4*)d_scalars, n, (uint4*)halves);
+    PLK_HIP_TRY(hipGetLastError());
+    return PLK_OK;
+}
+// stage 0: level-1 counts + scan (and this execution's chunk length); 1: level-1 scatter; 2: level 2 (skipped by one-level orderings)
+template <class C> int msm_launch_order_stage(int stage, const OrdCfg& o, const OrdBuffers& b, hipStream_t stream) {
+    const bool one_level = o.fine_bits == 0;
+    if (stage == 0) {
+        k_ord_count<C><<<o.nt1, ORD_THREADS, 0, stream>>>((const uint4*)b.scalars, b.n, o, (uint32_t*)b.cnt1);
+        k_ord_scan1<<<o.nbins, 256, 0, stream>>>((uint32_t*)b.cnt1, o.nt1, o.nbins, b.bin_total, b.bin_base, b.seg_base, b.done_counter, b.done_counter + 2,
+                                                 b.chunk, b.lanes, one_level ? (uint32_t*)b.off : nullptr);
+    } else if (stage == 1) {
+        k_ord_scatter<C><<<o.nt1, ORD_THREADS, 0, stream>>>((const uint4*)b.scalars, b.n, o, (const uint32_t*)b.cnt1, b.bin_base, (uint2*)b.tmp,
+                                                            one_level ? (uint32_t*)b.sorted : nullptr);
+    } else if (!one_level) {
+        // the number of segments is only known on the device: launch for the upper bound (+ nbins blocks that write the
+        // offsets of the empty bins), blocks past the end exit
+        const unsigned segs = (unsigned)(b.n * (size_t)o.windows / ORD_SEG + o.nbins + 1);
+        k_ord_bin_count<<<segs, ORD_BIN_THREADS, 0, stream>>>((const uint2*)b.tmp, b.bin_base, b.seg_base, o.fine_bits, o.nbins, (uint32_t*)b.cnt2);
+        k_ord_bin_scatter<<<segs + o.nbins, ORD_BIN_THREADS, 0, stream>>>((const uint2*)b.tmp, b.bin_base, b.seg_base, o.fine_bits, o.nbins, b.buckets,
+                                                                          (const uint32_t*)b.cnt2, (uint32_t*)b.off, (uint32_t*)b.sorted, o.entries_cap);
+    }
+    PLK_HIP_TRY(hipGetLastError());
+    return PLK_OK;
+}
+template <class C> int msm_launch_digits(const void* d_scalars, size_t n, const OrdCfg& o, void* d_digits, hipStream_t stream) {
+    k_ord_digits<C><<<(unsigned)((n + ORD_THREADS - 1) / ORD_THREADS), ORD_THREADS, 0, stream>>>((const uint4*)d_scalars, n, o, (int32_t*)d_digits);
+    PLK_HIP_TRY(hipGetLastError());
+    return PLK_OK;
+}
+#define PLK_ORD_INSTANTIATE(C)                                                                     \
+    template int msm_launch_glv_split<C>(const void*, size_t, void*, hipStream_t);                \
+    template int msm_launch_order_stage<C>(int, const OrdCfg&, const OrdBuffers&, hipStream_t);   \
+    template int msm_launch_digits<C>(const void*, size_t, const OrdCfg&, void*, hipStream_t);
+PLK_ORD_INSTANTIATE(TweedledeeCurve)
+PLK_ORD_INSTANTIATE(TweedledumCurve)
+PLK_ORD_INSTANTIATE(Bls12377Curve)
+PLK_ORD_INSTANTIATE(PallasCurve)
+PLK_ORD_INSTANTIATE(VestaCurve)
+#undef PLK_ORD_INSTANTIATE
+
+PLK_CHK_READER(msm_order_checked_failures)
+
+}  // namespace plk

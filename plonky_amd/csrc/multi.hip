@@ -79,6 +79,64 @@ unsigned multi_min_log_n() {
     return v;
 }
 
+// ---- copies between two devices of the group -------------------------------------------------------------------------------
+// Device-resident inputs (generators, scalar vectors) and the records of partial results cross from one device to another.  With
+// peer access (xGMI; enabled pair by pair in group_init, the outcome kept in g_peer) that is ONE hipMemcpyAsync on the worker's
+// stream.  Without it the library does not lean on the runtime's silent staging: the copy goes through a pinned host buffer,
+// explicitly and synchronously - the source device's null stream after the worker's stream has been synchronised (its inputs are
+// complete), then the destination's - and is counted (plk_group_copy_stats), so that a test can tell which path ran.
+// PLK_PEER_MODE=host forces that path for every pair, ALSO between the logical devices of PLK_VIRTUAL_DEVICES (which then stop
+// sharing their buffers: a one-GPU box executes the no-peer branch line by line).
+static bool g_peer[PLK_MAX_DEVICES][PLK_MAX_DEVICES] = {};
+static bool g_force_host_copies = false;
+static std::atomic<unsigned long long> g_copies_peer{0}, g_copies_staged{0};
+bool group_force_host_copies() { return g_force_host_copies; }
+void group_copy_stats(unsigned long long* peer, unsigned long long* staged) {
+    if (peer) *peer = g_copies_peer.load();
+    if (staged) *staged = g_copies_staged.load();
+}
+// the worker of logical device `me` (current device, stream `st` of it) copies `bytes` between its device and logical device `other`;
+// pull: other -> me, else me -> other.  On return the copy is enqueued on `st` (peer) or complete (staged).
+static int group_copy(int me, int other, bool pull, void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (!bytes) return PLK_OK;
+    const bool direct = me == other || (!g_force_host_copies && (g_phys[me] == g_phys[other] || g_peer[me][other]));
+    if (direct) {
+        PLK_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st));
+        g_copies_peer.fetch_add(1, std::memory_order_relaxed);
+        return PLK_OK;
+    }
+    void* bounce = nullptr;
+    PLK_HIP_TRY(hipHostMalloc(&bounce, bytes, hipHostMallocPortable));
+    struct Free {
+        void* p;
+        ~Free() { (void)hipHostFree(p); }
+    } free_bounce{bounce};
+    PLK_HIP_TRY(hipStreamSynchronize(st));  // what the copy reads (pull: the caller's stream, through ev_in; push: this stream's kernels) is complete
+    const int from = pull ? other : me, to = pull ? me : other;
+    PLK_HIP_TRY(hipSetDevice(g_phys[from]));
+    hipError_t e = hipMemcpy(bounce, src, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) {
+        (void)hipSetDevice(g_phys[to]);
+        e = hipMemcpy(dst, bounce, bytes, hipMemcpyHostToDevice);
+    }
+    (void)hipSetDevice(g_phys[me]);
+    PLK_HIP_TRY(e);
+    g_copies_staged.fetch_add(1, std::memory_order_relaxed);
+    return PLK_OK;
+}
+// PLK_TEST_WORKER_JITTER_US=n: every worker sleeps a random 0..n microseconds before and after it enqueues its share - the
+// hand-overs of a fan-out call must not depend on the workers arriving in step (tests/test_gpu_multi.py: 200 calls)
+static void test_jitter() {
+    static const int max_us = [] {
+        const char* e = getenv("PLK_TEST_WORKER_JITTER_US");
+        return e ? atoi(e) : 0;
+    }();
+    if (max_us <= 0) return;
+    static thread_local unsigned state = (unsigned)std::hash<std::thread::id>()(std::this_thread::get_id()) | 1u;
+    state = state * 1664525u + 1013904223u;
+    std::this_thread::sleep_for(std::chrono::microseconds((state >> 8) % (unsigned)(max_us + 1)));
+}
+
 int ensure_device() {
     int n = g_n.load(std::memory_order_acquire);
     if (n == 0) {
@@ -101,8 +159,26 @@ int ensure_device() {
     return PLK_OK;
 }
 
-DeviceScope::DeviceScope(int logical) : prev(t_logical) { t_logical = logical; }
-DeviceScope::~DeviceScope() { t_logical = prev; }
+DeviceScope::DeviceScope(int logical) : prev(t_logical), prev_hip(-1) {
+    if (hipGetDevice(&prev_hip) != hipSuccess) prev_hip = -1;
+    t_logical = logical;
+}
+DeviceScope::~DeviceScope() {
+    t_logical = prev;
+    if (prev_hip >= 0) (void)hipSetDevice(prev_hip);
+}
+
+static thread_local int t_api_depth = 0;
+ApiGuard::ApiGuard() : outer(t_api_depth++ == 0) {
+    if (outer && hipGetDevice(&dev) != hipSuccess) {
+        dev = -1;
+        (void)hipGetLastError();
+    }
+}
+ApiGuard::~ApiGuard() {
+    --t_api_depth;
+    if (outer && dev >= 0) (void)hipSetDevice(dev);
+}
 
 // ---- worker threads: one per logical device ----
 struct Worker {
@@ -288,14 +364,21 @@ int group_init(int n_devices) {
         if (d == 0 || phys[d] != phys[d - 1]) PLK_TRY(check_gfx950(phys[d]));
     // peer access both ways between every pair of distinct devices (xGMI): the exchange of partial results and the device-source
     // forms copy straight from one HBM to another.  Where it cannot be enabled the runtime stages such copies through the host.
+    bool peer[PLK_MAX_DEVICES][PLK_MAX_DEVICES] = {};
+    const char* pm = getenv("PLK_PEER_MODE");
+    const bool force_host = pm && strcmp(pm, "host") == 0;
     for (int a = 0; a < n; ++a)
         for (int b = 0; b < n; ++b) {
-            if (phys[a] == phys[b]) continue;
+            if (phys[a] == phys[b] || force_host) continue;
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, phys[a], phys[b]) != hipSuccess || !can) continue;
+            if (hipDeviceCanAccessPeer(&can, phys[a], phys[b]) != hipSuccess || !can) {
+                (void)hipGetLastError();
+                continue;
+            }
             PLK_HIP_TRY(hipSetDevice(phys[a]));
             const hipError_t pe = hipDeviceEnablePeerAccess(phys[b], 0);
-            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) peer[a][b] = true;
+            if (pe != hipSuccess) (void)hipGetLastError();
         }
     PLK_HIP_TRY(hipSetDevice(phys[0]));
     std::lock_guard<std::mutex> dl(g_dispatch_mu);
@@ -306,6 +389,21 @@ int group_init(int n_devices) {
         workers_stop_locked();
         for (int d = 0; d < n; ++d) g_phys[d] = phys[d];
         g_n.store(n, std::memory_order_release);
+    }
+    // a copy between a and b is one peer copy only when BOTH directions are open (the copy engine of either side may run it)
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) g_peer[a][b] = peer[a][b] && peer[b][a];
+    g_force_host_copies = force_host;
+    if (getenv("PLK_VERBOSE")) {
+        int open = 0, pairs = 0;
+        for (int a = 0; a < n; ++a)
+            for (int b = a + 1; b < n; ++b)
+                if (phys[a] != phys[b]) {
+                    ++pairs;
+                    open += g_peer[a][b] ? 1 : 0;
+                }
+        fprintf(stderr, "[plonky_hip] device group of %d: %d of %d device pairs with peer access%s\n", n, open, pairs,
+                force_host ? " (PLK_PEER_MODE=host: every cross-device copy staged through pinned host memory)" : "");
     }
     return PLK_OK;
 }
@@ -355,7 +453,8 @@ int msm_precompute_multi(int curve, size_t n, const void* bases, const void* zer
     const int world = group_size();
     const size_t pt = (size_t)2 * L * 8;
     PLK_TRY(ensure_device());
-    const int src_phys = group_phys(thread_logical_device());
+    const int src_logical = thread_logical_device();
+    const int src_phys = group_phys(src_logical);
     std::lock_guard<std::mutex> dl(g_dispatch_mu);
     PLK_TRY(workers_ensure());
     if (!host_src) PLK_HIP_TRY(hipStreamSynchronize(caller_stream));  // the generators are complete before another device reads them
@@ -371,13 +470,18 @@ int msm_precompute_multi(int curve, size_t n, const void* bases, const void* zer
         const void* b = bases;
         const void* z = zero;
         LaneBuf db, dz;
-        if (host_src || group_phys(d) != src_phys) {
+        test_jitter();
+        // the caller's buffers serve as they are only on the caller's own device (PLK_PEER_MODE=host: only on its own LOGICAL device)
+        const bool in_place = !host_src && group_phys(d) == src_phys && (d == src_logical || !group_force_host_copies());
+        if (!in_place) {
             PLK_TRY(db.alloc(n * pt, l->stream));
-            PLK_HIP_TRY(hipMemcpyAsync(db.p, bases, n * pt, hipMemcpyDefault, l->stream));
+            if (host_src) PLK_HIP_TRY(hipMemcpyAsync(db.p, bases, n * pt, hipMemcpyHostToDevice, l->stream));  // over this device's own PCIe link
+            else PLK_TRY(group_copy(d, src_logical, true, db.p, bases, n * pt, l->stream));
             b = db.p;
             if (zero) {
                 PLK_TRY(dz.alloc(n, l->stream));
-                PLK_HIP_TRY(hipMemcpyAsync(dz.p, zero, n, hipMemcpyDefault, l->stream));
+                if (host_src) PLK_HIP_TRY(hipMemcpyAsync(dz.p, zero, n, hipMemcpyHostToDevice, l->stream));
+                else PLK_TRY(group_copy(d, src_logical, true, dz.p, zero, n, l->stream));
                 z = dz.p;
             }
         }
@@ -427,7 +531,8 @@ int msm_execute_multi(plk_msm_ctx* ctx, unsigned batch, const void* const* vecs,
     const unsigned whole = batch / (unsigned)world, rem = batch - whole * (unsigned)world, slots = whole + rem;
     const size_t rec = msm_partials_bytes(curve, slots);
     PLK_TRY(ensure_device());
-    const int src_phys = group_phys(thread_logical_device());
+    const int src_logical = thread_logical_device();
+    const int src_phys = group_phys(src_logical);
     std::lock_guard<std::mutex> dl(g_dispatch_mu);
     PLK_TRY(workers_ensure());
     uint8_t* gathered = (uint8_t*)scratch_acquire(rec * (size_t)world, caller_stream);
@@ -453,6 +558,9 @@ int msm_execute_multi(plk_msm_ctx* ctx, unsigned batch, const void* const* vecs,
     auto job = [&](int d) -> int {
         HostLane* l = nullptr;
         PLK_TRY(lane_get(l));
+        test_jitter();
+        // ev_in was recorded on the caller's stream, possibly on another device: an event without hipEventDisableSystemFence releases
+        // at system scope when it is recorded and the waiting stream acquires - the caller's inputs are visible to this device
         PLK_HIP_TRY(hipStreamWaitEvent(l->stream, ev_in, 0));
         PLK_TRY(lane_fork(*l));  // the copy stream starts after the main one, i.e. after the caller's inputs
         while (l->ev_ready.size() < slots) {
@@ -473,8 +581,18 @@ int msm_execute_multi(plk_msm_ctx* ctx, unsigned batch, const void* const* vecs,
             count[s] = c;
             need += c;
         }
-        const bool direct = !host_src && group_phys(d) == src_phys;  // the vectors already live on this device
+        // the vectors already live on this device (PLK_PEER_MODE=host: only the caller's own logical device reads them in place)
+        const bool direct = !host_src && group_phys(d) == src_phys && (d == src_logical || !group_force_host_copies());
         LaneBuf sbuf, rbuf;
+        // declared AFTER the buffers, so it runs BEFORE they go back to the pool: a job that fails half way has uploads in flight on
+        // aux[0] into sbuf, and the pool orders a released buffer after l->stream only
+        struct DrainOnFailure {
+            HostLane* l;
+            bool armed = true;
+            ~DrainOnFailure() {
+                if (armed) (void)lane_join(*l);
+            }
+        } drain_guard{l};
         if (!direct) PLK_TRY(sbuf.alloc(need * 32, l->stream));
         PLK_TRY(rbuf.alloc(rec, l->stream));
         size_t off = 0;
@@ -485,7 +603,8 @@ int msm_execute_multi(plk_msm_ctx* ctx, unsigned batch, const void* const* vecs,
             } else {
                 uint8_t* dst = (uint8_t*)sbuf.p + off * 32;
                 // host memory crosses this device's own PCIe link; memory of the caller's device crosses xGMI
-                PLK_HIP_TRY(hipMemcpyAsync(dst, src, count[s] * 32, hipMemcpyDefault, l->aux[0]));
+                if (host_src) PLK_HIP_TRY(hipMemcpyAsync(dst, src, count[s] * 32, hipMemcpyHostToDevice, l->aux[0]));
+                else PLK_TRY(group_copy(d, src_logical, true, dst, src, count[s] * 32, l->aux[0]));
                 ptr[s] = dst;
                 off += count[s];
             }
@@ -496,13 +615,19 @@ int msm_execute_multi(plk_msm_ctx* ctx, unsigned batch, const void* const* vecs,
         plk_msm_ctx* c = pure_shard ? shards[(size_t)d] : (d == 0 ? ctx : peers[(size_t)d - 1]);
         uint8_t* r = (uint8_t*)rbuf.p;
         PLK_TRY(msm_execute_dev_impl(c, slots, nullptr, 0, r, r + (size_t)slots * 2 * L * 8, l->stream, l->ev_ready.data(), &parts));
-        PLK_HIP_TRY(hipMemcpyAsync(gathered + (size_t)d * rec, r, rec, hipMemcpyDefault, l->stream));
+        // this device's record into its slot of the gathered buffer on the caller's device; the event below is recorded after it on
+        // the same stream (system-scope release), the caller's stream waits for it, and k_combine_partials reads at system scope
+        PLK_TRY(group_copy(d, src_logical, false, gathered + (size_t)d * rec, r, rec, l->stream));
+        test_jitter();
+        // the aux stream's copies feed kernels of l->stream through ev_ready, so l->stream's event below covers them too; sbuf / rbuf
+        // go back to the pool ordered after l->stream
         PLK_HIP_TRY(hipEventRecord((*g_workers)[(size_t)d]->ev_done, l->stream));
+        drain_guard.armed = false;
         return PLK_OK;
     };
-    const int rc = run_on_devices_locked(world, job);
-    if (rc != PLK_OK) {
-        // whatever was enqueued must not outlive the caller's vectors
+    // whatever was enqueued must not outlive the caller's vectors, `gathered` or the workers' buffers: EVERY failure after the
+    // fan-out has started drains the workers' lanes before this function returns
+    auto drain_workers = [&]() {
         auto drain = [&](int) -> int {
             HostLane* l = nullptr;
             if (lane_get(l) == PLK_OK) (void)lane_join(*l);
@@ -512,11 +637,18 @@ int msm_execute_multi(plk_msm_ctx* ctx, unsigned batch, const void* const* vecs,
         (void)run_on_devices_locked(world, drain);
         last_error_ref() = keep;
         (void)ensure_device();
-        return rc;
+    };
+    int rc = run_on_devices_locked(world, job);
+    if (rc == PLK_OK) {
+        auto tail = [&]() -> int {
+            PLK_TRY(ensure_device());
+            for (int d = 0; d < world; ++d) PLK_HIP_TRY(hipStreamWaitEvent(caller_stream, (*g_workers)[(size_t)d]->ev_done, 0));
+            return msm_combine_partials_dev_impl(curve, (unsigned)world, batch, whole, gathered, d_out_xy, d_out_zero, caller_stream);
+        };
+        rc = tail();
     }
-    PLK_TRY(ensure_device());
-    for (int d = 0; d < world; ++d) PLK_HIP_TRY(hipStreamWaitEvent(caller_stream, (*g_workers)[(size_t)d]->ev_done, 0));
-    return msm_combine_partials_dev_impl(curve, (unsigned)world, batch, whole, gathered, d_out_xy, d_out_zero, caller_stream);
+    if (rc != PLK_OK) drain_workers();
+    return rc;
 }
 
 }  // namespace plk

@@ -123,8 +123,14 @@ template <class P> struct LzSplit {
             if ((P::MOD[b >> 5] >> (b & 31)) & 1u) return b;
         return 0;
     }
-    static constexpr int S = top_bit() - 5;  // X_low = X mod 2^S
-    static_assert(S >= 29 * (FzCfg<P>::NZ - 1) - 5 && S >= 32 * (P::NL - 1), "the cut must lie in the top limb and the top word");
+    // R' / R = 2^SH: the re-slicing of lz_from_rform shifts by SH, so the cut and the table's exponent must use the same SH (5 for the
+    // 256-bit fields on nine 29-bit limbs - the only instantiation today; a field with another SH gets the right table, not a wrong residue)
+    static constexpr int SH = 29 * FzCfg<P>::NZ - 32 * P::NL;
+    static constexpr int S = top_bit() - SH;  // X_low = X mod 2^S
+    static constexpr int E = S + SH;          // table row t = (t 2^E) mod p, 2^E <= p
+    static_assert(SH > 0 && SH < 29, "R' / R must be a shift by less than a limb");
+    static_assert(S >= 29 * (FzCfg<P>::NZ - 1) - SH && S >= 32 * (P::NL - 1), "the cut must lie in the top limb and the top word");
+    static_assert((P::MOD[P::NL - 1] >> (S - 32 * (P::NL - 1))) < 64u, "the top part of a canonical word must index the table (LZ_TOP_ROWS)");
 };
 // LDS copy of the table: a row is read with three 16-byte accesses (a limb-major copy read word by word - no two rows in one bank -
 // was measured too: 10.44-10.51 ms against 10.27-10.28 for this layout, profiles/r04_quotient_diet.txt)
@@ -132,7 +138,8 @@ template <class P> using LzTop = uint32_t[LZ_TOP_ROWS][LZ_TOP_STRIDE];
 template <class P> PLK_DI Lz<P, 16> lz_from_rform(const Fe<P>& x, const LzTop<P>& top) {
     constexpr int NZ = FzCfg<P>::NZ, SH = 29 * NZ - 32 * P::NL, S = LzSplit<P>::S;
     static_assert(SH > 0 && SH < 29 && NZ <= LZ_TOP_STRIDE, "R' / R must be a shift by less than a limb");
-    // t <= (p - 1) >> S for a canonical word; the clamp keeps a non-canonical one inside the table (any row is a valid residue)
+    // t <= (p - 1) >> S for a canonical word.  Words >= p violate the boundary's contract (include/plonky_hip.h: elements are fully reduced,
+    // as every element of the reference is - monty.rs:41-45,103-106); the clamp only keeps such a word's load inside the table
     const uint32_t t = min(x.v[P::NL - 1] >> (S - 32 * (P::NL - 1)), (uint32_t)LZ_TOP_ROWS - 1u);
     const uint4 t0 = *reinterpret_cast<const uint4*>(&top[t][0]), t1 = *reinterpret_cast<const uint4*>(&top[t][4]),
                 t2 = *reinterpret_cast<const uint4*>(&top[t][8]);
@@ -218,7 +225,7 @@ template <class P> __global__ void k_plonk_xs(const uint4* __restrict__ pw, int 
     } else if (idx < n_lo + n_hi + 7 + LZ_TOP_ROWS) {
         // (t 2^(S + 5)) mod p as a plain integer: the product of the two numbers in Montgomery form, brought back
         const uint32_t tt = (uint32_t)(idx - n_lo - n_hi - 7);
-        constexpr int E = LzSplit<P>::S + 5;  // 2^E <= p
+        constexpr int E = LzSplit<P>::E;  // 2^E <= p
         Fe<P> a = fe_zero<P>(), b = fe_zero<P>();
         a.v[0] = tt;
         b.v[E >> 5] = 1u << (E & 31);

@@ -27,6 +27,8 @@ SYMBOLS = [
     ("plk_init_devices", _i, [_i]),
     ("plk_device_count", _i, []),
     ("plk_set_thread_device", _i, [_i]),
+    ("plk_group_copy_stats", _i, [_vp, _vp]),
+    ("plk_thread_hip_device", _i, [_i]),
     ("plk_multi_plan", _i, [_u, _u, _sz, _u, _vp, _vp, _vp, _vp]),
     ("plk_shutdown", None, []),
     ("plk_last_error", _cp, []),
@@ -99,6 +101,8 @@ SYMBOLS = [
     ("plk_ntt_get_timings", _i, [_vp, _vp]),
     ("plk_msm_set_profiling", _i, [_vp, _i]),
     ("plk_msm_get_timings", _i, [_vp, _vp, _vp]),
+    ("plk_bench_ceilings", _i, [_vp, _u]),
+    ("plk_msm_debug_digits", _i, [_i, _u, _sz, _vp, _vp, _vp]),
     ("plk_field_op", _i, [_i, _i, _vp, _vp, _vp, _sz]),
     ("plk_curve_gen_bases_dev", _i, [_i, _sz, _u64, _vp, _vp, _vp, _vp]),
 ]

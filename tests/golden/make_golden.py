@@ -85,7 +85,7 @@ def main():
     print("golden vectors written to", OUT)
 
 
-SEEDED_MSM = [(br.TWEEDLEDEE, 16), (br.TWEEDLEDEE, 18), (br.TWEEDLEDEE, 20), (br.BLS12_377, 16), (br.BLS12_377, 18)]
+SEEDED_MSM = [(br.TWEEDLEDEE, 16), (br.TWEEDLEDEE, 18), (br.TWEEDLEDEE, 20), (br.BLS12_377, 16), (br.BLS12_377, 18), (br.BLS12_377, 20)]
 
 
 def msm_seeded_generators():

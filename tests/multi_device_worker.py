@@ -89,6 +89,48 @@ def main():
         [t.join() for t in th]
         res[tag + "_ntt_threads"] = np.stack(outs)
 
+    def hip_device(set_to=-1):
+        """The calling thread's current HIP device, from the runtime the library itself is linked to (torch keeps its own idea of it)."""
+        d = int(L.plk_thread_hip_device(set_to))
+        assert d >= 0, d
+        return d
+
+    def copy_stats():
+        import ctypes
+        a, b = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+        lib.check(L.plk_group_copy_stats(ctypes.byref(a), ctypes.byref(b)))
+        return np.array([a.value, b.value], dtype=np.uint64)
+
+    if len(sys.argv) > 4 and sys.argv[4] == "stress":
+        # 200 fan-out calls with the workers arriving out of step (PLK_TEST_WORKER_JITTER_US, set by the test): single MSMs sharded by
+        # base range, device-resident vectors, every tenth call a hybrid batch - every result must equal the first of its kind
+        got = pa.init_devices(world)
+        assert got == world
+        bases = dev.to_host(dev.gen_bases_dev(curve, n, g0, dd)).reshape(n, 2, 4)
+        vecs = np.stack([synth.rand_field(1, 0x350A20 + v, n) for v in range(world + 1)])
+        pre = pa.msm_precompute(curve, bases, 11)
+        first_single = pa.msm_execute_parallel(pre, vecs[0])
+        first_batch = pa.msm_execute_batch(pre, vecs)
+        dvec = dev.to_device(vecs[:1])
+        bad = 0
+        for it in range(200):
+            if it % 10 == 9:
+                xy, z = pa.msm_execute_batch(pre, vecs)
+                bad += int(not (np.array_equal(xy, first_batch[0]) and np.array_equal(z, first_batch[1])))
+            elif it % 10 == 4:
+                dxy, dz = dev.msm_execute_dev(pre, dvec)
+                torch.cuda.synchronize()
+                bad += int(not (np.array_equal(dev.to_host(dxy).reshape(2, 4), first_single[0]) and int(dz.cpu()[0]) == first_single[1]))
+            else:
+                xy, z = pa.msm_execute_parallel(pre, vecs[0])
+                bad += int(not (np.array_equal(xy, first_single[0]) and z == first_single[1]))
+        assert np.array_equal(first_batch[0][0], first_single[0])
+        pre.free()
+        res.update(bad=np.array([bad]), copy_stats=copy_stats(), world=np.array([got, torch.cuda.device_count()]))
+        L.plk_shutdown()
+        np.savez(out_path, **res)
+        print("multi_device_worker stress: %d mismatches in 200 calls, copies peer / staged %s" % (bad, res["copy_stats"]))
+        return
     lib.check(L.plk_init(0))
     run("one")
     L.plk_shutdown()
@@ -96,6 +138,27 @@ def main():
     assert got == world, (got, world)
     res["world"] = np.array([got, torch.cuda.device_count()])
     run("multi")
+    # A host shim (or torch) allocates on "the current device" between two calls: every public call must leave the calling thread's
+    # HIP device as it found it.  The thread parks on the LAST visible GPU - with several physical GPUs that is not
+    # the device the library's logical device 0 lives on - and makes host-pointer calls of every fan-out form (numpy only: torch
+    # would move the current device itself).
+    park = torch.cuda.device_count() - 1
+    seen = [hip_device(park)]
+    small = res["bases"][: 1 << 10]
+    pre2 = pa.msm_precompute(curve, small, 11)
+    seen.append(hip_device())
+    pa.msm_execute_batch(pre2, res["vecs"][:3, : 1 << 10])
+    seen.append(hip_device())
+    pa.msm_execute_parallel(pre2, res["vecs"][0, : 1 << 10])
+    seen.append(hip_device())
+    api.fft_batch(0, res["polys"][:3])
+    seen.append(hip_device())
+    pa.fft_with_precomputation_power_of_2(res["polys"][0], pa.fft_precompute(0, n))
+    seen.append(hip_device())
+    pre2.free()
+    seen.append(hip_device())
+    res["hip_device"] = np.array([park] + seen)
+    res["copy_stats"] = copy_stats()
     L.plk_shutdown()
     np.savez(out_path, **res)
     print("multi_device_worker: ok, %d logical devices on %d GPU(s), n = 2^%d" % (world, torch.cuda.device_count(), log_n))

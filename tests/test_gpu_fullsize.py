@@ -270,6 +270,24 @@ def test_bench_single_process_virtual_devices():
         assert c["one_device"][k] > 0 and c["group"][k] > 0
 
 
+def test_bench_single_process_eight_virtual_devices():
+    """BASELINE configs 4 / 5 are quoted on 8 GPUs: `python bench.py --gpus 8 --single-process --virtual-devices` at 2^16 runs the plan an
+    8-GPU node would run (one whole vector per device + eighths of the ninth, a single MSM in eighths, nine transforms over eight
+    devices) - on a real node only the physical devices behind the eight logical ones differ."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PLK_VIRTUAL_DEVICES")}
+    env["PLK_MULTI_MIN_LOG_N"] = "10"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--single-process", "--virtual-devices", "--log-n", "16", "--steps", "8"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    c = r["components"]
+    assert r["n_gpus"] == 8 and c["devices"] == 8 and c["virtual"] and c["bit_identical_to_one_device"] and c["msm_closed_form_bit_exact"] and c["ntt_roundtrip_bit_exact"]
+
+
 def test_bench_single_process_child_form():
     """The same case the way the driver's N > 1 line runs it: bench.single_process_child (a child process with a time limit,
     launcher variables stripped), here on two virtual devices."""

@@ -18,14 +18,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_worker(tmp_path, world, log_n, env_extra=None):
+def _run_worker(tmp_path, world, log_n, env_extra=None, mode=None):
     out = str(tmp_path / ("multi_%d_%d.npz" % (world, log_n)))
     env = dict(os.environ)
-    env.pop("PLK_VIRTUAL_DEVICES", None)
+    for k in ("PLK_VIRTUAL_DEVICES", "PLK_PEER_MODE", "PLK_TEST_WORKER_JITTER_US"):
+        env.pop(k, None)
     if env_extra:
         env.update(env_extra)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multi_device_worker.py"), str(world), str(log_n), out], env=env, cwd=ROOT,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multi_device_worker.py"), str(world), str(log_n), out] + ([mode] if mode else []),
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:]
     return np.load(out)
 
@@ -76,6 +77,37 @@ def test_device_group_2p16_nine_vectors(tmp_path):
     for v in (0, 3):
         exp, ez = pre.execute(res["vecs"][v])
         assert ez == 0 and np.array_equal(res["multi_batch9_xy"][v], exp), v
+
+
+def test_device_group_without_peer_access(tmp_path):
+    """PLK_PEER_MODE=host: every copy between two devices of the group goes through a pinned host buffer - the branch a node whose
+    GPUs cannot open peer access takes (multi.hip: group_copy), here also between the virtual devices of a one-GPU box, which then
+    stop reading each other's buffers in place.  Same bits as one device, and the staged path is the one that ran."""
+    res = _run_worker(tmp_path, 2, 14, {"PLK_PEER_MODE": "host"})
+    _same_as_one_device(res)
+    peer, staged = (int(v) for v in res["copy_stats"])
+    assert staged > 0, (peer, staged)      # device-resident vectors + the records of partial results
+    res2 = _run_worker(tmp_path, 2, 14)
+    peer2, staged2 = (int(v) for v in res2["copy_stats"])
+    assert staged2 == 0 and peer2 > 0, (peer2, staged2)
+
+
+def test_public_calls_leave_the_hip_device_unchanged(tmp_path):
+    """Every public call returns with the calling thread's HIP device as it found it (plonky_hip.h): the worker parks
+    its thread on the last visible GPU and runs every fan-out form.  On a one-GPU box that is device 0 either way (the guard's code
+    path still runs); with more GPUs the thread's device differs from the devices the library works on."""
+    res = _run_worker(tmp_path, 2, 12)
+    park, seen = int(res["hip_device"][0]), [int(v) for v in res["hip_device"][1:]]
+    assert len(seen) == 7 and all(v == park for v in seen), (park, seen)
+
+
+def test_device_group_200_calls_with_worker_jitter(tmp_path):
+    """200 fan-out calls while every worker sleeps a random 0..300 us before and after it enqueues its share: the hand-overs (the
+    caller's event, the per-vector copy events, the workers' done events, the gathered records) must not depend on timing."""
+    res = _run_worker(tmp_path, 3, 12, {"PLK_TEST_WORKER_JITTER_US": "300"}, mode="stress")
+    assert int(res["bad"][0]) == 0
+    res = _run_worker(tmp_path, 2, 12, {"PLK_TEST_WORKER_JITTER_US": "300", "PLK_PEER_MODE": "host"}, mode="stress")
+    assert int(res["bad"][0]) == 0 and int(res["copy_stats"][1]) > 0
 
 
 def test_device_group_real_devices(tmp_path):

@@ -170,6 +170,43 @@ def test_msm():
         assert z == 0 and np.array_equal(r, result_msm), win
 
 
+def test_to_digits_reference_vector_on_device():
+    """curve_msm.rs:186-216 (test_to_digits): the device never stores digits - it recodes them, signed, inside the ordering kernels
+    (ord_digit, msm.hip).  plk_msm_debug_digits runs exactly that code; the reference's unsigned digits follow from the signed ones
+    by u_j = d_j - carry_j + 2^w carry_(j+1), and must be the reference's vector.  Then the same identity on random scalars of every
+    curve and several windows against the oracle's to_digits, plus the defining property sum_j d_j 2^(w j) = the canonical scalar."""
+    x_canonical = [
+        0b1010101010101010101010101010101010101010101010101010101010101010,
+        0b1100110011001100110011001100110011001100110011001100110011001100,
+        0b1111000011110000111100001111000011110000111100001111000011110000,
+        0b0000111111111111111111111111111111111111111111111111111111111111,
+    ]
+    expected = [
+        0b01010101010101010, 0b10101010101010101, 0b01010101010101010, 0b11001010101010101,
+        0b01100110011001100, 0b00110011001100110, 0b10011001100110011, 0b11110000110011001,
+        0b01111000011110000, 0b00111100001111000, 0b00011110000111100, 0b11111111111111110,
+        0b11111111111111111, 0b11111111111111111, 0b00011111111111111,
+    ]
+    x = ol.field_unop(2, "from_canonical", np.array([x_canonical], dtype=np.uint64))
+    signed, unsigned, top_carry = pa.msm_debug_digits(pa.BLS12_377, x, 17)
+    assert signed.shape == (1, 15) and top_carry[0] == 0
+    assert list(unsigned[0]) == expected
+    assert np.abs(signed).max() <= 1 << 16
+    rng = np.random.default_rng(0xD161)
+    for curve, c in ((pa.TWEEDLEDEE, br.TWEEDLEDEE), (pa.TWEEDLEDUM, br.TWEEDLEDUM), (pa.BLS12_377, br.BLS12_377)):
+        r = c.scalar.p
+        vals = [0, 1, 2, r - 1, r - 2, (1 << 200) - 1, 1 << 200, (r - 1) // 2] + [int(v) ** 4 % r for v in rng.integers(0, 2 ** 63, 56)]
+        sc = mont_arr(c.scalar, vals)
+        for w in (3, 5, 11, 13, 16, 17, 20, 21):
+            signed, unsigned, top_carry = pa.msm_debug_digits(curve, sc, w)
+            assert not top_carry.any() and np.abs(signed).max() <= 1 << (w - 1)
+            for i, v in enumerate(vals):
+                assert sum(int(d) << (w * j) for j, d in enumerate(signed[i])) == v, (curve, w, i)
+                ref = ol.to_digits(curve, sc[i], w)    # the reference's digit count: ceil(BITS / w)
+                got = [int(u) for u in unsigned[i]]
+                assert got[:len(ref)] == ref and not any(got[len(ref):]), (curve, w, i)
+
+
 def test_msm_tweedledee_mini_kat():
     c = br.TWEEDLEDEE
     G = (c.gx, c.gy)
