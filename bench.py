@@ -14,6 +14,8 @@ step    one pass of the hot path over one batch of synthetic input (--workload):
           commit9 BASELINE configs[3]: the 9-wire commitment batch of poly_commit.rs:52-66 - nine 2^20 scalar vectors against
                   the same 2^20 generators.  N > 1: STRONG scaling - the generators are sharded by base range (each rank holds
                   2^20 / N of them and the matching slice of every vector), one packed all-gather of 9 partial points.
+          crossover  the drop-in HOST-pointer entry points against the CPU path (the oracle) as a size sweep 2^8..2^log_n: where the
+                  GPU path starts to pay (the size gate PLK_MIN_GPU_LOG_N); table on stderr, one JSON line on stdout.
         --curve bls12_377 --log-n 22 --workload msm  is BASELINE configs[4] (the reference has BLS12-377, not -381);
                   with --shard it is the STRONG-scaling form: one fixed 2^log_n MSM, generators sharded by base range.
         --emulate-rank r/N  runs rank r's shard of a strong-scaling problem (commit9, msm --shard) alone on one GPU: the
@@ -50,6 +52,9 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         from benchlib.multi import spawn_ranks
         return spawn_ranks(args, argv)
+    if args.workload == "crossover":
+        from benchlib.cpu import crossover_sweep
+        return crossover_sweep(args)
     from benchlib.headline import run
     return run(args)
 

@@ -154,7 +154,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", choices=["both", "ntt", "msm", "commit9", "quotient"], default="both")
+    ap.add_argument("--workload", choices=["both", "ntt", "msm", "commit9", "quotient", "crossover"], default="both")
     ap.add_argument("--curve", choices=sorted(CURVES), default="tweedledee")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--shard", action="store_true", help="--workload msm: strong scaling - ONE 2^log_n MSM, generators sharded by base range")

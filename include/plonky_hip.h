@@ -92,7 +92,7 @@ int plk_multi_plan(unsigned world, unsigned batch, size_t n, unsigned device, un
 int plk_set_thread_device(int logical_device); /* the _dev entry points of the calling thread run on this logical device */
 void plk_shutdown(void);
 /* Size gate for the binding: problems below 2^plk_min_gpu_log_n() elements / pairs stay on the reference's
- * own CPU path - the library itself has no CPU path.  Environment PLK_MIN_GPU_LOG_N, default 12.  plk_init(-1) takes the
+ * own CPU path - the library itself has no CPU path.  Environment PLK_MIN_GPU_LOG_N, default 10 (the measured crossover of the host-pointer entry points, profiles/r05_crossover_host_pointer_vs_cpu.txt).  plk_init(-1) takes the
  * device from the environment variable PLK_DEVICE (default 0). */
 unsigned plk_min_gpu_log_n(void);
 /* Text of the last error on the calling thread (never NULL). */

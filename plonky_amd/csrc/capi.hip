@@ -437,7 +437,11 @@ void plk_shutdown(void) {
 const char* plk_last_error(void) { return last_error_ref().c_str(); }
 unsigned plk_min_gpu_log_n(void) {
     const char* e = getenv("PLK_MIN_GPU_LOG_N");
-    const int v = e ? atoi(e) : 12;
+    // Default 10, set from the measured crossover (profiles/r05_crossover_host_pointer_vs_cpu.txt: through the HOST-pointer entry points, PCIe
+    // inside, a 2^10 transform takes 59 us against 148 us on the CPU restatement's best thread count, a 2^8 one 34 against 37; an MSM
+    // over prebuilt tables wins at every size measured).  The Rust of the reference is faster than the restatement by a small factor,
+    // which is why the gate sits two sizes above the measured tie rather than on it.
+    const int v = e ? atoi(e) : 10;
     return v < 0 ? 0u : (unsigned)v;
 }
 int plk_field_limbs(int field) { return field_limbs(field); }

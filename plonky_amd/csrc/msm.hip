@@ -58,6 +58,7 @@ template <class C> int msm_launch_order_stage(int stage, const OrdCfg& o, const 
 template <class C> int msm_launch_digits(const void* d_scalars, size_t n, const OrdCfg& o, void* d_digits, hipStream_t stream);
 template <class C> int msm_launch_reduce_stage(int stage, const TailGeom& g, const TailBatch& tb, hipStream_t stream);
 constexpr size_t COMB_MAX_N = (size_t)1 << 15;  // generators up to which a tabled context with an automatic window is a comb (1 GB of table at 2^15)
+constexpr size_t COMB_AUTO_MAX_N = (size_t)1 << 12;  // ... and up to which it is chosen without being asked for (measured faster than the bucket method)
 constexpr int COMB_WINDOW = 4, COMB_WINDOWS = 64;
 
 
@@ -454,7 +455,7 @@ struct plk_msm_ctx {
     // contiguous share of the generators with the window such a share deserves (shards[d]): whole vectors of a batch run on the
     // full tables, a single MSM runs sharded by base range.
     std::vector<plk_msm_ctx*> peers, shards;
-    // With PLK_MSM_COMB=1 a tabled context over few generators (<= COMB_MAX_N, automatic window) is a COMB (comb.hip): no window tables,
+    // A tabled context over few generators (automatic window; <= COMB_AUTO_MAX_N by default, PLK_MSM_COMB) is a COMB (comb.hip): no window tables,
     // no workspaces, no bucket method - executions are mixed additions of table entries and a tree over the lanes' sums.
     plk::CombPlan* comb = nullptr;
     bool auto_window = false;
@@ -685,12 +686,15 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
                             const size_t* also_n, int also_count) {
     using FP = typename C::FP;
     const size_t pt_bytes = (size_t)2 * FP::NL * 4;
-    // PLK_MSM_COMB=1 (read at every precompute): off by default - measured in round 4 (profiles/r04_comb_small_msm.txt): an execution
-    // is faster than the bucket method only up to ~2^12 generators (0.19 / 0.25 ms against 0.30 / 0.33 at 2^10 / 2^12; equal at 2^14,
-    // slower at 2^15: eight dependent gathers + additions per lane and two trees of full additions are latency too), its table costs
-    // 2-4 x the window tables to build, and the frozen generators of an opening argument (2^14 + 2) gain nothing.
+    // Few generators with an automatic window are a COMB (comb.hip) - chosen BY SIZE since round 5: measured in round 4
+    // (profiles/r04_comb_small_msm.txt) an execution takes 0.19 / 0.25 ms against 0.30 / 0.33 for the bucket method at 2^10 / 2^12
+    // generators, the same at 2^14 and more at 2^15 (eight dependent gathers + additions per lane and two trees of full additions are
+    // latency too), and its table costs 2-4 x the window tables to build: up to COMB_AUTO_MAX_N = 2^12 generators it is the default.
+    // PLK_MSM_COMB=0 turns it off, PLK_MSM_COMB=1 forces it up to COMB_MAX_N (the parity suites run through it that way too).  The frozen
+    // generators of an opening argument (2^14 + 2, explicit window) stay on the bucket method.
     const char* comb_env = getenv("PLK_MSM_COMB");
-    const bool want_comb = comb_env && atoi(comb_env) != 0;
+    const int comb_mode = comb_env ? atoi(comb_env) : -1;
+    const bool want_comb = comb_mode > 0 || (comb_mode < 0 && ctx->n <= COMB_AUTO_MAX_N);
     if (!ctx->table_free && ctx->auto_window && ctx->n >= 1 && ctx->n <= COMB_MAX_N && want_comb) {
         // the doubling chain [2^(4 j)] G_i on quads (window 0 affine in `base0`, the others raw in `raw`), then comb.hip turns every
         // window's point into its multiples 1 .. 8

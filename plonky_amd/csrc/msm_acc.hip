@@ -44,6 +44,18 @@ template <class FP> PLK_DI void acc_pin(Fe<FP>& x, Fe<FP>& y, uint32_t& a, uint3
     for (int i = 0; i < FP::NL; ++i) asm volatile("" : "+v"(x.v[i]), "+v"(y.v[i]));
     asm volatile("" : "+v"(a), "+v"(b) : : "memory");
 }
+// tuning builds only (tools/gpu: A/B libraries in ab_libs/, never the product): -DPLK_ACC_EXPERIMENT=2 keeps every gather inside the first
+// 4 MiB of the table (wrong sums, L2-resident reads) - the time this kernel would take if the random HBM gathers cost nothing
+#ifndef PLK_ACC_EXPERIMENT
+#define PLK_ACC_EXPERIMENT 0
+#endif
+PLK_DI size_t acc_table_index(size_t idx) {
+#if PLK_ACC_EXPERIMENT == 2
+    return idx & 0xFFFFu;
+#else
+    return idx;
+#endif
+}
 template <class FP> PLK_DI void acc_gather(const uint4* src, Fe<FP>& x, Fe<FP>& y) {
     x = fe_load<FP>(src);
     y = fe_load<FP>(src + FP::NL / 4);
@@ -82,7 +94,7 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
         // only looked at when the point is consumed - testing it here would wait for the gather that was just issued
         Fe<FP> x = fe_zero<FP>(), y = fe_zero<FP>();
         y.v[FP::NL - 1] = AFF_IDENTITY_BIT;
-        if (PLK_CHK((ent >> 1) - ent_sub < tab_entries, CHK_TABLE_INDEX)) acc_gather<FP>(tab + (size_t)((ent >> 1) - ent_sub) * 2 * W, x, y);
+        if (PLK_CHK((ent >> 1) - ent_sub < tab_entries, CHK_TABLE_INDEX)) acc_gather<FP>(tab + acc_table_index((ent >> 1) - ent_sub) * 2 * W, x, y);
         for (uint32_t k = begin; k < end; ++k) {
             // (1) everything this iteration reads from memory was requested at least one addition ago: entry k's table point, the id
             // of entry k + 1, off[b + 2].  The ONE wait of the iteration sits here (acc_pin keeps the compiler from sinking it below
@@ -94,7 +106,7 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
             const bool cident = (cy.v[FP::NL - 1] & AFF_IDENTITY_BIT) != 0;
             cy.v[FP::NL - 1] &= ~AFF_IDENTITY_BIT;
             if (k == next) {  // (2) entry k opens a new bucket: the piece of the old one is closed
-                xyzzz_settle<FP>(acc);  // the additions keep Y uncarried (ecz.cuh): move its carries before the piece is stored
+                // (the additions keep Y uncarried, ecz.cuh: the piece is stored as it is, xyzzz_load_raw moves the carries)
                 if (head) {
                     xyzzz_store_raw<FP>(s_head + tid * RU, acc);
                     parked = true;
@@ -126,7 +138,7 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
 #ifdef PLK_CHECKED
                 y.v[FP::NL - 1] = AFF_IDENTITY_BIT;  // a guarded (skipped) gather leaves the identity behind
 #endif
-                if (PLK_CHK((ent >> 1) - nsub < tab_entries, CHK_TABLE_INDEX)) acc_gather<FP>(tab + (size_t)((ent >> 1) - nsub) * 2 * W, x, y);
+                if (PLK_CHK((ent >> 1) - nsub < tab_entries, CHK_TABLE_INDEX)) acc_gather<FP>(tab + acc_table_index((ent >> 1) - nsub) * 2 * W, x, y);
             }
             if (cident) continue;
             xyzzz_madd_entry<FP>(acc, cx, cy, (cur & 1u) != 0);  // (4)

@@ -57,6 +57,9 @@ template <class FP> PLK_DI XyzzZ<FP> xyzzz_load_raw(const uint4* src) {
         any |= w[2 * NZ + i];
     }
     r.inf = any == 0;  // a live accumulator never has ZZ = 0 (that case is caught as the identity in ecz.cuh)
+    // a piece closed inside the accumulation's loop is stored with its Y UNCARRIED (limbs <= 3 * 2^29 - 3, ecz.cuh: the carry pass
+    // would sit on the path some lane of a wave takes almost every round); the carries are moved here, where the piece is read
+    fz_carry<FP>(r.y);
     return r;
 }
 

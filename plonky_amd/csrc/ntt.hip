@@ -41,6 +41,7 @@ constexpr int TILE_LOG = PLK_NTT_TILE_LOG;  // elements per workgroup tile
 constexpr int TILE = 1 << TILE_LOG;
 constexpr int NTT_THREADS = TILE / 4;        // one radix-4 group per thread and stage pair
 constexpr int MAX_PASSES = 6;
+constexpr int NTT_STAGGER_DEFAULT = 0;  // phases of a one-round pass (k_ntt_pass), sleep quanta per phase; 0: off
 constexpr size_t NTT_LDS_MAX = 160 * 1024;  // per workgroup on gfx950
 constexpr int INNER_LOG = TILE_LOG;      // inner twiddle table: w_TILE^e, e < TILE / 2
 
@@ -58,6 +59,8 @@ struct NttPassArgs {
     int skip;         // first pass of a zero-padded transform: the first `skip` stages only replicate (see tile_stages)
     int tw_global;    // 1: the stage twiddles do not fit in LDS next to the tile: they are read from the inner table (L1 / L2)
     int shuffle;      // 1: the first two radix-4 steps of a tile are joined by wave shuffles instead of an LDS round trip
+    int stagger;      // > 0: a pass that is ONE round of workgroups starts them in phases (see k_ntt_pass): sleep quanta (~0.5 us) per phase
+    int stagger_div;  // workgroups per phase (the number of CUs)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -412,6 +415,15 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const void* in, void* 
     uint32_t* s_dat = s_mem;
     uint32_t* s_tw = s_mem + NZ * TILE;
 
+    // A pass whose workgroups all fit the GPU at once (a single 2^20 transform: 1024 tiles, four per CU) would run in lockstep - every
+    // workgroup loads, then every workgroup computes, then every workgroup stores: ~20 us of memory phases beside ~21 us of issue
+    // (SQ_WAVE_CYCLES, round 4: 39.5 % of the wave cycles parked).  The k-th workgroup of a CU therefore starts k phases late: the first
+    // ones get the memory system to themselves and compute while the others load; in a multi-round launch (batches, 2^23) the rounds
+    // stagger by themselves and a.stagger is 0.
+    if (a.stagger > 0) {
+        const int ph = (int)(blockIdx.x / (unsigned)a.stagger_div);
+        for (int i = 0; i < ph * a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     const TileGeom tg = tile_geom(a, blockIdx.x);
     // stage twiddles (R'-form): w_A^e = inner[e * (1024 / A)], e < A/2
     for (int e = tid; e < ((TILE_LOG >= 12 && a.tw_global) ? 0 : half_a); e += NTT_THREADS) {
@@ -670,6 +682,19 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
         if (lds_bytes > NTT_LDS_MAX) {
             a.tw_global = 1;
             lds_bytes = (size_t)FzCfg<P>::NZ * TILE * 4;
+        }
+        // one round of workgroups (at most four 39 KB tiles per CU) and more than one per CU: start them in phases
+        {
+            static const int cus = [] {
+                int dev = 0, c = 256;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+                return c > 0 ? c : 256;
+            }();
+            const char* se = getenv("PLK_NTT_STAGGER");  // sleep quanta (~0.5 us) per phase; tuning
+            const int quanta = se ? atoi(se) : NTT_STAGGER_DEFAULT;
+            a.stagger = (quanta > 0 && tiles > (size_t)cus && tiles <= (size_t)4 * cus) ? quanta : 0;
+            a.stagger_div = cus;
         }
         const uint4* scale = (const uint4*)pl.pw + (a.scale ? 66 : 65) * 2;
         const bool use_hooks = hooks && (a.first || a.last);

@@ -811,7 +811,8 @@ def test_fft_precompute_table_2p20_spot_layers():
 # ---------------- small fixed-base MSMs without buckets (comb.hip) ----------------
 @pytest.mark.parametrize("c", [br.TWEEDLEDEE, br.BLS12_377, br.PALLAS], ids=lambda c: c.name)
 def test_msm_comb_small_contexts(c):
-    """With PLK_MSM_COMB=1 a tabled context over <= 2^15 generators with an automatic window is a COMB (comb.hip: a table of the multiples 1 .. 8 of
+    """A tabled context over few generators with an automatic window is a COMB (by size up to 2^12 generators since round 5; PLK_MSM_COMB=1, set
+    here, takes it to 2^15; comb.hip: a table of the multiples 1 .. 8 of
     every window's point, executions = mixed additions + a tree): against the oracle and against the bucket method (explicit
     window) - sizes around the lane / block geometry, identity generators, duplicate and opposite generators, edge scalars, batches
     larger than one launch pair takes, sub-ranges of the generators."""
