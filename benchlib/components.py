@@ -201,8 +201,9 @@ def host_pointer_components(c, do_ntt_c, do_msm_c):
         del hs
     if "host_ntt9_ms" in host and "ntt_batch9_ms" in comp:
         host["host_ntt9_vs_max_pcie_device"] = host["host_ntt9_ms"] / max(host["host_ntt9_pcie_floor_ms"], comp["ntt_batch9_ms"])
-        # both directions carry 9 x 32 MiB; the link's two directions overlap only partly on this platform: nine pinned uploads
-        # + downloads on three streams take 8.9 ms (profiles/r03_h2d_probe.txt), 1.65 x the one-way time
-        host["host_ntt9_pinned_duplex_floor_ms"] = 8.9
+        # both directions carry 9 x 32 MiB.  Since round 5 plk_ntt_batch keeps one stream per direction (uploads back to back, kernels on
+        # the main stream, downloads back to back): both directions of the link are busy from the second transform on
+        # (profiles/r05_host_ntt9_pipeline_ab.txt: 9.7 -> 7.0 ms same lease; round 3's three-stream probe measured 8.9 ms from pinned memory)
+        host["host_ntt9_duplex_floor_ms"] = host["host_ntt9_pcie_floor_ms"] * 10.0 / 9.0  # first upload + nine downloads, the rest overlapped
     host["note"] = "host-pointer C ABI calls on pageable numpy buffers, one caller thread; pcie_floor = bytes one way / 56 GB/s"
     comp["host_pointer"] = host

@@ -20,7 +20,13 @@
  *  - functions with the _dev suffix take DEVICE pointers (HBM-resident data) and a hipStream_t
  *    passed as void*; the others take HOST pointers and copy through PCIe;
  *  - the library is thread safe: calls may come from many host threads (the reference calls
- *    these paths from Rayon workers, src/plonk_util.rs:173-189).
+ *    these paths from Rayon workers, src/plonk_util.rs:173-189);
+ *  - a call leaves the calling thread's current HIP device as it found it (the library selects devices
+ *    freely inside a call); only plk_init, plk_init_devices and plk_set_thread_device select a device
+ *    for the caller;
+ *  - device-group contexts (plk_init_devices) live on logical device 0: plk_halo_begin_tabled_dev over such
+ *    tables must be called from a thread on that device, and per-stage timings (plk_msm_set_profiling)
+ *    exist for one-device contexts only - both are refused with PLK_ERR_INVALID_ARG otherwise.
  */
 #ifndef PLONKY_HIP_H
 #define PLONKY_HIP_H

@@ -501,19 +501,42 @@ static int ntt_batch_local(int field, unsigned log_n, int inverse, unsigned batc
         return c.finish();
     }
     // several large transforms (the nine wire polynomials, plonk_util.rs:169-190): PCIe is the long pole (2 x 32 MiB per 2^20
-    // transform against 0.13 ms of kernels), so transform b runs upload -> kernels -> download on stream b mod 3: the upload of
-    // the next transform and the download of the previous one share the link's two directions
+    // transform against 0.12 ms of kernels).  Round 5: ONE stream per direction - the uploads follow each other at the full rate of
+    // the link on aux[0], the kernels of transform b start on the main stream when its upload has landed (one event), its download
+    // goes on aux[1] when they are done (one event): from the second transform on both directions of the link are busy all the time.
+    // (Until round 4 transform b ran upload -> kernels -> download on stream b mod 3: three uploads shared the link, nothing ran
+    // before all three had landed 1.8 ms in, and the last three downloads had the link to themselves; PLK_NTT_HOST_PIPE=0 is that form.)
     for (unsigned b = 0; b < batch; ++b) {
         c.pin(in[b], bytes);
         if ((const void*)out[b] != (const void*)in[b]) c.pin(out[b], bytes);
     }
     PLK_TRY(lane_fork(*l));
-    for (unsigned b = 0; b < batch; ++b) {
-        hipStream_t st = b % 3 == 0 ? l->stream : l->aux[b % 3 - 1];
-        uint8_t* d = (uint8_t*)buf + b * bytes;
-        if (hipMemcpyAsync(d, in[b], bytes, hipMemcpyHostToDevice, st) != hipSuccess) return set_error(PLK_ERR_HIP, "upload of transform %u failed", b);
-        PLK_TRY(ntt_dev_impl(field, log_n, inverse, 1, d, d, st));
-        if (hipMemcpyAsync(out[b], d, bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return set_error(PLK_ERR_HIP, "download of transform %u failed", b);
+    const char* pe = getenv("PLK_NTT_HOST_PIPE");
+    if (pe && atoi(pe) == 0) {
+        for (unsigned b = 0; b < batch; ++b) {
+            hipStream_t st = b % 3 == 0 ? l->stream : l->aux[b % 3 - 1];
+            uint8_t* d = (uint8_t*)buf + b * bytes;
+            if (hipMemcpyAsync(d, in[b], bytes, hipMemcpyHostToDevice, st) != hipSuccess) return set_error(PLK_ERR_HIP, "upload of transform %u failed", b);
+            PLK_TRY(ntt_dev_impl(field, log_n, inverse, 1, d, d, st));
+            if (hipMemcpyAsync(out[b], d, bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return set_error(PLK_ERR_HIP, "download of transform %u failed", b);
+        }
+    } else {
+        while (l->ev_ready.size() < 2 * (size_t)batch) {
+            hipEvent_t e = nullptr;
+            PLK_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            l->ev_ready.push_back(e);
+        }
+        hipStream_t up = l->aux[0], down = l->aux[1];
+        for (unsigned b = 0; b < batch; ++b) {
+            uint8_t* d = (uint8_t*)buf + b * bytes;
+            if (hipMemcpyAsync(d, in[b], bytes, hipMemcpyHostToDevice, up) != hipSuccess) return set_error(PLK_ERR_HIP, "upload of transform %u failed", b);
+            PLK_HIP_TRY(hipEventRecord(l->ev_ready[2 * b], up));
+            PLK_HIP_TRY(hipStreamWaitEvent(l->stream, l->ev_ready[2 * b], 0));
+            PLK_TRY(ntt_dev_impl(field, log_n, inverse, 1, d, d, l->stream));
+            PLK_HIP_TRY(hipEventRecord(l->ev_ready[2 * b + 1], l->stream));
+            PLK_HIP_TRY(hipStreamWaitEvent(down, l->ev_ready[2 * b + 1], 0));
+            if (hipMemcpyAsync(out[b], d, bytes, hipMemcpyDeviceToHost, down) != hipSuccess) return set_error(PLK_ERR_HIP, "download of transform %u failed", b);
+        }
     }
     PLK_TRY(lane_join(*l));  // before the registrations and the device buffer go
     return c.finish();

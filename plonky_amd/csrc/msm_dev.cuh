@@ -76,6 +76,7 @@ constexpr int ORD_MAX_BINS = 1024;  // coarse bins
 constexpr int ORD_MAX_FINE = 11;    // fine bits: buckets per coarse bin <= 2048
 constexpr int ORD_BIN_THREADS = 512;
 constexpr uint32_t ORD_SEG = 8192;  // entries per level-2 workgroup
+constexpr int ORD_SEG_EPT = (int)(ORD_SEG / ORD_BIN_THREADS);  // ... and per thread of it
 // k_ord_bin_scatter stages a whole segment in LDS (3 fine-bit tables + the staged entries): ~74 KB, above the 64 KB a workgroup
 // gets on gfx90a / gfx942 - this library is built for gfx950 (160 KB of LDS per CU) only, plk_init refuses other devices
 static_assert(3 * (4u << ORD_MAX_FINE) + 4 * ORD_BIN_THREADS + 6 * ORD_SEG <= 160 * 1024, "k_ord_bin_scatter's LDS tile must fit a gfx950 CU");

@@ -13,16 +13,31 @@ namespace plk {
 // a 4-byte write and two 4-byte reads per (scalar, window) by two extra reads of the 32-byte scalar.
 // The canonical limbs are parked in LDS (limb-major: conflict-free) so that the window loop can index them.
 
-template <class SP> PLK_DI void ord_park_scalar(const uint4* __restrict__ scalars, size_t i, uint32_t* s_lim, int tid, bool raw_signed) {
+// the scalar of a lane as loaded (two 16-byte words); requested one sub-tile ahead of its use (k_ord_count, k_ord_scatter)
+struct OrdRaw {
+    uint4 lo, hi;
+};
+PLK_DI OrdRaw ord_load_scalar(const uint4* __restrict__ scalars, size_t i, bool live) {
+    OrdRaw r;
+    r.lo = r.hi = make_uint4(0u, 0u, 0u, 0u);
+    if (live) {
+        r.lo = scalars[i * 2];
+        r.hi = scalars[i * 2 + 1];
+    }
+    return r;
+}
+template <class SP> PLK_DI void ord_park_loaded(const OrdRaw& r, uint32_t* s_lim, int tid, bool raw_signed) {
     static_assert(SP::NL == 8, "scalar fields are 256-bit");
-    const uint4 lo = scalars[i * 2], hi = scalars[i * 2 + 1];
     Fe<SP> s;
-    s.v[0] = lo.x; s.v[1] = lo.y; s.v[2] = lo.z; s.v[3] = lo.w;
-    s.v[4] = hi.x; s.v[5] = hi.y; s.v[6] = hi.z; s.v[7] = hi.w;
+    s.v[0] = r.lo.x; s.v[1] = r.lo.y; s.v[2] = r.lo.z; s.v[3] = r.lo.w;
+    s.v[4] = r.hi.x; s.v[5] = r.hi.y; s.v[6] = r.hi.z; s.v[7] = r.hi.w;
     // Montgomery -> canonical in the SCALAR field (to_canonical_u64_vec, curve_msm.rs:164); half scalars are canonical already
     if (!raw_signed) s = fe_to_canonical<SP>(s);
 #pragma unroll
     for (int k = 0; k < 8; ++k) s_lim[k * ORD_THREADS + tid] = s.v[k];
+}
+template <class SP> PLK_DI void ord_park_scalar(const uint4* __restrict__ scalars, size_t i, uint32_t* s_lim, int tid, bool raw_signed) {
+    ord_park_loaded<SP>(ord_load_scalar(scalars, i, true), s_lim, tid, raw_signed);
 }
 // digit j of the parked scalar: signed c-bit window by carry-based integer recoding (never s -> r - s, so it is valid on
 // BLS12-377 G1 whose cofactor is even).  Returns (bucket << 1) | negative, or CODE_INVALID for a zero digit.
@@ -127,11 +142,16 @@ __global__ void __launch_bounds__(ORD_THREADS) k_ord_count(const uint4* __restri
     const int tid = threadIdx.x;
     const uint32_t tile = blockIdx.x;
     for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_hist[k] = 0;
+    // the scalar of sub-tile st + 1 is requested before sub-tile st is worked on: two workgroups per CU do not hide a load each
+    auto sub_index = [&](uint32_t st) { return ((size_t)tile * cfg.sub + st) * cfg.spt + tid; };
+    auto sub_live = [&](uint32_t st) { return st < cfg.sub && (uint32_t)tid < cfg.spt && sub_index(st) < n; };
+    OrdRaw nxt = ord_load_scalar(scalars, sub_index(0), sub_live(0));
     for (uint32_t st = 0; st < cfg.sub; ++st) {
-        const size_t i = ((size_t)tile * cfg.sub + st) * cfg.spt + tid;
-        const bool live = (uint32_t)tid < cfg.spt && i < n;
+        const bool live = sub_live(st);
+        const OrdRaw cur = nxt;
+        nxt = ord_load_scalar(scalars, sub_index(st + 1), sub_live(st + 1));
         __syncthreads();
-        if (live) ord_park_scalar<SP>(scalars, i, s_lim, tid, cfg.raw_signed != 0);
+        if (live) ord_park_loaded<SP>(cur, s_lim, tid, cfg.raw_signed != 0);
         __syncthreads();
         if (live) {
             uint32_t carry = 0;
@@ -245,12 +265,17 @@ __global__ void __launch_bounds__(ORD_THREADS) k_ord_scatter(const uint4* __rest
     const int tid = threadIdx.x;
     const uint32_t tile = blockIdx.x;
     for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_gbase[k] = bin_base[k] + cnt1[(size_t)k * cfg.nt1 + tile];
+    auto sub_index = [&](uint32_t st) { return ((size_t)tile * cfg.sub + st) * cfg.spt + tid; };
+    auto sub_live = [&](uint32_t st) { return st < cfg.sub && (uint32_t)tid < cfg.spt && sub_index(st) < n; };
+    OrdRaw nxt = ord_load_scalar(scalars, sub_index(0), sub_live(0));  // one sub-tile ahead (k_ord_count)
     for (uint32_t st = 0; st < cfg.sub; ++st) {
-        const size_t i = ((size_t)tile * cfg.sub + st) * cfg.spt + tid;
-        const bool live = (uint32_t)tid < cfg.spt && i < n;
+        const size_t i = sub_index(st);
+        const bool live = sub_live(st);
+        const OrdRaw cur = nxt;
+        nxt = ord_load_scalar(scalars, sub_index(st + 1), sub_live(st + 1));
         __syncthreads();  // the previous sub-tile has been written out
         for (int k = tid; k < cfg.nbins; k += ORD_THREADS) s_cnt[k] = 0;
-        if (live) ord_park_scalar<SP>(scalars, i, s_lim, tid, cfg.raw_signed != 0);
+        if (live) ord_park_loaded<SP>(cur, s_lim, tid, cfg.raw_signed != 0);
         __syncthreads();
         if (live) {
             // one atomic per entry: its return value is the entry's rank inside its bin, kept for the placement below
@@ -316,9 +341,18 @@ __global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_count(const uint2* 
     if (!ord_segment(seg_base, bin_base, nbins, blockIdx.x, bin, seg, lo, hi)) return;
     const int nf = 1 << fine_bits;
     const uint32_t fmask = (uint32_t)nf - 1u;
+    // a thread's sixteen entries are requested together (one round trip instead of sixteen behind each other's LDS atomics)
+    uint32_t code[ORD_SEG_EPT];
+#pragma unroll
+    for (int k = 0; k < ORD_SEG_EPT; ++k) {
+        const uint32_t p = lo + tid + k * ORD_BIN_THREADS;
+        code[k] = tmp[p < hi ? p : lo].x;
+    }
     for (int k = tid; k < nf; k += ORD_BIN_THREADS) s_hist[k] = 0;
     __syncthreads();
-    for (uint32_t p = lo + tid; p < hi; p += ORD_BIN_THREADS) atomicAdd(&s_hist[(tmp[p].x >> 1) & fmask], 1u);
+#pragma unroll
+    for (int k = 0; k < ORD_SEG_EPT; ++k)
+        if (lo + tid + k * ORD_BIN_THREADS < hi) atomicAdd(&s_hist[(code[k] >> 1) & fmask], 1u);
     __syncthreads();
     for (int k = tid; k < nf; k += ORD_BIN_THREADS) cnt2[((size_t)blockIdx.x << fine_bits) + k] = s_hist[k];
 }
@@ -347,6 +381,13 @@ __global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_scatter(const uint2
     }
     const int nf = 1 << fine_bits;
     const uint32_t fmask = (uint32_t)nf - 1u;
+    // this thread's sixteen entries of the segment, requested now: they arrive while the bucket offsets are worked out
+    uint2 ent[ORD_SEG_EPT];
+#pragma unroll
+    for (int k = 0; k < ORD_SEG_EPT; ++k) {
+        const uint32_t p = lo + tid + k * ORD_BIN_THREADS;
+        ent[k] = tmp[p < hi ? p : lo];
+    }
     const uint32_t s0 = seg_base[bin], s1 = seg_base[bin + 1];
     for (int k = tid; k < nf; k += ORD_BIN_THREADS) {
         uint32_t tot = 0, before = 0, own = 0;
@@ -371,8 +412,10 @@ __global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_scatter(const uint2
         s_cur[k] = s_loc[k];       // LDS cursor
     }
     __syncthreads();
-    for (uint32_t p = lo + tid; p < hi; p += ORD_BIN_THREADS) {
-        const uint2 e = tmp[p];
+#pragma unroll
+    for (int k = 0; k < ORD_SEG_EPT; ++k) {
+        if (lo + tid + k * ORD_BIN_THREADS >= hi) continue;
+        const uint2 e = ent[k];
         const uint32_t f = (e.x >> 1) & fmask;
         const uint32_t idx = atomicAdd(&s_cur[f], 1u);
         if (PLK_CHK(idx < ORD_SEG, CHK_SEG_STAGE)) {

@@ -400,8 +400,20 @@ PLK_DI Fz<P> tile_emit(const NttPassArgs& a, const NttHooks& hk, Fz<P> v, const 
 // One tile per workgroup; any tile shape (transforms shorter than a tile included).  IN_LIMBS / OUT_LIMBS: the pass reads /
 // writes the library's own scratch buffer in limb form (every pass but the first / the last); the caller's buffers are the
 // reference's 32-byte elements.  `in` and `out` may be the same buffer (a tile reads all of its elements before it writes).
+// tuning builds (tools/gpu/r05_ntt_variants.sh): bit 0 the loads of a tile requested together, bit 1 the inter-pass twiddles likewise,
+// bit 2 the register allocation held to four waves per SIMD.  Measured on one lease (profiles/r05_ntt_variants.txt): bit 0 is worth 1-2.5 %
+// on multi-round launches (nine 2^20 transforms 98.0 -> 96.4 us each, 2^23 971 -> 948 us) and costs 1.7-2.3 us on a lone 2^18 / 2^19
+// transform; bit 1 gains nothing anywhere and costs a lone 2^18 transform 4 us - the memory latency of a tile is NOT what a pass waits for.
+#ifndef PLK_NTT_VARIANT
+#define PLK_NTT_VARIANT 5
+#endif
+#if PLK_NTT_VARIANT & 4
+#define PLK_NTT_BOUNDS __launch_bounds__(NTT_THREADS, 4)
+#else
+#define PLK_NTT_BOUNDS __launch_bounds__(NTT_THREADS)
+#endif
 template <class P, bool HOOKS, bool IN_LIMBS, bool OUT_LIMBS>
-__global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const void* in, void* out, const uint4* __restrict__ inner_tw,
+__global__ void PLK_NTT_BOUNDS k_ntt_pass(const void* in, void* out, const uint4* __restrict__ inner_tw,
                                                           const uint32_t* __restrict__ outer_tw, const uint4* __restrict__ scale_ptr, NttPassArgs a,
                                                           NttHooks hk) {
     static_assert(P::NL == 8, "NTT kernels are written for the 256-bit fields");
@@ -425,13 +437,55 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const void* in, void* 
         for (int i = 0; i < ph * a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
     }
     const TileGeom tg = tile_geom(a, blockIdx.x);
+    // The loads of a thread's EPT = 4 elements are ISSUED before any of them is waited for (round 5; until round 4: load, wait, LDS store,
+    // four round trips behind each other).
+    constexpr int EPT = TILE / NTT_THREADS;
+    const bool by_slot = HOOKS && !IN_LIMBS && a.skip > 0;
+    Fe<P> scale_raw = fe_zero<P>();  // the last pass's factor (1 or n^-1): requested with the tile, used when it is written out
+    if (a.last) scale_raw = fe_load<P>(scale_ptr);
+#if PLK_NTT_VARIANT & 1
+    size_t gin[EPT];
+    Fz<P> xin[EPT];
+    Fe<P> vin[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        // a thread past the end of a short tile reads the tile's last element again (and drops it): no branch around the loads
+        const int e = min(tid + k * NTT_THREADS, tile_elems - 1);
+        gin[k] = tile_in_index(a, tg, by_slot ? tile_slot_source(a, e) : e);
+        if constexpr (IN_LIMBS) {
+            xin[k] = limbs_load<P>((const uint32_t*)in, tg.b * n + gin[k]);
+        } else {
+            const uint4* inb = (const uint4*)in + tg.b * ((HOOKS && a.first) ? hk.in_stride : n) * 2;
+            if constexpr (HOOKS) {
+                vin[k] = fe_zero<P>();
+                if (!a.first || gin[k] < hk.in_len) vin[k] = fe_load<P>(inb + gin[k] * 2);
+            } else {
+                vin[k] = fe_load<P>(inb + gin[k] * 2);
+            }
+        }
+    }
+    // stage twiddles (R'-form): w_A^e = inner[e * (1024 / A)], e < A/2
+    for (int e = tid; e < ((TILE_LOG >= 12 && a.tw_global) ? 0 : half_a); e += NTT_THREADS) {
+        const Fe<P> w = fe_load<P>(inner_tw + ((size_t)e << (INNER_LOG - log_a)) * 2);
+        lds_store<P>(s_tw, half_a, e, fz_from_fe<P>(w));
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * NTT_THREADS;
+        if (e < tile_elems) {
+            Fz<P> x;
+            if constexpr (IN_LIMBS) x = xin[k];
+            else x = tile_ingest<P, HOOKS>(a, hk, vin[k], gin[k]);
+            lds_store<P>(s_dat, TILE, by_slot ? e : tile_in_slot(a, e), x);
+        }
+    }
+#else
     // stage twiddles (R'-form): w_A^e = inner[e * (1024 / A)], e < A/2
     for (int e = tid; e < ((TILE_LOG >= 12 && a.tw_global) ? 0 : half_a); e += NTT_THREADS) {
         const Fe<P> w = fe_load<P>(inner_tw + ((size_t)e << (INNER_LOG - log_a)) * 2);
         lds_store<P>(s_tw, half_a, e, fz_from_fe<P>(w));
     }
     for (int e = tid; e < tile_elems; e += NTT_THREADS) {
-        const bool by_slot = HOOKS && !IN_LIMBS && a.skip > 0;
         const size_t g = tile_in_index(a, tg, by_slot ? tile_slot_source(a, e) : e);
         Fz<P> x;
         if constexpr (IN_LIMBS) {
@@ -444,9 +498,31 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const void* in, void* 
         }
         lds_store<P>(s_dat, TILE, by_slot ? e : tile_in_slot(a, e), x);
     }
+#endif
     __syncthreads();
     tile_stages<P>(s_dat, s_tw, tid, log_a, log_q, tile_elems, (HOOKS && !IN_LIMBS) ? a.skip : 0, inner_tw, a.tw_global != 0, a.shuffle != 0);
-    const Fz<P> scale = fz_from_fe<P>(fe_load<P>(scale_ptr));
+    const Fz<P> scale = fz_from_fe<P>(scale_raw);
+#if PLK_NTT_VARIANT & 2
+    // the inter-pass twiddles of this thread's four outputs: requested together, one round trip
+    Fz<P> otw[EPT];
+    if (!a.last) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) otw[k] = limbs_load<P>(outer_tw, tile_tw_index(a, tg, min(tid + k * NTT_THREADS, tile_elems - 1)));
+    } else {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) otw[k] = fz_zero<P>();
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * NTT_THREADS;
+        if (e < tile_elems) {
+            const size_t g = tile_out_index(a, tg, e);
+            const Fz<P> r = tile_emit<P, HOOKS>(a, hk, lds_load<P>(s_dat, TILE, e), otw[k], scale, g);
+            if constexpr (OUT_LIMBS) limbs_store<P>((uint32_t*)out, tg.b * n + g, r);
+            else fe_store<P>((uint4*)out + (tg.b * n + g) * 2, fz_to_fe_canonical<P>(r));
+        }
+    }
+#else
     for (int e = tid; e < tile_elems; e += NTT_THREADS) {
         const size_t g = tile_out_index(a, tg, e);
         Fz<P> tw = fz_zero<P>();
@@ -455,6 +531,7 @@ __global__ void __launch_bounds__(NTT_THREADS) k_ntt_pass(const void* in, void* 
         if constexpr (OUT_LIMBS) limbs_store<P>((uint32_t*)out, tg.b * n + g, r);
         else fe_store<P>((uint4*)out + (tg.b * n + g) * 2, fz_to_fe_canonical<P>(r));
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
