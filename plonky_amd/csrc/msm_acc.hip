@@ -38,6 +38,50 @@ PLK_DI uint32_t bucket_search(const uint32_t* __restrict__ off, uint32_t lo, uin
     }
     return lo;
 }
+// The mixed addition of the loop in a form whose ONE exit leaves the sum in the accumulator's own registers (round 5).  ecz.cuh's
+// xyzzz_madd_lazy has three exits (identity accumulator, equal / opposite points, normal) that meet in ~80 register copies per
+// iteration; here the arithmetic always runs to the end and the exceptional case (the operands share x: probability 2^-250 for
+// random points, the rule for duplicate generators) comes back as a FLAG - 1: equal points, 2: opposite points - that the caller
+// repairs out of line, re-reading the entry instead of keeping it alive across the addition.  Same formulas, same bounds
+// (ecz.cuh); precondition: acc is not the identity.
+#ifndef PLK_ACC_FORM
+#define PLK_ACC_FORM 2
+#endif
+template <class FP> PLK_DI int acc_madd_flag(XyzzZ<FP>& acc, const Fz<FP>& x2, const Fz<FP>& y2) {
+    // ordered so that every coordinate of the old accumulator dies as early as it can (the kernel lives at the edge of its register budget)
+    Fz<FP> u2 = fz_mul<FP>(x2, acc.zz);                      // < 2
+    Fz<FP> p = fz_sub<FP, 4>(u2, acc.x);                     // < 18
+    Fz<FP> pp = fz_sqr<FP>(p);                               // < 3.6
+    Fz<FP> zz3 = fz_mul<FP>(acc.zz, pp);                     // < 1.1      (ZZ dead)
+    Fz<FP> q = fz_mul<FP>(acc.x, pp);                        // < 1.3      (X dead)
+    Fz<FP> ppp = fz_mul<FP>(p, pp);                          // < 1.6      (p, pp dead)
+    Fz<FP> s2 = fz_mul<FP>(y2, acc.zzz);                     // < 2
+    Fz<FP> r = fz_sub_nc<FP, 2, 31>(s2, acc.y);              // < 6
+    fz_carry<FP>(r);
+    Fz<FP> zzz3 = fz_mul<FP>(acc.zzz, ppp);                  // < 1.1      (ZZZ dead)
+    Fz<FP> yp = fz_mul<FP>(acc.y, ppp);                      //            (Y dead)
+    Fz<FP> rr = fz_sqr<FP>(r);                               // < 1.3
+    int special = 0;
+    if (zz3.l[0] <= 1u && fz_is_zero_mod_p<FP>(zz3)) special = fz_is_zero_mod_p<FP>(rr) ? 1 : 2;
+    Fz<FP> x3 = fz_sub_nc<FP, 2, 30>(fz_sub_nc<FP, 1, 29>(rr, ppp), fz_add_nc<FP>(q, q));  // < 7.3
+    fz_carry<FP>(x3);
+    Fz<FP> t;
+    if constexpr (FzCfg<FP>::NZ <= 10) t = fz_sub_nc<FP, 3, 30>(q, x3);
+    else t = fz_sub<FP, 3>(q, x3);
+    acc.y = fz_sub_nc<FP, 1, 29>(fz_mul<FP>(r, t), yp);      // < 3.5: both products exactly normalised, the difference keeps its carries
+    acc.x = x3;
+    acc.zz = zz3;
+    acc.zzz = zzz3;
+    return special;
+}
+// the table entry in the working form: x, and +-y (2p - y without a carry pass: limbs <= 2^30 - 2, ecz.cuh)
+template <class FP> PLK_DI void acc_entry(const Fe<FP>& x, const Fe<FP>& y, bool negate, Fz<FP>& xz, Fz<FP>& yz) {
+    xz = fz_from_fe<FP>(x);
+    const Fz<FP> yp = fz_from_fe<FP>(y);
+    const Fz<FP> yn = fz_sub_nc<FP, 1, 29>(fz_zero<FP>(), yp);
+#pragma unroll
+    for (int i = 0; i < FzCfg<FP>::NZ; ++i) yz.l[i] = negate ? yn.l[i] : yp.l[i];
+}
 // the loaded values are materialised HERE (an empty asm the compiler must feed with registers)
 template <class FP> PLK_DI void acc_pin(Fe<FP>& x, Fe<FP>& y, uint32_t& a, uint32_t& b) {
 #pragma unroll
@@ -141,7 +185,34 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
                 if (PLK_CHK((ent >> 1) - nsub < tab_entries, CHK_TABLE_INDEX)) acc_gather<FP>(tab + acc_table_index((ent >> 1) - nsub) * 2 * W, x, y);
             }
             if (cident) continue;
+#if PLK_ACC_FORM == 2
+            {  // (4)
+                Fz<FP> xz, yz;
+                acc_entry<FP>(cx, cy, (cur & 1u) != 0, xz, yz);
+                if (acc.inf) {  // first entry of a piece (or after a sum that cancelled)
+                    acc.x = xz;
+                    acc.y = yz;
+                    acc.zz = fz_one_rprime<FP>();
+                    acc.zzz = acc.zz;
+                    acc.inf = false;
+                } else {
+                    const int special = acc_madd_flag<FP>(acc, xz, yz);
+                    if (special == 2) {
+                        acc.inf = true;  // P + (-P)
+                    } else if (special == 1) {
+                        // P + P: the entry is read again (rare: nothing of it was kept alive across the addition) and doubled
+                        Fe<FP> rx, ry;
+                        (void)affine_load<FP>(tab + acc_table_index((cur >> 1) - (b >> wshift) * n_sub) * 2 * W, rx, ry);
+                        Fz<FP> dx, dy;
+                        acc_entry<FP>(rx, ry, (cur & 1u) != 0, dx, dy);
+                        fz_carry<FP>(dy);
+                        acc = xyzzz_mdbl<FP>(dx, dy);
+                    }
+                }
+            }
+#else
             xyzzz_madd_entry<FP>(acc, cx, cy, (cur & 1u) != 0);  // (4)
+#endif
         }
         xyzzz_settle<FP>(acc);
     }
