@@ -44,23 +44,35 @@ PLK_DI uint32_t bucket_search(const uint32_t* __restrict__ off, uint32_t lo, uin
 // random points, the rule for duplicate generators) comes back as a FLAG - 1: equal points, 2: opposite points - that the caller
 // repairs out of line, re-reading the entry instead of keeping it alive across the addition.  Same formulas, same bounds
 // (ecz.cuh); precondition: acc is not the identity.
-#ifndef PLK_ACC_FORM
-#define PLK_ACC_FORM 2
+// tuning: -DPLK_ACC_SERIAL=1 puts a scheduling barrier after every product of the addition (less interleaving, fewer live temporaries)
+#if defined(PLK_ACC_SERIAL) && PLK_ACC_SERIAL
+#define PLK_ACC_SB __builtin_amdgcn_sched_barrier(0)
+#else
+#define PLK_ACC_SB (void)0
 #endif
 template <class FP> PLK_DI int acc_madd_flag(XyzzZ<FP>& acc, const Fz<FP>& x2, const Fz<FP>& y2) {
     // ordered so that every coordinate of the old accumulator dies as early as it can (the kernel lives at the edge of its register budget)
     Fz<FP> u2 = fz_mul<FP>(x2, acc.zz);                      // < 2
+    PLK_ACC_SB;
     Fz<FP> p = fz_sub<FP, 4>(u2, acc.x);                     // < 18
     Fz<FP> pp = fz_sqr<FP>(p);                               // < 3.6
+    PLK_ACC_SB;
     Fz<FP> zz3 = fz_mul<FP>(acc.zz, pp);                     // < 1.1      (ZZ dead)
+    PLK_ACC_SB;
     Fz<FP> q = fz_mul<FP>(acc.x, pp);                        // < 1.3      (X dead)
+    PLK_ACC_SB;
     Fz<FP> ppp = fz_mul<FP>(p, pp);                          // < 1.6      (p, pp dead)
+    PLK_ACC_SB;
     Fz<FP> s2 = fz_mul<FP>(y2, acc.zzz);                     // < 2
+    PLK_ACC_SB;
     Fz<FP> r = fz_sub_nc<FP, 2, 31>(s2, acc.y);              // < 6
     fz_carry<FP>(r);
     Fz<FP> zzz3 = fz_mul<FP>(acc.zzz, ppp);                  // < 1.1      (ZZZ dead)
+    PLK_ACC_SB;
     Fz<FP> yp = fz_mul<FP>(acc.y, ppp);                      //            (Y dead)
+    PLK_ACC_SB;
     Fz<FP> rr = fz_sqr<FP>(r);                               // < 1.3
+    PLK_ACC_SB;
     int special = 0;
     if (zz3.l[0] <= 1u && fz_is_zero_mod_p<FP>(zz3)) special = fz_is_zero_mod_p<FP>(rr) ? 1 : 2;
     Fz<FP> x3 = fz_sub_nc<FP, 2, 30>(fz_sub_nc<FP, 1, 29>(rr, ppp), fz_add_nc<FP>(q, q));  // < 7.3
@@ -158,7 +170,7 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
                     xyzzz_store_raw<FP>(p_start + (size_t)b * RU, acc);
                 }
                 head = false;
-                acc.inf = true;  // the coordinates stay as they are (36 register clears less): the next addition overwrites them (ecz.cuh)
+                acc.inf = true;  // the coordinates stay as they are (36 register clears less): the next entry overwrites them
                 uint32_t nb = b + 1, nn = n2;
                 if (n2 <= k) {  // bucket b + 1 is empty (e^-26 of the buckets at c = 20; the rule for sparse vectors)
                     nb = bucket_search(off, b + 1, buckets, k);
@@ -185,7 +197,6 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
                 if (PLK_CHK((ent >> 1) - nsub < tab_entries, CHK_TABLE_INDEX)) acc_gather<FP>(tab + acc_table_index((ent >> 1) - nsub) * 2 * W, x, y);
             }
             if (cident) continue;
-#if PLK_ACC_FORM == 2
             {  // (4)
                 Fz<FP> xz, yz;
                 acc_entry<FP>(cx, cy, (cur & 1u) != 0, xz, yz);
@@ -210,9 +221,6 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
                     }
                 }
             }
-#else
-            xyzzz_madd_entry<FP>(acc, cx, cy, (cur & 1u) != 0);  // (4)
-#endif
         }
         xyzzz_settle<FP>(acc);
     }

@@ -146,6 +146,22 @@ template <class P> PLK_DI void lds_store(uint32_t* base, int stride, int idx, co
     for (int l = 0; l < FzCfg<P>::NZ; ++l) base[l * stride + idx] = v.l[l];
 }
 
+// The tile itself, with an optional bank skew (tuning bit 3 of PLK_NTT_VARIANT): element i of a plane sits at word i + (i >> 5), so the
+// groups of Q lanes that a stage with a small half-size (and the bit-reversed placement of the inputs) put 32 words apart fall on
+// different banks instead of the same Q ones.
+#ifndef PLK_NTT_VARIANT
+#define PLK_NTT_VARIANT 5
+#endif
+#if PLK_NTT_VARIANT & 8
+constexpr int DAT_STRIDE = TILE + TILE / 32;
+PLK_DI int dat_index(int i) { return i + (i >> 5); }
+#else
+constexpr int DAT_STRIDE = TILE;
+PLK_DI int dat_index(int i) { return i; }
+#endif
+template <class P> PLK_DI Fz<P> dat_load(const uint32_t* base, int idx) { return lds_load<P>(base, DAT_STRIDE, dat_index(idx)); }
+template <class P> PLK_DI void dat_store(uint32_t* base, int idx, const Fz<P>& v) { lds_store<P>(base, DAT_STRIDE, dat_index(idx), v); }
+
 // b^i from a two-level geometric table (R'-form): hi[i >> 10] * lo[i & 1023], < 1.01p
 template <class P> PLK_DI Fz<P> geom_pow(const void* lo, const void* hi, size_t i) {
     const Fz<P> l = fz_from_fe<P>(fe_load<P>((const uint4*)lo + (i & ((1u << NTT_POW_LO_LOG) - 1)) * 2));
@@ -301,7 +317,7 @@ PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw, int tid, int log_
         {
             const int i0 = ((pq << 2) << log_q) + q, st = Q;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] = lds_load<P>(s_dat, TILE, i0 + k * st);
+            for (int k = 0; k < 4; ++k) x[k] = dat_load<P>(s_dat, i0 + k * st);
             const Fz<P> wb1 = stage_tw(1 << (log_a - 2));
             radix4_step<P, true>(x, wb1, wb1, wb1);
         }
@@ -315,7 +331,7 @@ PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw, int tid, int log_
             // is wave-wide, but lanes of OTHER waves may still be loading - they load rows 4 pq .. 4 pq + 3 of their own pq only,
             // and the rows written here, 16 blk + j + 4 k, belong to the four pq of THIS lane group: no overlap across waves
 #pragma unroll
-            for (int k = 0; k < 4; ++k) lds_store<P>(s_dat, TILE, i0 + k * st, x[k]);
+            for (int k = 0; k < 4; ++k) dat_store<P>(s_dat, i0 + k * st, x[k]);
         }
         __syncthreads();
         log_h = 4;
@@ -328,7 +344,7 @@ PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw, int tid, int log_
             const int i0 = (((blk << (log_h + 2)) + j) << log_q) + q, st = h << log_q;
             Fz<P> x[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] = lds_load<P>(s_dat, TILE, i0 + k * st);
+            for (int k = 0; k < 4; ++k) x[k] = dat_load<P>(s_dat, i0 + k * st);
             if (log_h > 0) {
                 const Fz<P> wa = stage_tw(j << (log_a - 1 - log_h));
                 const Fz<P> wb1 = stage_tw((j + h) << (log_a - 2 - log_h));
@@ -339,7 +355,7 @@ PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw, int tid, int log_
                 radix4_step<P, true>(x, wb1, wb1, wb1);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) lds_store<P>(s_dat, TILE, i0 + k * st, x[k]);
+            for (int k = 0; k < 4; ++k) dat_store<P>(s_dat, i0 + k * st, x[k]);
         }
         __syncthreads();
     }
@@ -349,15 +365,15 @@ PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw, int tid, int log_
             const int q = bf & (Q - 1), pb = bf >> log_q;
             const int j = pb & (h - 1), blk = pb >> log_h;
             const int i0 = (((blk << (log_h + 1)) + j) << log_q) + q, i1 = i0 + (h << log_q);
-            Fz<P> x = lds_load<P>(s_dat, TILE, i0);
-            Fz<P> t = lds_load<P>(s_dat, TILE, i1);
+            Fz<P> x = dat_load<P>(s_dat, i0);
+            Fz<P> t = dat_load<P>(s_dat, i1);
             if (log_h > 0) {
                 fz_carry<P>(x);
                 t = fz_mul<P>(t, stage_tw(j << (log_a - 1 - log_h)));  // w_{2h}^j, product < 1.2p
             }
             // log_h == 0: a two-point transform of exactly normalised inputs
-            lds_store<P>(s_dat, TILE, i0, fz_add_nc<P>(x, t));
-            lds_store<P>(s_dat, TILE, i1, fz_sub_nc<P, 1, 29>(x, t));  // t < 2p - margin in both cases
+            dat_store<P>(s_dat, i0, fz_add_nc<P>(x, t));
+            dat_store<P>(s_dat, i1, fz_sub_nc<P, 1, 29>(x, t));  // t < 2p - margin in both cases
         }
         __syncthreads();
     }
@@ -425,7 +441,7 @@ __global__ void PLK_NTT_BOUNDS k_ntt_pass(const void* in, void* out, const uint4
     const int half_a = (1 << log_a) >> 1;
     const size_t n = (size_t)1 << a.log_n;
     uint32_t* s_dat = s_mem;
-    uint32_t* s_tw = s_mem + NZ * TILE;
+    uint32_t* s_tw = s_mem + NZ * DAT_STRIDE;
 
     // A pass whose workgroups all fit the GPU at once (a single 2^20 transform: 1024 tiles, four per CU) would run in lockstep - every
     // workgroup loads, then every workgroup computes, then every workgroup stores: ~20 us of memory phases beside ~21 us of issue
@@ -476,7 +492,7 @@ __global__ void PLK_NTT_BOUNDS k_ntt_pass(const void* in, void* out, const uint4
             Fz<P> x;
             if constexpr (IN_LIMBS) x = xin[k];
             else x = tile_ingest<P, HOOKS>(a, hk, vin[k], gin[k]);
-            lds_store<P>(s_dat, TILE, by_slot ? e : tile_in_slot(a, e), x);
+            dat_store<P>(s_dat, by_slot ? e : tile_in_slot(a, e), x);
         }
     }
 #else
@@ -496,7 +512,7 @@ __global__ void PLK_NTT_BOUNDS k_ntt_pass(const void* in, void* out, const uint4
             if (!HOOKS || !a.first || g < hk.in_len) v = fe_load<P>(inb + g * 2);
             x = tile_ingest<P, HOOKS>(a, hk, v, g);
         }
-        lds_store<P>(s_dat, TILE, by_slot ? e : tile_in_slot(a, e), x);
+        dat_store<P>(s_dat, by_slot ? e : tile_in_slot(a, e), x);
     }
 #endif
     __syncthreads();
@@ -517,7 +533,7 @@ __global__ void PLK_NTT_BOUNDS k_ntt_pass(const void* in, void* out, const uint4
         const int e = tid + k * NTT_THREADS;
         if (e < tile_elems) {
             const size_t g = tile_out_index(a, tg, e);
-            const Fz<P> r = tile_emit<P, HOOKS>(a, hk, lds_load<P>(s_dat, TILE, e), otw[k], scale, g);
+            const Fz<P> r = tile_emit<P, HOOKS>(a, hk, dat_load<P>(s_dat, e), otw[k], scale, g);
             if constexpr (OUT_LIMBS) limbs_store<P>((uint32_t*)out, tg.b * n + g, r);
             else fe_store<P>((uint4*)out + (tg.b * n + g) * 2, fz_to_fe_canonical<P>(r));
         }
@@ -527,7 +543,7 @@ __global__ void PLK_NTT_BOUNDS k_ntt_pass(const void* in, void* out, const uint4
         const size_t g = tile_out_index(a, tg, e);
         Fz<P> tw = fz_zero<P>();
         if (!a.last) tw = limbs_load<P>(outer_tw, tile_tw_index(a, tg, e));
-        const Fz<P> r = tile_emit<P, HOOKS>(a, hk, lds_load<P>(s_dat, TILE, e), tw, scale, g);
+        const Fz<P> r = tile_emit<P, HOOKS>(a, hk, dat_load<P>(s_dat, e), tw, scale, g);
         if constexpr (OUT_LIMBS) limbs_store<P>((uint32_t*)out, tg.b * n + g, r);
         else fe_store<P>((uint4*)out + (tg.b * n + g) * 2, fz_to_fe_canonical<P>(r));
     }
@@ -752,13 +768,13 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
         void* dst = a.last ? d_out : scratch;
         std::pair<hipEvent_t, hipEvent_t> pev;
         const bool prof = prof_begin(stream, pev);
-        size_t lds_bytes = ((size_t)FzCfg<P>::NZ * TILE + (size_t)FzCfg<P>::NZ * ((size_t)1 << a.log_a) / 2) * 4;
+        size_t lds_bytes = ((size_t)FzCfg<P>::NZ * DAT_STRIDE + (size_t)FzCfg<P>::NZ * ((size_t)1 << a.log_a) / 2) * 4;
         static const int shuffle_mode = getenv("PLK_NTT_SHUFFLE") ? atoi(getenv("PLK_NTT_SHUFFLE")) : 0;
         a.shuffle = shuffle_mode;
         a.tw_global = 0;
         if (lds_bytes > NTT_LDS_MAX) {
             a.tw_global = 1;
-            lds_bytes = (size_t)FzCfg<P>::NZ * TILE * 4;
+            lds_bytes = (size_t)FzCfg<P>::NZ * DAT_STRIDE * 4;
         }
         // one round of workgroups (at most four 39 KB tiles per CU) and more than one per CU: start them in phases
         {
