@@ -51,7 +51,7 @@ extern "C" {
 #define PLK_FIELD_TWEEDLEDEE_BASE 0
 #define PLK_FIELD_TWEEDLEDUM_BASE 1
 #define PLK_FIELD_BLS12_377_SCALAR 2
-#define PLK_FIELD_BLS12_377_BASE 3 /* curve coordinates only; no NTT entry point needs it */
+#define PLK_FIELD_BLS12_377_BASE 3 /* 6 x u64 per element; curve coordinates, and the plain / zero-padded NTT entry points (no polynomial callers) */
 #define PLK_FIELD_PALLAS_BASE 4    /* src/field/pallas_base.rs */
 #define PLK_FIELD_VESTA_BASE 5     /* src/field/vesta_base.rs */
 /* curve ids (reference: src/curve/) */

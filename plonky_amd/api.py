@@ -96,10 +96,11 @@ def fft_precompute(field, degree):
 
 def fft_precompute_table(field, degree):
     """The CONTENTS of the reference's FftPrecomputation (fft.rs:28-59), built on the device: the list subgroups_rev[i],
-    i = 0 ..= log2_ceil(degree), each a (2^i, 4) array of the bit-reversed powers of primitive_root_of_unity(i)."""
+    i = 0 ..= log2_ceil(degree), each a (2^i, L) array of the bit-reversed powers of primitive_root_of_unity(i) (L = 4 limbs; 6 for
+    Bls12377Base)."""
     degree_pow = log2_ceil(degree)
     assert degree_pow <= _TWO_ADICITY[field], "n_power <= TWO_ADICITY"  # field.rs:430
-    flat = np.empty(((2 << degree_pow) - 1, 4), dtype=np.uint64)
+    flat = np.empty(((2 << degree_pow) - 1, _FIELD_LIMBS[field]), dtype=np.uint64)
     _lib.check(_lib.load().plk_ntt_precompute_table(field, degree_pow, _ptr(flat)))
     return [flat[(1 << i) - 1: (2 << i) - 1] for i in range(degree_pow + 1)]
 

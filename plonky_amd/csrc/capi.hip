@@ -465,12 +465,12 @@ int plk_ntt_precompute_table_dev(int field, unsigned log_n, void* d_out, void* s
 }
 int plk_ntt_precompute_table(int field, unsigned log_n, uint64_t* out) {
     PLK_API;
-    if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
+    if (field_limbs(field) < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
     if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
     if (!out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     HostLane* l = nullptr;
     PLK_TRY(lane_get(l));
-    const size_t bytes = (((size_t)2 << log_n) - 1) * 32;
+    const size_t bytes = (((size_t)2 << log_n) - 1) * (size_t)field_limbs(field) * 8;
     LaneBuf buf;
     PLK_TRY(buf.alloc(bytes, l->stream));
     PLK_TRY(ntt_reference_table_dev_impl(field, log_n, buf.p, l->stream));
@@ -487,7 +487,7 @@ int plk_ntt_dev(int field, unsigned log_n, int inverse, unsigned batch, const vo
 // `batch` transforms from / to host memory on the calling thread's current device
 static int ntt_batch_local(int field, unsigned log_n, int inverse, unsigned batch, const uint64_t* const* in, uint64_t* const* out) {
     if (batch == 0) return PLK_OK;
-    const size_t bytes = ((size_t)1 << log_n) * 32;
+    const size_t bytes = ((size_t)1 << log_n) * (size_t)field_limbs(field) * 8;  // 32 per element, 48 for Bls12377Base
     LaneCall c;
     PLK_TRY(c.begin());
     HostLane* l = c.l;
@@ -557,7 +557,7 @@ static int deal_units(unsigned log_n, unsigned batch, const std::function<int(un
 
 int plk_ntt_batch(int field, unsigned log_n, int inverse, unsigned batch, const uint64_t* const* in, uint64_t* const* out) {
     PLK_API;
-    if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
+    if (field_limbs(field) < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
     if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
     if (batch == 0) return PLK_OK;
     if (!in || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
@@ -596,27 +596,28 @@ static int ntt_padded_batch_local(int field, unsigned log_n, unsigned batch, con
     LaneCall c;
     PLK_TRY(c.begin());
     void *din = nullptr, *dout = nullptr;
-    PLK_TRY(c.tmp(din, max_in * 32 * batch));
-    PLK_TRY(c.tmp(dout, n * 32 * batch));
+    const size_t EB = (size_t)field_limbs(field) * 8;  // bytes per element
+    PLK_TRY(c.tmp(din, max_in * EB * batch));
+    PLK_TRY(c.tmp(dout, n * EB * batch));
     for (unsigned b = 0; b < batch; ++b) {
-        uint8_t* slot = (uint8_t*)din + (size_t)b * max_in * 32;
+        uint8_t* slot = (uint8_t*)din + (size_t)b * max_in * EB;
         // in place (out[b] == in[b]): ONE registration of the larger range, made here
-        c.pin(in[b], (const void*)out[b] == (const void*)in[b] && n > n_in[b] ? n * 32 : n_in[b] * 32);
-        PLK_TRY(lane_h2d(*c.l, slot, in[b], n_in[b] * 32));
+        c.pin(in[b], (const void*)out[b] == (const void*)in[b] && n > n_in[b] ? n * EB : n_in[b] * EB);
+        PLK_TRY(lane_h2d(*c.l, slot, in[b], n_in[b] * EB));
         // shorter polynomials of the batch: F::ZERO is all-zero limbs in Montgomery form too
-        if (n_in[b] < max_in) PLK_HIP_TRY(hipMemsetAsync(slot + n_in[b] * 32, 0, (max_in - n_in[b]) * 32, c.stream()));
+        if (n_in[b] < max_in) PLK_HIP_TRY(hipMemsetAsync(slot + n_in[b] * EB, 0, (max_in - n_in[b]) * EB, c.stream()));
     }
     PLK_TRY(ntt_padded_dev_impl(field, log_n, batch, din, max_in, max_in, dout, c.stream()));
     for (unsigned b = 0; b < batch; ++b) {
-        c.pin(out[b], n * 32);  // in place: inside the registration made above
-        PLK_TRY(c.out(out[b], (uint8_t*)dout + (size_t)b * n * 32, n * 32));
+        c.pin(out[b], n * EB);  // in place: inside the registration made above
+        PLK_TRY(c.out(out[b], (uint8_t*)dout + (size_t)b * n * EB, n * EB));
     }
     return c.finish();
 }
 
 int plk_ntt_padded_batch(int field, unsigned log_n, unsigned batch, const uint64_t* const* in, const size_t* n_in, uint64_t* const* out) {
     PLK_API;
-    if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
+    if (field_limbs(field) < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
     if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
     if (batch == 0) return PLK_OK;
     if (!in || !n_in || !out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");

@@ -1,4 +1,4 @@
-// ntt.hip -- natural-order in / natural-order out NTT over the 256-bit fields, gfx950.
+// ntt.hip -- natural-order in / natural-order out NTT over the reference's six prime fields (tuned for the 256-bit ones), gfx950.
 //
 // Replaces the reference's src/fft.rs:
 //   fft_precompute                         fft.rs:47-59    -> NttPlan (device twiddle tables)
@@ -44,6 +44,8 @@ constexpr int MAX_PASSES = 6;
 constexpr int NTT_STAGGER_DEFAULT = 0;  // phases of a one-round pass (k_ntt_pass), sleep quanta per phase; 0: off
 constexpr size_t NTT_LDS_MAX = 160 * 1024;  // per workgroup on gfx950
 constexpr int INNER_LOG = TILE_LOG;      // inner twiddle table: w_TILE^e, e < TILE / 2
+// 16-byte words per element in the caller's buffers and in the R-form / R'-form word tables: 2 for the 256-bit fields, 3 for Bls12377Base
+template <class P> constexpr int EU() { return P::NL / 4; }
 
 struct NttPassArgs {
     int log_n;        // whole transform
@@ -80,20 +82,20 @@ template <class P> __global__ void k_ntt_pow2(uint4* pw, int log_t, int log_n) {
     for (int i = 0; i < P::TWO_ADICITY - log_t; ++i) w = fe_sqr<P>(w);
     Fe<P> cur = w, winv = fe_one<P>();
     for (int b = 0; b < log_t; ++b) {
-        fe_store<P>(pw + b * 2, cur);
+        fe_store<P>(pw + b * EU<P>(), cur);
         winv = fe_mul<P>(winv, cur);  // w^(2^log_t - 1) = w^-1
         cur = fe_sqr<P>(cur);
     }
     cur = winv;
     for (int b = 0; b < log_t; ++b) {
-        fe_store<P>(pw + (32 + b) * 2, cur);
+        fe_store<P>(pw + (32 + b) * EU<P>(), cur);
         cur = fe_sqr<P>(cur);
     }
     Fe<P> ninv = fe_one<P>();
     for (int i = 0; i < log_n; ++i) ninv = fe_half<P>(ninv);
-    fe_store<P>(pw + 64 * 2, ninv);
-    fe_store<P>(pw + 65 * 2, fz_to_fe_canonical<P>(fz_one_rprime<P>()));
-    fe_store<P>(pw + 66 * 2, to_rprime<P>(ninv));
+    fe_store<P>(pw + 64 * EU<P>(), ninv);
+    fe_store<P>(pw + 65 * EU<P>(), fz_to_fe_canonical<P>(fz_one_rprime<P>()));
+    fe_store<P>(pw + 66 * EU<P>(), to_rprime<P>(ninv));
 }
 
 // inner table: tw[e] = w_1024^(+-e), e < 512, expressed through the 2^log_t-th root
@@ -101,7 +103,7 @@ template <class P> __global__ void k_ntt_fill_inner(uint4* tw, const uint4* pw, 
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (1 << (INNER_LOG - 1))) return;
     uint64_t ex = (uint64_t)e << (log_t - INNER_LOG);
-    fe_store<P>(tw + e * 2, to_rprime<P>(pow_from_table<P>(pw, inverse ? 32 : 0, ex, log_t)));
+    fe_store<P>(tw + e * EU<P>(), to_rprime<P>(pow_from_table<P>(pw, inverse ? 32 : 0, ex, log_t)));
 }
 // outer table of a pass: W[k * S + r] = w_{N_t}^(+- r k) (* n^-1 when scale != 0), R'-form, limb form
 template <class P> __global__ void k_ntt_fill_outer(uint32_t* tw, const uint4* pw, int log_t, int log_nt, int log_s, int inverse, int scale) {
@@ -112,7 +114,7 @@ template <class P> __global__ void k_ntt_fill_outer(uint32_t* tw, const uint4* p
     uint64_t ex = (r * k) & (((uint64_t)1 << log_nt) - 1);
     ex <<= (log_t - log_nt);
     Fe<P> v = pow_from_table<P>(pw, inverse ? 32 : 0, ex, log_t);
-    if (scale) v = fe_mul<P>(v, fe_load<P>(pw + 64 * 2));
+    if (scale) v = fe_mul<P>(v, fe_load<P>(pw + 64 * EU<P>()));
     limbs_store<P>(tw, idx, fz_from_fe<P>(to_rprime<P>(v)));
 }
 
@@ -125,7 +127,7 @@ template <class P> __global__ void __launch_bounds__(256) k_ntt_reference_table(
     const int i = 63 - __clzll((unsigned long long)(e + 1));
     const uint32_t k = (uint32_t)(e + 1 - ((size_t)1 << i));
     const uint64_t ex = (uint64_t)bitrev_u32(k, i) << (log_t - i);
-    fe_store<P>(out + e * 2, pow_from_table<P>(pw, 0, ex, log_t));
+    fe_store<P>(out + e * EU<P>(), pow_from_table<P>(pw, 0, ex, log_t));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -164,8 +166,8 @@ template <class P> PLK_DI void dat_store(uint32_t* base, int idx, const Fz<P>& v
 
 // b^i from a two-level geometric table (R'-form): hi[i >> 10] * lo[i & 1023], < 1.01p
 template <class P> PLK_DI Fz<P> geom_pow(const void* lo, const void* hi, size_t i) {
-    const Fz<P> l = fz_from_fe<P>(fe_load<P>((const uint4*)lo + (i & ((1u << NTT_POW_LO_LOG) - 1)) * 2));
-    const Fz<P> h = fz_from_fe<P>(fe_load<P>((const uint4*)hi + (i >> NTT_POW_LO_LOG) * 2));
+    const Fz<P> l = fz_from_fe<P>(fe_load<P>((const uint4*)lo + (i & ((1u << NTT_POW_LO_LOG) - 1)) * EU<P>()));
+    const Fz<P> h = fz_from_fe<P>(fe_load<P>((const uint4*)hi + (i >> NTT_POW_LO_LOG) * EU<P>()));
     return fz_mul<P>(l, h);
 }
 
@@ -243,6 +245,27 @@ PLK_DI size_t tile_tw_index(const NttPassArgs& a, const TileGeom& t, int e) {
 // the same rows.  FIRST: the step with half-size h = 1 (unit twiddles w_2^0, w_4^0: one multiplication, exactly normalised inputs).
 template <class P, bool FIRST>
 PLK_DI void radix4_step(Fz<P> (&x)[4], const Fz<P>& wa, const Fz<P>& wb0, const Fz<P>& wb1) {
+    if constexpr (FzCfg<P>::NZ > 10) {
+        // Bls12377Base (14 limbs): the column sums of a product have no room for uncarried operands (FzLazyBound: 3.57 * 2^29), so
+        // every sum and difference moves its carries and LDS holds limbs below 2^29 + 8.  Values grow by 2p per stage as below,
+        // far under R' / 8 = 2^403.  No caller of the reference transforms over this field (it is a `Field`, so fft::<Bls12377Base>
+        // type-checks, bls12_377_base.rs:18-262); the path is kept simple rather than tuned.
+        if constexpr (!FIRST) {
+            x[1] = fz_mul<P>(x[1], wa);
+            x[3] = fz_mul<P>(x[3], wa);
+        }
+        const Fz<P> y0 = fz_add<P>(x[0], x[1]), y1 = fz_sub<P, 1>(x[0], x[1]);
+        Fz<P> y2 = fz_add<P>(x[2], x[3]), y3 = fz_sub<P, 1>(x[2], x[3]);
+        y3 = fz_mul<P>(y3, wb1);
+        if constexpr (!FIRST) y2 = fz_mul<P>(y2, wb0);
+        x[1] = fz_add<P>(y1, y3);
+        x[3] = fz_sub<P, 1>(y1, y3);
+        x[0] = fz_add<P>(y0, y2);
+        // FIRST: y2 = x2 + x3 is a sum of two canonical values, below 2p but not below p: it is taken off 4p
+        if constexpr (FIRST) x[2] = fz_sub<P, 2>(y0, y2);
+        else x[2] = fz_sub<P, 1>(y0, y2);
+        return;
+    }
     if constexpr (!FIRST) {
         // Carries are moved twice per step instead of eight times (fz_add_nc / fz_sub_nc): LDS holds limbs up to
         // MUL_LIMB_MAX = 2.5 * 2^30 + 16; x1 and x3 go straight into a multiplication by a table entry; x0 and x2 are
@@ -305,7 +328,7 @@ PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw, int tid, int log_
     // w_A^e, e < A / 2
     auto stage_tw = [&](int e) -> Fz<P> {
         if (TILE_LOG >= 12 && tw_global)  // tuning builds only (tools/gpu/ntt_variants.sh): a 1024-element tile always has room
-            return fz_from_fe<P>(fe_load<P>(g_tw + ((size_t)e << (INNER_LOG - log_a)) * 2));
+            return fz_from_fe<P>(fe_load<P>(g_tw + ((size_t)e << (INNER_LOG - log_a)) * EU<P>()));
         return lds_load<P>(s_tw, half_a, e);
     };
     int log_h = first_stage;
@@ -372,8 +395,13 @@ PLK_DI void tile_stages(uint32_t* s_dat, const uint32_t* s_tw, int tid, int log_
                 t = fz_mul<P>(t, stage_tw(j << (log_a - 1 - log_h)));  // w_{2h}^j, product < 1.2p
             }
             // log_h == 0: a two-point transform of exactly normalised inputs
-            dat_store<P>(s_dat, i0, fz_add_nc<P>(x, t));
-            dat_store<P>(s_dat, i1, fz_sub_nc<P, 1, 29>(x, t));  // t < 2p - margin in both cases
+            if constexpr (FzCfg<P>::NZ > 10) {  // 14 limbs: carried sums (see radix4_step)
+                dat_store<P>(s_dat, i0, fz_add<P>(x, t));
+                dat_store<P>(s_dat, i1, fz_sub<P, 1>(x, t));
+            } else {
+                dat_store<P>(s_dat, i0, fz_add_nc<P>(x, t));
+                dat_store<P>(s_dat, i1, fz_sub_nc<P, 1, 29>(x, t));  // t < 2p - margin in both cases
+            }
         }
         __syncthreads();
     }
@@ -400,7 +428,7 @@ PLK_DI Fz<P> tile_emit(const NttPassArgs& a, const NttHooks& hk, Fz<P> v, const 
     if constexpr (HOOKS) {
         // g is the natural output index; every factor is an R'-form value below 2p
         if (hk.out_tab) {
-            const Fz<P> t = fz_from_fe<P>(fe_load<P>((const uint4*)hk.out_tab + (g & hk.out_mask) * 2));
+            const Fz<P> t = fz_from_fe<P>(fe_load<P>((const uint4*)hk.out_tab + (g & hk.out_mask) * EU<P>()));
             mult = have ? fz_mul<P>(t, mult) : t;
             have = true;
         }
@@ -410,7 +438,11 @@ PLK_DI Fz<P> tile_emit(const NttPassArgs& a, const NttHooks& hk, Fz<P> v, const 
             have = true;
         }
     }
-    return have ? fz_mul<P>(v, mult) : fz_reduce_small<P>(v);
+    if (have) return fz_mul<P>(v, mult);
+    // fz_reduce_small estimates the quotient from the modulus' top 26 bits above limb NZ - 2; Bls12377Base (377 bits in 14 limbs) leaves
+    // three there, so its outputs are reduced by a multiplication by one (R'-form) instead
+    if constexpr (FzCfg<P>::NZ > 10) return fz_mul<P>(v, fz_one_rprime<P>());
+    else return fz_reduce_small<P>(v);
 }
 
 // One tile per workgroup; any tile shape (transforms shorter than a tile included).  IN_LIMBS / OUT_LIMBS: the pass reads /
@@ -424,7 +456,8 @@ PLK_DI Fz<P> tile_emit(const NttPassArgs& a, const NttHooks& hk, Fz<P> v, const 
 #define PLK_NTT_VARIANT 5
 #endif
 #if PLK_NTT_VARIANT & 4
-#define PLK_NTT_BOUNDS __launch_bounds__(NTT_THREADS, 4)
+// (the 14 limbs of Bls12377Base: a 56 KiB tile, two workgroups per CU at most - the registers of two waves per SIMD are theirs)
+#define PLK_NTT_BOUNDS __launch_bounds__(NTT_THREADS, FzCfg<P>::NZ > 10 ? 2 : 4)
 #else
 #define PLK_NTT_BOUNDS __launch_bounds__(NTT_THREADS)
 #endif
@@ -432,7 +465,6 @@ template <class P, bool HOOKS, bool IN_LIMBS, bool OUT_LIMBS>
 __global__ void PLK_NTT_BOUNDS k_ntt_pass(const void* in, void* out, const uint4* __restrict__ inner_tw,
                                                           const uint32_t* __restrict__ outer_tw, const uint4* __restrict__ scale_ptr, NttPassArgs a,
                                                           NttHooks hk) {
-    static_assert(P::NL == 8, "NTT kernels are written for the 256-bit fields");
     constexpr int NZ = FzCfg<P>::NZ;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     const int tid = threadIdx.x;
@@ -471,18 +503,18 @@ __global__ void PLK_NTT_BOUNDS k_ntt_pass(const void* in, void* out, const uint4
         if constexpr (IN_LIMBS) {
             xin[k] = limbs_load<P>((const uint32_t*)in, tg.b * n + gin[k]);
         } else {
-            const uint4* inb = (const uint4*)in + tg.b * ((HOOKS && a.first) ? hk.in_stride : n) * 2;
+            const uint4* inb = (const uint4*)in + tg.b * ((HOOKS && a.first) ? hk.in_stride : n) * EU<P>();
             if constexpr (HOOKS) {
                 vin[k] = fe_zero<P>();
-                if (!a.first || gin[k] < hk.in_len) vin[k] = fe_load<P>(inb + gin[k] * 2);
+                if (!a.first || gin[k] < hk.in_len) vin[k] = fe_load<P>(inb + gin[k] * EU<P>());
             } else {
-                vin[k] = fe_load<P>(inb + gin[k] * 2);
+                vin[k] = fe_load<P>(inb + gin[k] * EU<P>());
             }
         }
     }
     // stage twiddles (R'-form): w_A^e = inner[e * (1024 / A)], e < A/2
     for (int e = tid; e < ((TILE_LOG >= 12 && a.tw_global) ? 0 : half_a); e += NTT_THREADS) {
-        const Fe<P> w = fe_load<P>(inner_tw + ((size_t)e << (INNER_LOG - log_a)) * 2);
+        const Fe<P> w = fe_load<P>(inner_tw + ((size_t)e << (INNER_LOG - log_a)) * EU<P>());
         lds_store<P>(s_tw, half_a, e, fz_from_fe<P>(w));
     }
 #pragma unroll
@@ -498,7 +530,7 @@ __global__ void PLK_NTT_BOUNDS k_ntt_pass(const void* in, void* out, const uint4
 #else
     // stage twiddles (R'-form): w_A^e = inner[e * (1024 / A)], e < A/2
     for (int e = tid; e < ((TILE_LOG >= 12 && a.tw_global) ? 0 : half_a); e += NTT_THREADS) {
-        const Fe<P> w = fe_load<P>(inner_tw + ((size_t)e << (INNER_LOG - log_a)) * 2);
+        const Fe<P> w = fe_load<P>(inner_tw + ((size_t)e << (INNER_LOG - log_a)) * EU<P>());
         lds_store<P>(s_tw, half_a, e, fz_from_fe<P>(w));
     }
     for (int e = tid; e < tile_elems; e += NTT_THREADS) {
@@ -507,9 +539,9 @@ __global__ void PLK_NTT_BOUNDS k_ntt_pass(const void* in, void* out, const uint4
         if constexpr (IN_LIMBS) {
             x = limbs_load<P>((const uint32_t*)in, tg.b * n + g);
         } else {
-            const uint4* inb = (const uint4*)in + tg.b * ((HOOKS && a.first) ? hk.in_stride : n) * 2;
+            const uint4* inb = (const uint4*)in + tg.b * ((HOOKS && a.first) ? hk.in_stride : n) * EU<P>();
             Fe<P> v = fe_zero<P>();
-            if (!HOOKS || !a.first || g < hk.in_len) v = fe_load<P>(inb + g * 2);
+            if (!HOOKS || !a.first || g < hk.in_len) v = fe_load<P>(inb + g * EU<P>());
             x = tile_ingest<P, HOOKS>(a, hk, v, g);
         }
         dat_store<P>(s_dat, by_slot ? e : tile_in_slot(a, e), x);
@@ -535,7 +567,7 @@ __global__ void PLK_NTT_BOUNDS k_ntt_pass(const void* in, void* out, const uint4
             const size_t g = tile_out_index(a, tg, e);
             const Fz<P> r = tile_emit<P, HOOKS>(a, hk, dat_load<P>(s_dat, e), otw[k], scale, g);
             if constexpr (OUT_LIMBS) limbs_store<P>((uint32_t*)out, tg.b * n + g, r);
-            else fe_store<P>((uint4*)out + (tg.b * n + g) * 2, fz_to_fe_canonical<P>(r));
+            else fe_store<P>((uint4*)out + (tg.b * n + g) * EU<P>(), fz_to_fe_canonical<P>(r));
         }
     }
 #else
@@ -545,7 +577,7 @@ __global__ void PLK_NTT_BOUNDS k_ntt_pass(const void* in, void* out, const uint4
         if (!a.last) tw = limbs_load<P>(outer_tw, tile_tw_index(a, tg, e));
         const Fz<P> r = tile_emit<P, HOOKS>(a, hk, dat_load<P>(s_dat, e), tw, scale, g);
         if constexpr (OUT_LIMBS) limbs_store<P>((uint32_t*)out, tg.b * n + g, r);
-        else fe_store<P>((uint4*)out + (tg.b * n + g) * 2, fz_to_fe_canonical<P>(r));
+        else fe_store<P>((uint4*)out + (tg.b * n + g) * EU<P>(), fz_to_fe_canonical<P>(r));
     }
 #endif
 }
@@ -650,12 +682,12 @@ template <class P> static int build_plan_t(NttPlan& pl) {
     const int log_n = pl.log_n;
     const int log_t = log_n > INNER_LOG ? log_n : INNER_LOG;
     if (log_t > P::TWO_ADICITY) return set_error(PLK_ERR_TWO_ADICITY, "log_n %d exceeds the field's 2-adicity %d", log_n, P::TWO_ADICITY);
-    PLK_HIP_TRY(hipMalloc(&pl.pw, 67 * 32));
+    PLK_HIP_TRY(hipMalloc(&pl.pw, 67 * (size_t)P::NL * 4));
     k_ntt_pow2<P><<<1, 64>>>((uint4*)pl.pw, log_t, log_n);
     PLK_HIP_TRY(hipGetLastError());
     const int m = (int)pl.pass_log.size();
     for (int dir = 0; dir < 2; ++dir) {
-        PLK_HIP_TRY(hipMalloc(&pl.inner[dir], (size_t)(1 << (INNER_LOG - 1)) * 32));
+        PLK_HIP_TRY(hipMalloc(&pl.inner[dir], (size_t)(1 << (INNER_LOG - 1)) * P::NL * 4));
         k_ntt_fill_inner<P><<<((1 << (INNER_LOG - 1)) + 255) / 256, 256>>>((uint4*)pl.inner[dir], (const uint4*)pl.pw, log_t, dir);
         PLK_HIP_TRY(hipGetLastError());
         int log_nt = log_n;
@@ -696,6 +728,7 @@ static int get_plan(int field, unsigned log_n, std::shared_ptr<NttPlan>& out) {
         case PLK_FIELD_TWEEDLEDEE_BASE: rc = build_plan_t<TweedledeeBaseParams>(*pl); break;
         case PLK_FIELD_TWEEDLEDUM_BASE: rc = build_plan_t<TweedledumBaseParams>(*pl); break;
         case PLK_FIELD_BLS12_377_SCALAR: rc = build_plan_t<Bls12377ScalarParams>(*pl); break;
+        case PLK_FIELD_BLS12_377_BASE: rc = build_plan_t<Bls12377BaseParams>(*pl); break;
         case PLK_FIELD_PALLAS_BASE: rc = build_plan_t<PallasBaseParams>(*pl); break;
         case PLK_FIELD_VESTA_BASE: rc = build_plan_t<VestaBaseParams>(*pl); break;
         default: return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
@@ -724,7 +757,7 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
     const int m = (int)pl.pass_log.size();
     const int dir = inverse ? 1 : 0;
     if (log_n == 0 && !hooks) {
-        if (d_in != d_out) PLK_HIP_TRY(hipMemcpyAsync(d_out, d_in, (size_t)batch * 32, hipMemcpyDeviceToDevice, stream));
+        if (d_in != d_out) PLK_HIP_TRY(hipMemcpyAsync(d_out, d_in, (size_t)batch * P::NL * 4, hipMemcpyDeviceToDevice, stream));
         return PLK_OK;
     }
     // The last pass is a transposition (reads contiguous blocks, writes digit-reversed), so with
@@ -789,14 +822,20 @@ static int run_plan_t(const NttPlan& pl, int inverse, unsigned batch, const void
             a.stagger = (quanta > 0 && tiles > (size_t)cus && tiles <= (size_t)4 * cus) ? quanta : 0;
             a.stagger_div = cus;
         }
-        const uint4* scale = (const uint4*)pl.pw + (a.scale ? 66 : 65) * 2;
+        const uint4* scale = (const uint4*)pl.pw + (a.scale ? 66 : 65) * EU<P>();
         const bool use_hooks = hooks && (a.first || a.last);
         const NttHooks hk = use_hooks ? *hooks : NttHooks{};
         const unsigned tl = (unsigned)tiles;
         const uint32_t* otw = (const uint32_t*)outer;
         // the first pass reads the caller's elements, the last one writes them; everything in between is limb form in scratch
-#define PLK_NTT_LAUNCH(H, IL, OL) \
-    k_ntt_pass<P, H, IL, OL><<<tl, NTT_THREADS, lds_bytes, stream>>>(src, dst, (const uint4*)pl.inner[dir], otw, scale, a, hk)
+        // (more than 64 KiB of dynamic LDS - a one-pass transform over the 14 limbs of Bls12377Base: 56 KiB tile + up to 28 KiB of stage
+        // twiddles - has to be asked for per kernel)
+#define PLK_NTT_LAUNCH(H, IL, OL)                                                                                                             \
+    do {                                                                                                                                      \
+        if (lds_bytes > 64 * 1024)                                                                                                            \
+            (void)hipFuncSetAttribute((const void*)k_ntt_pass<P, H, IL, OL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
+        k_ntt_pass<P, H, IL, OL><<<tl, NTT_THREADS, lds_bytes, stream>>>(src, dst, (const uint4*)pl.inner[dir], otw, scale, a, hk);           \
+    } while (0)
         if (a.first && a.last) {
             if (use_hooks) PLK_NTT_LAUNCH(true, false, false); else PLK_NTT_LAUNCH(false, false, false);
         } else if (a.first) {
@@ -831,6 +870,11 @@ static int ntt_dispatch(int field, unsigned log_n, int inverse, unsigned batch, 
         case PLK_FIELD_TWEEDLEDEE_BASE: return run_plan_t<TweedledeeBaseParams>(*pl, inverse, batch, d_in, d_out, hooks, stream);
         case PLK_FIELD_TWEEDLEDUM_BASE: return run_plan_t<TweedledumBaseParams>(*pl, inverse, batch, d_in, d_out, hooks, stream);
         case PLK_FIELD_BLS12_377_SCALAR: return run_plan_t<Bls12377ScalarParams>(*pl, inverse, batch, d_in, d_out, hooks, stream);
+        case PLK_FIELD_BLS12_377_BASE:
+            // only the plain transform and its zero-padded form (fft_with_precomputation, fft.rs:61-80); the polynomial callers' hooks
+            // (coset factors, denominators) belong to the circuit's scalar fields
+            if (hooks && (hooks->in_lo || hooks->out_tab || hooks->out_lo)) return set_error(PLK_ERR_INVALID_ARG, "field %d has no polynomial entry points", field);
+            return run_plan_t<Bls12377BaseParams>(*pl, inverse, batch, d_in, d_out, hooks, stream);
         case PLK_FIELD_PALLAS_BASE: return run_plan_t<PallasBaseParams>(*pl, inverse, batch, d_in, d_out, hooks, stream);
         case PLK_FIELD_VESTA_BASE: return run_plan_t<VestaBaseParams>(*pl, inverse, batch, d_in, d_out, hooks, stream);
     }
@@ -847,7 +891,7 @@ int ntt_dev_hooked_impl(int field, unsigned log_n, int inverse, unsigned batch, 
 }
 
 int ntt_reference_table_dev_impl(int field, unsigned log_n, void* d_out, hipStream_t stream) {
-    if (field_limbs(field) != 4) return set_error(PLK_ERR_INVALID_ARG, "field %d has no NTT entry point", field);
+    if (field_limbs(field) < 0) return set_error(PLK_ERR_INVALID_ARG, "bad field id %d", field);
     if (log_n > 30) return set_error(PLK_ERR_TWO_ADICITY, "log_n %u too large (max 30)", log_n);
     if (!d_out) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     std::shared_ptr<NttPlan> pl;
@@ -860,6 +904,7 @@ int ntt_reference_table_dev_impl(int field, unsigned log_n, void* d_out, hipStre
         CASE(PLK_FIELD_TWEEDLEDEE_BASE, TweedledeeBaseParams)
         CASE(PLK_FIELD_TWEEDLEDUM_BASE, TweedledumBaseParams)
         CASE(PLK_FIELD_BLS12_377_SCALAR, Bls12377ScalarParams)
+        CASE(PLK_FIELD_BLS12_377_BASE, Bls12377BaseParams)
         CASE(PLK_FIELD_PALLAS_BASE, PallasBaseParams)
         CASE(PLK_FIELD_VESTA_BASE, VestaBaseParams)
 #undef CASE

@@ -16,7 +16,7 @@ template <class P> PLK_DI Fe<P> to_rprime(const Fe<P>& v) {
 template <class P> PLK_DI Fe<P> pow_from_table(const uint4* pw, int base_off, uint64_t e, int log_t) {
     Fe<P> r = fe_one<P>();
     for (int b = 0; b < log_t; ++b)
-        if ((e >> b) & 1) r = fe_mul<P>(r, fe_load<P>(pw + (base_off + b) * 2));
+        if ((e >> b) & 1) r = fe_mul<P>(r, fe_load<P>(pw + (base_off + b) * (P::NL / 4)));
     return r;
 }
 

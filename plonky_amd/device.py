@@ -34,11 +34,12 @@ def to_host(t):
 
 
 def ntt_dev(field, x, inverse=False, out=None):
-    """x: (batch, n, 4) or (n, 4) int64 CUDA tensor; returns the transforms (natural order)."""
+    """x: (batch, n, L) or (n, L) int64 CUDA tensor, L = 4 (6 for Bls12377Base); returns the transforms (natural order)."""
     assert x.is_cuda and x.dtype == torch.int64 and x.is_contiguous()
-    assert x.shape[-1] == _FIELD_LIMBS[field] == 4
+    L = _FIELD_LIMBS[field]
+    assert x.shape[-1] == L
     n = x.shape[-2]
-    batch = x.numel() // (n * 4)
+    batch = x.numel() // (n * L)
     log_n = log2_strict(n)
     if out is None:
         out = torch.empty_like(x)
@@ -49,13 +50,14 @@ def ntt_dev(field, x, inverse=False, out=None):
 
 def ntt_padded_dev(field, x, log_n, out=None):
     """polynomials_to_values_padded on device-resident coefficients: x (batch, len, 4) or (len, 4) with
-    len <= 2^log_n; returns (batch, 2^log_n, 4) evaluations.  The zero padding is never stored."""
-    assert x.is_cuda and x.dtype == torch.int64 and x.is_contiguous() and x.shape[-1] == 4
+    len <= 2^log_n; returns (batch, 2^log_n, 4) evaluations.  The zero padding is never stored.  (6 limbs for Bls12377Base.)"""
+    L = _FIELD_LIMBS[field]
+    assert x.is_cuda and x.dtype == torch.int64 and x.is_contiguous() and x.shape[-1] == L
     import math
     length = x.shape[-2]
     batch = math.prod(x.shape[:-2])  # independent of the length: (B, 0, 4) is B zero polynomials, every output is written
     n = 1 << log_n
-    shape = x.shape[:-2] + (n, 4)
+    shape = x.shape[:-2] + (n, L)
     if out is None:
         out = torch.empty(shape, dtype=torch.int64, device=x.device)
     _lib.check(_lib.load().plk_ntt_padded_dev(field, log_n, batch, ctypes.c_void_p(x.data_ptr()), length, length,

@@ -20,7 +20,7 @@ from tests.test_oracle_kats import (MSM_KAT_X_MONT, MSM_KAT_Y_MONT, _bls_test_ms
 from tests.util import ints_to_array, limbs_to_int
 
 FIELDS = [br.TWEEDLEDEE_BASE, br.TWEEDLEDUM_BASE, br.BLS12_377_SCALAR, br.BLS12_377_BASE, br.PALLAS_BASE, br.VESTA_BASE]
-NTT_FIELDS = FIELDS[:3] + FIELDS[4:]
+NTT_FIELDS = FIELDS  # all six: Bls12377Base (14 working limbs) since round 5
 CURVES = [br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377, br.PALLAS, br.VESTA]
 
 
@@ -91,6 +91,57 @@ def test_ntt_matches_oracle(f, log_n):
     assert np.array_equal(pa.ifft_with_precomputation_power_of_2(fwd, pre), x)
 
 
+def test_fft_and_ifft_bls12_377_base():
+    """The unit-test shape of fft.rs:164-185 over Bls12377Base (a `Field`, bls12_377_base.rs:18-262, so fft::<Bls12377Base> type-checks
+    in the reference): zero-padded transform of 200 and 1000 coefficients against the big-integer transform and the oracle, inverse,
+    a batch from host pointers, device tensors (plain and zero-padded), a three-pass size by linearity and round trip."""
+    import torch
+    from plonky_amd import device as dev
+    f = br.BLS12_377_BASE
+    for degree in (200, 1000):
+        n = 1 << pa.log2_ceil(degree)
+        ints = [(i * 1337 + (i * i) % 89) % f.p for i in range(degree)]
+        coefficients = mont_arr(f, ints)
+        pre = pa.fft_precompute(pa.BLS12_377_BASE, degree)
+        assert pre.size() == n
+        points = pa.fft_with_precomputation(coefficients, pre)
+        assert points.shape == (n, 6)
+        assert from_mont_arr(f, points) == br.ntt(f, ints + [0] * (n - degree))
+        opre = ol.FftPrecomputation(3, degree)
+        assert np.array_equal(points, opre.fft_with_precomputation(coefficients))
+        back = pa.ifft_with_precomputation_power_of_2(points, pre)
+        assert np.array_equal(back[:degree], coefficients) and not back[degree:].any()
+        assert np.array_equal(back, opre.ifft_with_precomputation_power_of_2(points))
+        # device-resident forms
+        d = dev.to_device(coefficients)
+        assert np.array_equal(dev.to_host(dev.ntt_padded_dev(3, d, pa.log2_ceil(degree))), points)
+        assert np.array_equal(dev.to_host(dev.ntt_dev(3, dev.to_device(points), inverse=True)), back)
+    n = 1 << 12
+    polys = np.stack([synth.rand_field(3, 0xB377 + k, n) for k in range(5)])
+    outs = api.fft_batch(3, polys)
+    opre = ol.FftPrecomputation(3, n)
+    for k in range(5):
+        assert np.array_equal(outs[k], opre.fft_with_precomputation_power_of_2(polys[k], threads=4)), k
+    assert np.array_equal(api.fft_batch(3, outs, inverse=True), polys)
+    assert np.array_equal(dev.to_host(dev.ntt_dev(3, dev.to_device(polys))), outs)
+    # 2^20 (three passes; 48 MiB per operand): linearity and the round trip, and a slice of outputs against direct evaluation
+    n = 1 << 20
+    a, b = synth.rand_field(3, 21, n), synth.rand_field(3, 22, n)
+    fa, fb, fs = api.fft_batch(3, np.stack([a, b, api.field_op(3, "add", a, b)]))
+    assert np.array_equal(api.field_op(3, "add", fa, fb), fs)
+    assert np.array_equal(pa.ifft_with_precomputation_power_of_2(fa, pa.fft_precompute(3, n)), a)
+    sparse = np.zeros((n, 6), dtype=np.uint64)
+    idx = [0, 1, 5, 1 << 10, (1 << 19) + 3, n - 1]
+    vals = [3, 5, f.p - 2, 7, 11, 13]
+    sparse[idx] = mont_arr(f, vals)
+    got = from_mont_arr(f, pa.fft_with_precomputation_power_of_2(sparse, pa.fft_precompute(3, n)))
+    g = f.primitive_root_of_unity(20)
+    for j in (0, 1, 2, 12345, (1 << 19) + 77, n - 1):
+        assert got[j] == sum(v * pow(g, (i * j) % n, f.p) for i, v in zip(idx, vals)) % f.p, j
+    with pytest.raises(Exception):  # the polynomial callers stay with the circuit's scalar fields
+        pa.polynomial_divide_by_z_h(3, synth.rand_field(3, 1, 64), 16)
+
+
 def test_ntt_config1_2p14_golden():
     """BASELINE config 1 shape (benches/fft.rs: TweedledeeBase, 2^14), seed 0xF70014."""
     x = synth.rand_field(0, 0xF70014, 1 << 14)
@@ -141,7 +192,7 @@ def test_ntt_padding_and_errors():
     # the raw C ABI reports codes instead of aborting
     from plonky_amd import lib
     L = lib.load()
-    assert L.plk_ntt(3, 4, 0, x.ctypes.data, x.ctypes.data) == lib.PLK_ERR_INVALID_ARG
+    assert L.plk_ntt(6, 4, 0, x.ctypes.data, x.ctypes.data) == lib.PLK_ERR_INVALID_ARG  # no such field
     assert L.plk_ntt(0, 4, 0, None, None) == lib.PLK_ERR_INVALID_ARG
     assert L.plk_ntt(0, 31, 0, x.ctypes.data, x.ctypes.data) == lib.PLK_ERR_TWO_ADICITY
     assert len(L.plk_last_error()) > 0
@@ -783,7 +834,7 @@ def test_msm_context_shared_by_two_streams():
     assert ev.shape == (3, 64, 4) and not dev.to_host(ev).any()
 
 
-@pytest.mark.parametrize("field", [0, 1, 2, 4, 5])
+@pytest.mark.parametrize("field", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("log_n", [0, 1, 5, 12])
 def test_fft_precompute_table_matches_oracle(field, log_n):
     """plk_ntt_precompute_table: the reference's FftPrecomputation::subgroups_rev (fft.rs:28-59), layer by layer against the

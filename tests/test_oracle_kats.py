@@ -211,6 +211,29 @@ def test_fft_and_ifft_reference_unit_test():
                           pre.fft_with_precomputation_power_of_2(points, threads=1))
 
 
+def test_fft_and_ifft_shape_on_bls12_377_base():
+    """The same unit-test shape over the sixth field (fft::<Bls12377Base> type-checks in the reference, bls12_377_base.rs:18-262; no caller
+    uses it): the oracle's generic restatement against the naive DFT and the big-integer radix-2 transform, two sizes, table layers."""
+    f = br.BLS12_377_BASE
+    for degree in (200, 1000):
+        n = 1 << (degree - 1).bit_length()
+        coeffs = [(i * 1337 + (i * i) % 89) % f.p for i in range(degree)]
+        pre = ol.FftPrecomputation(3, degree)
+        assert pre.size() == n
+        points = pre.fft_with_precomputation(mont_arr(f, coeffs))
+        assert points.shape == (n, 6)
+        expected = br.ntt(f, coeffs + [0] * (n - degree))
+        if degree == 200:
+            assert br.ntt_naive(f, coeffs + [0] * (n - degree)) == expected
+        assert from_mont_arr(f, points) == expected
+        back = from_mont_arr(f, pre.ifft_with_precomputation_power_of_2(points))
+        assert back[:degree] == coeffs and not any(back[degree:])
+    pre = ol.FftPrecomputation(3, 16)
+    for i in range(5):
+        g = f.primitive_root_of_unity(i)
+        assert from_mont_arr(f, pre.layer(i)) == [pow(g, ol.reverse_bits(k, i), f.p) for k in range(1 << i)]
+
+
 def test_reverse_bits():
     assert ol.reverse_bits(0b00110101, 8) == 0b10101100
     # reverse_index_bits([a,b,c,d]) == [a,c,b,d]
