@@ -173,7 +173,7 @@ template <class FP, bool SINGLE_LANE = false> PLK_DI bool xyzz_to_affine(const X
         return true;
     }
     Fe<FP> i3;
-    if constexpr (SINGLE_LANE) i3 = fe_inv_safegcd_var<FP>(p.zzz);  // one lane: runs of division steps at once (fp.cuh)
+    if constexpr (SINGLE_LANE) i3 = fe_inv_safegcd_one_lane<FP>(p.zzz);  // ONE active lane in the wave: runs of division steps on the scalar unit (fp.cuh)
     else i3 = fe_inv_safegcd<FP>(p.zzz);
     Fe<FP> iz = fe_mul<FP>(p.zz, i3);
     Fe<FP> izz = fe_sqr<FP>(iz);

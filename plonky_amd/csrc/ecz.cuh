@@ -15,6 +15,7 @@
 
 namespace plk {
 
+// (PLK_FT: the shader-clock stamps of tuning builds, fp.cuh)
 template <class FP> struct XyzzZ {
     Fz<FP> x, y, zz, zzz;
     bool inf;
@@ -229,6 +230,33 @@ template <class FP> PLK_DI XyzzZ<FP> xyzzz_load_packed_volatile(const uint4* src
 // ONE_LANE: the caller is a single lane (the end of an MSM) - the inversion takes its data-dependent form (fp.cuh)
 template <class FP, bool ONE_LANE = false> PLK_DI void emit_affine(const XyzzZ<FP>& acc, uint4* out_xy, uint8_t* out_zero) {
     constexpr int W = FP::NL / 4;
+    if constexpr (ONE_LANE) {
+        // Round 5: the normalisation stays on the working limbs.  Only ZZZ goes back to words (the inversion works on the integer); its
+        // plain inverse returns through ONE product by a constant that also carries the Montgomery fix-up, 1 / Z = ZZ / ZZZ, x = X / ZZ,
+        // y = Y / ZZZ are products on 29-bit limbs, and the two coordinates alone are taken back to the reference's form: 8 products +
+        // 3 conversions where the word-form route (below) made 4 + 4 and 5 products on 32-bit words with their carry chains.
+        // Same field values, unique representatives: the same bits (profiles/r05_final_kernel_trace.txt: a third of k_msm_final).
+        const Fz<FP> back = fz_const_rprime_to_r<FP>();
+        Fe<FP> zr = fe_zero<FP>();
+        if (!acc.inf) zr = fz_to_fe_canonical<FP>(fz_mul<FP>(acc.zzz, back));  // ZZZ x 2^(32 NL), canonical
+        if (acc.inf || fe_is_zero<FP>(zr)) {
+            fe_store<FP>(out_xy, fe_zero<FP>());
+            fe_store<FP>(out_xy + W, fe_zero<FP>());
+            *out_zero = 1;
+            return;
+        }
+        PLK_FT(10);
+        const Fe<FP> raw = fe_inv_safegcd_one_lane_raw<FP>(zr);
+        PLK_FT(11);
+        const Fz<FP> i3 = fz_mul<FP>(fz_from_fe<FP>(raw), fz_const_raw_inverse_to_rprime<FP>());  // 1 / ZZZ
+        const Fz<FP> iz = fz_mul<FP>(acc.zz, i3);                                                                                    // 1 / Z
+        const Fz<FP> xa = fz_mul<FP>(acc.x, fz_sqr<FP>(iz)), ya = fz_mul<FP>(acc.y, i3);
+        fe_store<FP>(out_xy, fz_to_fe_canonical<FP>(fz_mul<FP>(xa, back)));
+        fe_store<FP>(out_xy + W, fz_to_fe_canonical<FP>(fz_mul<FP>(ya, back)));
+        *out_zero = 0;
+        PLK_FT(12);
+        return;
+    }
     Xyzz<FP> r = xyzz_identity<FP>();
     if (!acc.inf) {
         const Fz<FP> back = fz_const_rprime_to_r<FP>();

@@ -8,6 +8,10 @@ namespace plk {
 
 template <class P> __global__ void k_field_op(int op, const uint4* a, const uint4* b, uint4* out, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (op == 11) {  // the one-lane inversion: ONE active lane per wave, element = wave index
+        if (threadIdx.x & 63) return;
+        i >>= 6;
+    }
     if (i >= count) return;
     constexpr int W = P::NL / 4;
     Fe<P> x = fe_load<P>(a + i * W), y = fe_zero<P>(), r;
@@ -22,7 +26,8 @@ template <class P> __global__ void k_field_op(int op, const uint4* a, const uint
         case 6: r = fe_to_canonical<P>(x); break;
         case 7: r = fe_from_canonical<P>(x); break;
         case 8: r = fe_inv_eea<P>(x); break;       // the reference's Euclid (bigint_inverse.rs:6-55)
-        case 10: r = fe_inv_safegcd_var<P>(x); break;  // its one-lane form (the end of an MSM)
+        case 10: r = fe_inv_safegcd_var<P>(x); break;  // the data-dependent form (runs of division steps)
+        case 11: r = fe_inv_safegcd_one_lane<P>(x); break;  // the same with its low-word loop on the scalar unit (the end of an MSM)
         default: r = fe_inv_safegcd<P>(x); break;      // what the kernels use
     }
     fe_store<P>(out + i * W, r);
@@ -37,7 +42,8 @@ template <class P> static int field_op_t(int op, const uint64_t* a, const uint64
     PLK_HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
     if (op <= 2) PLK_HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
     if (count) {
-        k_field_op<P><<<(unsigned)((count + 127) / 128), 128>>>(op, (const uint4*)da.p, (const uint4*)db.p, (uint4*)dout.p, count);
+        const size_t lanes = op == 11 ? count * 64 : count;
+        k_field_op<P><<<(unsigned)((lanes + 127) / 128), 128>>>(op, (const uint4*)da.p, (const uint4*)db.p, (uint4*)dout.p, count);
         PLK_HIP_TRY(hipGetLastError());
     }
     PLK_HIP_TRY(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
@@ -298,7 +304,7 @@ int field_fold_slices_dev_impl(int field, const void* d_lo, const void* d_hi, co
 }
 
 int field_op_impl(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count) {
-    if (op < 0 || op > 10) return set_error(PLK_ERR_INVALID_ARG, "bad field op %d", op);
+    if (op < 0 || op > 11) return set_error(PLK_ERR_INVALID_ARG, "bad field op %d", op);
     if (!a || !out || (op <= 2 && !b)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     PLK_TRY(ensure_device());
     switch (field) {

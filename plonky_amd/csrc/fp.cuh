@@ -298,7 +298,42 @@ template <class P> PLK_DNI Fe<P> fe_inv_eea(const Fe<P>& a) {
 // w = -g / f mod 2^k of f (f^-1 = f (2 - f^2) mod 2^6 for odd f), as long as no swap falls due inside the run (k <= eta + 1).
 // About a third of the instructions of the fixed-length loop; the matrix and its application to (d, e), (f, g) are the same.
 // A wave whose lanes all invert (the fold kernels) keeps the branch-free form: there the longest lane is what everyone pays.
-template <class P, bool VAR> PLK_DNI Fe<P> fe_inv_safegcd_impl(const Fe<P>& a) {
+//
+// tuning builds (-DPLK_FINAL_TRACE, one translation unit: msm_tail.hip): shader-clock stamps of thread 0 of the first two blocks along
+// k_msm_final's chain and inside the normalisation, read back by plk_debug_final_trace (tools/final_trace_probe.py)
+#if defined(PLK_FINAL_TRACE) && defined(__HIPCC__)
+__device__ unsigned long long g_final_trace[2][16];
+#define PLK_FT(i)                                                                          \
+    do {                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < 2) g_final_trace[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define PLK_FT_NOW() __builtin_amdgcn_s_memtime()
+#define g_final_trace_get(i) ((threadIdx.x == 0 && blockIdx.x < 2) ? g_final_trace[blockIdx.x][i] : 0ull)
+#define PLK_FT_ADD(i, v)                                                                   \
+    do {                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < 2) g_final_trace[blockIdx.x][i] += (v);       \
+    } while (0)
+#else
+#define PLK_FT(i) do { } while (0)
+#define PLK_FT_NOW() 0ull
+#define g_final_trace_get(i) 0ull
+#define PLK_FT_ADD(i, v) do { } while (0)
+#endif
+// MODE 0: the fixed form; 1: VAR; 2: VAR with ONE active lane in the wave (round 5).  The runs of division steps work on the low words
+// of f and g alone - a chain of ~15 dependent 32-bit operations per run, three of them multiplications, twelve runs per 30 steps - and on
+// the vector unit every one of them waits out the pipeline's latency.  With one lane active the low words, the matrix and eta are uniform
+// by construction: they are read into scalar registers (readfirstlane) and the whole inner loop runs on the scalar unit with scalar
+// branches; the matrix then multiplies the vector limbs as scalar operands.  profiles/r05_final_kernel_trace.txt has the kernel's stamps.
+// RAW: return the plain inverse of the INTEGER a (no Montgomery fix-up) - the caller folds the fix-up into a product it makes anyway.
+PLK_DI uint32_t plk_uniform_u32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#else
+    return v;
+#endif
+}
+template <class P, int MODE, bool RAW = false> PLK_DNI Fe<P> fe_inv_safegcd_impl(const Fe<P>& a) {
+    constexpr bool VAR = MODE == 1 || MODE == 2, UNI = MODE >= 2;  // MODE 3: the fixed form with scalar low words
     constexpr int NL = P::NL;
     constexpr int N = (NL * 32 + 29) / 30;          // 9 limbs for 256 bits, 13 for 384
     // fixed form (half-delta steps): 590 steps suffice below 2^256, 886 below 2^384; plain steps (VAR): 741 / 1103 at most
@@ -323,9 +358,19 @@ template <class P, bool VAR> PLK_DNI Fe<P> fe_inv_safegcd_impl(const Fe<P>& a) {
     }
     e[0] = 1;
     int32_t zeta = -1;  // -(delta + 1/2), delta = 1/2
+    if constexpr (UNI && RAW) {
+        PLK_FT_ADD(13, 0ull - g_final_trace_get(13));
+        PLK_FT_ADD(14, 0ull - g_final_trace_get(14));
+        PLK_FT_ADD(15, 0ull - g_final_trace_get(15));
+    }
     for (int it = 0; it < ITER; ++it) {
+        const unsigned long long ft0 = PLK_FT_NOW();
         // 30 division steps on the low words; (u v; q r) is 2^30 times the transition matrix
         uint32_t u = 1, v = 0, q = 0, r = 1, fl = (uint32_t)f[0], gl = (uint32_t)g[0];
+        if constexpr (UNI) {
+            fl = plk_uniform_u32(fl);
+            gl = plk_uniform_u32(gl);
+        }
         if constexpr (VAR) {
             // here zeta is eta = -delta of the plain steps (same start: -1)
             int left = 30;
@@ -352,6 +397,7 @@ template <class P, bool VAR> PLK_DNI Fe<P> fe_inv_safegcd_impl(const Fe<P>& a) {
                 r += v * w;
             }
         } else
+#pragma unroll
         for (int i = 0; i < 30; ++i) {
             uint32_t c1 = (uint32_t)(zeta >> 31);           // zeta < 0
             const uint32_t c2 = (uint32_t)0 - (gl & 1u);     // g odd
@@ -368,6 +414,8 @@ template <class P, bool VAR> PLK_DNI Fe<P> fe_inv_safegcd_impl(const Fe<P>& a) {
             u <<= 1;
             v <<= 1;
         }
+        const unsigned long long ft1 = PLK_FT_NOW();
+        if constexpr (UNI && RAW) PLK_FT_ADD(13, ft1 - ft0);
         const int64_t tu = (int32_t)u, tv = (int32_t)v, tq = (int32_t)q, tr = (int32_t)r;
         // (d, e) <- t (d, e) / 2^30 mod p: a multiple of p makes the low 30 bits vanish first
         {
@@ -422,6 +470,11 @@ template <class P, bool VAR> PLK_DNI Fe<P> fe_inv_safegcd_impl(const Fe<P>& a) {
 #ifdef PLK_INV_STATS
         if (gz == 0) { ++plk_inv_stats[it]; }
 #endif
+        if constexpr (UNI) gz = (int32_t)plk_uniform_u32((uint32_t)gz);
+        if constexpr (UNI && RAW) {
+            PLK_FT_ADD(14, PLK_FT_NOW() - ft1);
+            PLK_FT_ADD(15, 1ull);
+        }
         if (gz == 0) break;
     }
     // g = 0, f = +-1 and d = +-a^-1 in (-2p, p): fix the sign, bring into [0, p)
@@ -455,11 +508,21 @@ template <class P, bool VAR> PLK_DNI Fe<P> fe_inv_safegcd_impl(const Fe<P>& a) {
         r.v[w] = (uint32_t)acc;
         r3.v[w] = P::R3[w];
     }
+    if constexpr (RAW) return r;
     return fe_mul<P>(r, r3);
 }
 
-template <class P> PLK_DI Fe<P> fe_inv_safegcd(const Fe<P>& a) { return fe_inv_safegcd_impl<P, false>(a); }
-template <class P> PLK_DI Fe<P> fe_inv_safegcd_var(const Fe<P>& a) { return fe_inv_safegcd_impl<P, true>(a); }
+template <class P> PLK_DI Fe<P> fe_inv_safegcd(const Fe<P>& a) { return fe_inv_safegcd_impl<P, 0>(a); }
+template <class P> PLK_DI Fe<P> fe_inv_safegcd_var(const Fe<P>& a) { return fe_inv_safegcd_impl<P, 1>(a); }
+// ONE active lane in the wave (see MODE 2 above); _raw: the inverse of the integer, without the Montgomery fix-up
+// What the single-lane callers use.  tools/inv_latency.hip (profiles/r05_inversion_latency.txt), ticks per inversion on one lane of a lone
+// wave: MODE 1 75 k, MODE 0 86 k, MODE 2 82 k, MODE 3 107 k - the scalar unit does not run the dependent low-word chain any faster than
+// the vector unit does, so the forms with scalar low words stay tuning options (-DPLK_ONE_LANE_INV_MODE=2 / 3).
+#ifndef PLK_ONE_LANE_INV_MODE
+#define PLK_ONE_LANE_INV_MODE 1
+#endif
+template <class P> PLK_DI Fe<P> fe_inv_safegcd_one_lane(const Fe<P>& a) { return fe_inv_safegcd_impl<P, PLK_ONE_LANE_INV_MODE>(a); }
+template <class P> PLK_DI Fe<P> fe_inv_safegcd_one_lane_raw(const Fe<P>& a) { return fe_inv_safegcd_impl<P, PLK_ONE_LANE_INV_MODE, true>(a); }
 
 // x/2 mod p for Montgomery or canonical x alike (used to build n^-1 = 2^-log n)
 template <class P> PLK_DI Fe<P> fe_half(const Fe<P>& a) {

@@ -387,6 +387,14 @@ template <class P> PLK_DI Fz<P> fz_const_rprime_to_r() {
     for (int i = 0; i < FzCfg<P>::NZ; ++i) r.l[i] = c.l[i];
     return r;
 }
+// multiply by this to take the plain inverse of an R-form INTEGER, (x 2^(32 NL))^-1, to the R'-form of x^-1:  2^(32 NL + 2 * 29 NZ)
+template <class P> PLK_DI Fz<P> fz_const_raw_inverse_to_rprime() {
+    constexpr auto c = FzConst<P>::pow2(32 * P::NL + 2 * 29 * FzCfg<P>::NZ);
+    Fz<P> r;
+#pragma unroll
+    for (int i = 0; i < FzCfg<P>::NZ; ++i) r.l[i] = c.l[i];
+    return r;
+}
 // 1 in R'-form: 2^(29 NZ)
 template <class P> PLK_DI Fz<P> fz_one_rprime() {
     constexpr auto c = FzConst<P>::pow2(29 * FzCfg<P>::NZ);

@@ -267,6 +267,7 @@ __global__ void __launch_bounds__(PLANE_THREADS) k_msm_planes(TailBatch tb, int 
 // (table-free mode) it doubles its window into place, 2^(c * window), and k_msm_combine adds the windows.
 // (256-thread workgroups - one wave per SIMD - were measured for the planes and this kernel: the same 66 / 139 us at c = 20, and the
 // one-shot MSM with its 2 x 13 tail windows went from 2.8 to 4.4 ms)
+// (PLK_FT: the shader-clock stamps of tuning builds, ecz.cuh)
 template <class C>
 __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int windows, int parts, int planes, int window_bits, int pair_shift) {
     using FP = typename C::FP;
@@ -281,26 +282,33 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int w
     const int win = blockIdx.x % windows;
     const bool live = plane < planes;
     const uint4* src = plane_part + ((size_t)(win * planes + plane) * parts + sub * ipq) * 4 * W;
+    PLK_FT(0);
     XyzzZ<FP> acc = live ? xyzzz_load_packed<FP>(src) : xyzzz_identity<FP>();
     if (ipq == 2) acc = xyzzz_add_q<FP>(acc, live ? xyzzz_load_packed<FP>(src + 4 * W) : xyzzz_identity<FP>(), ql);
     acc = wave_sum_q<FP>(acc, qpp, ql);  // the quads of a plane are adjacent in one wave
+    PLK_FT(1);
     if (live && sub == 0) {
         for (int k = 0; k < plane; ++k) acc = xyzzz_dbl_q<FP>(acc, ql);
         if (ql == 0) xyzzz_store_packed<FP>(s_pts + plane * 4 * W, acc);
     }
+    PLK_FT(2);
     __syncthreads();
+    PLK_FT(3);
     if (tid < 128) {  // the planes: 32 quads, two waves
         acc = item < planes ? xyzzz_load_packed<FP>(s_pts + item * 4 * W) : xyzzz_identity<FP>();
         acc = wave_sum_q<FP>(acc, 16, ql);
         if (tid == 64) xyzzz_store_packed<FP>(s_pts + 32 * 4 * W, acc);
     }
+    PLK_FT(4);
     __syncthreads();
+    PLK_FT(5);
     if (tid < 4) {
         if (planes > 16) acc = xyzzz_add_q<FP>(acc, xyzzz_load_packed<FP>(s_pts + 32 * 4 * W), ql);
         // pair_shift < 0: window `win` weighs 2^(win * window_bits).  Two-level tail: the windows come in pairs (column sums,
         // row sums) of real window win / 2, the row sums shifted by pair_shift = L more
         const int shift = pair_shift < 0 ? win * window_bits : (win >> 1) * window_bits + (win & 1) * pair_shift;
         for (int k = 0; k < shift; ++k) acc = xyzzz_dbl_q<FP>(acc, ql);
+        PLK_FT(6);
         if (windows == 1) {
             if (tid == 0) emit_affine<FP, true>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
         } else {
@@ -314,14 +322,17 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int w
                     seen = atomicAdd(tb.s[slot].final_done, 1u);
                 }
                 seen = __shfl(seen, 0, 4);
+                PLK_FT(7);
                 if (seen == (uint32_t)windows - 1u) {
                     __threadfence();
                     for (int o = 0; o < windows; ++o)
                         if (o != win) acc = xyzzz_add_q<FP>(acc, xyzzz_load_packed_volatile<FP>(win_pts + (size_t)o * 4 * W), ql);
+                    PLK_FT(8);
                     if (tid == 0) {
                         *tb.s[slot].final_done = 0;
                         emit_affine<FP, true>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
                     }
+                    PLK_FT(9);
                 }
             }
         }
@@ -348,6 +359,12 @@ __global__ void __launch_bounds__(COMBINE_THREADS) k_msm_combine(TailBatch tb, i
         if (tid == 0) emit_affine<FP, true>(acc, out_xy, out_zero);
     }
 }
+
+#ifdef PLK_FINAL_TRACE
+extern "C" int plk_debug_final_trace(unsigned long long* out) {  // 2 x 16 stamps of the last k_msm_final
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_final_trace), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // ---- host side: what msm.hip sees of this file ----------------------------------------------------------------------------
 // pieces -> buckets -> (row / column sums ->) bit-plane sums -> result, for the tb.count MSMs of a batch at once.

@@ -54,6 +54,7 @@ def test_device_field_inverse_and_random(f):
         assert np.array_equal(api.field_op(f.field_id, "inverse_euclid", arr), want)
         assert np.array_equal(api.field_op(f.field_id, "inverse_divsteps", arr), want)
         assert np.array_equal(api.field_op(f.field_id, "inverse_divsteps_var", arr), want)
+        assert np.array_equal(api.field_op(f.field_id, "inverse_divsteps_one_lane", arr[:200]), want[:200])  # one lane per wave, scalar low words
 
 
 # ---------------- NTT ----------------
