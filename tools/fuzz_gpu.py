@@ -127,17 +127,22 @@ def one_case(rng):
             assert int(bz[at]) == ez and (ez or np.array_equal(bo[at], exp)), ("msm batch", c.name, n, style, tf, win, k)
         pre.free()
     elif kind == "ntt":
-        f = rng.choice(FIELDS)
+        f = rng.choice(FIELDS + [br.BLS12_377_BASE])  # the sixth field: plain and zero-padded transforms only (6 limbs)
         log_n = rng.randrange(0, 17)
         batch = rng.choice([1, 1, 2, 5])
-        x = synth.rand_field(f.field_id, rng.randrange(1 << 30), batch << log_n).reshape(batch, 1 << log_n, 4)
+        x = synth.rand_field(f.field_id, rng.randrange(1 << 30), batch << log_n).reshape(batch, 1 << log_n, f.n_limbs)
         opre = ol.FftPrecomputation(f.field_id, 1 << log_n)
         inv = rng.random() < 0.5
         got = pa.api.fft_batch(f.field_id, x, inverse=inv)
         for b in range(batch):
             want = opre.ifft_with_precomputation_power_of_2(x[b], threads=8) if inv else opre.fft_with_precomputation_power_of_2(x[b], threads=8)
             assert np.array_equal(got[b], want), ("ntt", f.name, log_n, batch, inv)
-        if log_n >= 3 and rng.random() < 0.5:
+        if f.n_limbs == 6 and rng.random() < 0.5:
+            # fft_with_precomputation (fft.rs:61-80): any length, zero-padded to the next power of two
+            ln = rng.randrange(1, (1 << log_n) + 1)
+            pre = pa.fft_precompute(f.field_id, ln)
+            assert np.array_equal(pa.fft_with_precomputation(x[0][:ln], pre), ol.FftPrecomputation(f.field_id, ln).fft_with_precomputation(x[0][:ln])), ("padded6", log_n, ln)
+        if f.n_limbs == 4 and log_n >= 3 and rng.random() < 0.5:
             # padded evaluation of shorter polynomials on the same domain (polynomials_to_values_padded)
             lens = [rng.randrange(1, (1 << log_n) // 8 + 1) for _ in range(batch)]
             polys = [x[b][: lens[b]] for b in range(batch)]
