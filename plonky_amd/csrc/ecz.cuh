@@ -38,7 +38,7 @@ template <class FP> PLK_DNI XyzzZ<FP> xyzzz_mdbl(Fz<FP> x, Fz<FP> y) {
     Fz<FP> mm = fz_sqr<FP>(m);                               // < 2
     r.x = fz_sub<FP, 2>(mm, fz_dbl<FP>(s));                  // < 2 + 4 = 6   (2s < 4 <= 4p - margin)
     Fz<FP> t = fz_sub<FP, 3>(s, r.x);                        // < 2 + 8 = 10
-    r.y = fz_sub<FP, 1>(fz_mul<FP>(m, t), fz_mul<FP>(w, y));  // < 2 + 2 = 4   (m t / 128 + 1 < 1.5)
+    r.y = fz_mul_sub2<FP, 1>(m, t, w, y);                    // m t - w y through one reduction (fz.cuh): (6 * 10 + 2 * 2) / 128 + 1 < 1.6
     r.zz = v;
     r.zzz = w;
     r.inf = fz_is_zero_mod_p<FP>(v);
@@ -100,7 +100,13 @@ template <class FP> PLK_DI void xyzzz_madd_lazy(XyzzZ<FP>& acc, const Fz<FP>& x2
     if constexpr (FzCfg<FP>::NZ <= 10) t = fz_sub_nc<FP, 3, 30>(q, x3);  // limbs <= 2^31 <= FzNcBound::MUL_LIMB_MAX
     else t = fz_sub<FP, 3>(q, x3);                                      // 14 limbs: the column sums have no room for it
     // Y3 = r t - Y1 PPP, both products exactly normalised: the difference keeps its carries (limbs <= 3 * 2^29 - 3)
-    acc.y = fz_sub_nc<FP, 1, 29>(fz_mul<FP>(r, t), fz_mul<FP>(acc.y, ppp));  // < (6*9.3/128 + 1) + 2 < 3.5 < 4
+    // round 5: through ONE reduction (fz_mul_add2): y1 enters as 4p - y1 (limbs <= 2^31 + 2^29, carried on 14 limbs)
+    {
+        Fz<FP> yn = fz_sub_nc<FP, 2, 31>(fz_zero<FP>(), acc.y);
+        if constexpr (FzCfg<FP>::NZ <= 9) fz_carry<FP>(t);
+        else fz_carry<FP>(yn);
+        acc.y = fz_mul_add2<FP>(r, t, yn, ppp);                        // (6 * 9.3 + 8 * 1.6) / 128 + 1 < 1.6, exactly normalised
+    }
     acc.x = x3;
     acc.zz = zz3;
     acc.zzz = fz_mul<FP>(acc.zzz, ppp);                                 // < 1.1
@@ -137,7 +143,7 @@ template <class FP> PLK_DI XyzzZ<FP> xyzzz_dbl(const XyzzZ<FP>& a) {
     Fz<FP> mm = fz_sqr<FP>(m);                               // < 1.2
     r.x = fz_sub<FP, 2>(mm, fz_dbl<FP>(s));                  // < 1.2 + 4 = 5.2
     Fz<FP> t = fz_sub<FP, 3>(s, r.x);                        // < 9.1
-    r.y = fz_sub<FP, 1>(fz_mul<FP>(m, t), fz_mul<FP>(w, a.y));  // < 3.4
+    r.y = fz_mul_sub2<FP, 1>(m, t, w, a.y);                  // m t - w y through one reduction: (4.5 * 9.1 + 2 * 4) / 128 + 1 < 1.4
     r.zz = fz_mul<FP>(v, a.zz);
     r.zzz = fz_mul<FP>(w, a.zzz);
     r.inf = fz_is_zero_mod_p<FP>(r.zz);                      // 2-torsion point
@@ -168,7 +174,7 @@ template <class FP> PLK_DI XyzzZ<FP> xyzzz_add(const XyzzZ<FP>& a, const XyzzZ<F
     }
     o.x = fz_sub<FP, 2>(fz_sub<FP, 1>(rr, ppp), fz_dbl<FP>(q));        // < 7.3
     Fz<FP> t = fz_sub<FP, 3>(q, o.x);                                  // < 9.3
-    o.y = fz_sub<FP, 1>(fz_mul<FP>(r, t), fz_mul<FP>(s1, ppp));        // < 3.3
+    o.y = fz_mul_sub2<FP, 1>(r, t, s1, ppp);                           // r t - s1 ppp through one reduction: < 1.3
     o.zzz = fz_mul<FP>(fz_mul<FP>(a.zzz, b.zzz), ppp);
     o.inf = false;
     return o;

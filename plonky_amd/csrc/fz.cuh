@@ -246,6 +246,54 @@ template <class P> PLK_DI Fz<P> fz_mul(const Fz<P>& a, const Fz<P>& b) {
     return r;
 }
 
+// (a b + c d) / R' with ONE Montgomery reduction (round 5): a sum of two products shares its quotient digits - NZ x (non-zero limbs of p)
+// multiplier instructions, NZ digit extractions and the second result's carries less than two products and an addition.  The point
+// formulas end in such a sum, Y3 = r t - y1 ppp (the subtrahend enters as c = 2^K p - y1).  Column bound
+//   NZ (La Lb + Lc Ld) + NZ 2^58 + 2^37 < 2^64:
+//   * every operand carried (limbs < 2^29 + 2^27): any NZ <= 14;
+//   * NZ <= 9, a and b carried (< 2^29 + 8), d exactly normalised (< 2^29): c may keep limbs up to 2^31 + 2^29 (a carry-free negation).
+// Value < (a b + c d) / R' + p; limbs exactly normalised.
+template <class P> PLK_DI Fz<P> fz_mul_add2(const Fz<P>& a, const Fz<P>& b, const Fz<P>& c, const Fz<P>& d) {
+    constexpr int NZ = FzCfg<P>::NZ;
+    constexpr uint32_t M = FzCfg<P>::M;
+    static_assert(NZ <= 14, "column bound of the two-product form");
+    uint32_t q[NZ];
+    Fz<P> r;
+    const uint64_t m64 = fz_opaque64((uint64_t)M);
+    uint64_t acc = 0;
+    const uint32_t p_pow2 = FzPow2Limb<P>::index() >= 0 ? fz_opaque(FzCfg<P>::plimb(FzPow2Limb<P>::index() >= 0 ? FzPow2Limb<P>::index() : 0)) : 0u;
+#pragma unroll
+    for (int k = 0; k <= 2 * NZ - 2; ++k) {
+        if (k < NZ) acc += m64;
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            const int j = k - i;
+            if (j >= 0 && j < NZ) {
+                acc = (uint64_t)a.l[i] * b.l[j] + acc;
+                acc = (uint64_t)c.l[i] * d.l[j] + acc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            const int j = k - i;
+            if (i < k && j >= 1 && j < NZ && FzCfg<P>::plimb(j) != 0u)
+                acc = (uint64_t)q[i] * (j == FzPow2Limb<P>::index() ? p_pow2 : FzCfg<P>::plimb(j)) + acc;
+        }
+        if (k < NZ) q[k] = ~(uint32_t)acc & M;
+        else r.l[k - NZ] = (uint32_t)acc & M;
+        acc = fz_shr29(acc);
+    }
+    r.l[NZ - 1] = (uint32_t)acc;
+    return r;
+}
+// a b - c d (+ 2^K p d): every operand carried, value(c) <= 2^K p - margin (fz_sub); value < (a b + 2^K p d) / R' + p
+template <class P, int K> PLK_DI Fz<P> fz_mul_sub2(const Fz<P>& a, const Fz<P>& b, const Fz<P>& c, const Fz<P>& d) {
+    Fz<P> z;
+#pragma unroll
+    for (int i = 0; i < FzCfg<P>::NZ; ++i) z.l[i] = 0u;
+    return fz_mul_add2<P>(a, b, fz_sub<P, K>(z, c), d);
+}
+
 // a^2 / R': the 2 a_i a_j cross terms are formed once from a doubled copy of a (NZ (NZ+1) / 2 products)
 template <class P> PLK_DI Fz<P> fz_sqr(const Fz<P>& a) {
     constexpr int NZ = FzCfg<P>::NZ;

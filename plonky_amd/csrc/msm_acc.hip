@@ -50,6 +50,11 @@ PLK_DI uint32_t bucket_search(const uint32_t* __restrict__ off, uint32_t lo, uin
 #else
 #define PLK_ACC_SB (void)0
 #endif
+// Y3 = r t - y1 ppp through ONE Montgomery reduction (fz_mul_add2, fz.cuh; round 5).  PLK_ACC_MERGE_Y=0 builds the two-product form.
+// Same lease, alternating (tools/acc_ab.py, profiles/r05_accumulate_merged_y.txt): accumulation 0.8325 -> 0.8095 ms, execution 1.509 -> 1.478 ms.
+#ifndef PLK_ACC_MERGE_Y
+#define PLK_ACC_MERGE_Y 1
+#endif
 template <class FP> PLK_DI int acc_madd_flag(XyzzZ<FP>& acc, const Fz<FP>& x2, const Fz<FP>& y2) {
     // ordered so that every coordinate of the old accumulator dies as early as it can (the kernel lives at the edge of its register budget)
     Fz<FP> u2 = fz_mul<FP>(x2, acc.zz);                      // < 2
@@ -69,7 +74,9 @@ template <class FP> PLK_DI int acc_madd_flag(XyzzZ<FP>& acc, const Fz<FP>& x2, c
     fz_carry<FP>(r);
     Fz<FP> zzz3 = fz_mul<FP>(acc.zzz, ppp);                  // < 1.1      (ZZZ dead)
     PLK_ACC_SB;
-    Fz<FP> yp = fz_mul<FP>(acc.y, ppp);                      //            (Y dead)
+    constexpr bool MERGE_Y = PLK_ACC_MERGE_Y != 0;
+    Fz<FP> yp = fz_zero<FP>();
+    if constexpr (!MERGE_Y) yp = fz_mul<FP>(acc.y, ppp);     //            (Y dead)
     PLK_ACC_SB;
     Fz<FP> rr = fz_sqr<FP>(r);                               // < 1.3
     PLK_ACC_SB;
@@ -80,7 +87,15 @@ template <class FP> PLK_DI int acc_madd_flag(XyzzZ<FP>& acc, const Fz<FP>& x2, c
     Fz<FP> t;
     if constexpr (FzCfg<FP>::NZ <= 10) t = fz_sub_nc<FP, 3, 30>(q, x3);
     else t = fz_sub<FP, 3>(q, x3);
-    acc.y = fz_sub_nc<FP, 1, 29>(fz_mul<FP>(r, t), yp);      // < 3.5: both products exactly normalised, the difference keeps its carries
+    if constexpr (MERGE_Y) {
+        // y1 < 3.6 (limbs <= 3 * 2^29 - 3 on entry, exactly normalised after the first merged addition): 4p - y1, limbs <= 2^31 + 2^29
+        Fz<FP> yn = fz_sub_nc<FP, 2, 31>(fz_zero<FP>(), acc.y);
+        if constexpr (FzCfg<FP>::NZ <= 9) fz_carry<FP>(t);   // (14 limbs: t is carried already, and the column sums want yn carried too)
+        else fz_carry<FP>(yn);
+        acc.y = fz_mul_add2<FP>(r, t, yn, ppp);              // (6 * 9.3 + 8 * 1.6) / 128 + 1 < 1.6, exactly normalised
+    } else {
+        acc.y = fz_sub_nc<FP, 1, 29>(fz_mul<FP>(r, t), yp);  // < 3.5: both products exactly normalised, the difference keeps its carries
+    }
     acc.x = x3;
     acc.zz = zz3;
     acc.zzz = zzz3;
