@@ -89,9 +89,15 @@ template <class FP> PLK_DI int acc_madd_flag(XyzzZ<FP>& acc, const Fz<FP>& x2, c
     else t = fz_sub<FP, 3>(q, x3);
     if constexpr (MERGE_Y) {
         // y1 < 3.6 (limbs <= 3 * 2^29 - 3 on entry, exactly normalised after the first merged addition): 4p - y1, limbs <= 2^31 + 2^29
-        Fz<FP> yn = fz_sub_nc<FP, 2, 31>(fz_zero<FP>(), acc.y);
-        if constexpr (FzCfg<FP>::NZ <= 9) fz_carry<FP>(t);   // (14 limbs: t is carried already, and the column sums want yn carried too)
-        else fz_carry<FP>(yn);
+        // Y is EXACTLY normalised in this loop (a product, or the first entry of a piece normalised where it is taken): 4p - y1 has limbs
+        // <= 2^30 and t may keep its carries (limbs <= 2^31, r carried): 9 (2^29 2^31 + 2^30 2^29 + 2^58) = 15.75 * 2^60 < 2^64.
+        Fz<FP> yn;
+        if constexpr (FzCfg<FP>::NZ <= 9) {
+            yn = fz_sub_nc<FP, 2, 29>(fz_zero<FP>(), acc.y);
+        } else {  // 14 limbs: t is carried already, and the column sums want yn carried too
+            yn = fz_sub_nc<FP, 2, 31>(fz_zero<FP>(), acc.y);
+            fz_carry<FP>(yn);
+        }
         acc.y = fz_mul_add2<FP>(r, t, yn, ppp);              // (6 * 9.3 + 8 * 1.6) / 128 + 1 < 1.6, exactly normalised
     } else {
         acc.y = fz_sub_nc<FP, 1, 29>(fz_mul<FP>(r, t), yp);  // < 3.5: both products exactly normalised, the difference keeps its carries
@@ -218,6 +224,7 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
                 if (acc.inf) {  // first entry of a piece (or after a sum that cancelled)
                     acc.x = xz;
                     acc.y = yz;
+                    fz_normalize<FP>(acc.y);  // 2p - y comes without its carries; the additions want Y exactly normalised (acc_madd_flag)
                     acc.zz = fz_one_rprime<FP>();
                     acc.zzz = acc.zz;
                     acc.inf = false;
