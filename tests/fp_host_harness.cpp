@@ -86,6 +86,30 @@ template <class P> static void run(int op, const uint32_t* a, const uint32_t* b,
                 r = ok ? fz_to_fe_canonical<P>(fz_mul<P>(O[op - 20], fz_one_rprime<P>())) : fe_zero<P>();
                 }
             } break;
+            case 24: {
+                // fz_mul_add2 at the edge of its column bound (fz.cuh): every limb below the top one at the largest value the callers may
+                // pass (9 limbs: a carried, b with its carries - 2^31 -, c a carry-free negation - 2^30 -, d exactly normalised; 14 limbs:
+                // all carried), top limbs as large as a value below 16p leaves them; low bits varied by the inputs
+                constexpr int NZ = FzCfg<P>::NZ;
+                constexpr bool SMALL = NZ <= 9;
+                const uint32_t la = SMALL ? (1u << 29) + 7u : (1u << 29) + (1u << 27), lb = SMALL ? 0x80000000u : la, lc = SMALL ? (1u << 30) : la,
+                               ld = (1u << 29) - 1u, top = SMALL ? (1u << 25) : 3u;
+                Fz<P> a, b, c, d;
+                for (int k = 0; k < NZ - 1; ++k) {
+                    a.l[k] = la - (x.v[0] & 7u);
+                    b.l[k] = lb - (y.v[0] & 0xffu);
+                    c.l[k] = lc - (x.v[2] & 0xffu);
+                    d.l[k] = ld - (y.v[1] & 0xffu);
+                }
+                a.l[NZ - 1] = top + (x.v[1] & 0xffffu);
+                b.l[NZ - 1] = c.l[NZ - 1] = top;
+                d.l[NZ - 1] = SMALL ? (1u << 22) : 1u;
+                r = fz_to_fe_canonical<P>(fz_mul<P>(fz_mul_add2<P>(a, b, c, d), fz_one_rprime<P>()));
+            } break;
+            case 25: {  // x y - y x' (x' = x + y): fz_mul_sub2, the generic form every XYZZ formula uses
+                const Fz<P> xz = fz_from_fe<P>(x), yz = fz_from_fe<P>(y);
+                r = fz_to_fe_canonical<P>(fz_mul<P>(fz_mul_sub2<P, 1>(xz, yz, yz, fz_add<P>(xz, yz)), fz_one_rprime<P>()));
+            } break;
             default: r = fe_neg<P>(x); break;
         }
         for (int k = 0; k < P::NL; ++k) out[i * P::NL + k] = r.v[k];

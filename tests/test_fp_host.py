@@ -103,6 +103,8 @@ def test_lazy_29bit_arithmetic_on_host(host_lib, f):
     got_lin = run(host_lib, f, 13, a, b)
     got_chain = run(host_lib, f, 16, a, b)
     got_zero = run(host_lib, f, 17, a, b)
+    got_ma2 = run(host_lib, f, 24, a, b)   # fz_mul_add2 at the edge of its column bound
+    got_ms2 = run(host_lib, f, 25, a, b)   # fz_mul_sub2 on ordinary operands
     got_red = run(host_lib, f, 19, a, b) if n == 4 else None  # fz_reduce_small: the NTT fields
     got_nc = [run(host_lib, f, 20 + t, a, b) for t in range(4)] if n == 4 else None  # carry-free radix-4 steps of the NTT tile
     k = 0
@@ -116,6 +118,20 @@ def test_lazy_29bit_arithmetic_on_host(host_lib, f):
             v = (ai + bj) * bj * Rp_inv
             assert got_chain[k] == (u - 2 * v) * (ai - bj) * Rp_inv % p
             assert got_zero[k] == (1 if ai * bj % p == 0 else 0)
+            assert got_ms2[k] == (ai * bj - bj * (ai + bj)) * Rp_inv % p
+            # the limb patterns of harness op 24, rebuilt from the same input words
+            xw = [(ai >> (32 * t)) & 0xFFFFFFFF for t in range(3)]
+            yw = [(bj >> (32 * t)) & 0xFFFFFFFF for t in range(2)]
+            small = nz <= 9
+            la = (1 << 29) + 7 if small else (1 << 29) + (1 << 27)
+            lb, lc, ld, top = (1 << 31 if small else la), (1 << 30 if small else la), (1 << 29) - 1, (1 << 25 if small else 3)
+            def val(limb, tl):
+                return sum(limb << (29 * t) for t in range(nz - 1)) + (tl << (29 * (nz - 1)))
+            A = val(la - (xw[0] & 7), top + (xw[1] & 0xFFFF))
+            B = val(lb - (yw[0] & 0xFF), top)
+            C = val(lc - (xw[2] & 0xFF), top)
+            Dv = val(ld - (yw[1] & 0xFF), (1 << 22) if small else 1)
+            assert got_ma2[k] == (A * B + C * Dv) * Rp_inv % p, (hex(ai), hex(bj))
             if got_red is not None:
                 assert got_red[k] == (ai + 13 * bj) % p
             if got_nc is not None:
