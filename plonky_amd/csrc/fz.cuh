@@ -294,6 +294,59 @@ template <class P, int K> PLK_DI Fz<P> fz_mul_sub2(const Fz<P>& a, const Fz<P>& 
     return fz_mul_add2<P>(a, b, fz_sub<P, K>(z, c), d);
 }
 
+// A SUM of products (and plain values) through one reduction, one pair at a time: 2 NZ - 1 column accumulators (operand scanning), so a
+// term is dead as soon as it has been multiplied in - a product-scanning form would have to hold every pair to the end.
+//   FzWide w; fz_wide_clear(w); fz_wide_mac(w, a, b); ...; fz_wide_add(w, v); r = fz_wide_reduce(w);   r = (sum a b) / R' + sum v  (mod p)
+// Column bound, in units of NZ 2^58 (one product of a carried operand, limbs < 2^29 + 8, with an exactly normalised one, < 2^29): the
+// reduction adds one unit + 2^37, so a 64-bit column holds (2^64 - NZ 2^58) / (NZ 2^58) = 6 units for nine limbs (FZ_WIDE_UNITS; a product
+// with one operand of limbs < 2^30 - a row as it is loaded - counts two units, with both four).  Real values leave the top limb far
+// smaller than the others, so the fullest column has NZ - 1 such terms, not NZ.
+// fz_wide_add puts a value in at weight R' (its limbs join the upper columns; limbs below 2^31): the result's value grows by it.
+template <class P> struct FzWide {
+    uint64_t t[2 * FzCfg<P>::NZ];  // t[2 NZ - 1]: the top limbs of added values
+};
+constexpr int FZ_WIDE_UNITS = 6;
+template <class P> PLK_DI void fz_wide_clear(FzWide<P>& w) {
+#pragma unroll
+    for (int k = 0; k < 2 * FzCfg<P>::NZ; ++k) w.t[k] = 0;
+}
+template <class P> PLK_DI void fz_wide_mac(FzWide<P>& w, const Fz<P>& a, const Fz<P>& b) {
+    constexpr int NZ = FzCfg<P>::NZ;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i)
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) w.t[i + j] = (uint64_t)a.l[i] * b.l[j] + w.t[i + j];
+}
+template <class P> PLK_DI void fz_wide_add(FzWide<P>& w, const Fz<P>& v) {
+#pragma unroll
+    for (int i = 0; i < FzCfg<P>::NZ; ++i) w.t[FzCfg<P>::NZ + i] += v.l[i];
+}
+template <class P> PLK_DI Fz<P> fz_wide_reduce(const FzWide<P>& w) {
+    constexpr int NZ = FzCfg<P>::NZ;
+    constexpr uint32_t M = FzCfg<P>::M;
+    uint32_t q[NZ];
+    Fz<P> r;
+    const uint64_t m64 = fz_opaque64((uint64_t)M);
+    uint64_t acc = 0;
+    const uint32_t p_pow2 = FzPow2Limb<P>::index() >= 0 ? fz_opaque(FzCfg<P>::plimb(FzPow2Limb<P>::index() >= 0 ? FzPow2Limb<P>::index() : 0)) : 0u;
+#pragma unroll
+    for (int k = 0; k <= 2 * NZ - 2; ++k) {
+        acc += w.t[k];
+        if (k < NZ) acc += m64;
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            const int j = k - i;
+            if (i < k && j >= 1 && j < NZ && FzCfg<P>::plimb(j) != 0u)
+                acc = (uint64_t)q[i] * (j == FzPow2Limb<P>::index() ? p_pow2 : FzCfg<P>::plimb(j)) + acc;
+        }
+        if (k < NZ) q[k] = ~(uint32_t)acc & M;
+        else r.l[k - NZ] = (uint32_t)acc & M;
+        acc = fz_shr29(acc);
+    }
+    r.l[NZ - 1] = (uint32_t)(acc + w.t[2 * NZ - 1]);
+    return r;
+}
+
 // a^2 / R': the 2 a_i a_j cross terms are formed once from a doubled copy of a (NZ (NZ+1) / 2 products)
 template <class P> PLK_DI Fz<P> fz_sqr(const Fz<P>& a) {
     constexpr int NZ = FzCfg<P>::NZ;

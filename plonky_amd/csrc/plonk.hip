@@ -84,6 +84,33 @@ template <class P, int A, int B> PLK_DI Lz<P, lz_mul_bound(A, B)> operator*(cons
     static_assert(A <= LZ_MUL_MAX && B <= LZ_MUL_MAX, "operand of a product above 15p");
     return {fz_mul<P>(a.v, b.v)};
 }
+// A sum of products (and plain values) through ONE reduction (fz.cuh: FzWide; round 5).  B: bound of the accumulated value in eighths of p
+// (a product of values below a p and b p adds a b / 1023; the reduction's own + p is added when it is taken), U: the column budget used
+// (FZ_WIDE_UNITS).  RAW_A / RAW_B: the operand may have limbs up to 2^30 (a row as lz_load returns it) instead of carried / normalised ones.
+template <class P, int B, int U> struct LzWide {
+    FzWide<P> w;
+};
+template <class P> PLK_DI LzWide<P, 0, 0> lz_wide() {
+    LzWide<P, 0, 0> r;
+    fz_wide_clear<P>(r.w);
+    return r;
+}
+template <bool RAW_A = false, bool RAW_B = false, class P, int B, int U, int A1, int A2>
+PLK_DI LzWide<P, B + A1 * A2 / 1023 + 1, U + (RAW_A ? 2 : 1) * (RAW_B ? 2 : 1)> lz_mac(const LzWide<P, B, U>& acc, const Lz<P, A1>& a, const Lz<P, A2>& b) {
+    static_assert(A1 <= LZ_MUL_MAX && A2 <= LZ_MUL_MAX, "operand of a product above 15p");
+    static_assert(U + (RAW_A ? 2 : 1) * (RAW_B ? 2 : 1) <= FZ_WIDE_UNITS, "the column sums have no room for another product");
+    static_assert(B + A1 * A2 / 1023 + 1 <= LZ_VAL_MAX, "value could leave the representation");
+    LzWide<P, B + A1 * A2 / 1023 + 1, U + (RAW_A ? 2 : 1) * (RAW_B ? 2 : 1)> r{acc.w};
+    fz_wide_mac<P>(r.w, a.v, b.v);
+    return r;
+}
+template <class P, int B, int U, int A> PLK_DI LzWide<P, B + A, U> lz_wide_add(const LzWide<P, B, U>& acc, const Lz<P, A>& v) {
+    static_assert(B + A <= LZ_VAL_MAX, "value could leave the representation");
+    LzWide<P, B + A, U> r{acc.w};
+    fz_wide_add<P>(r.w, v.v);
+    return r;
+}
+template <class P, int B, int U> PLK_DI Lz<P, B + 9> lz_reduce(const LzWide<P, B, U>& acc) { return {fz_wide_reduce<P>(acc.w)}; }
 // keeps a running value small: past 30p it is brought back below 2p
 template <class P, int B> PLK_DI auto lz_tame(const Lz<P, B>& a) {
     if constexpr (B > 240) return a.rs();
@@ -356,7 +383,10 @@ template <class A, class C0, class... Cs> PLK_DI auto lz_horner(const A& alpha, 
 //           (its constraints 2 i + 1 are rows of the MDS matrix, mds.rs:63-77 - sixteen products by matrix entries become four by W_c);
 //   [4..7]  W'_c = sum_i alpha^i / (4 + i - c): the same for RescueStepB (constraint i is MDS row i over the fifth powers);
 //   [8..13] beta k_is[j] (plonk.rs:431: beta * k_i * x is one product per wire instead of two).
-constexpr int NUM_WEIGHTS = 8 + NUM_ROUTED_WIRES;
+//   [14..21] alpha^1 .. alpha^8: a gate's share of reduce_with_powers is the DOT product of its constraints with them - one reduction for up
+//           to six constraints instead of one per Horner step, no sums in between (round 5).
+constexpr int WEIGHT_ALPHA = 8 + NUM_ROUTED_WIRES, NUM_ALPHA_POWERS = 8;
+constexpr int NUM_WEIGHTS = 8 + NUM_ROUTED_WIRES + NUM_ALPHA_POWERS;
 template <class P> struct ReducedSink {
     static constexpr bool kReduced = true;
     Lz<P, 16> alpha;
@@ -368,15 +398,31 @@ template <class P> struct ReducedSink {
         for (int i = 0; i < FzCfg<P>::NZ; ++i) r.v.l[i] = weights[w][i];
         return r;
     }
-    template <int GATE, class F, class... Cs> PLK_DI void gate(const F& f, const Cs&... cs) {
+    // c_I alpha^I + ... into the accumulator; when its columns are full the partial sum is reduced and re-enters as a value
+    template <int I, class W> PLK_DI auto dot(const W& w) const { return lz_reduce(w); }
+    template <int I, int B, int U, class C, class... Cs> PLK_DI auto dot(const LzWide<P, B, U>& w, const C& c, const Cs&... cs) const {
+        static_assert(I >= 1 && I <= NUM_ALPHA_POWERS, "alpha^I is not staged");
+        if constexpr (U + 1 > FZ_WIDE_UNITS) {
+            return dot<I>(lz_wide_add(lz_wide<P>(), lz_reduce(w)), c, cs...);
+        } else {
+            return dot<I + 1>(lz_mac(w, c, weight(WEIGHT_ALPHA + I - 1)), cs...);
+        }
+    }
+    // value below 15p for the product by the filter
+    template <int B> PLK_DI static auto tamed(const Lz<P, B>& h) {
+        if constexpr (B > LZ_MUL_MAX) return h.rs();
+        else return h;
+    }
+    template <int GATE, class F, class C0, class... Cs> PLK_DI void gate(const F& f, const C0& c0, const Cs&... cs) {
         gate_fence();
-        add_product<GATE>(total, f * lz_horner(alpha, cs...));
+        if constexpr (sizeof...(cs) == 0) add_product<GATE>(total, f * tamed(c0));
+        else add_product<GATE>(total, f * tamed(dot<1>(lz_wide_add(lz_wide<P>(), c0), cs...)));
         gate_fence();
     }
     // filter * (c_0 + alpha c_1 + ... + extra): `extra` is the part of the gate's sum that was folded into the launch's weights
-    template <int GATE, class F, class E, class... Cs> PLK_DI void gate_extra(const F& f, const E& extra, const Cs&... cs) {
+    template <int GATE, class F, class E, class C0, class... Cs> PLK_DI void gate_extra(const F& f, const E& extra, const C0& c0, const Cs&... cs) {
         gate_fence();
-        add_product<GATE>(total, f * (lz_horner(alpha, cs...) + extra));
+        add_product<GATE>(total, f * tamed(dot<1>(lz_wide_add(lz_wide_add(lz_wide<P>(), c0), extra), cs...)));
         gate_fence();
     }
 };
@@ -426,7 +472,13 @@ PLK_DI void all_constraints(const K& k, const LW& l, const RW& r, const D& b2, c
             const D l4 = l[4], l5 = l[5], l6 = l[6], l7 = l[7];
             if constexpr (Sink::kReduced) {
                 // sum_t alpha^t c_t with the matrix part of the odd constraints taken out: sum_c l_(4 + c) W_c (weights 0..3)
-                const auto folded = l4 * sink.weight(0) + l5 * sink.weight(1) + l6 * sink.weight(2) + l7 * sink.weight(3);
+                // four products, one reduction; the rows as loaded have limbs up to 2^30 (two column units each: carried copies go in)
+                auto carried = [](D v) {
+                    fz_carry<P>(v.v);
+                    return v;
+                };
+                const auto folded = lz_reduce(lz_mac(lz_mac(lz_mac(lz_mac(lz_wide<P>(), carried(l4), sink.weight(0)), carried(l5), sink.weight(1)),
+                                                            carried(l6), sink.weight(2)), carried(l7), sink.weight(3)));
                 sink.template gate_extra<7>(filter_a(), folded,                      //
                                             l4.pow5() - l[0], k[2] - r[0],            //
                                             l5.pow5() - l[1], k[3] - r[1],            //
@@ -443,7 +495,8 @@ PLK_DI void all_constraints(const K& k, const LW& l, const RW& r, const D& b2, c
         if constexpr ((MASK & GATES_RESCUE_B) != 0) {
             const auto e0 = l[0].pow5(), e1 = l[1].pow5(), e2 = l[2].pow5(), e3 = l[3].pow5();
             if constexpr (Sink::kReduced) {
-                const auto folded = e0 * sink.weight(4) + e1 * sink.weight(5) + e2 * sink.weight(6) + e3 * sink.weight(7);
+                const auto folded = lz_reduce(lz_mac(lz_mac(lz_mac(lz_mac(lz_wide<P>(), e0, sink.weight(4)), e1, sink.weight(5)), e2, sink.weight(6)),
+                                                     e3, sink.weight(7)));
                 sink.template gate_extra<8>(f_step_b, folded, k[2] - r[0], k[3] - r[1], k[4] - r[2], k[5] - r[3]);
             } else {
                 sink.template gate<8>(f_step_b, PLK_MDS_ROW(0, e0, e1, e2, e3), PLK_MDS_ROW(1, e0, e1, e2, e3), PLK_MDS_ROW(2, e0, e1, e2, e3),
@@ -479,7 +532,8 @@ PLK_DI void all_constraints(const K& k, const LW& l, const RW& r, const D& b2, c
         const auto f_arith = p100 * k[3];
         const auto f_base4 = p100 - f_arith;
         // ArithmeticGate 1001, arithmetic.rs:30-46
-        sink.template gate<6>(f_arith, k[4] * l[0] * l[1] + k[5] * l[2] - l[3]);
+        // k4 l0 l1 + k5 l2 - l3: the two outer products through one reduction (rows as loaded: two column units per raw operand)
+        sink.template gate<6>(f_arith, lz_reduce(lz_mac<true, true>(lz_mac<false, true>(lz_wide<P>(), k[4] * l[0], l[1]), k[5], l[2])) - l[3]);
         {  // Base4SumGate 1000, base_4_sum.rs:34-63: 7 limbs in wires 2..8
             const auto two = one.dbl();
             // (limb - 0) (limb - 1) (limb - 2) (limb - 3), times ONE in the reference: with t = limb^2 - 3 limb = limb (limb - 3) it is
@@ -589,8 +643,12 @@ template <class P> __global__ void __launch_bounds__(64) k_plonk_weights(const u
             pw = (pw * step).template widen<16>();
         }
         res = acc;
-    } else {
+    } else if (t < WEIGHT_ALPHA) {
         res = (load(sc.beta) * load(sc.k_is[t - 8])).template widen<16>();
+    } else {
+        const D alpha = load(sc.alpha);
+        res = alpha.rs();  // exactly normalised limbs, like the products below
+        for (int e = 1; e < t - WEIGHT_ALPHA + 1; ++e) res = (res * alpha).template widen<16>();
     }
 #pragma unroll
     for (int i = 0; i < FzCfg<P>::NZ; ++i) out[t * FzCfg<P>::NZ + i] = res.v.l[i];
@@ -652,7 +710,7 @@ __global__ void __launch_bounds__(128, PLK_VANISH_WAVES) k_vanishing_points(cons
         const auto one = lz_one<P>();
         const auto x = lz_table<P>(xs_lo_z, i & (((size_t)1 << XS_LO_LOG) - 1)) * lz_table<P>(xs_hi_z, i >> XS_LO_LOG);  // hi[0] = 1
         const D z_x = lz_load<P>(z, i, s_top), z_gz = lz_load<P>(z, i_right, s_top);
-        const auto z_1_term = lz_table<P>(l1, i) * (z_x - one);  // plonk.rs:425
+        // (z_1_term = L_1(x) (Z(x) - 1), plonk.rs:425, joins the last reduction below)
         const D beta = scalar_at<P>(s_sc, 7), gamma = scalar_at<P>(s_sc, 8);
         Lz<P, 9> f_prime = one.template widen<9>(), g_prime = f_prime;
 #pragma unroll
@@ -663,10 +721,14 @@ __global__ void __launch_bounds__(128, PLK_VANISH_WAVES) k_vanishing_points(cons
             f_prime = f_prime * (lj + beta_s_id + gamma);
             g_prime = g_prime * (lj + beta * s_sig + gamma);
         }
-        const auto v_shift_term = f_prime * z_x - g_prime * z_gz;  // plonk.rs:438
-        // reduce_with_powers over [z_1_term, v_shift_term, constraint terms] (plonk.rs:440-447, plonk_util.rs:27-33)
-        const auto with_shift = total.rs() * alpha + v_shift_term;
-        fe_store<P>(out + i * 2, lz_to_rform<P>(with_shift * alpha + z_1_term));
+        // Z(x) f'(x) - g'(x) Z(g x), plonk.rs:438: two products, one reduction (z_x / z_gz are rows as loaded: two column units each)
+        const auto zero = Lz<P, 0>{fz_zero<P>()};
+        const auto v_shift_term = lz_reduce(lz_mac<false, true>(lz_mac<false, true>(lz_wide<P>(), f_prime, z_x), zero - g_prime, z_gz));
+        // reduce_with_powers over [z_1_term, v_shift_term, constraint terms] (plonk.rs:440-447, plonk_util.rs:27-33):
+        // total alpha^2 + v_shift alpha + L_1 (Z - 1), three products through one reduction
+        const auto res = lz_reduce(lz_mac(lz_mac(lz_mac(lz_wide<P>(), total.rs(), scalar_at<P>(s_sc, NUM_SCALARS + WEIGHT_ALPHA + 1)), v_shift_term, alpha),
+                                          lz_table<P>(l1, i), z_x - one));
+        fe_store<P>(out + i * 2, lz_to_rform<P>(res));
     }
 }
 
