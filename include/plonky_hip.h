@@ -403,7 +403,10 @@ int plk_msm_get_timings(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls);
 /* Element-wise field ops on host arrays of `count` elements: op 0 add, 1 sub, 2 mul, 3 neg(a),
  * 4 square(a), 5 inverse(a) by Fermat (0 -> 0), 6 to_canonical(a), 7 from_canonical(a), 8 inverse by the
  * reference's binary Euclid (bigint_inverse.rs:6-55), 9 inverse by division steps (the one the kernels
- * use), 10 the same in its data-dependent one-lane form (the normalisation at the end of an MSM).  b ignored for unary. */
+ * use), 10 the same in its data-dependent form, 11 that form with ONE active lane per wave (the normalisation at the end of an MSM);
+ * 12 / 13: the shared-reduction arithmetic of the kernels on fixed limb patterns derived from a and b (sums of two products through one
+ * Montgomery reduction at the edge of their column bound; the column accumulators of the quotient numerator) - parity tests only.
+ * b ignored for unary. */
 int plk_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count);
 /* The integer-ALU ceilings of the GPU the calling thread runs on, measured now (~60 ms; G operations per second over the whole GPU):
  * out[0] v_mad_u64_u32 lane-operations (8 waves per SIMD, 8 independent chains per lane) - the raw issue rate of the instruction a

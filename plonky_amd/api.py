@@ -371,7 +371,8 @@ def curve_sum_affine(curve, points, zero=None):
 def field_op(field, op, a, b=None):
     """Element-wise device field arithmetic (parity tests of the HIP field code)."""
     ops = {"add": 0, "sub": 1, "mul": 2, "neg": 3, "square": 4, "inverse": 5, "to_canonical": 6, "from_canonical": 7,
-           "inverse_euclid": 8, "inverse_divsteps": 9, "inverse_divsteps_var": 10, "inverse_divsteps_one_lane": 11}
+           "inverse_euclid": 8, "inverse_divsteps": 9, "inverse_divsteps_var": 10, "inverse_divsteps_one_lane": 11,
+           "mul_add2_edge": 12, "wide_sum": 13}
     a = _elems(field, a)
     out = np.empty_like(a)
     bb = _elems(field, b) if b is not None else a

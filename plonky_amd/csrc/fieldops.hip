@@ -3,6 +3,7 @@
 // tests can run the HIP field arithmetic itself against the oracle on the edge-value inputs.
 #include "common.h"
 #include "fp.cuh"
+#include "fz.cuh"
 
 namespace plk {
 
@@ -15,7 +16,7 @@ template <class P> __global__ void k_field_op(int op, const uint4* a, const uint
     if (i >= count) return;
     constexpr int W = P::NL / 4;
     Fe<P> x = fe_load<P>(a + i * W), y = fe_zero<P>(), r;
-    if (op <= 2) y = fe_load<P>(b + i * W);
+    if (op <= 2 || op >= 12) y = fe_load<P>(b + i * W);
     switch (op) {
         case 0: r = fe_add<P>(x, y); break;
         case 1: r = fe_sub<P>(x, y); break;
@@ -28,6 +29,34 @@ template <class P> __global__ void k_field_op(int op, const uint4* a, const uint
         case 8: r = fe_inv_eea<P>(x); break;       // the reference's Euclid (bigint_inverse.rs:6-55)
         case 10: r = fe_inv_safegcd_var<P>(x); break;  // the data-dependent form (runs of division steps)
         case 11: r = fe_inv_safegcd_one_lane<P>(x); break;  // the same with its low-word loop on the scalar unit (the end of an MSM)
+        case 12: {
+            // fz_mul_add2 with every limb below the top one at the largest value its callers pass (fz.cuh; the limb patterns of
+            // tests/fp_host_harness.cpp op 24, rebuilt from the same input words by tests/test_gpu_parity.py)
+            constexpr int NZ = FzCfg<P>::NZ;
+            constexpr bool SMALL = NZ <= 9;
+            const uint32_t la = SMALL ? (1u << 29) + 7u : (1u << 29) + (1u << 27), lb = SMALL ? 0x80000000u : la, lc = SMALL ? (1u << 30) : la,
+                           ld = (1u << 29) - 1u, top = SMALL ? (1u << 25) : 3u;
+            Fz<P> a, b, c, d;
+            for (int k = 0; k < NZ - 1; ++k) {
+                a.l[k] = la - (x.v[0] & 7u);
+                b.l[k] = lb - (y.v[0] & 0xffu);
+                c.l[k] = lc - (x.v[2] & 0xffu);
+                d.l[k] = ld - (y.v[1] & 0xffu);
+            }
+            a.l[NZ - 1] = top + (x.v[1] & 0xffffu);
+            b.l[NZ - 1] = c.l[NZ - 1] = top;
+            d.l[NZ - 1] = SMALL ? (1u << 22) : 1u;
+            r = fz_to_fe_canonical<P>(fz_mul<P>(fz_mul_add2<P>(a, b, c, d), fz_one_rprime<P>()));
+        } break;
+        case 13: {  // the same sum through the column accumulators of the quotient numerator (FzWide): a b + c d + (a as a plain value)
+            const Fz<P> xz = fz_from_fe<P>(x), yz = fz_from_fe<P>(y);
+            FzWide<P> w;
+            fz_wide_clear<P>(w);
+            fz_wide_mac<P>(w, xz, yz);
+            fz_wide_mac<P>(w, fz_add<P>(xz, yz), yz);
+            fz_wide_add<P>(w, xz);
+            r = fz_to_fe_canonical<P>(fz_mul<P>(fz_wide_reduce<P>(w), fz_one_rprime<P>()));
+        } break;
         default: r = fe_inv_safegcd<P>(x); break;      // what the kernels use
     }
     fe_store<P>(out + i * W, r);
@@ -40,7 +69,7 @@ template <class P> static int field_op_t(int op, const uint64_t* a, const uint64
     PLK_TRY(db.alloc(bytes));
     PLK_TRY(dout.alloc(bytes));
     PLK_HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
-    if (op <= 2) PLK_HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
+    if (op <= 2 || op >= 12) PLK_HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
     if (count) {
         const size_t lanes = op == 11 ? count * 64 : count;
         k_field_op<P><<<(unsigned)((lanes + 127) / 128), 128>>>(op, (const uint4*)da.p, (const uint4*)db.p, (uint4*)dout.p, count);
@@ -304,8 +333,8 @@ int field_fold_slices_dev_impl(int field, const void* d_lo, const void* d_hi, co
 }
 
 int field_op_impl(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t count) {
-    if (op < 0 || op > 11) return set_error(PLK_ERR_INVALID_ARG, "bad field op %d", op);
-    if (!a || !out || (op <= 2 && !b)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    if (op < 0 || op > 13) return set_error(PLK_ERR_INVALID_ARG, "bad field op %d", op);
+    if (!a || !out || ((op <= 2 || op >= 12) && !b)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
     PLK_TRY(ensure_device());
     switch (field) {
         case PLK_FIELD_TWEEDLEDEE_BASE: return field_op_t<TweedledeeBaseParams>(op, a, b, out, count);

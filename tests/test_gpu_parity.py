@@ -57,6 +57,38 @@ def test_device_field_inverse_and_random(f):
         assert np.array_equal(api.field_op(f.field_id, "inverse_divsteps_one_lane", arr[:200]), want[:200])  # one lane per wave, scalar low words
 
 
+@pytest.mark.parametrize("f", FIELDS, ids=lambda f: f.name)
+def test_device_shared_reductions(f):
+    """fz_mul_add2 and the column accumulators (FzWide) on the DEVICE: sums of products through one Montgomery reduction, with every
+    limb below the top one at the largest value the kernels pass (the limb patterns of tests/fp_host_harness.cpp op 24) and on ordinary
+    operands, against Python integers."""
+    p, n = f.p, f.n_limbs
+    nz = (64 * n + 28) // 29
+    Rp_inv = pow(1 << (29 * nz), -1, p)
+    inputs = reference_test_inputs(p)[:40] + [synth.to_int(r) for r in synth.rand_field(f.field_id, 0x5EED, 60)]
+    m = len(inputs)
+    x = ints_to_array(inputs, n)
+    a, b = x[np.repeat(np.arange(m), m)], x[np.tile(np.arange(m), m)]
+    got_edge = [limbs_to_int(r) for r in api.field_op(f.field_id, "mul_add2_edge", a, b)]
+    got_wide = [limbs_to_int(r) for r in api.field_op(f.field_id, "wide_sum", a, b)]
+    small = nz <= 9
+    la = (1 << 29) + 7 if small else (1 << 29) + (1 << 27)
+    lb, lc, ld, top = (1 << 31 if small else la), (1 << 30 if small else la), (1 << 29) - 1, (1 << 25 if small else 3)
+
+    def val(limb, tl):
+        return sum(limb << (29 * t) for t in range(nz - 1)) + (tl << (29 * (nz - 1)))
+    k = 0
+    for ai in inputs:
+        xw = [(ai >> (32 * t)) & 0xFFFFFFFF for t in range(3)]
+        for bj in inputs:
+            yw = [(bj >> (32 * t)) & 0xFFFFFFFF for t in range(2)]
+            A, B = val(la - (xw[0] & 7), top + (xw[1] & 0xFFFF)), val(lb - (yw[0] & 0xFF), top)
+            C, Dv = val(lc - (xw[2] & 0xFF), top), val(ld - (yw[1] & 0xFF), (1 << 22) if small else 1)
+            assert got_edge[k] == (A * B + C * Dv) * Rp_inv % p, (hex(ai), hex(bj))
+            assert got_wide[k] == ((ai * bj + (ai + bj) * bj) * Rp_inv + ai) % p, (hex(ai), hex(bj))
+            k += 1
+
+
 # ---------------- NTT ----------------
 def test_fft_and_ifft():
     """fft.rs:164-185 verbatim: degree 200, coeffs i*1337 % 100 in Bls12377Scalar."""
