@@ -1,4 +1,5 @@
-// ecj.cuh -- Jacobian coordinates (X, Y, Z: x = X / Z^2, y = Y / Z^3) on the lazily reduced limbs of fz.cuh, for the kernels that
+// ecj_lab.cuh -- NOT part of the library (round 5: built into the fold kernels, bit-identical, measured slower, dropped - profiles/NOTES.md;
+// include with -I plonky_amd/csrc).  Jacobian coordinates (X, Y, Z: x = X / Z^2, y = Y / Z^3) on the lazily reduced limbs of fz.cuh, for the kernels that
 // DOUBLE more than they add: the generator folds of the opening argument (fold.hip) run one chain of ~128 doublings per output with
 // 64-192 mixed additions beside it.  A doubling here is 4 squarings + 4 products with 6 reductions (dbl-2009-l, a = 0, with 2 X Y^2
 // and 2 Y Z as products and the closing E (D - X3) - 8 Y^4 through one reduction: 729 multiplier instructions on nine limbs) where
