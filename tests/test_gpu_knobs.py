@@ -1,0 +1,55 @@
+"""GPU parity: the alternative code paths the library keeps behind process-wide environment knobs.
+
+Several mechanisms that were measured and NOT made the default stay in the library as options (README "Tuning / debugging knobs"):
+the wave-shuffle form of a tile's first stages, the staggered start of a one-round pass, round 4's host pipeline of plk_ntt_batch,
+batches strictly one MSM after the other, reductions of a batch on a second stream, no fork for small batches, the fused table
+build, the table-free MSM and the generator fold without the endomorphism split, another table-free window, the pair kernel for
+every pairwise fold, the quotient numerator in slabs, and copies between the devices of a group staged through the host.  They
+are read once per process, so each one runs a slice of the parity suite - the same oracle comparisons as the default path - in a
+process of its own.  A knob that changes nothing it should not: every selected test still passes bit-exact.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+NTT = ["tests/test_gpu_parity.py", "tests/test_gpu_poly.py", "-k",
+       "test_fft_and_ifft or (test_ntt_matches_oracle and (Tweedledee or Bls12377Base)) or test_ntt_linearity or test_ntt_padding or "
+       "test_polynomials_to_values_padded or test_division_by_z_h_plonk_shape or test_ntt_2p20_full_size"]
+MSM = ["tests/test_gpu_parity.py", "-k",
+       "test_msm_tweedledee_mini_kat or (test_msm_matches_oracle and (Tweedledee or Bls12377)) or test_msm_parallel_one_shot or "
+       "test_msm_batch_and_sum_affine or test_msm_batch_larger_than_one_group or test_coeffs_vec_to_commitments or test_msm_heavy_buckets"]
+FOLD = ["tests/test_gpu_parity.py", "tests/test_gpu_halo.py", "-k",
+        "test_fold_generators or test_halo_round_matches_oracle or test_halo_whole_argument_closed_form or test_fold_multi_matches_big_integers"]
+VANISH = ["tests/test_gpu_plonk.py", "-k", "test_vanishing_points_match_oracle or test_honest_witness"]
+
+CASES = [
+    ("PLK_NTT_SHUFFLE", "1", NTT),
+    ("PLK_NTT_STAGGER", "2", NTT),
+    ("PLK_NTT_HOST_PIPE", "0", NTT),
+    ("PLK_MSM_NO_OVERLAP", "1", MSM),
+    ("PLK_MSM_TAIL_PIPELINE", "1", MSM),
+    ("PLK_MSM_NO_FORK", "1", MSM),
+    ("PLK_MSM_TABLE_FUSED", "1", MSM),
+    ("PLK_MSM_NO_GLV", "1", MSM),
+    ("PLK_MSM_WINDOW_TF", "9", MSM),
+    ("PLK_FOLD_NO_GLV", "1", FOLD),
+    ("PLK_HALO_PAIR_FOLD", "1", FOLD),
+    ("PLK_VANISH_SLAB_LOG", "10", VANISH),
+]
+
+
+@pytest.mark.parametrize("knob,value,selection", CASES, ids=[c[0] for c in CASES])
+def test_parity_slice_under_knob(knob, value, selection):
+    env = dict(os.environ)
+    env[knob] = value
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + selection,
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    tail = (out.stdout + out.stderr)[-1500:]
+    assert out.returncode == 0, "%s=%s: %s" % (knob, value, tail)
+    assert " passed" in out.stdout and "failed" not in out.stdout, tail
