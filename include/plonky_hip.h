@@ -241,8 +241,10 @@ int plk_msm_execute_parts_dev(plk_msm_ctx* ctx, unsigned batch, const uint64_t* 
 int plk_msm(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, const uint64_t* scalars, uint64_t* out_xy,
             uint8_t* out_zero);
 
-/* Sum of k affine points -> affine (combining per-GPU partial MSM results after the all-gather;
- * point addition is not an RCCL reduction op).  Host pointers. */
+/* Sum of k affine points -> affine: affine_summation_best / _pairwise / _batch_inversion (curve_summations.rs:18-22, 39-68 - one
+ * group element whatever the form; identity operands, P = Q and P = -Q handled as :86-92, 113-141 do), and what combines per-GPU
+ * partial MSM results after the all-gather (point addition is not an RCCL reduction op).  affine_multisummation_best (:24-35) is
+ * one call per list.  Host pointers.  Pinned directly by tests/test_gpu_summations.py (the reference's own two unit tests, :164-184). */
 int plk_curve_sum_affine(int curve, size_t k, const uint64_t* pts_xy, const uint8_t* pts_zero, uint64_t* out_xy, uint8_t* out_zero);
 
 /* ---- multi-GPU exchange of partial results (no counterpart in the single-process reference) ----------- */

@@ -9,6 +9,6 @@ from .api import (  # noqa: F401
     fft_with_precomputation_power_of_2, ifft_with_precomputation_power_of_2, msm_execute, msm_execute_batch, msm_execute_parallel,
     msm_parallel, msm_precompute, log2_ceil, log2_strict, polynomial_divide_by_z_h, polynomial_mul,
     polynomials_to_values_padded, values_to_polynomials, fold_generators, msm_precompute_table, commitment_precompute, coeffs_vec_to_commitments,
-    init_devices, device_count, msm_debug_digits,
+    init_devices, device_count, msm_debug_digits, affine_summation_best, affine_multisummation_best, curve_sum_affine,
 )
 from .lib import PlonkyHipError  # noqa: F401

@@ -368,6 +368,24 @@ def curve_sum_affine(curve, points, zero=None):
     return out, int(oz[0])
 
 
+def affine_summation_best(curve, summation, zero=None):
+    """curve_summations.rs:18-22 (and the _pairwise / _batch_inversion forms it chooses between, :39-58 / :60-68: one group element,
+    whatever the form): the sum of a list of affine points, identity operands, P = Q and P = -Q included.  On the device the list is
+    one workgroup's XYZZ sum (k_sum_affine); returns ((2, L) affine limbs, zero flag)."""
+    return curve_sum_affine(curve, summation, zero)
+
+
+def affine_multisummation_best(curve, summations, zeros=None):
+    """curve_summations.rs:24-35: k independent sums of affine points -> k points, one device sum per list (inside the MSM the
+    reference's call site, curve_msm.rs:131-145, is replaced by the bucket accumulation - DESIGN.md section 5)."""
+    L = _CURVE_LIMBS[curve]
+    out = []
+    for k, pts in enumerate(summations):
+        arr = np.asarray(pts, dtype=np.uint64).reshape(-1, 2, L)
+        out.append(curve_sum_affine(curve, arr, None if zeros is None else zeros[k]))
+    return out
+
+
 def field_op(field, op, a, b=None):
     """Element-wise device field arithmetic (parity tests of the HIP field code)."""
     ops = {"add": 0, "sub": 1, "mul": 2, "neg": 3, "square": 4, "inverse": 5, "to_canonical": 6, "from_canonical": 7,
