@@ -32,6 +32,43 @@ counts = {"msm": 0, "ntt": 0, "poly": 0, "fold": 0, "plonk": 0, "misc": 0, "halo
 seeds = {k: [] for k in counts}
 
 
+# FUZZ_GEOMETRY=1: every MSM case also draws the lane length / reduction group size of its context (PLK_MSM_SLICE / PLK_MSM_GLOG, read when a
+# context is built) and every transform case a random factorisation of its size into passes (PLK_NTT_PLAN, read when a plan is built; the
+# plan cache is dropped first) - the geometries the sizes alone would never produce.  Off by default so that old case seeds replay as they ran.
+GEOMETRY = os.environ.get("FUZZ_GEOMETRY") == "1"
+
+
+def draw_msm_geometry(rng):
+    for k in ("PLK_MSM_SLICE", "PLK_MSM_GLOG"):
+        os.environ.pop(k, None)
+    if not GEOMETRY:
+        return None
+    sl, gl = rng.choice([None, 2, 3, 5, 8, 24, 50, 96, 1000]), rng.choice([None, None, 0, 1, 2, 3, 4, 5])
+    if sl is not None:
+        os.environ["PLK_MSM_SLICE"] = str(sl)
+    if gl is not None:
+        os.environ["PLK_MSM_GLOG"] = str(gl)
+    return sl, gl
+
+
+def draw_ntt_plan(rng, log_n):
+    os.environ.pop("PLK_NTT_PLAN", None)
+    if not GEOMETRY:
+        return None
+    plan = None
+    if log_n >= 2 and rng.random() < 0.8:
+        parts, left = [], log_n
+        while left > 0 and len(parts) < 5:
+            a = rng.randrange(1, min(left, 10) + 1)
+            parts.append(a)
+            left -= a
+        if left == 0:
+            plan = ",".join(str(a) for a in parts)
+            os.environ["PLK_NTT_PLAN"] = plan
+    pa.lib.check(pa.lib.load().plk_ntt_clear_cache())
+    return plan
+
+
 def mont(f, vals):
     return ints_to_array([f.to_mont(v % f.p) for v in vals], f.n_limbs)
 
@@ -114,9 +151,10 @@ def one_case(rng):
         exp, ez = ol.MsmPrecomputation(c.curve_id, bases, 8, zero=zero, threads=8).execute(sc, parallel=True, threads=8)
         tf = rng.random() < 0.5
         win = rng.choice([0, 0, 3, 5, 8, 11] + ([] if tf else [13, 14, 16, 18, 20]))
+        geom = draw_msm_geometry(rng)
         pre = pa.msm_precompute(c.curve_id, bases, 8, zero=zero, device_window=win, table_free=tf)
         got, gz = pa.msm_execute_parallel(pre, sc)
-        assert gz == ez and (ez or np.array_equal(got, exp)), ("msm", c.name, n, style, tf, win)
+        assert gz == ez and (ez or np.array_equal(got, exp)), ("msm", c.name, n, style, tf, win, geom)
         if rng.random() < 0.3:
             # the same vector inside a batch (shared reduction), next to other vectors
             k = rng.choice([2, 3, 17])
@@ -133,10 +171,11 @@ def one_case(rng):
         x = synth.rand_field(f.field_id, rng.randrange(1 << 30), batch << log_n).reshape(batch, 1 << log_n, f.n_limbs)
         opre = ol.FftPrecomputation(f.field_id, 1 << log_n)
         inv = rng.random() < 0.5
+        plan = draw_ntt_plan(rng, log_n)  # named in a failure by the case seed (FUZZ_CASE replays it under the same FUZZ_GEOMETRY)
         got = pa.api.fft_batch(f.field_id, x, inverse=inv)
         for b in range(batch):
             want = opre.ifft_with_precomputation_power_of_2(x[b], threads=8) if inv else opre.fft_with_precomputation_power_of_2(x[b], threads=8)
-            assert np.array_equal(got[b], want), ("ntt", f.name, log_n, batch, inv)
+            assert np.array_equal(got[b], want), ("ntt", f.name, log_n, batch, inv, plan)
         if f.n_limbs == 6 and rng.random() < 0.5:
             # fft_with_precomputation (fft.rs:61-80): any length, zero-padded to the next power of two
             ln = rng.randrange(1, (1 << log_n) + 1)
