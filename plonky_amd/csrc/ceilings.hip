@@ -7,7 +7,7 @@
 //   [1] [2] fz_mul of THIS build (fz.cuh) at 4 waves per SIMD, 9-limb (Tweedledee base) and 14-limb (BLS12-377 base) fields;
 //   [3] [4] the lazy mixed addition of the bucket accumulation (ecz.cuh, 8 M + 2 S) at 3 / 2 waves per SIMD - the occupancies
 //       k_msm_accumulate runs at on the two field sizes - with no memory traffic at all.
-// Same kernels as tools/field_ceilings.hip (which sweeps more operations and occupancies for profiles/rNN_field_op_costs.txt).
+// Same kernels as tools/lab/field_ceilings.hip (which sweeps more operations and occupancies for profiles/rNN_field_op_costs.txt).
 #include "common.h"
 #include "fp.cuh"
 #include "fz.cuh"

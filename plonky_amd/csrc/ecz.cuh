@@ -46,7 +46,7 @@ template <class FP> PLK_DNI XyzzZ<FP> xyzzz_mdbl(Fz<FP> x, Fz<FP> y) {
 }
 
 // ---- the mixed addition of the bucket accumulation ------------------------------------------------------------------------
-// Round 4 put it on an instruction diet (tools/madd_lab.hip; SQ_INSTS_VALU per addition 2446 -> ~2290):
+// Round 4 put it on an instruction diet (tools/lab/madd_lab.hip; SQ_INSTS_VALU per addition 2446 -> ~2290):
 //   * the products lost their "+ q_k" additions (fz_mul / fz_sqr, fz.cuh);
 //   * Y may stay UNCARRIED between additions ("lazy Y": limbs <= 3 * 2^29 - 3 instead of < 2^29 + 8).  Inside an addition Y only
 //     meets a subtraction that borrows 2^31 per limb and a product with the exactly normalised PPP, both of which accept such

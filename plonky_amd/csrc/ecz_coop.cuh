@@ -17,7 +17,7 @@ template <int SRC> PLK_DI uint32_t quad_bcast_u32(uint32_t v) {
     uint32_t r = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, SRC * 0x55, 0xf, 0xf, true);  // quad_perm:[SRC,SRC,SRC,SRC]
     // Keep the move a move: ROCm 7.2's DPP combiner folds it into the consuming VALU instruction and gets
     // a - b wrong when both operands are broadcasts of the same register (observed on gfx950: only the lane
-    // that owns the subtrahend computed the right difference; tools/dpp_combine_repro.hip and plk_selftest_quad pin it).
+    // that owns the subtrahend computed the right difference; tools/lab/dpp_combine_repro.hip and plk_selftest_quad pin it).
     asm volatile("" : "+v"(r));
     return r;
 }

@@ -293,7 +293,7 @@ template <class C> __global__ void k_fold_digits(ScalarPair sp, const uint32_t* 
 // inversion); k_fold_multi_glv streams them (64 coalesced bytes per addition) - a lane holds its accumulator and one operand,
 // not the 2 x 4 precomputed points of the pair kernel.  Workgroups of ONE wave: at 2^16 outputs (one wave per SIMD on average) the waves
 // of two-wave workgroups were seen to share SIMDs while others idle - 2.85 ms against 1.82 ms for the 4-to-1 fold 2^18 -> 2^16
-// (tools/mul_latency.hip shows the same for a bare chain of doublings: 3.6 against 2.2 us per step).
+// (tools/lab/mul_latency.hip shows the same for a bare chain of doublings: 3.6 against 2.2 us per step).
 constexpr int FOLD_MULTI_MAX_LOG = 4;
 constexpr int FOLD_MULTI_MAX = 1 << FOLD_MULTI_MAX_LOG;
 struct MultiDigits {

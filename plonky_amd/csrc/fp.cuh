@@ -515,7 +515,7 @@ template <class P, int MODE, bool RAW = false> PLK_DNI Fe<P> fe_inv_safegcd_impl
 template <class P> PLK_DI Fe<P> fe_inv_safegcd(const Fe<P>& a) { return fe_inv_safegcd_impl<P, 0>(a); }
 template <class P> PLK_DI Fe<P> fe_inv_safegcd_var(const Fe<P>& a) { return fe_inv_safegcd_impl<P, 1>(a); }
 // ONE active lane in the wave (see MODE 2 above); _raw: the inverse of the integer, without the Montgomery fix-up
-// What the single-lane callers use.  tools/inv_latency.hip (profiles/r05_inversion_latency.txt), ticks per inversion on one lane of a lone
+// What the single-lane callers use.  tools/lab/inv_latency.hip (profiles/r05_inversion_latency.txt), ticks per inversion on one lane of a lone
 // wave: MODE 1 75 k, MODE 0 86 k, MODE 2 82 k, MODE 3 107 k - the scalar unit does not run the dependent low-word chain any faster than
 // the vector unit does, so the forms with scalar low words stay tuning options (-DPLK_ONE_LANE_INV_MODE=2 / 3).
 #ifndef PLK_ONE_LANE_INV_MODE

@@ -74,7 +74,7 @@ PLK_DI uint32_t fz_opaque(uint32_t c) {
 // M = 2^29 - 1.  The column adds the CONSTANT M (kept opaque in scalar registers: one v_lshl_add_u64, where "+ q_k" needed the
 // digit first) and with acc'_k = acc_k + M the digit is q_k = ~acc'_k & M (-x = ~x + 1 and M = -1 mod 2^29): one v_bitop3_b32
 // instead of a subtraction and a mask, no register copies around the 64-bit pair.  fz_mul 201 -> 184 VALU instructions per
-// product on gfx950, fz_sqr 173 -> 155 (tools/madd_lab.hip + tools/isa_count.py).  (Starting the column's multiply-add chain
+// product on gfx950, fz_sqr 173 -> 155 (tools/lab/madd_lab.hip + tools/isa_count.py).  (Starting the column's multiply-add chain
 // from M through inline assembly was tried: the compiler still joins two chains with an addition - 183 - and pads with s_nop.)
 PLK_DI uint64_t fz_opaque64(uint64_t c) {
 #ifdef __HIPCC__

@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) k_msm_table_export(const uint4* __restric
 // c doublings.  Here the chain only doubles - c (windows - 1) doublings without a normalisation in between, every window's
 // XYZZ point parked in scratch memory - and a second kernel normalises all (window, generator) pairs side by side:
 // 1.75 -> 1.2 ms for 2^14 + 2 generators at c = 13 with a lane per generator, 0.65 ms on quads in one-wave workgroups (a chain of quad
-// doublings takes 3.6 us per step in two-wave workgroups at this occupancy, 2.2 us in one-wave ones: tools/mul_latency.hip).  Same points, so the same (unique) affine table entries.
+// doublings takes 3.6 us per step in two-wave workgroups at this occupancy, 2.2 us in one-wave ones: tools/lab/mul_latency.hip).  Same points, so the same (unique) affine table entries.
 template <class C>
 __global__ void __launch_bounds__(64) k_msm_table_chain(const uint4* __restrict__ bases, const uint8_t* __restrict__ base_zero, uint4* __restrict__ tab,
                                                          uint4* __restrict__ raw, size_t n, int c, int windows, size_t n_main, const uint4* __restrict__ extra) {

@@ -85,18 +85,32 @@ def main():
     print("golden vectors written to", OUT)
 
 
-SEEDED_MSM = [(br.TWEEDLEDEE, 16), (br.TWEEDLEDEE, 18), (br.TWEEDLEDEE, 20), (br.BLS12_377, 16), (br.BLS12_377, 18), (br.BLS12_377, 20)]
+# (curve, n, device window the test asks for: 0 = the library's own choice).  Round 6 added the reference's own benchmark curve
+# (src/bin/msms.rs:12 is Tweedledum) at 2^18 / 2^20, a Pasta curve at 2^18, and two lengths that are NOT powers of two at the c = 20
+# geometry: 1 000 003 (the reference takes any length, curve_msm.rs:102-107) and 349 525 = a third of 2^20, what a rank of three holds.
+SEEDED_MSM = [(br.TWEEDLEDEE, 1 << 16, 0), (br.TWEEDLEDEE, 1 << 18, 0), (br.TWEEDLEDEE, 1 << 20, 0),
+              (br.BLS12_377, 1 << 16, 0), (br.BLS12_377, 1 << 18, 0), (br.BLS12_377, 1 << 20, 0),
+              (br.TWEEDLEDUM, 1 << 18, 0), (br.TWEEDLEDUM, 1 << 20, 0), (br.PALLAS, 1 << 18, 0),
+              (br.TWEEDLEDEE, 1000003, 0), (br.TWEEDLEDUM, 349525, 20)]
 
 
-def msm_seeded_generators():
+def seeded_name(c, n):
+    return "seeded_msm_%s_%s.npz" % (c.name, "2p%d" % (n.bit_length() - 1) if n & (n - 1) == 0 else "n%d" % n)
+
+
+def msm_seeded_generators(only_missing=False):
     """MSMs at production geometry over generators WITHOUT structure (curve_msm.rs:218-241 tests arbitrary generators): G_i = [h_i] G
     for seeded h_i, seeded scalars s_i - the fixture holds only the seeds and the expected affine point [sum s_i h_i mod r] G, one
     scalar multiplication on Python integers (the generators lie in the r-subgroup).  The tests rebuild
     the generators from the seeds with the oracle's scalar multiplication (curve_multiplication.rs)."""
-    for c, log_n in SEEDED_MSM:
-        n = 1 << log_n
+    for c, n, window in SEEDED_MSM:
+        path = os.path.join(OUT, seeded_name(c, n))
+        if only_missing and os.path.exists(path):
+            continue
         f, r = c.scalar, c.scalar.p
-        seed_h, seed_s = 0x601D6000 + 0x100 * c.curve_id + log_n, 0x601D7000 + 0x100 * c.curve_id + log_n
+        log_n = n.bit_length() - 1  # the seeds of the power-of-two cases are those of rounds 4 / 5; the ragged lengths mix n in
+        tag = log_n if n & (n - 1) == 0 else 0x40 + (n % 61)
+        seed_h, seed_s = 0x601D6000 + 0x100 * c.curve_id + tag, 0x601D7000 + 0x100 * c.curve_id + tag
         h = synth.rand_field(f.field_id, seed_h, n)
         sv = synth.rand_field(f.field_id, seed_s, n)
         hb, sb = h.tobytes(), sv.tobytes()
@@ -107,9 +121,12 @@ def msm_seeded_generators():
         k = acc % r * rinv % r * rinv % r
         P = br.ec_mul(c, k, (c.gx, c.gy))
         L = c.base.n_limbs
-        np.savez(os.path.join(OUT, "seeded_msm_%s_2p%d.npz" % (c.name, log_n)), curve=c.curve_id, log_n=log_n, seed_h=seed_h, seed_s=seed_s,
+        np.savez(path, curve=c.curve_id, log_n=log_n, n=n, device_window=window, seed_h=seed_h, seed_s=seed_s,
                  expected_xy=arr([c.base.to_mont(P[0]), c.base.to_mont(P[1])], L), expected_zero=0)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "seeded-missing":
+        msm_seeded_generators(only_missing=True)  # adds fixtures without touching the committed ones
+    else:
+        main()

@@ -19,7 +19,12 @@ from tests.test_golden import GOLD, seeded_msm_inputs
 # the 2^20 cases (c = 20 on Tweedledee: two-level 9 + 10-bit ordering, 8192-entry segments, row / column sums; the 14-limb field of
 # BLS12-377 at the same geometry) run in the driver's suite since round 5: ~35 s and ~90 s of host-side oracle work
 CASES = ["seeded_msm_Tweedledee_2p16.npz", "seeded_msm_Bls12377_2p16.npz", "seeded_msm_Tweedledee_2p18.npz", "seeded_msm_Bls12377_2p18.npz",
-         "seeded_msm_Tweedledee_2p20.npz", "seeded_msm_Bls12377_2p20.npz"]
+         "seeded_msm_Tweedledee_2p20.npz", "seeded_msm_Bls12377_2p20.npz",
+         # round 6: the curve of the reference's own MSM benchmark (src/bin/msms.rs:12-44 is Tweedledum) at production geometry, a Pasta
+         # curve, and lengths that are NOT powers of two at the c = 20 geometry (the reference takes any length, curve_msm.rs:102-107;
+         # 349 525 = a third of 2^20 is what one rank of three holds - the fixture asks for the 20-bit window explicitly)
+         "seeded_msm_Tweedledum_2p18.npz", "seeded_msm_Pallas_2p18.npz", "seeded_msm_Tweedledum_2p20.npz",
+         "seeded_msm_Tweedledee_n1000003.npz", "seeded_msm_Tweedledum_n349525.npz"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -29,8 +34,11 @@ def test_msm_seeded_generators_vs_oracle_and_golden(name):
     lib.check(lib.load().plk_init(0))
     threads = min(128, os.cpu_count() or 1)
     g, curve, bases, s = seeded_msm_inputs(os.path.join(GOLD, name), threads)
-    pre = pa.msm_precompute(curve, bases, 11)
+    want_window = int(g["device_window"]) if "device_window" in g.files else 0
+    pre = pa.msm_precompute(curve, bases, 11, device_window=want_window)
     assert pre.window >= 16, pre.window          # the production geometry, not a small-window special case
+    if want_window or len(s) >= 1 << 19:
+        assert pre.window == 20, pre.window      # two-level 9 + 10-bit ordering, row / column sums over 2^19 buckets
     xy, z = pa.msm_execute_parallel(pre, s)
     assert z == 0 and np.array_equal(xy, g["expected_xy"]), "tabled MSM differs from the golden point"
     # the same vector in a batch with a sparse and a shifted companion (shared reduction, per-execution chunk length)

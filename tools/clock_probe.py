@@ -1,5 +1,5 @@
 """Samples the shader clock (clock64 against the 100 MHz wall clock) on 8 probe waves while NTT variants run on another
-stream.  Needs: hipcc -O2 --offload-arch=gfx950 -shared -fPIC -o build_exp/libclockprobe.so tools/clockprobe.hip and the
+stream.  Needs: hipcc -O2 --offload-arch=gfx950 -shared -fPIC -o build_exp/libclockprobe.so tools/lab/clockprobe.hip and the
 variant libraries of tools/ntt_experiments.sh (EXPS="3 6").  Run on the GPU box from the repo root."""
 import ctypes, os, sys, time
 import numpy as np, torch

@@ -1,6 +1,6 @@
-// tools/bench_field.hip -- per-operation throughput of the device field arithmetic on the GPU
+// tools/lab/bench_field.hip -- per-operation throughput of the device field arithmetic on the GPU
 // (wave-cycles per operation per SIMD at 4 waves/SIMD), feeding DESIGN.md's ALU ceiling.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iplonky_amd/csrc -o build/bench_field tools/bench_field.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iplonky_amd/csrc -o build/bench_field tools/lab/bench_field.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include "fp.cuh"

@@ -1,7 +1,7 @@
-// tools/dpp_combine_repro.hip -- reproduces / pins the ROCm 7.2 DPP-combiner miscompile worked around in
+// tools/lab/dpp_combine_repro.hip -- reproduces / pins the ROCm 7.2 DPP-combiner miscompile worked around in
 // plonky_amd/csrc/ecz_coop.cuh (quad_bcast_u32): without the empty asm after the v_mov_b32_dpp, the y coordinate
 // of xyzzz_dbl_q / xyzzz_add_q (= bcast<0>(r) - bcast<1>(r)) is right only in the lane that owns the subtrahend.
-// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iplonky_amd/csrc -o dpp_repro tools/dpp_combine_repro.hip
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iplonky_amd/csrc -o dpp_repro tools/lab/dpp_combine_repro.hip
 // Run on the GPU: prints one byte per lane (low nibble: doubling, high nibble: addition; bit k = coordinate k differs
 // from the one-lane arithmetic), all-lanes-active and divergent; all zeros on a healthy build.
 #include <hip/hip_runtime.h>

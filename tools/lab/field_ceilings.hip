@@ -1,4 +1,4 @@
-// tools/field_ceilings.hip -- the integer-ALU ceilings bench.py prices the kernels against, measured on THIS tree's arithmetic
+// tools/lab/field_ceilings.hip -- the integer-ALU ceilings bench.py prices the kernels against, measured on THIS tree's arithmetic
 // headers: fz_mul / fz_sqr / fz_add / the lazy mixed addition per field (Gop/s over the whole GPU at 1..4 waves per SIMD) and
 // the raw issue rate of v_mad_u64_u32 (the instruction a multiplication is made of), at 8 waves per SIMD.
 // tools/measure_ceilings.py builds and runs it and writes profiles/r03_field_op_costs.{txt,json}.

@@ -1,7 +1,7 @@
 // inv_latency.hip -- the division-step inversion of fp.cuh as a dependency chain on ONE lane of one wave (what the normalisation at the
 // end of an MSM runs, k_msm_final): shader-clock ticks per inversion of its forms (MODE 0 fixed / 1 data-dependent runs / 2 runs with the
 // low words on the scalar unit / 3 fixed with scalar low words), and the same with all 64 lanes of the wave inverting different values.
-// hipcc -O3 -std=c++17 --offload-arch=gfx950 -I plonky_amd/csrc tools/inv_latency.hip -o build/inv_latency && build/inv_latency
+// hipcc -O3 -std=c++17 --offload-arch=gfx950 -I plonky_amd/csrc tools/lab/inv_latency.hip -o build/inv_latency && build/inv_latency
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "field_params.cuh"

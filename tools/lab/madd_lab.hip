@@ -1,8 +1,8 @@
-// tools/madd_lab.hip -- laboratory for the instruction diet of the MSM accumulation's mixed addition (round-3 review item 2b).
+// tools/lab/madd_lab.hip -- laboratory for the instruction diet of the MSM accumulation's mixed addition (round-3 review item 2b).
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iplonky_amd/csrc tools/madd_lab.hip -o build/madd_lab   (run on the GPU box)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iplonky_amd/csrc tools/lab/madd_lab.hip -o build/madd_lab   (run on the GPU box)
 //   hipcc ... --cuda-device-only -S ... -o /tmp/madd_lab.s                                              (instruction counts: tools/isa_count.py)
-//   g++ -x c++ -O2 -std=c++17 -DLAB_HOST -Iplonky_amd/csrc tools/madd_lab.hip -o build/madd_lab_host    (the same formulas on the CPU: old == new)
+//   g++ -x c++ -O2 -std=c++17 -DLAB_HOST -Iplonky_amd/csrc tools/lab/madd_lab.hip -o build/madd_lab_host    (the same formulas on the CPU: old == new)
 //
 // Kernels: V = 0 the product's xyzzz_madd / fz_mul (ecz.cuh / fz.cuh as built into the library); V = 1 the same entry points built with
 // -DLAB_NEW... there is only one set of headers, so the "old" forms are kept here verbatim under the names *_r3.

@@ -1,6 +1,6 @@
-// tools/microbench.hip -- issue-rate probes for the integer instructions the field arithmetic
+// tools/lab/microbench.hip -- issue-rate probes for the integer instructions the field arithmetic
 // is built from (v_mad_u64_u32, 64-bit add, add/addc, v_mul_lo/hi, 24-bit mad, f64 fma).
-// Build: hipcc --offload-arch=gfx950 -O3 -o microbench tools/microbench.hip ; run on the GPU box.
+// Build: hipcc --offload-arch=gfx950 -O3 -o microbench tools/lab/microbench.hip ; run on the GPU box.
 // Output feeds DESIGN.md "ALU ceiling": cycles per wave-instruction per SIMD.
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -7,7 +7,7 @@
 //   PLACE the same 1024 waves as workgroups of 1 .. 16 waves: with this small kernel two-wave workgroups run 1.6x slower than one- or
 //         four-wave ones (their waves share SIMDs); the library's kernels did not change when their workgroups were resized accordingly
 //         (fold, table, row / column sums, accumulation: all within noise) - their register use already spreads them.
-// hipcc -O3 -std=c++17 --offload-arch=gfx950 -I plonky_amd/csrc tools/mul_latency.hip -o build/mul_latency && build/mul_latency
+// hipcc -O3 -std=c++17 --offload-arch=gfx950 -I plonky_amd/csrc tools/lab/mul_latency.hip -o build/mul_latency && build/mul_latency
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "field_params.cuh"

@@ -1,4 +1,4 @@
-// tools/tail_lab.hip -- why does the MSM's reduction tail (k_msm_planes, k_msm_final: a handful of points, long dependency chains of
+// tools/lab/tail_lab.hip -- why does the MSM's reduction tail (k_msm_planes, k_msm_final: a handful of points, long dependency chains of
 // quad point operations) run at ~13 cycles per instruction of its critical wave when a lone wave's field product is issue-bound at
 // ~4.7?  Hypothesis: the kernels are ~160 KB of straight-line code that runs ONCE (every xyzzz_add_q / xyzzz_dbl_q call site is its
 // own inline copy), so the critical wave waits for instruction fetch, not for the ALU.
@@ -9,7 +9,7 @@
 // Between two measured launches a filler kernel with its own large body runs, so that every launch starts with a cold instruction cache
 // the way k_msm_final does after the accumulation.
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iplonky_amd/csrc tools/tail_lab.hip -o ab_libs/tail_lab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iplonky_amd/csrc tools/lab/tail_lab.hip -o ab_libs/tail_lab
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Builds and runs tools/field_ceilings.hip on the GPU box and writes the ceilings bench.py reads:
+"""Builds and runs tools/lab/field_ceilings.hip on the GPU box and writes the ceilings bench.py reads:
 gpurun_out/<round>_field_op_costs.txt (the raw lines) and .json ({"fz_mul_gops": {curve: G modmul/s at 4 waves per SIMD},
 "mad_u64_u32_glaneops": raw issue rate at 8 waves per SIMD, "arith_source_sha": hash of the arithmetic headers}).
 Copy both into profiles/ (bench.py reads the newest round's file and ignores it when the headers have changed since).  The file
@@ -19,9 +19,9 @@ RN = sys.argv[2] if len(sys.argv) > 2 else "r04"
 os.makedirs(out_dir, exist_ok=True)
 exe = os.path.join(ROOT, "build", "field_ceilings")
 os.makedirs(os.path.dirname(exe), exist_ok=True)
-if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(os.path.join(ROOT, "tools", "field_ceilings.hip")):
+if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(os.path.join(ROOT, "tools", "lab", "field_ceilings.hip")):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "plonky_amd", "csrc"),
-                           "-o", exe, os.path.join(ROOT, "tools", "field_ceilings.hip")])
+                           "-o", exe, os.path.join(ROOT, "tools", "lab", "field_ceilings.hip")])
 txt = subprocess.check_output([exe], text=True)
 open(os.path.join(out_dir, RN + "_field_op_costs.txt"), "w").write(txt)
 res = {"arith_source_sha": arith_source_hash(), "fz_mul_gops": {}, "fz_sqr_gops": {}, "lazy_madd_gops": {}, "all": []}
@@ -37,7 +37,7 @@ for line in txt.splitlines():
         res["mad_u64_u32_glaneops"] = float(kv["glaneops"])
     elif line.startswith("INFO"):
         res["max_clock_khz"] = int(kv["max_clock_khz"])
-res["source"] = "tools/field_ceilings.hip: Gop/s over the whole GPU at 4 waves per SIMD; v_mad_u64_u32 lane-ops/s at 8 waves per SIMD"
+res["source"] = "tools/lab/field_ceilings.hip: Gop/s over the whole GPU at 4 waves per SIMD; v_mad_u64_u32 lane-ops/s at 8 waves per SIMD"
 try:
     import torch
     from bench import gpu_identity
