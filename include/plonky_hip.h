@@ -98,7 +98,10 @@ int plk_multi_plan(unsigned world, unsigned batch, size_t n, unsigned device, un
 int plk_set_thread_device(int logical_device); /* the _dev entry points of the calling thread run on this logical device */
 void plk_shutdown(void);
 /* Size gate for the binding: problems below 2^plk_min_gpu_log_n() elements / pairs stay on the reference's
- * own CPU path - the library itself has no CPU path.  Environment PLK_MIN_GPU_LOG_N, default 10 (the measured crossover of the host-pointer entry points, profiles/r05_crossover_host_pointer_vs_cpu.txt).  plk_init(-1) takes the
+ * own CPU path - the library itself has no CPU path.  Environment PLK_MIN_GPU_LOG_N, default 12: PROVISIONAL - the measured crossover of
+ * the host-pointer entry points (profiles/r05_crossover_host_pointer_vs_cpu.txt: GPU ahead from 2^8-2^10) is against the C++ restatement
+ * of the reference's algorithm, not against its Rust, which cannot be built in this image; one gate for transforms and MSM pairs (a
+ * first MSM call also pays its precomputation).  plk_init(-1) takes the
  * device from the environment variable PLK_DEVICE (default 0). */
 unsigned plk_min_gpu_log_n(void);
 /* Text of the last error on the calling thread (never NULL). */
@@ -398,6 +401,10 @@ int plk_ntt_set_profiling(int enable);
 int plk_ntt_get_timings(double* sum_ms, unsigned* launches);
 /* MSM pipeline: sum_ms[7] = scalar digits, scan, scatter, bucket accumulation, chunk sums, plane sums,
  * final -- summed over `calls` executions since the previous read. */
+/* (a context over few generators with an automatic window is a COMB - comb.hip, <= 2^12 generators: 32 KiB of table per generator,
+ * 48 for BLS12-377, i.e. 128-192 MiB at 2^12, ~20 x the window tables; it has no stages: enabling the timings on it returns
+ * PLK_ERR_INVALID_ARG.  PLK_MSM_COMB=0 keeps every context on the bucket method; when the comb's table cannot be allocated the
+ * library falls back to the bucket method by itself.) */
 int plk_msm_set_profiling(plk_msm_ctx* ctx, int enable);
 int plk_msm_get_timings(plk_msm_ctx* ctx, double* sum_ms, unsigned* calls);
 

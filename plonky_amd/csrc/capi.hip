@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" surface declared in include/plonky_hip.h.
 // Thin: argument validation, host<->device staging for the host-pointer variants, dispatch.
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstring>
@@ -238,7 +239,9 @@ int lane_get(HostLane*& out) {
 // registered interval shares it; a request that extends or partly overlaps one never leaves a half-registered range behind (HIP
 // resolves a pointer to the registered object it starts in - an asynchronous copy longer than that object is rejected, and the
 // first holder's release would unregister pages under the second caller's DMA):
-//  * held by OTHER threads: wait until they have released it (they do not depend on us), then register the union;
+//  * held by OTHER threads: wait until they have released it, then register the union - for at most two seconds in all: holders that
+//    in turn wait for this thread (or for a lock its dispatcher holds) would otherwise never release; past that the request fails and
+//    the caller's copies go without a registration;
 //  * held by the calling thread alone (two overlapping buffers of one batched call, an in-place padded transform): every device
 //    of the group is synchronised - the thread's own copies over the old interval are complete - and the interval is re-registered
 //    as the union, the thread's holds carried over.
@@ -270,6 +273,8 @@ bool pin_registry_acquire(const void* ptr, size_t bytes) {
     const uint8_t* lo = (const uint8_t*)ptr;
     const uint8_t* hi = lo + bytes;
     const std::thread::id me = std::this_thread::get_id();
+    constexpr long PIN_WAIT_MS = 2000;
+    long waited_ms = 0;
     std::unique_lock<std::mutex> lk(g_pin_mu);
     for (;;) {
         // the registered intervals that touch [lo, hi)
@@ -297,7 +302,14 @@ bool pin_registry_acquire(const void* ptr, size_t bytes) {
             for (const auto& who : h->second.holders)
                 if (who.first != me && who.second) others = true;
         if (others) {
-            g_pin_cv.wait(lk);  // a release wakes us; then look again
+            // Never wait unboundedly: two threads that each hold a range and ask for one overlapping the other's, or a
+            // worker that waits here while its dispatcher holds the fan-out lock another holder is queued for, would wait for ever.  After
+            // PIN_WAIT_MS in all the request goes on WITHOUT a registration of its own - the caller's copies then take the runtime's
+            // pageable path (they block the calling thread), as they do when a registration fails.
+            if (waited_ms >= PIN_WAIT_MS) return false;
+            const auto t0 = std::chrono::steady_clock::now();
+            (void)g_pin_cv.wait_for(lk, std::chrono::milliseconds(PIN_WAIT_MS - waited_ms));  // a release wakes us; then look again
+            waited_ms += (long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() + 1;
             continue;
         }
         // every interval in the way is held by this thread alone: replace them by their union with the request
@@ -437,11 +449,12 @@ void plk_shutdown(void) {
 const char* plk_last_error(void) { return last_error_ref().c_str(); }
 unsigned plk_min_gpu_log_n(void) {
     const char* e = getenv("PLK_MIN_GPU_LOG_N");
-    // Default 10, set from the measured crossover (profiles/r05_crossover_host_pointer_vs_cpu.txt: through the HOST-pointer entry points, PCIe
-    // inside, a 2^10 transform takes 59 us against 148 us on the CPU restatement's best thread count, a 2^8 one 34 against 37; an MSM
-    // over prebuilt tables wins at every size measured).  The Rust of the reference is faster than the restatement by a small factor,
-    // which is why the gate sits two sizes above the measured tie rather than on it.
-    const int v = e ? atoi(e) : 10;
+    // Default 12 - PROVISIONAL.  The crossover that is measured (profiles/r05_crossover_host_pointer_vs_cpu.txt: through the
+    // HOST-pointer entry points, PCIe inside, a 2^10 transform takes 59 us against 148 us, a 2^8 one 34 against 37) is against the C++
+    // RESTATEMENT of the reference's algorithm on this host, not against the reference's Rust on Rayon, which cannot be built here and is
+    // faster by an unknown small factor; and the gate also covers MSM pairs, where a first call pays the precomputation.  Until the Rust
+    // path itself has been timed beside it the gate stays at round 4's conservative 2^12; PLK_MIN_GPU_LOG_N=10 is the measured tie + 2.
+    const int v = e ? atoi(e) : 12;
     return v < 0 ? 0u : (unsigned)v;
 }
 int plk_field_limbs(int field) { return field_limbs(field); }

@@ -173,7 +173,7 @@ template <class FP, bool SINGLE_LANE = false> PLK_DI bool xyzz_to_affine(const X
         return true;
     }
     Fe<FP> i3;
-    if constexpr (SINGLE_LANE) i3 = fe_inv_safegcd_one_lane<FP>(p.zzz);  // ONE active lane in the wave: runs of division steps on the scalar unit (fp.cuh)
+    if constexpr (SINGLE_LANE) i3 = fe_inv_safegcd_one_lane<FP>(p.zzz);  // ONE active lane in the wave: the data-dependent (variable-time) division steps, fp.cuh MODE 1; the scalar-unit forms (MODE 2 / 3) are build options that measured slower
     else i3 = fe_inv_safegcd<FP>(p.zzz);
     Fe<FP> iz = fe_mul<FP>(p.zz, i3);
     Fe<FP> izz = fe_sqr<FP>(iz);

@@ -28,7 +28,7 @@ template <class P> __global__ void k_field_op(int op, const uint4* a, const uint
         case 7: r = fe_from_canonical<P>(x); break;
         case 8: r = fe_inv_eea<P>(x); break;       // the reference's Euclid (bigint_inverse.rs:6-55)
         case 10: r = fe_inv_safegcd_var<P>(x); break;  // the data-dependent form (runs of division steps)
-        case 11: r = fe_inv_safegcd_one_lane<P>(x); break;  // the same with its low-word loop on the scalar unit (the end of an MSM)
+        case 11: r = fe_inv_safegcd_one_lane<P>(x); break;  // what the end of an MSM calls: MODE 1 (variable-time, vector unit) in the shipped build - the same routine as op 10, kept as the entry point of the one-lane form; its scalar-unit variants (-DPLK_ONE_LANE_INV_MODE=2 / 3) are tuning builds only
         case 12: {
             // fz_mul_add2 with every limb below the top one at the largest value its callers pass (fz.cuh; the limb patterns of
             // tests/fp_host_harness.cpp op 24, rebuilt from the same input words by tests/test_gpu_parity.py)

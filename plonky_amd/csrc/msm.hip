@@ -51,7 +51,8 @@ int comb_execute(const CombPlan* p, unsigned batch, const void* const* d_scalars
 template <class C> int msm_accumulate_blocks_per_cu();
 template <class C>
 void msm_launch_accumulate(unsigned blocks, hipStream_t stream, const void* tab, const void* sorted, const void* off, void* p_start, void* p_head,
-                           void* head_live, uint32_t buckets, const uint32_t* dyn_chunk, int wshift, uint32_t n_sub, uint32_t tab_entries);
+                           void* head_live, void* head_bucket, void* live_list, uint32_t* live_count, uint32_t buckets, const uint32_t* dyn_chunk, int wshift,
+                           uint32_t n_sub, uint32_t tab_entries);
 // msm_order.hip: digits + the two-level bucket ordering; msm_tail.hip: the reduction
 template <class C> int msm_launch_glv_split(const void* d_scalars, size_t n, void* halves, hipStream_t stream);
 template <class C> int msm_launch_order_stage(int stage, const OrdCfg& o, const OrdBuffers& b, hipStream_t stream);
@@ -567,6 +568,11 @@ template <class C> static size_t accumulate_slots() {
     return s;
 }
 
+// head_live[] (bytes) and head_bucket[] (words) share one workspace part: the words start at this offset
+static size_t head_lanes_padded(size_t max_lanes) { return (max_lanes + ACC_THREADS + 15) & ~(size_t)15; }
+static uint32_t* head_bucket_of(const plk_msm_ctx* ctx, const MsmWork& w);
+static uint32_t* live_list_of(const plk_msm_ctx* ctx, const MsmWork& w);
+
 // One slab per workspace: a single hipMalloc / hipFree instead of a dozen (they dominate a one-shot msm_parallel).
 constexpr int MSM_WORK_PARTS = 15;
 struct WorkPart { void** p; size_t bytes; };
@@ -587,7 +593,8 @@ template <class C> static void msm_work_parts(const plk_msm_ctx* ctx, MsmWork& w
         {&w.off, ((size_t)ctx->buckets + 2) * 4},
         {&w.p_start, (size_t)ctx->buckets * raw_bytes},
         {&w.p_head, (ctx->max_lanes + 1) * raw_bytes},
-        {&w.head_live, ctx->max_lanes + ACC_THREADS},
+        // one flag byte per lane, then the lanes' head buckets (4 bytes each), then the list of live lanes (a counter word + 4 bytes each)
+        {&w.head_live, 9 * head_lanes_padded(ctx->max_lanes)},
         {&w.bucket, tail_slots * packed_bytes},
         {&w.heavy, (size_t)(2 + 3 * ctx->heavy_cap) * 4},
         {&w.heavy_part, (size_t)ctx->heavy_cap * raw_bytes},
@@ -711,11 +718,19 @@ static int msm_precompute_t(plk_msm_ctx* ctx, const void* d_bases, const void* d
         if (rc == PLK_OK) rc = comb_build(ctx->curve, n, base0, raw, stream, &ctx->comb);
         if (raw) scratch_release(raw, stream);
         if (base0) scratch_release(base0, stream);
-        PLK_TRY(rc);
-        ctx->c = COMB_WINDOW;
-        ctx->windows = COMB_WINDOWS;
-        PLK_HIP_TRY(hipStreamSynchronize(stream));
-        return PLK_OK;
+        // The comb's table is ~20 x the window tables it replaces (32 KiB per generator, 48 for BLS12-377: 128-192 MiB at 2^12).  A host
+        // that holds many small contexts can run out of HBM on it: when the comb was the library's own choice and its
+        // table cannot be had, the context falls back to the bucket method below instead of failing.
+        if (rc == PLK_ERR_OOM && comb_mode < 0) {
+            (void)hipGetLastError();
+            ctx->comb = nullptr;
+        } else {
+            PLK_TRY(rc);
+            ctx->c = COMB_WINDOW;
+            ctx->windows = COMB_WINDOWS;
+            PLK_HIP_TRY(hipStreamSynchronize(stream));
+            return PLK_OK;
+        }
     }
     ctx->ws.resize(1);
     size_t tab_min = 0;
@@ -848,6 +863,17 @@ static int msm_configure(plk_msm_ctx* ctx, int curve, size_t n, unsigned window_
         o.entries_cap = (uint32_t)(n_eff * (size_t)windows);
         o.ent_stride = (uint32_t)n_eff;
         o.ent_first = 0;
+        // round 6: the tile-major level 1 with the bins taken from the LOW bits of the bucket number (OrdCfg::perm) - tabled contexts whose
+        // buckets split into at least as many fine as coarse bits (c = 19 .. 21: the 2^19 generators and up that get such windows), tiles
+        // of 1024 scalars, records of at most 16 windows.  PLK_MSM_ORDER_V1 keeps round 5's kernels (A/B, tests/test_gpu_knobs.py).
+        static const bool order_v1 = getenv("PLK_MSM_ORDER_V1") != nullptr;
+        // ... and a bin's expected share of the entries fits the LDS of k_ord_bin_sort with 15 % to spare (2^20 scalars of 13 windows over 512
+        // bins: 26.6 k of 32 k; larger problems keep round 5's kernels, hot bins of a skewed vector take the segmented ones).
+        const bool bins_fit = (double)n_eff * windows / (double)o.nbins * 1.15 <= (double)ORD2_BIN_CAP;
+        o.perm = (!order_v1 && !table_free && coarse == 9 && o.fine_bits >= coarse && o.nbins == (1 << coarse) && o.sub == 4 && o.spt * o.sub == 1024u &&
+                  windows <= 16 && o.nt1 <= 2048u && bins_fit)
+                     ? 1
+                     : 0;
     }
     // tail geometry
     ctx->two_level = c - 1 >= 12;
@@ -855,6 +881,12 @@ static int msm_configure(plk_msm_ctx* ctx, int curve, size_t n, unsigned window_
     if (ctx->two_level) {
         ctx->L = (c - 1) / 2;
         ctx->H = c - 1 - ctx->L;
+        if (ctx->ord.perm) {
+            // the bucket slots are numbered [coarse bin = LOW bits of the bucket | fine = its high bits]: the weighting splits where the
+            // ordering does (TailGeom::transposed)
+            ctx->L = c - 1 - ctx->ord.fine_bits;
+            ctx->H = ctx->ord.fine_bits;
+        }
         ctx->g_log = c - 1 >= 17 ? 3 : 2;
         if (const char* e = getenv("PLK_MSM_GLOG")) ctx->g_log = atoi(e);
         if (ctx->g_log > ctx->L) ctx->g_log = ctx->L;
@@ -925,13 +957,21 @@ int msm_rebind_dev_impl(plk_msm_ctx* ctx, size_t n, const void* d_bases, const v
     }
 }
 
+static uint32_t* head_bucket_of(const plk_msm_ctx* ctx, const MsmWork& w) {
+    return (uint32_t*)((uint8_t*)w.head_live + head_lanes_padded(ctx->max_lanes));
+}
+static uint32_t* live_list_of(const plk_msm_ctx* ctx, const MsmWork& w) {
+    return (uint32_t*)((uint8_t*)w.head_live + 5 * head_lanes_padded(ctx->max_lanes));
+}
 static TailSlot tail_slot(const plk_msm_ctx* ctx, const MsmWork& w, void* d_out_xy, void* d_out_zero) {
-    (void)ctx;
     TailSlot t;
     t.off = (const uint32_t*)w.off;
     t.p_start = (uint4*)w.p_start;
     t.p_head = (const uint4*)w.p_head;
     t.head_live = (const uint8_t*)w.head_live;
+    t.head_bucket = head_bucket_of(ctx, w);
+    t.live_list = live_list_of(ctx, w);
+    t.live_count = (uint32_t*)w.meta + (1024 + 1025 + 1025 + 3);
     t.bucket = (uint4*)w.bucket;
     t.heavy = (uint32_t*)w.heavy;
     t.heavy_part = (uint4*)w.heavy_part;
@@ -949,10 +989,10 @@ static TailSlot tail_slot(const plk_msm_ctx* ctx, const MsmWork& w, void* d_out_
 template <class C, class Mark>
 static int msm_reduce_t(plk_msm_ctx* ctx, const TailBatch& tb, hipStream_t stream, Mark&& mark) {
     TailGeom g;
-    g.buckets = ctx->buckets; g.heavy_cap = ctx->heavy_cap; g.tail_wbuckets = ctx->tail_wbuckets;
+    g.buckets = ctx->buckets; g.heavy_cap = ctx->heavy_cap; g.tail_wbuckets = ctx->tail_wbuckets; g.max_lanes = (uint32_t)ctx->max_lanes;
     g.lpb_log = ctx->lpb_log; g.two_level = ctx->two_level ? 1 : 0; g.L = ctx->L; g.H = ctx->H; g.g_log = ctx->g_log; g.lpl_log = ctx->lpl_log;
     g.table_free = ctx->table_free ? 1 : 0; g.windows = ctx->windows; g.tail_windows = ctx->tail_windows; g.plane_blocks = ctx->plane_blocks;
-    g.planes = ctx->planes; g.tail_shift = ctx->tail_shift;
+    g.planes = ctx->planes; g.tail_shift = ctx->tail_shift; g.transposed = ctx->ord.perm;
     for (int stage = 0; stage < 3; ++stage) {
         PLK_TRY(msm_launch_reduce_stage<C>(stage, g, tb, stream));
         mark();
@@ -1046,7 +1086,7 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
     if (phases & PH_ACC) {
         // the entry count is only known on the device: launch for the upper bound, lanes past it exit
         const unsigned ablocks = (unsigned)((ctx->max_lanes + ACC_THREADS - 1) / ACC_THREADS);
-        msm_launch_accumulate<C>(ablocks, stream, ctx->tab, w.sorted, off, w.p_start, w.p_head, w.head_live, buckets, done_counter + 2,
+        msm_launch_accumulate<C>(ablocks, stream, ctx->tab, w.sorted, off, w.p_start, w.p_head, w.head_live, head_bucket_of(ctx, w), live_list_of(ctx, w), done_counter + 3, buckets, done_counter + 2,
                                  ctx->table_free ? ctx->c - 1 : 31, ctx->table_free ? (uint32_t)n : 0u,
                                  // tabled: sorted[] entries index the table; table-free: the table holds the n_eff points, sorted[] the entries
                                  ctx->table_free ? (uint32_t)ctx->n_eff : o.entries_cap);
@@ -1253,7 +1293,9 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
 int msm_set_profiling_impl(plk_msm_ctx* ctx, int enable) {
     if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->profiling = enable != 0 && !ctx->comb;  // a comb has no stages to time: two launches
+    ctx->profiling = enable != 0 && !ctx->comb;
+    // a comb (few generators, automatic window: comb.hip) has no stages to time - two launches - and says so instead of staying silently off
+    if (enable && ctx->comb) return set_error(PLK_ERR_INVALID_ARG, "per-stage timings: this context over %zu generators is a comb (no bucket stages)", ctx->n);
     return PLK_OK;
 }
 // sum_ms[7]: digits, partition (counts), bucket scan + final scatter, accumulate, bucket sums, planes, final -- summed over `calls` executions since the last read

@@ -139,8 +139,9 @@ template <class FP> PLK_DI void acc_gather(const uint4* src, Fe<FP>& x, Fe<FP>& 
 }
 template <class C>
 PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ off,
-                                uint4* __restrict__ p_start, uint4* __restrict__ p_head, uint8_t* __restrict__ head_live, uint32_t buckets,
-                                const uint32_t* __restrict__ dyn_chunk, int wshift, uint32_t n_sub, uint4* s_head, uint8_t* s_parked, uint32_t tab_entries) {
+                                uint4* __restrict__ p_start, uint4* __restrict__ p_head, uint8_t* __restrict__ head_live, uint32_t* __restrict__ head_bucket,
+                                uint32_t* __restrict__ live_list, uint32_t* __restrict__ live_count, uint32_t buckets, const uint32_t* __restrict__ dyn_chunk, int wshift,
+                                uint32_t n_sub, uint4* s_head, uint8_t* s_parked, uint32_t tab_entries) {
     using FP = typename C::FP;
     constexpr int W = FP::NL / 4;
     constexpr int RU = raw_u4<FP>();
@@ -161,6 +162,9 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
         uint32_t next = off[b + 1];
         uint32_t next2 = off[min(b + 2, buckets)];  // looked at when bucket b closes
         head = off[b] < begin;  // the bucket was already running: this lane's first piece is a head piece
+        // the bucket that piece belongs to, for the lane-driven assembly of the reduction (k_msm_heads, msm_tail.hip): written here,
+        // before the loop, so that nothing of it stays live across the additions
+        head_bucket[lane] = head ? b : HEAD_NONE;
         // entry ids are window * n + generator; with tables that is the table index, without (table-free mode:
         // n_sub = n, buckets of window w are [w << wshift, (w + 1) << wshift)) the window part is taken off
         const uint32_t ent_sub = (b >> wshift) * n_sub;
@@ -260,7 +264,11 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
             xyzzz_store_raw<FP>(p_head + (size_t)lane * RU, h);
         }
     }
-    head_live[lane] = (head || (parked && tid == 0)) ? 1 : 0;
+    const bool live = head || (parked && tid == 0);
+    head_live[lane] = live ? 1 : 0;
+    // the lanes whose head piece is still a piece of its own, as a list (order: whoever gets there first; *live_count counts them and is
+    // zero between executions): the reduction visits these ~1.5 k lanes of 2^17.6 instead of every bucket (k_msm_heads, msm_tail.hip)
+    if (live) live_list[atomicAdd(live_count, 1u)] = lane;
 }
 #ifndef PLK_ACC_WAVES
 #define PLK_ACC_WAVES 1  // waves per SIMD the register allocation of the accumulation is held to (tuning builds: tools/acc_ab.sh)
@@ -273,11 +281,12 @@ PLK_DI void msm_accumulate_body(const uint4* __restrict__ tab, const uint32_t* _
 template <class C>
 __global__ void PLK_ACC_BOUNDS k_msm_accumulate(const uint4* __restrict__ tab, const uint32_t* __restrict__ sorted,
                                                                 const uint32_t* __restrict__ off, uint4* __restrict__ p_start, uint4* __restrict__ p_head,
-                                                                uint8_t* __restrict__ head_live, uint32_t buckets, const uint32_t* __restrict__ dyn_chunk,
-                                                                int wshift, uint32_t n_sub, uint32_t tab_entries) {
+                                                                uint8_t* __restrict__ head_live, uint32_t* __restrict__ head_bucket,
+                                                                uint32_t* __restrict__ live_list, uint32_t* __restrict__ live_count, uint32_t buckets,
+                                                                const uint32_t* __restrict__ dyn_chunk, int wshift, uint32_t n_sub, uint32_t tab_entries) {
     __shared__ uint4 s_head[ACC_THREADS * raw_u4<typename C::FP>()];
     __shared__ uint8_t s_parked[ACC_THREADS];
-    msm_accumulate_body<C>(tab, sorted, off, p_start, p_head, head_live, buckets, dyn_chunk, wshift, n_sub, s_head, s_parked, tab_entries);
+    msm_accumulate_body<C>(tab, sorted, off, p_start, p_head, head_live, head_bucket, live_list, live_count, buckets, dyn_chunk, wshift, n_sub, s_head, s_parked, tab_entries);
 }
 
 // ---- host side: what msm.hip sees of this file ----------------------------------------------------------------------------
@@ -289,13 +298,14 @@ template <class C> int msm_accumulate_blocks_per_cu() {
 }
 template <class C>
 void msm_launch_accumulate(unsigned blocks, hipStream_t stream, const void* tab, const void* sorted, const void* off, void* p_start, void* p_head,
-                           void* head_live, uint32_t buckets, const uint32_t* dyn_chunk, int wshift, uint32_t n_sub, uint32_t tab_entries) {
+                           void* head_live, void* head_bucket, void* live_list, uint32_t* live_count, uint32_t buckets, const uint32_t* dyn_chunk, int wshift,
+                           uint32_t n_sub, uint32_t tab_entries) {
     k_msm_accumulate<C><<<blocks, ACC_THREADS, 0, stream>>>((const uint4*)tab, (const uint32_t*)sorted, (const uint32_t*)off, (uint4*)p_start, (uint4*)p_head,
-                                                            (uint8_t*)head_live, buckets, dyn_chunk, wshift, n_sub, tab_entries);
+                                                            (uint8_t*)head_live, (uint32_t*)head_bucket, (uint32_t*)live_list, live_count, buckets, dyn_chunk, wshift, n_sub, tab_entries);
 }
 #define PLK_ACC_INSTANTIATE(C)                                                                                                          \
     template int msm_accumulate_blocks_per_cu<C>();                                                                                    \
-    template void msm_launch_accumulate<C>(unsigned, hipStream_t, const void*, const void*, const void*, void*, void*, void*, uint32_t, \
+    template void msm_launch_accumulate<C>(unsigned, hipStream_t, const void*, const void*, const void*, void*, void*, void*, void*, void*, uint32_t*, uint32_t, \
                                            const uint32_t*, int, uint32_t, uint32_t);
 PLK_ACC_INSTANTIATE(TweedledeeCurve)
 PLK_ACC_INSTANTIATE(TweedledumCurve)

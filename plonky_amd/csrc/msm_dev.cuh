@@ -80,6 +80,7 @@ constexpr int ORD_SEG_EPT = (int)(ORD_SEG / ORD_BIN_THREADS);  // ... and per th
 // k_ord_bin_scatter stages a whole segment in LDS (3 fine-bit tables + the staged entries): ~74 KB, above the 64 KB a workgroup
 // gets on gfx90a / gfx942 - this library is built for gfx950 (160 KB of LDS per CU) only, plk_init refuses other devices
 static_assert(3 * (4u << ORD_MAX_FINE) + 4 * ORD_BIN_THREADS + 6 * ORD_SEG <= 160 * 1024, "k_ord_bin_scatter's LDS tile must fit a gfx950 CU");
+constexpr uint32_t ORD2_BIN_CAP = 32768;  // round 6 (k_ord_bin_sort): entries of a coarse bin that are ordered inside LDS by one workgroup (128 KiB)
 constexpr int PLANE_THREADS = 512;
 constexpr int FINAL_FUSE_WINDOWS = 4;  // up to this many tail windows are added by the last block of k_msm_final itself
 constexpr int FINAL_THREADS = 512;  // <= 8 waves, so the compiler may use 256 VGPRs: the point arithmetic must not spill
@@ -98,6 +99,11 @@ struct OrdCfg {
     uint32_t entries_cap;    // n_eff * windows: size of tmp[] / sorted[] and of the table (checked build)
     uint32_t ent_stride;     // entry id of (window j, scalar i) = j * ent_stride + ent_first + i: the table index.  ent_stride = n_eff of the
     uint32_t ent_first;      // context; ent_first > 0 when the scalars belong to generators first .. first + n - 1 only (plk_msm_execute_parts_dev)
+    // round 6: 1 = the tile-major level 1 (k_ord_tiles, msm_order.hip) with the coarse bin taken from the LOW bits of the bucket id: the
+    // buckets are ordered (and numbered, for everything downstream) by v = [low coarse bits | high fine bits] of the digit's bucket
+    // b = |d| - 1, so that a short top window - whose digits are all small - spreads over every bin instead of filling the first few.
+    // The reduction reads the weight of v off its two halves (TailGeom::transposed).
+    int perm;
 };
 
 constexpr int TAIL_MAX = 16;
@@ -106,6 +112,9 @@ struct TailSlot {
     uint4* p_start;       // raw, one per bucket (becomes the assembled bucket)
     const uint4* p_head;  // raw, one per accumulation lane
     const uint8_t* head_live;  // 1: p_head[lane] holds a piece that is not part of a start piece yet
+    const uint32_t* head_bucket;  // the bucket lane's head piece belongs to (HEAD_NONE: the lane starts at a bucket boundary)
+    const uint32_t* live_list;    // the lanes whose head piece is live, in no particular order (k_msm_accumulate appends)
+    uint32_t* live_count;         // how many; zero between executions (reset by the reduction)
     uint4* bucket;        // packed points: the operands of the plane sums
     uint32_t* heavy;
     uint4* heavy_part;    // raw
@@ -122,13 +131,18 @@ struct TailBatch {
     TailSlot s[TAIL_MAX];
 };
 
+constexpr uint32_t HEAD_NONE = 0xFFFFFFFFu;
 constexpr uint32_t HEAVY_HEADS = 32;   // more head pieces than this PER LANE of k_msm_assemble (2^lpb_log lanes per bucket): the bucket is summed by workgroups
 constexpr uint32_t HEAVY_CHUNK = 2048;
 
 // what the reduction's launches need of a context (msm_tail.hip: msm_launch_reduce_stage)
 struct TailGeom {
     uint32_t buckets, heavy_cap, tail_wbuckets;
+    uint32_t max_lanes;  // upper bound of the accumulation lanes of an execution (k_msm_heads is launched for it)
     int lpb_log, two_level, L, H, g_log, lpl_log, table_free, windows, tail_windows, plane_blocks, planes, tail_shift;
+    // 1: bucket slot v = lo * 2^H + hi holds the bucket of weight hi * 2^L + lo + 1 (OrdCfg::perm): the grid in memory is 2^L rows of
+    // 2^H slots, its ROW sums are the column sums C_lo of the weighting and its column sums the row sums R_hi
+    int transposed;
 };
 // the buffers of one ordering (msm_order.hip: msm_launch_order_stage)
 struct OrdBuffers {

@@ -2,6 +2,7 @@
 // replaces the reference's serial digit_occurrences scatter (curve_msm.rs:117-126).  Split from msm.hip in round 5 (build time).
 #include "msm_dev.cuh"
 #include "glv.cuh"
+#include <cstdlib>
 
 namespace plk {
 
@@ -433,6 +434,424 @@ __global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_scatter(const uint2
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// round 6: TILE-MAJOR level 1 (large MSMs: two-level bucket ids, >= 2^16 scalars, <= 16 windows)
+// ---------------------------------------------------------------------------------------------
+// Level 1 above is count -> scan -> scatter: the scalars are read and recoded twice, the [bin][tile] counts need a grid-wide scan before
+// anything can be written, and what is written are runs of ~6 eight-byte records (one sub-tile's entries of one bin).  Here a tile of
+// 1024 scalars is ordered by coarse bin ENTIRELY inside LDS by one workgroup and written once, contiguously, into the tile's own region
+// of tmp[] - no global position to wait for - as FOUR-byte records: inside a tile the entry is (window, scalar of the tile), 14 bits,
+// beside the fine bucket bits and the sign (the tile is known to whoever reads the region).  What the rest needs of a tile is one word
+// per bin - where the bin's run starts in the region and how long it is - and the bins' totals (atomics: 512 per tile); one small
+// workgroup turns the totals into bin offsets, the level-2 segment table and this execution's chunk length (k_ord_scan1's last block),
+// and level 2 GATHERS a segment from the tiles' runs (a prefix over the tiles' counts of its bin, one search per thread, sixteen
+// consecutive positions each).  Three launches + a one-workgroup one instead of five; the scalars are read once; tmp[] holds 4 bytes per
+// entry, written in whole lines, read in runs of ~26 records.
+constexpr int ORD2_TS = 1024;        // scalars per tile
+constexpr int ORD2_THREADS = 512;    // ... two per thread
+constexpr int ORD2_SPT = ORD2_TS / ORD2_THREADS;
+constexpr int ORD2_MAX_WINDOWS = 16; // 4 bits of a record
+constexpr uint32_t ORD2_MAX_TILES = 8192;  // level 2 keeps a prefix over the tiles in LDS
+// record: bit 0 sign, bits 1..11 fine bucket bits, 12..15 window, 16..25 scalar of the tile
+PLK_DI uint32_t ord2_record(uint32_t sign, uint32_t fine, int j, uint32_t loc) { return sign | (fine << 1) | ((uint32_t)j << 12) | (loc << 16); }
+// digit j of the scalar parked in column `slot` of a limb-major LDS array with `stride` columns (ord_digit with the stride as a parameter)
+PLK_DI uint32_t ord_digit_at(const uint32_t* s_lim, int stride, int slot, int j, const OrdCfg& cfg, uint32_t& carry) {
+    const int c = cfg.c;
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    const int bp = j * c, li = bp >> 5, sh = bp & 31;
+    uint64_t two = li < 8 ? s_lim[li * stride + slot] : 0u;
+    if (li + 1 < 8) two |= (uint64_t)s_lim[(li + 1) * stride + slot] << 32;
+    const uint32_t v = ((uint32_t)(two >> sh) & mask) + carry;
+    const uint32_t neg = v > half ? 1u : 0u;
+    const uint32_t mag = neg ? (1u << c) - v : v;
+    carry = neg;
+    if (mag == 0) return CODE_INVALID;
+    const uint32_t flip = cfg.raw_signed ? s_lim[7 * stride + slot] >> 31 : 0u;
+    return ((mag - 1u + (uint32_t)j * cfg.window_buckets) << 1) | (neg ^ flip);
+}
+// The same digits from REGISTERS: the canonical scalar is shifted down by c bits per window, so the digit is always the low bits of
+// word 0 and nothing is indexed - no LDS copy of the limbs (32 KiB for a 1024-scalar tile: the difference between one and two
+// workgroups per CU).  Same recoding as ord_digit (carry-based, zero digits skipped, the sign of a GLV half scalar in bit 255).
+struct OrdWalk {
+    uint32_t w[8];
+    uint32_t carry, flip;
+};
+template <class SP> PLK_DI void ord_walk_start(OrdWalk& s, const Fe<SP>& canon, const OrdCfg& cfg) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s.w[k] = canon.v[k];
+    s.carry = 0;
+    s.flip = cfg.raw_signed ? canon.v[7] >> 31 : 0u;
+}
+PLK_DI uint32_t ord_walk_next(OrdWalk& s, int j, const OrdCfg& cfg) {
+    const int c = cfg.c;  // 2 .. 21
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    const uint32_t v = (s.w[0] & mask) + s.carry;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s.w[k] = (s.w[k] >> c) | (s.w[k + 1] << (32 - c));
+    s.w[7] >>= c;
+    const uint32_t neg = v > half ? 1u : 0u;
+    const uint32_t mag = neg ? (1u << c) - v : v;
+    s.carry = neg;
+    if (mag == 0) return CODE_INVALID;
+    return ((mag - 1u + (uint32_t)j * cfg.window_buckets) << 1) | (neg ^ s.flip);
+}
+// cnt1[bin * nt + tile] = (start of the bin's run in the tile's region) << 16 | (its length)   (both <= 16384)
+template <class C>
+__global__ void __launch_bounds__(ORD2_THREADS) k_ord_tiles(const uint4* __restrict__ scalars, size_t n, OrdCfg cfg, uint32_t* __restrict__ cnt1,
+                                                            uint32_t* __restrict__ bin_total, uint32_t* __restrict__ tmp) {
+    using SP = typename C::SP;
+    static_assert(SP::NL == 8, "scalar fields are 256-bit");
+    __shared__ uint32_t s_cnt[ORD_MAX_BINS], s_base[ORD_MAX_BINS];
+    __shared__ uint32_t s_tmp[ORD2_THREADS];
+    __shared__ uint32_t s_total;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_ent[];  // ORD2_TS * windows records
+    const int tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t cap = (uint32_t)ORD2_TS * (uint32_t)cfg.windows;
+    static_assert(ORD2_SPT == 2, "two scalars per thread, held in named registers (an indexed array of them is promoted to LDS by the compiler: 32 KiB)");
+    const size_t i0 = (size_t)tile * ORD2_TS + tid, i1 = i0 + ORD2_THREADS;
+    const bool live0 = i0 < n, live1 = i1 < n;
+    const OrdRaw raw0 = ord_load_scalar(scalars, i0, live0), raw1 = ord_load_scalar(scalars, i1, live1);
+    for (int k = tid; k < cfg.nbins; k += ORD2_THREADS) s_cnt[k] = 0;
+    // Montgomery -> canonical in the SCALAR field (to_canonical_u64_vec, curve_msm.rs:164); half scalars are canonical already
+    auto canonical = [&](const OrdRaw& r) {
+        Fe<SP> sc;
+        sc.v[0] = r.lo.x; sc.v[1] = r.lo.y; sc.v[2] = r.lo.z; sc.v[3] = r.lo.w;
+        sc.v[4] = r.hi.x; sc.v[5] = r.hi.y; sc.v[6] = r.hi.z; sc.v[7] = r.hi.w;
+        if (!cfg.raw_signed) sc = fe_to_canonical<SP>(sc);
+        return sc;
+    };
+    const Fe<SP> canon0 = canonical(raw0), canon1 = canonical(raw1);
+    __syncthreads();
+    // bucket slot v = [bin | fine]: the bin is the LOW coarse bits of the digit's bucket |d| - 1 and the fine part its high bits (OrdCfg::perm),
+    // so that the small digits of a short top window land in every bin
+    const int cbits = cfg.c - 1 - cfg.fine_bits;
+    const uint32_t bmask = (1u << cbits) - 1u;
+    auto count = [&](const Fe<SP>& canon) {
+        OrdWalk wk;
+        ord_walk_start<SP>(wk, canon, cfg);
+        for (int j = 0; j < cfg.windows; ++j) {
+            const uint32_t code = ord_walk_next(wk, j, cfg);
+            if (code != CODE_INVALID) atomicAdd(&s_cnt[(code >> 1) & bmask], 1u);
+        }
+    };
+    if (live0) count(canon0);
+    if (live1) count(canon1);
+    __syncthreads();
+    for (int k = tid; k < cfg.nbins; k += ORD2_THREADS) s_base[k] = s_cnt[k];
+    __syncthreads();
+    block_excl_scan4(s_base, cfg.nbins, s_tmp);
+    if (tid == 0) s_total = s_base[cfg.nbins - 1] + s_cnt[cfg.nbins - 1];
+    for (int k = tid; k < cfg.nbins; k += ORD2_THREADS) {
+        const uint32_t cn = s_cnt[k];
+        cnt1[(size_t)k * cfg.nt1 + tile] = (s_base[k] << 16) | cn;
+        if (cn) atomicAdd(&bin_total[k], cn);
+    }
+    __syncthreads();
+    auto place = [&](const Fe<SP>& canon, uint32_t loc) {
+        OrdWalk wk;
+        ord_walk_start<SP>(wk, canon, cfg);
+        for (int j = 0; j < cfg.windows; ++j) {
+            const uint32_t code = ord_walk_next(wk, j, cfg);
+            if (code != CODE_INVALID) {
+                const uint32_t slot = atomicAdd(&s_base[(code >> 1) & bmask], 1u);  // the bin's cursor (its start was written out above)
+                if (PLK_CHK(slot < cap, CHK_TILE_STAGE)) s_ent[slot] = ord2_record(code & 1u, code >> (cbits + 1), j, loc);
+            }
+        }
+    };
+    if (live0) place(canon0, (uint32_t)tid);
+    if (live1) place(canon1, (uint32_t)(ORD2_THREADS + tid));
+    __syncthreads();
+    const uint32_t total = s_total;
+    uint32_t* __restrict__ region = tmp + (size_t)tile * cap;
+    for (uint32_t i = tid; i < total; i += ORD2_THREADS)
+        if (PLK_CHK((size_t)tile * cap + i < (size_t)cfg.nt1 * cap, CHK_TMP_INDEX)) region[i] = s_ent[i];
+}
+
+// the bins' totals -> bin offsets, level-2 segment table, this execution's chunk length (k_ord_scan1's last block); the totals are
+// left at zero for the next execution's atomics
+// (segments only for HOT bins - more than `hot` entries: every other bin is ordered by ONE workgroup of k_ord_bin_sort)
+__global__ void __launch_bounds__(256) k_ord_scan_bins(uint32_t* __restrict__ bin_total, int nbins, uint32_t* __restrict__ bin_base,
+                                                       uint32_t* __restrict__ seg_base, uint32_t* __restrict__ dyn_chunk, uint32_t chunk_cfg,
+                                                       uint32_t lanes_cfg, uint32_t hot) {
+    __shared__ uint32_t s_sum[256];
+    __shared__ uint32_t s_bins[ORD_MAX_BINS], s_tot[ORD_MAX_BINS];
+    for (int k = threadIdx.x; k < nbins; k += 256) {
+        s_tot[k] = s_bins[k] = bin_total[k];
+        bin_total[k] = 0;
+    }
+    __syncthreads();
+    const uint32_t last_total = s_bins[nbins - 1];
+    block_excl_scan4(s_bins, nbins, s_sum);
+    for (int k = threadIdx.x; k < nbins; k += 256) bin_base[k] = s_bins[k];
+    if (threadIdx.x == 0) {
+        const uint32_t total = s_bins[nbins - 1] + last_total;
+        bin_base[nbins] = total;
+        uint32_t ch = lanes_cfg ? (total + lanes_cfg - 1) / lanes_cfg : chunk_cfg;
+        if (ch < 8u) ch = 8u;
+        if (ch > chunk_cfg) ch = chunk_cfg;
+        dyn_chunk[0] = ch;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nbins; k += 256) s_bins[k] = s_tot[k] > hot ? (s_tot[k] + ORD_SEG - 1) / ORD_SEG : 0u;
+    __syncthreads();
+    const uint32_t last_segs = s_bins[nbins - 1];
+    block_excl_scan4(s_bins, nbins, s_sum);
+    for (int k = threadIdx.x; k < nbins; k += 256) seg_base[k] = s_bins[k];
+    if (threadIdx.x == 0) seg_base[nbins] = s_bins[nbins - 1] + last_segs;
+}
+
+// A level-2 workgroup's view of its segment: positions plo .. phi of the bin's entries, which lie in the tiles' runs one after the
+// other.  s_pre[t] = entries of the bin in tiles before t (exclusive prefix of the runs' lengths; s_pre[nt] = the bin's total),
+// s_run[t] = the packed word of tile t.
+struct Ord2Seg {
+    uint32_t bin, seg, plo, phi;
+};
+PLK_DI bool ord2_segment(const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ bin_base, int nbins, uint32_t blk, Ord2Seg& sg) {
+    if (blk >= seg_base[nbins]) return false;
+    uint32_t a = 0, b = (uint32_t)nbins;  // seg_base[a] <= blk < seg_base[b]
+    while (b - a > 1) {
+        const uint32_t m = (a + b) >> 1;
+        if (seg_base[m] <= blk) a = m; else b = m;
+    }
+    sg.bin = a;
+    sg.seg = blk - seg_base[a];
+    sg.plo = sg.seg * ORD_SEG;
+    sg.phi = min(bin_base[a + 1] - bin_base[a], sg.plo + ORD_SEG);
+    return true;
+}
+// s_run / s_pre: nt + 1 words each.  Ends with a barrier.
+PLK_DI void ord2_prefix(const uint32_t* __restrict__ cnt1, uint32_t nt, uint32_t bin, uint32_t* s_run, uint32_t* s_pre, uint32_t* s_tmp) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const uint32_t per = (nt + nthr - 1) / nthr;
+    const uint32_t lo = min(nt, (uint32_t)tid * per), hi = min(nt, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t t = lo; t < hi; ++t) {
+        const uint32_t w = cnt1[(size_t)bin * nt + t];
+        s_run[t] = w;
+        sum += w & 0xFFFFu;
+    }
+    uint32_t total = 0;
+    uint32_t run = block_excl_prefix(sum, s_tmp, &total);
+    for (uint32_t t = lo; t < hi; ++t) {
+        s_pre[t] = run;
+        run += s_run[t] & 0xFFFFu;
+    }
+    if (tid == 0) {
+        s_pre[nt] = total;
+        s_run[nt] = 0;
+    }
+    __syncthreads();
+}
+// the records at positions plo + tid + k * ORD_BIN_THREADS (below phi) and the tile each comes from.  Consecutive LANES take consecutive
+// positions - a wave's load is 256 contiguous bytes but for the 2-3 run boundaries in it (sixteen consecutive positions per lane, one
+// search and a walk, made every lane's load a cache line of its own: 65 + 143 us for the two level-2 kernels against 20 + 68) - and
+// every position is found by its own search in the prefix (ten LDS reads, sixteen independent chains per lane).
+template <int THREADS = ORD_BIN_THREADS, int EPT = ORD_SEG_EPT>
+PLK_DI void ord2_gather(const uint32_t* __restrict__ tmp, const uint32_t* s_run, const uint32_t* s_pre, uint32_t nt, uint32_t cap, uint32_t plo, uint32_t phi,
+                        uint32_t (&rec)[EPT], uint32_t (&til)[EPT]) {
+    // largest t with s_pre[t] <= p (tiles without entries of the bin share their prefix with the next one: the largest is the one that holds
+    // p), for the sixteen positions of the lane AT ONCE: a fixed number of halving steps, every step sixteen independent LDS reads (sixteen
+    // searches one after the other - loops of their own - were ten dependent round trips EACH: 5 us per segment and pass)
+    uint32_t t[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) t[k] = 0;
+    uint32_t top = 1;
+    while (top * 2 <= nt) top *= 2;  // the largest power of two <= nt (nt >= 1)
+    for (uint32_t step = top; step; step >>= 1) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const uint32_t p = plo + threadIdx.x + (uint32_t)k * THREADS;
+            const uint32_t cand = t[k] + step;
+            if (cand < nt && s_pre[cand] <= p) t[k] = cand;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const uint32_t p = plo + threadIdx.x + (uint32_t)k * THREADS;
+        til[k] = t[k];
+        rec[k] = 0;
+        if (p < phi) rec[k] = tmp[(size_t)t[k] * cap + (s_run[t[k]] >> 16) + (p - s_pre[t[k]])];
+    }
+}
+// level 2, step 1: cnt2[segment][fine]
+__global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_count2(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ cnt1, uint32_t nt, uint32_t cap,
+                                                                    const uint32_t* __restrict__ bin_base, const uint32_t* __restrict__ seg_base, int fine_bits,
+                                                                    int nbins, uint32_t* __restrict__ cnt2) {
+    __shared__ uint32_t s_hist[1 << ORD_MAX_FINE];
+    __shared__ uint32_t s_tmp[ORD_BIN_THREADS];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // s_run[nt + 1] | s_pre[nt + 1]
+    uint32_t* s_run = s_dyn;
+    uint32_t* s_pre = s_dyn + (nt + 1);
+    const int tid = threadIdx.x;
+    const int nf = 1 << fine_bits;
+    const uint32_t fmask = (uint32_t)nf - 1u;
+    // a fixed grid that walks the segments: there are none at all unless some bin is hot, and then the grid must not cost a launch of
+    // thousands of workgroups that only look at the count and leave
+    for (uint32_t blk = blockIdx.x;; blk += gridDim.x) {
+        Ord2Seg sg;
+        if (!ord2_segment(seg_base, bin_base, nbins, blk, sg)) return;
+        for (int k = tid; k < nf; k += ORD_BIN_THREADS) s_hist[k] = 0;
+        ord2_prefix(cnt1, nt, sg.bin, s_run, s_pre, s_tmp);
+        uint32_t rec[ORD_SEG_EPT], til[ORD_SEG_EPT];
+        ord2_gather(tmp, s_run, s_pre, nt, cap, sg.plo, sg.phi, rec, til);
+#pragma unroll
+        for (int k = 0; k < ORD_SEG_EPT; ++k)
+            if (sg.plo + tid + k * ORD_BIN_THREADS < sg.phi) atomicAdd(&s_hist[(rec[k] >> 1) & fmask], 1u);
+        __syncthreads();
+        for (int k = tid; k < nf; k += ORD_BIN_THREADS) cnt2[((size_t)blk << fine_bits) + k] = s_hist[k];
+        __syncthreads();
+    }
+}
+// level 2, step 2: k_ord_bin_scatter over gathered records
+__global__ void __launch_bounds__(ORD_BIN_THREADS) k_ord_bin_scatter2(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ cnt1, uint32_t nt, uint32_t cap,
+                                                                      const uint32_t* __restrict__ bin_base, const uint32_t* __restrict__ seg_base, int fine_bits,
+                                                                      int nbins, uint32_t buckets, const uint32_t* __restrict__ cnt2, uint32_t* __restrict__ off,
+                                                                      uint32_t* __restrict__ sorted, uint32_t entries_cap, uint32_t ent_stride, uint32_t ent_first) {
+    __shared__ uint32_t s_tmp[ORD_BIN_THREADS];
+    __shared__ uint32_t s_out[ORD_SEG];
+    __shared__ uint16_t s_fine[ORD_SEG];
+    // the three fine-bit tables are sized for THIS ordering's 2^fine_bits buckets per bin, not for ORD_MAX_FINE: with the tiles' prefix beside
+    // them a workgroup holds 70 KiB at c = 20 (74 + 8 with the static tables of k_ord_bin_scatter: ONE workgroup per CU, and a level-2
+    // workgroup is latency - 143-185 us against 68)
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // s_glob[nf] | s_loc[nf] | s_cur[nf] | s_run[nt + 1] | s_pre[nt + 1]
+    uint32_t* s_glob = s_dyn;
+    uint32_t* s_loc = s_dyn + ((size_t)1 << fine_bits);
+    uint32_t* s_cur = s_dyn + ((size_t)2 << fine_bits);
+    uint32_t* s_run = s_dyn + ((size_t)3 << fine_bits);
+    uint32_t* s_pre = s_run + (nt + 1);
+    const int tid = threadIdx.x;
+    for (uint32_t blk = blockIdx.x;; blk += gridDim.x) {  // a fixed grid that walks the segments (k_ord_bin_count2)
+    Ord2Seg sg;
+    if (!ord2_segment(seg_base, bin_base, nbins, blk, sg)) return;  // (bins without entries get their offsets from k_ord_bin_sort)
+    const int nf = 1 << fine_bits;
+    const uint32_t fmask = (uint32_t)nf - 1u;
+    const uint32_t bin = sg.bin, seg = sg.seg;
+    ord2_prefix(cnt1, nt, bin, s_run, s_pre, s_tmp);
+    uint32_t rec[ORD_SEG_EPT], til[ORD_SEG_EPT];
+    ord2_gather(tmp, s_run, s_pre, nt, cap, sg.plo, sg.phi, rec, til);  // in flight while the bucket offsets are worked out
+    const uint32_t s0 = seg_base[bin], s1 = seg_base[bin + 1];
+    for (int k = tid; k < nf; k += ORD_BIN_THREADS) {
+        uint32_t tot = 0, before = 0, own = 0;
+        for (uint32_t sgi = s0; sgi < s1; ++sgi) {
+            const uint32_t v = cnt2[((size_t)sgi << fine_bits) + k];
+            if (sgi - s0 < seg) before += v;
+            if (sgi - s0 == seg) own = v;
+            tot += v;
+        }
+        s_glob[k] = tot;
+        s_cur[k] = before;
+        s_loc[k] = own;
+    }
+    __syncthreads();
+    block_excl_scan4(s_glob, nf, s_tmp);
+    block_excl_scan4(s_loc, nf, s_tmp);
+    const uint32_t bb = bin_base[bin];
+    for (int k = tid; k < nf; k += ORD_BIN_THREADS) {
+        const uint32_t o = bb + s_glob[k];
+        if (seg == 0) off[((size_t)bin << fine_bits) + k] = o;
+        s_glob[k] = o + s_cur[k];  // where this segment's entries of bucket k start
+        s_cur[k] = s_loc[k];       // LDS cursor
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ORD_SEG_EPT; ++k) {
+        if (sg.plo + tid + k * ORD_BIN_THREADS >= sg.phi) continue;
+        const uint32_t r = rec[k];
+        const uint32_t f = (r >> 1) & fmask;
+        const uint32_t idx = atomicAdd(&s_cur[f], 1u);
+        if (PLK_CHK(idx < ORD_SEG, CHK_SEG_STAGE)) {
+            // entry id = window * ent_stride + ent_first + scalar index (the table index; k_ord_scatter)
+            const uint32_t entry = ((r >> 12) & 15u) * ent_stride + ent_first + til[k] * (uint32_t)ORD2_TS + (r >> 16);
+            s_out[idx] = (entry << 1) | (r & 1u);
+            s_fine[idx] = (uint16_t)f;
+        }
+    }
+    __syncthreads();
+    const uint32_t count = sg.phi - sg.plo;
+    for (uint32_t i = tid; i < count; i += ORD_BIN_THREADS) {
+        const uint32_t f = s_fine[i];
+        const uint32_t at = s_glob[f] + (i - s_loc[f]);
+        if (PLK_CHK(at < entries_cap, CHK_SORTED_INDEX)) sorted[at] = s_out[i];
+    }
+    __syncthreads();  // LDS is reused by the next segment
+    }
+}
+
+// level 2 for a bin that is not hot: ONE workgroup orders the WHOLE bin inside LDS (round 6).  The segmented pair above stages 8192
+// entries at a time, so an entry leaves in a run of ~8 (a bucket's share of a segment: 32 bytes), sets up the tiles' prefix twice per
+// segment and keeps the fine-bit counts of every segment in global memory between its two launches.  A bin of the usual size (26.6 k
+// entries at c = 20 - and with OrdCfg::perm EVERY bin is of the usual size for uniform scalars, the top window included) fits LDS as
+// 4-byte entries: two passes of one workgroup over the bin's records - the fine-bit histogram, whose scan gives the bucket offsets
+// and the cursors, then the placement - and the bin leaves as ONE contiguous copy, bucket after bucket.  Hot bins (more than
+// ORD2_BIN_CAP entries: a skewed witness - zeros, ones, small values) keep the segmented kernels, many workgroups per bin.
+constexpr int ORD2_SORT_THREADS = 1024;
+constexpr int ORD2_SORT_UNROLL = 8;  // runs a half-wave has in flight
+// A half-wave (32 lanes) takes whole RUNS - the bin's entries of one tile, ~26 at c = 20 - eight at a time: no search for the tile a
+// position belongs to (a position-major walk - every lane its own binary search in the prefix over the tiles - was bound by the LDS
+// reads of the searches: 137 us for this kernel), a run is one contiguous read, and eight of them are in flight per half-wave.
+template <class F>
+PLK_DI void ord2_for_runs(const uint32_t* __restrict__ tmp, const uint32_t* s_run, uint32_t nt, uint32_t cap, F&& f) {
+    const uint32_t hw = threadIdx.x >> 5, hl = threadIdx.x & 31u;
+    constexpr uint32_t HW = ORD2_SORT_THREADS / 32;
+    for (uint32_t t0 = hw; t0 < nt; t0 += HW * ORD2_SORT_UNROLL) {
+        uint32_t w[ORD2_SORT_UNROLL], r[ORD2_SORT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < ORD2_SORT_UNROLL; ++u) {
+            const uint32_t t = t0 + (uint32_t)u * HW;
+            w[u] = t < nt ? s_run[t] : 0u;
+            r[u] = 0;
+            if (hl < (w[u] & 0xFFFFu)) r[u] = tmp[(size_t)t * cap + (w[u] >> 16) + hl];
+        }
+#pragma unroll
+        for (int u = 0; u < ORD2_SORT_UNROLL; ++u) {
+            const uint32_t t = t0 + (uint32_t)u * HW, cnt = w[u] & 0xFFFFu;
+            if (hl < cnt) f(r[u], t);
+            for (uint32_t i = hl + 32u; i < cnt; i += 32u) f(tmp[(size_t)t * cap + (w[u] >> 16) + i], t);  // a run longer than a half-wave (rare)
+        }
+    }
+}
+__global__ void __launch_bounds__(ORD2_SORT_THREADS) k_ord_bin_sort(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ cnt1, uint32_t nt, uint32_t cap,
+                                                                    const uint32_t* __restrict__ bin_base, int fine_bits, int nbins, uint32_t buckets,
+                                                                    uint32_t* __restrict__ off, uint32_t* __restrict__ sorted, uint32_t entries_cap,
+                                                                    uint32_t ent_stride, uint32_t ent_first) {
+    __shared__ uint32_t s_tmp[ORD2_SORT_THREADS];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // s_out[ORD2_BIN_CAP] | s_cur[nf] | s_run[nt]
+    const int nf = 1 << fine_bits;
+    uint32_t* s_out = s_dyn;
+    uint32_t* s_cur = s_dyn + ORD2_BIN_CAP;
+    uint32_t* s_run = s_cur + nf;
+    const int tid = threadIdx.x;
+    const uint32_t bin = blockIdx.x;
+    const uint32_t bb = bin_base[bin], total = bin_base[bin + 1] - bb;
+    if (bin == 0 && tid == 0) off[buckets] = bin_base[nbins];
+    if (total == 0) {  // a bin without entries still owns bucket offsets
+        for (int k = tid; k < nf; k += ORD2_SORT_THREADS) off[((size_t)bin << fine_bits) + k] = bb;
+        return;
+    }
+    if (total > ORD2_BIN_CAP) return;  // k_ord_bin_count2 / k_ord_bin_scatter2
+    const uint32_t fmask = (uint32_t)nf - 1u;
+    for (int k = tid; k < nf; k += ORD2_SORT_THREADS) s_cur[k] = 0;
+    for (uint32_t t = tid; t < nt; t += ORD2_SORT_THREADS) s_run[t] = cnt1[(size_t)bin * nt + t];
+    __syncthreads();
+    // pass 1: the bin's entries per bucket
+    ord2_for_runs(tmp, s_run, nt, cap, [&](uint32_t r, uint32_t) { atomicAdd(&s_cur[(r >> 1) & fmask], 1u); });
+    __syncthreads();
+    block_excl_scan4(s_cur, nf, s_tmp);
+    for (int k = tid; k < nf; k += ORD2_SORT_THREADS) off[((size_t)bin << fine_bits) + k] = bb + s_cur[k];
+    __syncthreads();
+    // pass 2: every entry to its bucket's cursor
+    ord2_for_runs(tmp, s_run, nt, cap, [&](uint32_t r, uint32_t t) {
+        const uint32_t idx = atomicAdd(&s_cur[(r >> 1) & fmask], 1u);
+        // entry id = window * ent_stride + ent_first + scalar index (the table index; k_ord_scatter)
+        const uint32_t entry = ((r >> 12) & 15u) * ent_stride + ent_first + t * (uint32_t)ORD2_TS + (r >> 16);
+        if (PLK_CHK(idx < ORD2_BIN_CAP, CHK_SEG_STAGE)) s_out[idx] = (entry << 1) | (r & 1u);
+    });
+    __syncthreads();
+    for (uint32_t i = tid; i < total; i += ORD2_SORT_THREADS)
+        if (PLK_CHK(bb + i < entries_cap, CHK_SORTED_INDEX)) sorted[bb + i] = s_out[i];
+}
+
 // ---- host side: what msm.hip sees of this file ----------------------------------------------------------------------------
 template <class C> int msm_launch_glv_split(const void* d_scalars, size_t n, void* halves, hipStream_t stream) {
     k_glv_split<C><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const uint4*)d_scalars, n, (uint4*)halves);
@@ -440,8 +859,38 @@ template <class C> int msm_launch_glv_split(const void* d_scalars, size_t n, voi
     return PLK_OK;
 }
 // stage 0: level-1 counts + scan (and this execution's chunk length); 1: level-1 scatter; 2: level 2 (skipped by one-level orderings)
+// the tile-major level 1 (round 6): where msm_configure set OrdCfg::perm
+static bool order_tiles2(const OrdCfg& o) { return o.perm != 0; }
 template <class C> int msm_launch_order_stage(int stage, const OrdCfg& o, const OrdBuffers& b, hipStream_t stream) {
     const bool one_level = o.fine_bits == 0;
+    if (order_tiles2(o)) {
+        const uint32_t cap = (uint32_t)ORD2_TS * (uint32_t)o.windows;
+        if (stage == 0) {
+            const size_t lds = (size_t)cap * 4;
+            // more than 64 KiB of LDS in all (42 KiB static + the tile's records): asked for per kernel, as the transform's launches do
+            (void)hipFuncSetAttribute((const void*)k_ord_tiles<C>, hipFuncAttributeMaxDynamicSharedMemorySize, ORD2_TS * ORD2_MAX_WINDOWS * 4);
+            k_ord_tiles<C><<<o.nt1, ORD2_THREADS, lds, stream>>>((const uint4*)b.scalars, b.n, o, (uint32_t*)b.cnt1, b.bin_total, (uint32_t*)b.tmp);
+            k_ord_scan_bins<<<1, 256, 0, stream>>>(b.bin_total, o.nbins, b.bin_base, b.seg_base, b.done_counter + 2, b.chunk, b.lanes, ORD2_BIN_CAP);
+        } else if (stage == 2) {
+            // hot bins hold more than ORD2_BIN_CAP entries each: at most entries / ORD2_BIN_CAP of them, entries / ORD_SEG + that many segments
+            const size_t entries = b.n * (size_t)o.windows;
+            const size_t hot_bins = entries / ORD2_BIN_CAP < (size_t)o.nbins ? entries / ORD2_BIN_CAP : (size_t)o.nbins;
+            const unsigned segs = (unsigned)(entries / ORD_SEG + hot_bins + 1);  // <= the entries / ORD_SEG + nbins + 1 rows cnt2[] holds
+            const size_t lds = (size_t)2 * (o.nt1 + 1) * 4, lds_s = lds + ((size_t)3 << o.fine_bits) * 4;
+            const size_t lds_b = ((size_t)ORD2_BIN_CAP + ((size_t)1 << o.fine_bits) + o.nt1) * 4;
+            (void)hipFuncSetAttribute((const void*)k_ord_bin_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+            k_ord_bin_sort<<<o.nbins, ORD2_SORT_THREADS, lds_b, stream>>>((const uint32_t*)b.tmp, (const uint32_t*)b.cnt1, o.nt1, cap, b.bin_base, o.fine_bits, o.nbins,
+                                                                         b.buckets, (uint32_t*)b.off, (uint32_t*)b.sorted, o.entries_cap, o.ent_stride, o.ent_first);
+            const unsigned hot_grid = segs < 512u ? segs : 512u;
+            k_ord_bin_count2<<<hot_grid, ORD_BIN_THREADS, lds, stream>>>((const uint32_t*)b.tmp, (const uint32_t*)b.cnt1, o.nt1, cap, b.bin_base, b.seg_base, o.fine_bits,
+                                                                   o.nbins, (uint32_t*)b.cnt2);
+            k_ord_bin_scatter2<<<hot_grid, ORD_BIN_THREADS, lds_s, stream>>>((const uint32_t*)b.tmp, (const uint32_t*)b.cnt1, o.nt1, cap, b.bin_base, b.seg_base,
+                                                                               o.fine_bits, o.nbins, b.buckets, (const uint32_t*)b.cnt2, (uint32_t*)b.off,
+                                                                               (uint32_t*)b.sorted, o.entries_cap, o.ent_stride, o.ent_first);
+        }
+        PLK_HIP_TRY(hipGetLastError());
+        return PLK_OK;
+    }
     if (stage == 0) {
         k_ord_count<C><<<o.nt1, ORD_THREADS, 0, stream>>>((const uint4*)b.scalars, b.n, o, (uint32_t*)b.cnt1);
         k_ord_scan1<<<o.nbins, 256, 0, stream>>>((uint32_t*)b.cnt1, o.nt1, o.nbins, b.bin_total, b.bin_base, b.seg_base, b.done_counter, b.done_counter + 2,

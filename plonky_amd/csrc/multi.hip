@@ -105,19 +105,23 @@ static int group_copy(int me, int other, bool pull, void* dst, const void* src, 
         g_copies_peer.fetch_add(1, std::memory_order_relaxed);
         return PLK_OK;
     }
-    void* bounce = nullptr;
-    PLK_HIP_TRY(hipHostMalloc(&bounce, bytes, hipHostMallocPortable));
-    struct Free {
-        void* p;
-        ~Free() { (void)hipHostFree(p); }
-    } free_bounce{bounce};
+    // ONE bounded pinned buffer per calling thread (a worker, or a host thread that drives a device itself), kept for the life of the
+    // thread, and a loop over pieces of it: a copy of n bytes used to take hipHostMalloc + hipHostFree of n bytes - 100 MiB per worker at
+    // once for 2^20 generators, both calls synchronising the device
+    constexpr size_t BOUNCE_BYTES = (size_t)16 << 20;
+    static thread_local void* bounce = nullptr;
+    if (!bounce) PLK_HIP_TRY(hipHostMalloc(&bounce, BOUNCE_BYTES, hipHostMallocPortable));
     PLK_HIP_TRY(hipStreamSynchronize(st));  // what the copy reads (pull: the caller's stream, through ev_in; push: this stream's kernels) is complete
     const int from = pull ? other : me, to = pull ? me : other;
-    PLK_HIP_TRY(hipSetDevice(g_phys[from]));
-    hipError_t e = hipMemcpy(bounce, src, bytes, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) {
-        (void)hipSetDevice(g_phys[to]);
-        e = hipMemcpy(dst, bounce, bytes, hipMemcpyHostToDevice);
+    hipError_t e = hipSuccess;
+    for (size_t at = 0; at < bytes && e == hipSuccess; at += BOUNCE_BYTES) {
+        const size_t piece = bytes - at < BOUNCE_BYTES ? bytes - at : BOUNCE_BYTES;
+        (void)hipSetDevice(g_phys[from]);
+        e = hipMemcpy(bounce, (const uint8_t*)src + at, piece, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) {
+            (void)hipSetDevice(g_phys[to]);
+            e = hipMemcpy((uint8_t*)dst + at, bounce, piece, hipMemcpyHostToDevice);
+        }
     }
     (void)hipSetDevice(g_phys[me]);
     PLK_HIP_TRY(e);
@@ -455,14 +459,16 @@ int msm_precompute_multi(int curve, size_t n, const void* bases, const void* zer
     PLK_TRY(ensure_device());
     const int src_logical = thread_logical_device();
     const int src_phys = group_phys(src_logical);
-    std::lock_guard<std::mutex> dl(g_dispatch_mu);
-    PLK_TRY(workers_ensure());
-    if (!host_src) PLK_HIP_TRY(hipStreamSynchronize(caller_stream));  // the generators are complete before another device reads them
+    // registrations BEFORE the fan-out lock (as plk_msm_execute_batch takes them): a thread never waits for another holder's range while it
+    // keeps every other fan-out call out; released after the lock, when the workers' copies are complete
     HostPin pin_b, pin_z;
     if (host_src) {
         pin_b.pin(bases, n * pt);
         if (zero) pin_z.pin(zero, n);
     }
+    std::lock_guard<std::mutex> dl(g_dispatch_mu);
+    PLK_TRY(workers_ensure());
+    if (!host_src) PLK_HIP_TRY(hipStreamSynchronize(caller_stream));  // the generators are complete before another device reads them
     std::vector<plk_msm_ctx*> full((size_t)world, nullptr), shard((size_t)world, nullptr);
     auto job = [&](int d) -> int {
         HostLane* l = nullptr;

@@ -1,0 +1,108 @@
+"""GPU parity: the round-6 bucket ordering (tile-major level 1, bins from the low bits of the bucket number, whole bins ordered in LDS,
+segmented kernels for hot bins) and reduction (list-driven assembly, tree levels inside the row / column sums, transposed bucket grid,
+one workgroup for both windows of the end) at the geometry they are built for - the 20-bit window - against the oracle.
+
+The default window reaches 20 bits only from 2^19 generators on, where the oracle takes a minute per vector; the new kernels are selected
+by the WINDOW and the tile count, not by the size, so `device_window=20` over 2^16 .. 2^17 generators runs exactly the code a 2^20 MSM
+runs (msm_configure: OrdCfg::perm needs >= 2^16 scalars) at sizes the oracle answers in seconds.  What the uniform vectors of the other
+suites never reach (curve_msm.rs:102-157 takes ANY scalars; a witness is full of zeros, ones and small values):
+  * every scalar the same, 16 distinct scalars: a few buckets hold everything - hot bins (more than 32768 entries: the segmented
+    level-2 kernels, many workgroups per bin), heavy buckets (k_msm_heavy_*), thousands of live head pieces in the list of k_msm_heads;
+  * scalars below 2^10 / 2^20: only the lowest window has entries - with the bins taken from the LOW bits they still spread over bins;
+  * the top window alone (multiples of 2^240), zeros everywhere else: empty bins that still own bucket offsets;
+  * a sub-range of the generators (plk_msm_execute_parts_dev: ent_first > 0, fewer tiles than the context was laid out for);
+  * lengths that are not a multiple of the 1024-scalar tile.
+Each against the oracle's msm_execute_parallel; the same vectors through round 5's kernels (PLK_MSM_ORDER_V1 / PLK_MSM_TAIL_V1) run in
+tests/test_gpu_knobs.py's processes."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import plonky_amd as pa
+from plonky_amd import synth
+from oracle import bigint_ref as br
+from oracle import oracle_lib as ol
+from tests.test_oracle_kats import mont_arr
+
+THREADS = min(64, os.cpu_count() or 1)
+
+
+def _bases(c, n, seed):
+    G = (c.gx, c.gy)
+    pt = lambda P: np.array([c.base.mont_limbs(P[0]), c.base.mont_limbs(P[1])], dtype=np.uint64)
+    return ol.gen_bases(c.curve_id, n, pt(G), pt(br.ec_mul(c, 0xB1A5 + seed, G)))
+
+
+def _vectors(c, n, seed):
+    f = c.scalar
+    rnd = synth.rand_field(f.field_id, 0x6F0000 + seed, n)
+    rng = np.random.default_rng(seed)
+    m = lambda vals: mont_arr(f, [int(v) % f.p for v in vals])
+    out = {"uniform": rnd}
+    out["all_equal"] = np.repeat(rnd[7:8], n, axis=0)
+    out["all_one"] = np.repeat(m([1]), n, axis=0)
+    pick = rnd[:16]
+    out["sixteen_distinct"] = pick[rng.integers(0, 16, size=n)]
+    small = m(rng.integers(0, 1 << 10, size=n))
+    out["below_2p10"] = small
+    out["below_2p20"] = m(rng.integers(0, 1 << 20, size=n))
+    out["top_window_only"] = m([(int(v) % 16000) << 240 for v in rng.integers(1, 1 << 30, size=n)])
+    half = rnd.copy()
+    half[rng.random(n) < 0.5] = 0
+    out["half_zero"] = half
+    mixed = rnd.copy()
+    mixed[: n // 3] = m([1])[0]
+    mixed[n // 3: n // 2] = m([f.p - 1])[0]
+    out["ones_minus_ones_random"] = mixed
+    return out
+
+
+@pytest.mark.parametrize("c,n", [(br.TWEEDLEDEE, (1 << 16) + 37), (br.TWEEDLEDUM, 1 << 17), (br.BLS12_377, (1 << 16) + 1024)],
+                         ids=["Tweedledee_2p16+37", "Tweedledum_2p17", "Bls12377_2p16+1024"])
+def test_window20_orderings_and_reduction_match_oracle(c, n):
+    bases = _bases(c, n, n & 0xFF)
+    pre = pa.msm_precompute(c.curve_id, bases, 11, device_window=20)
+    assert pre.window == 20
+    opre = ol.MsmPrecomputation(c.curve_id, bases, 13, threads=THREADS)
+    vecs = _vectors(c, n, n & 0xFFFF)
+    names = list(vecs)
+    expected = {name: opre.execute(vecs[name], parallel=True, threads=THREADS) for name in names}
+    for name in names:
+        exp, ez = expected[name]
+        got, gz = pa.msm_execute_parallel(pre, vecs[name])
+        assert gz == ez and np.array_equal(got, exp), name
+    # all of them in ONE batched call (shared reduction over nine slots, a workspace each) and once more (workspaces reused)
+    stack = np.stack([vecs[k] for k in names])
+    for _ in range(2):
+        bxy, bz = pa.msm_execute_batch(pre, stack)
+        for k, name in enumerate(names):
+            exp, ez = expected[name]
+            assert int(bz[k]) == ez and np.array_equal(bxy[k], exp), ("batch", name)
+    pre.free()
+
+
+def test_window20_sub_ranges_of_the_generators():
+    """plk_msm_execute_parts_dev over a 20-bit-window context: vector b covers generators first[b] .. first[b] + count[b] - 1 only (a rank's
+    share of a sharded commitment); entry ids start at first[b], the tiles are those of count[b] scalars."""
+    torch = pytest.importorskip("torch")
+    from plonky_amd import device as dev
+    c = br.TWEEDLEDEE
+    n = (1 << 17) + 513
+    dev.init(0)
+    bases = _bases(c, n, 3)
+    s = synth.rand_field(c.scalar.field_id, 0x6F7001, n)
+    s[1000:3000] = mont_arr(c.scalar, [1])[0]
+    db = dev.to_device(bases.reshape(n, 2, -1))
+    pre = dev.msm_precompute_dev(c.curve_id, db, device_window=20)
+    parts = [(0, n), (0, 70001), (70001, n - 70001), (12345, 1 << 16), (n - 1025, 1025), (5, 0)]
+    oxy, oz = dev.msm_execute_parts_dev(pre, [(f, dev.to_device(np.ascontiguousarray(s[f:f + cnt]).reshape(cnt, 4))) for f, cnt in parts])
+    got, gz = dev.to_host(oxy), oz.cpu().numpy()
+    opre = ol.MsmPrecomputation(c.curve_id, bases, 13, threads=THREADS)
+    for k, (f, cnt) in enumerate(parts):
+        v = np.zeros_like(s)
+        v[f:f + cnt] = s[f:f + cnt]
+        exp, ez = opre.execute(v, parallel=True, threads=THREADS)
+        assert int(gz[k]) == ez and np.array_equal(got[k].reshape(exp.shape), exp), (k, f, cnt)
