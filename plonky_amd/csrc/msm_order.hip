@@ -524,19 +524,25 @@ __global__ void __launch_bounds__(ORD2_THREADS) k_ord_tiles(const uint4* __restr
     const Fe<SP> canon0 = canonical(raw0), canon1 = canonical(raw1);
     __syncthreads();
     // bucket slot v = [bin | fine]: the bin is the LOW coarse bits of the digit's bucket |d| - 1 and the fine part its high bits (OrdCfg::perm),
-    // so that the small digits of a short top window land in every bin
+    // so that the small digits of a short top window land in every bin.  The digits are formed ONCE and kept (<= 16 per scalar).
     const int cbits = cfg.c - 1 - cfg.fine_bits;
     const uint32_t bmask = (1u << cbits) - 1u;
-    auto count = [&](const Fe<SP>& canon) {
-        OrdWalk wk;
-        ord_walk_start<SP>(wk, canon, cfg);
-        for (int j = 0; j < cfg.windows; ++j) {
-            const uint32_t code = ord_walk_next(wk, j, cfg);
-            if (code != CODE_INVALID) atomicAdd(&s_cnt[(code >> 1) & bmask], 1u);
+    uint32_t code0[ORD2_MAX_WINDOWS], code1[ORD2_MAX_WINDOWS];
+    {
+        OrdWalk w0, w1;
+        ord_walk_start<SP>(w0, canon0, cfg);
+        ord_walk_start<SP>(w1, canon1, cfg);
+#pragma unroll
+        for (int j = 0; j < ORD2_MAX_WINDOWS; ++j) {
+            code0[j] = (j < cfg.windows && live0) ? ord_walk_next(w0, j, cfg) : CODE_INVALID;
+            code1[j] = (j < cfg.windows && live1) ? ord_walk_next(w1, j, cfg) : CODE_INVALID;
         }
-    };
-    if (live0) count(canon0);
-    if (live1) count(canon1);
+    }
+#pragma unroll
+    for (int j = 0; j < ORD2_MAX_WINDOWS; ++j) {
+        if (code0[j] != CODE_INVALID) atomicAdd(&s_cnt[(code0[j] >> 1) & bmask], 1u);
+        if (code1[j] != CODE_INVALID) atomicAdd(&s_cnt[(code1[j] >> 1) & bmask], 1u);
+    }
     __syncthreads();
     for (int k = tid; k < cfg.nbins; k += ORD2_THREADS) s_base[k] = s_cnt[k];
     __syncthreads();
@@ -548,19 +554,17 @@ __global__ void __launch_bounds__(ORD2_THREADS) k_ord_tiles(const uint4* __restr
         if (cn) atomicAdd(&bin_total[k], cn);
     }
     __syncthreads();
-    auto place = [&](const Fe<SP>& canon, uint32_t loc) {
-        OrdWalk wk;
-        ord_walk_start<SP>(wk, canon, cfg);
-        for (int j = 0; j < cfg.windows; ++j) {
-            const uint32_t code = ord_walk_next(wk, j, cfg);
-            if (code != CODE_INVALID) {
-                const uint32_t slot = atomicAdd(&s_base[(code >> 1) & bmask], 1u);  // the bin's cursor (its start was written out above)
-                if (PLK_CHK(slot < cap, CHK_TILE_STAGE)) s_ent[slot] = ord2_record(code & 1u, code >> (cbits + 1), j, loc);
-            }
+#pragma unroll
+    for (int j = 0; j < ORD2_MAX_WINDOWS; ++j) {
+        if (code0[j] != CODE_INVALID) {
+            const uint32_t slot = atomicAdd(&s_base[(code0[j] >> 1) & bmask], 1u);  // the bin's cursor (its start was written out above)
+            if (PLK_CHK(slot < cap, CHK_TILE_STAGE)) s_ent[slot] = ord2_record(code0[j] & 1u, code0[j] >> (cbits + 1), j, (uint32_t)tid);
         }
-    };
-    if (live0) place(canon0, (uint32_t)tid);
-    if (live1) place(canon1, (uint32_t)(ORD2_THREADS + tid));
+        if (code1[j] != CODE_INVALID) {
+            const uint32_t slot = atomicAdd(&s_base[(code1[j] >> 1) & bmask], 1u);
+            if (PLK_CHK(slot < cap, CHK_TILE_STAGE)) s_ent[slot] = ord2_record(code1[j] & 1u, code1[j] >> (cbits + 1), j, (uint32_t)(ORD2_THREADS + tid));
+        }
+    }
     __syncthreads();
     const uint32_t total = s_total;
     uint32_t* __restrict__ region = tmp + (size_t)tile * cap;

@@ -482,8 +482,8 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int w
     }
 }
 
-// The two windows of a tabled two-level reduction (column sums, row sums) in ONE workgroup (round 6): threads 0..255 take the column
-// window, 256..511 the row window - the same steps as k_msm_final side by side - and the two results meet in LDS instead of through a
+// The two windows of a tabled two-level reduction (column sums, row sums) in ONE workgroup (round 6): its even waves take the column
+// window, its odd waves the row window - the same steps as k_msm_final side by side - and the two results meet in LDS instead of through a
 // packed point in global memory, a device-scope fence and an atomic counter (3.5 + 9.5 us of k_msm_final's 125, r05_final_kernel_trace).
 // Needs planes * parts / 2 <= 64 quads per window.
 template <class C>
@@ -494,7 +494,10 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final_pair(TailBatch tb, 
     static_assert(FINAL_THREADS == 512, "two windows of 256 threads");
     __shared__ uint4 s_pts[2 * 33 * 4 * W];
     __shared__ uint4 s_x[RU];
-    const int tid = threadIdx.x, ql = tid & 3, half = tid >> 8, ltid = tid & 255, item = ltid >> 2;
+    // the waves alternate between the windows (even: columns, odd: rows), so that the ONE wave of each window that runs the doubling chain
+    // sits on a SIMD of its own (waves go to the SIMDs in turn: with the windows in the two halves of the workgroup both chains shared
+    // SIMD 0 and the kernel took 135 us against k_msm_final's 121)
+    const int tid = threadIdx.x, ql = tid & 3, half = (tid >> 6) & 1, ltid = ((tid >> 7) << 6) | (tid & 63), item = ltid >> 2;
     const int slot = blockIdx.x;
     const uint4* __restrict__ plane_part = tb.s[slot].plane_part;
     const int ipq = parts > 1 ? 2 : 1, qpp = parts / ipq;  // quads per plane
@@ -524,7 +527,7 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final_pair(TailBatch tb, 
         }
     }
     __syncthreads();
-    if (tid < 4) {
+    if (tid < 4) {  // wave 0: the column window's quad
         acc = xyzzz_add_q<FP>(acc, xyzzz_load_raw<FP>(s_x), ql);
         if (tid == 0) emit_affine<FP, true>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
     }
