@@ -161,6 +161,7 @@ def parse_args(argv=None):
     ap.add_argument("--emulate-rank", default=None, metavar="r/N", help="run rank r's shard of the N-rank strong-scaling problem alone on one GPU")
     ap.add_argument("--same-device", action="store_true", help="all ranks on GPU 0, gloo backend (world-size-2 test on a one-GPU box)")
     ap.add_argument("--no-parts", action="store_true", help="strong scaling: a rank's share of a sharded vector as a zero-padded full-length vector (round-3 start) instead of its base range")
+    ap.add_argument("--bucket-shard", action="store_true", help="strong scaling: a sharded vector is shared by BUCKET range (every rank reads the whole vector and keeps its N-th of the coarse bins) instead of by base range")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--timed-only", action="store_true", help="run only the warm-up + timed region (for rocprofv3 --pmc passes)")

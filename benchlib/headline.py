@@ -77,7 +77,7 @@ def run(args):
         dd = np.stack([synth.mont(cv["base_field"], D[0]), synth.mont(cv["base_field"], D[1])])
         if strong:
             # whole vectors per rank + the remainder sharded by base range (parallel.BatchPlan); one MSM: the sharded case alone
-            plan = parallel.BatchPlan(batch, shard_world, shard_rank, n)
+            plan = parallel.BatchPlan(batch, shard_world, shard_rank, n, bucket_shard=args.bucket_shard)
             first, n_local = plan.first, plan.n_local
             s_host = np.stack([synth.rand_field(cv["scalar_field"], SEED_MSM + 0x900 + k, n) for k in range(batch)])
             s = dev.to_device(plan.local_scalars(s_host))
@@ -98,13 +98,14 @@ def run(args):
 
     # a rank that holds whole vectors AND a share of a sharded one passes the share with its base range (plk_msm_execute_parts_dev)
     msm_parts = plan.parts(s) if (do_msm and plan is not None and plan.full_context and plan.sharded and not args.no_parts) else None
+    msm_buckets = plan.buckets() if msm_parts is not None else None
 
     def step():
         if do_ntt:
             dev.ntt_dev(NTT_FIELD, x, out=y)
         if do_msm:
             if msm_parts is not None:
-                dev.msm_execute_parts_dev(pre, msm_parts, oxy, oz)
+                dev.msm_execute_parts_dev(pre, msm_parts, oxy, oz, buckets=msm_buckets)
             else:
                 dev.msm_execute_dev(pre, s, oxy, oz)
             if exchange:
@@ -203,14 +204,33 @@ def run(args):
             if "_ntt_ok" in comp.get("host_pointer", {}):
                 checks["host_pointer_ntt_equals_device"] = comp["host_pointer"].pop("_ntt_ok")
         if do_msm:
-            dev.msm_execute_dev(pre, s, oxy, oz)
+            if msm_buckets is not None:
+                dev.msm_execute_parts_dev(pre, msm_parts, oxy, oz, buckets=msm_buckets)
+            else:
+                dev.msm_execute_dev(pre, s, oxy, oz)
             if exchange:
                 ex.gather()
                 gxy, gz = ex.combine()
             torch.cuda.synchronize()
             got = dev.to_host(oxy).reshape(slots, 2, cv["limbs"])
             ok = int(oz.sum().item()) == 0
+            if msm_buckets is not None:
+                # a bucket range has no closed form of its own: the shares of ALL the ranks (computed here, one after the other) must add
+                # up to the whole vector's closed form, and this rank's share must be the one the timed region produced
+                for j in range(plan.sharded):
+                    row = s[whole + j]
+                    pts, zs = [], []
+                    for r in range(shard_world):
+                        pxy, pz = dev.msm_execute_parts_dev(pre, [(0, row)], buckets=[(r, shard_world)])
+                        pts.append(dev.to_host(pxy)[0])
+                        zs.append(int(pz.cpu()[0]))
+                    ok = ok and np.array_equal(pts[shard_rank], got[whole + j])
+                    tot, tz = api.curve_sum_affine(CURVE, np.stack(pts), np.array(zs, dtype=np.uint8))
+                    exp = closed_form_msm(CURVE, s_host[plan.rem[j]], G, D, first=0)
+                    ok = ok and tz == 0 and (synth.from_mont(cv["base_field"], tot[0]), synth.from_mont(cv["base_field"], tot[1])) == exp
             for k in range(slots):
+                if msm_buckets is not None and k >= whole:
+                    continue  # checked above
                 if not strong:
                     exp = closed_form_msm(CURVE, s_host, G, D, first=first)          # this rank's range of the global MSM
                 elif k < whole:

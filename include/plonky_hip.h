@@ -240,6 +240,14 @@ int plk_msm_execute_dev(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars,
  * zero scalars to skip: 1 % of a rank's step at 8 ranks - zero scalars were cheap already - and the padded copy of the vector.) */
 int plk_msm_execute_parts_dev(plk_msm_ctx* ctx, unsigned batch, const uint64_t* first, const uint64_t* count, const void* const* d_scalars,
                               void* d_out_xy, void* d_out_zero, void* stream);
+/* The same with a BUCKET range per vector (round 6): vector b keeps only the entries whose bucket falls into the bucket_part[b]-th of
+ * bucket_parts[b] equal ranges of the context's coarse bins (0 or 1 parts: every bucket).  The partial results of the bucket_parts[b]
+ * ranges add up to the vector's MSM (plk_msm_combine_partials_dev).  This is the other way to share ONE vector among N devices: every
+ * device reads the whole vector (and holds the whole table) but orders, accumulates and reduces an N-th of the entries over an N-th of
+ * the buckets at the window a full-size MSM deserves - where a base range of n / N generators pays a whole reduction over all the
+ * buckets of its (smaller) window for an N-th of the additions.  Tabled, non-comb contexts; host arrays of `batch` entries. */
+int plk_msm_execute_parts_buckets_dev(plk_msm_ctx* ctx, unsigned batch, const uint64_t* first, const uint64_t* count, const void* const* d_scalars,
+                                      const uint32_t* bucket_part, const uint32_t* bucket_parts, void* d_out_xy, void* d_out_zero, void* stream);
 /* msm_parallel (curve_msm.rs:54-61): precompute + execute + free in one call. */
 int plk_msm(int curve, size_t n, const uint64_t* bases_xy, const uint8_t* base_zero, const uint64_t* scalars, uint64_t* out_xy,
             uint8_t* out_zero);

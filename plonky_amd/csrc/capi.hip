@@ -34,11 +34,6 @@ int field_op_impl(int field, int op, const uint64_t* a, const uint64_t* b, uint6
 int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void* d_zero, unsigned window_bits, unsigned flags, hipStream_t stream,
                             plk_msm_ctx** out_ctx, const void* d_extra = nullptr, size_t n_extra = 0, const size_t* also_n = nullptr,
                             int also_count = 0);
-struct MsmParts {
-    const uint64_t* first;
-    const uint64_t* count;
-    const void* const* scalars;
-};
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
                          hipEvent_t* ready = nullptr, const MsmParts* parts = nullptr);
 int msm_reserve_workspaces_impl(plk_msm_ctx* ctx, unsigned count, hipStream_t stream);
@@ -840,6 +835,14 @@ int plk_msm_execute_parts_dev(plk_msm_ctx* ctx, unsigned batch, const uint64_t* 
                               void* d_out_zero, void* stream) {
     PLK_API;
     MsmParts parts{first, count, d_scalars};
+    return msm_execute_dev_impl(ctx, batch, nullptr, 0, d_out_xy, d_out_zero, as_stream(stream), nullptr, &parts);
+}
+
+int plk_msm_execute_parts_buckets_dev(plk_msm_ctx* ctx, unsigned batch, const uint64_t* first, const uint64_t* count, const void* const* d_scalars,
+                                      const uint32_t* bucket_part, const uint32_t* bucket_parts, void* d_out_xy, void* d_out_zero, void* stream) {
+    PLK_API;
+    if (!bucket_part || !bucket_parts) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    MsmParts parts{first, count, d_scalars, bucket_part, bucket_parts};
     return msm_execute_dev_impl(ctx, batch, nullptr, 0, d_out_xy, d_out_zero, as_stream(stream), nullptr, &parts);
 }
 

@@ -147,6 +147,16 @@ int plonk_vanishing_points_dev_impl(int field, unsigned log_degree, const void* 
 int plonk_all_constraints_dev_impl(int field, size_t count, const void* d_constants, const void* d_local, const void* d_right, const void* d_below,
                                    const uint64_t* inner_zeta, const uint64_t* inner_a, void* d_out, hipStream_t stream);
 
+// per-vector generator ranges (and, optionally, bucket ranges) of a batched MSM execution (msm.hip: msm_execute_dev_impl; host arrays of
+// `batch` entries; scalars[b]: a device pointer)
+struct MsmParts {
+    const uint64_t* first;
+    const uint64_t* count;
+    const void* const* scalars;
+    const uint32_t* bucket_part = nullptr;   // optional: vector b keeps the bucket_part[b]-th of bucket_parts[b] ranges of the coarse bins
+    const uint32_t* bucket_parts = nullptr;  // (absent, 0 or 1: every bucket)
+};
+
 int field_limbs(int field);
 int curve_limbs(int curve);
 int curve_scalar_field(int curve);

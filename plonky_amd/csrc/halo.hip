@@ -48,7 +48,6 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
                             plk_msm_ctx** out_ctx, const void* d_extra = nullptr, size_t n_extra = 0, const size_t* also_n = nullptr,
                             int also_count = 0);
 int msm_rebind_dev_impl(plk_msm_ctx* ctx, size_t n, const void* d_bases, const void* d_zero, const void* d_extra, size_t n_extra, hipStream_t stream);
-struct MsmParts;
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
                          hipEvent_t* ready = nullptr, const MsmParts* parts = nullptr);
 int msm_reserve_workspaces_impl(plk_msm_ctx* ctx, unsigned count, hipStream_t stream);

@@ -460,6 +460,7 @@ struct plk_msm_ctx {
     // no workspaces, no bucket method - executions are mixed additions of table entries and a tree over the lanes' sums.
     plk::CombPlan* comb = nullptr;
     bool auto_window = false;
+    bool many_heads = false;  // the call in progress holds a bucket share (set and cleared under `mu` by msm_execute_dev_impl)
     ~plk_msm_ctx() {
         if (comb) plk::comb_free(comb);
         for (auto* v : {&peers, &shards})
@@ -870,6 +871,8 @@ static int msm_configure(plk_msm_ctx* ctx, int curve, size_t n, unsigned window_
         // ... and a bin's expected share of the entries fits the LDS of k_ord_bin_sort with 15 % to spare (2^20 scalars of 13 windows over 512
         // bins: 26.6 k of 32 k; larger problems keep round 5's kernels, hot bins of a skewed vector take the segmented ones).
         const bool bins_fit = (double)n_eff * windows / (double)o.nbins * 1.15 <= (double)ORD2_BIN_CAP;
+        o.bin_lo = 0;
+        o.bin_hi = (uint32_t)o.nbins;
         o.perm = (!order_v1 && !table_free && coarse == 9 && o.fine_bits >= coarse && o.nbins == (1 << coarse) && o.sub == 4 && o.spt * o.sub == 1024u &&
                   windows <= 16 && o.nt1 <= 2048u && bins_fit)
                      ? 1
@@ -992,7 +995,7 @@ static int msm_reduce_t(plk_msm_ctx* ctx, const TailBatch& tb, hipStream_t strea
     g.buckets = ctx->buckets; g.heavy_cap = ctx->heavy_cap; g.tail_wbuckets = ctx->tail_wbuckets; g.max_lanes = (uint32_t)ctx->max_lanes;
     g.lpb_log = ctx->lpb_log; g.two_level = ctx->two_level ? 1 : 0; g.L = ctx->L; g.H = ctx->H; g.g_log = ctx->g_log; g.lpl_log = ctx->lpl_log;
     g.table_free = ctx->table_free ? 1 : 0; g.windows = ctx->windows; g.tail_windows = ctx->tail_windows; g.plane_blocks = ctx->plane_blocks;
-    g.planes = ctx->planes; g.tail_shift = ctx->tail_shift; g.transposed = ctx->ord.perm;
+    g.planes = ctx->planes; g.tail_shift = ctx->tail_shift; g.transposed = ctx->ord.perm; g.many_heads = ctx->many_heads ? 1 : 0;
     for (int stage = 0; stage < 3; ++stage) {
         PLK_TRY(msm_launch_reduce_stage<C>(stage, g, tb, stream));
         mark();
@@ -1000,18 +1003,12 @@ static int msm_reduce_t(plk_msm_ctx* ctx, const TailBatch& tb, hipStream_t strea
     return PLK_OK;
 }
 
-// per-vector generator ranges of plk_msm_execute_parts_dev (host arrays of `batch` entries; scalars[b]: a device pointer)
-struct MsmParts {
-    const uint64_t* first;
-    const uint64_t* count;
-    const void* const* scalars;
-};
 
 // phases: 1 = bucket ordering, 2 = accumulation, 4 = reduction; 7 = the whole MSM on one stream
 constexpr int PH_ORDER = 1, PH_ACC = 2, PH_REDUCE = 4, PH_ALL = 7;
 template <class C>
 static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
-                         int phases = PH_ALL, size_t first = 0, size_t count = (size_t)-1) {
+                         int phases = PH_ALL, size_t first = 0, size_t count = (size_t)-1, uint32_t bucket_part = 0, uint32_t bucket_parts = 1) {
     // count != -1: the scalars belong to generators first .. first + count - 1 (tabled contexts: the table index of an entry is its id)
     const bool ranged = count != (size_t)-1;
     const size_t n = ranged ? count : ctx->n_eff;
@@ -1021,6 +1018,11 @@ static int msm_execute_t(plk_msm_ctx* ctx, MsmWork& w, const void* d_scalars, vo
         o.nt1 = (uint32_t)((n + (size_t)o.spt * o.sub - 1) / ((size_t)o.spt * o.sub));
         if (o.nt1 == 0) o.nt1 = 1;
         o.ent_first = (uint32_t)first;
+    }
+    if (bucket_parts > 1) {  // this execution's range of the coarse bins (the larger ranges first, like shard_bounds)
+        const uint32_t nb = (uint32_t)o.nbins, base = nb / bucket_parts, rem = nb % bucket_parts;
+        o.bin_lo = bucket_part * base + (bucket_part < rem ? bucket_part : rem);
+        o.bin_hi = o.bin_lo + base + (bucket_part < rem ? 1u : 0u);
     }
     uint32_t* off = (uint32_t*)w.off;
     uint32_t* bin_total = (uint32_t*)w.meta;
@@ -1118,6 +1120,12 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
         // vector b: parts->count[b] scalars at parts->scalars[b] for the generators parts->first[b] .. (plk_msm_execute_parts_dev)
         if (ctx->table_free) return set_error(PLK_ERR_INVALID_ARG, "a sub-range of the generators needs a tabled context");
         if (!parts->first || !parts->count || !parts->scalars) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+        if ((parts->bucket_part == nullptr) != (parts->bucket_parts == nullptr)) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+        for (unsigned b = 0; b < batch && parts->bucket_parts; ++b) {
+            if (parts->bucket_parts[b] > 1 && (ctx->comb || parts->bucket_part[b] >= parts->bucket_parts[b] || parts->bucket_parts[b] > (uint32_t)ctx->ord.nbins))
+                return set_error(PLK_ERR_INVALID_ARG, "vector %u: bucket range %u of %u over %d coarse bins%s", b, parts->bucket_part[b], parts->bucket_parts[b],
+                                 ctx->ord.nbins, ctx->comb ? " (a comb context has no buckets)" : "");
+        }
         for (unsigned b = 0; b < batch; ++b) {
             if (parts->first[b] > ctx->n || parts->count[b] > ctx->n - parts->first[b])
                 return set_error(PLK_ERR_SIZE_MISMATCH, "vector %u covers generators %llu .. +%llu but the precomputation holds %zu", b,
@@ -1133,6 +1141,8 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
     PLK_HIP_TRY(hipSetDevice(ctx->device));  // a context works on the device it was built on, whichever device the thread last used
     std::lock_guard<std::mutex> lk(ctx->mu);
     const size_t L = (size_t)curve_limbs(ctx->curve);
+    ctx->many_heads = false;
+    for (unsigned b = 0; b < batch && parts && parts->bucket_parts; ++b) ctx->many_heads = ctx->many_heads || parts->bucket_parts[b] > 1;
     if (ctx->comb) {
         // few generators: additions of table entries and a tree, two launches for the whole batch (comb.hip)
         std::vector<const void*> ptr(batch);
@@ -1149,14 +1159,15 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
         if (ready && (phases & PH_ORDER)) PLK_HIP_TRY(hipStreamWaitEvent(st, ready[b], 0));
         const uint8_t* sc = parts ? (const uint8_t*)parts->scalars[b] : (const uint8_t*)d_scalars + (size_t)b * ctx->n * 32;
         const size_t first = parts ? (size_t)parts->first[b] : 0, count = parts ? (size_t)parts->count[b] : (size_t)-1;
+        const uint32_t bp = (parts && parts->bucket_parts) ? parts->bucket_part[b] : 0u, bps = (parts && parts->bucket_parts) ? parts->bucket_parts[b] : 1u;
         uint8_t* oxy = (uint8_t*)d_out_xy + (size_t)b * 2 * L * 8;
         uint8_t* oz = (uint8_t*)d_out_zero + b;
         switch (ctx->curve) {
-            case PLK_CURVE_TWEEDLEDEE: return msm_execute_t<TweedledeeCurve>(ctx, w, sc, oxy, oz, st, phases, first, count);
-            case PLK_CURVE_TWEEDLEDUM: return msm_execute_t<TweedledumCurve>(ctx, w, sc, oxy, oz, st, phases, first, count);
-            case PLK_CURVE_PALLAS: return msm_execute_t<PallasCurve>(ctx, w, sc, oxy, oz, st, phases, first, count);
-            case PLK_CURVE_VESTA: return msm_execute_t<VestaCurve>(ctx, w, sc, oxy, oz, st, phases, first, count);
-            default: return msm_execute_t<Bls12377Curve>(ctx, w, sc, oxy, oz, st, phases, first, count);
+            case PLK_CURVE_TWEEDLEDEE: return msm_execute_t<TweedledeeCurve>(ctx, w, sc, oxy, oz, st, phases, first, count, bp, bps);
+            case PLK_CURVE_TWEEDLEDUM: return msm_execute_t<TweedledumCurve>(ctx, w, sc, oxy, oz, st, phases, first, count, bp, bps);
+            case PLK_CURVE_PALLAS: return msm_execute_t<PallasCurve>(ctx, w, sc, oxy, oz, st, phases, first, count, bp, bps);
+            case PLK_CURVE_VESTA: return msm_execute_t<VestaCurve>(ctx, w, sc, oxy, oz, st, phases, first, count, bp, bps);
+            default: return msm_execute_t<Bls12377Curve>(ctx, w, sc, oxy, oz, st, phases, first, count, bp, bps);
         }
     };
     static const bool no_batching = getenv("PLK_MSM_NO_OVERLAP") != nullptr;  // every MSM of a batch start to end, one by one

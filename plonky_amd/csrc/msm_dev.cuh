@@ -104,6 +104,10 @@ struct OrdCfg {
     // b = |d| - 1, so that a short top window - whose digits are all small - spreads over every bin instead of filling the first few.
     // The reduction reads the weight of v off its two halves (TailGeom::transposed).
     int perm;
+    // round 6: only entries whose coarse bin lies in [bin_lo, bin_hi) are kept (0, nbins: all of them).  A rank of a device group that
+    // takes a BUCKET range of a sharded vector - every rank reads the whole vector and keeps its N-th of the bins - orders, accumulates
+    // and reduces an N-th of the entries over an N-th of the buckets (plk_msm_execute_parts_buckets_dev).
+    uint32_t bin_lo, bin_hi;
 };
 
 constexpr int TAIL_MAX = 16;
@@ -143,6 +147,9 @@ struct TailGeom {
     // 1: bucket slot v = lo * 2^H + hi holds the bucket of weight hi * 2^L + lo + 1 (OrdCfg::perm): the grid in memory is 2^L rows of
     // 2^H slots, its ROW sums are the column sums C_lo of the weighting and its column sums the row sums R_hi
     int transposed;
+    // 1: some vector of the batch is a BUCKET share (OrdCfg::bin_lo / bin_hi): its entries are spread over all the accumulation lanes in
+    // chains shorter than a bucket, so most lanes end inside a bucket and the list of live head pieces is long - k_msm_heads gets a wide grid
+    int many_heads;
 };
 // the buffers of one ordering (msm_order.hip: msm_launch_order_stage)
 struct OrdBuffers {

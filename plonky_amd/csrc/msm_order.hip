@@ -59,6 +59,9 @@ PLK_DI uint32_t ord_digit(const uint32_t* s_lim, int tid, int j, const OrdCfg& c
     return ((mag - 1u + (uint32_t)j * cfg.window_buckets) << 1) | (neg ^ flip);
 }
 
+// the bucket range of a sharded execution (OrdCfg::bin_lo / bin_hi): entries of other bins are dropped where the digits are formed
+PLK_DI bool ord_bin_kept(uint32_t bin, const OrdCfg& cfg) { return bin - cfg.bin_lo < cfg.bin_hi - cfg.bin_lo; }
+
 // exclusive prefix of `v` over the threads of the block (blockDim.x a multiple of 64, <= 1024); *total (optional) = the block sum.
 // Shuffles inside a wave, one LDS word per wave across: two barriers instead of two per doubling step.  s_tmp: >= 16 words,
 // free again when the call returns.
@@ -158,7 +161,7 @@ __global__ void __launch_bounds__(ORD_THREADS) k_ord_count(const uint4* __restri
             uint32_t carry = 0;
             for (int j = 0; j < cfg.windows; ++j) {
                 const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
-                if (code != CODE_INVALID) atomicAdd(&s_hist[code >> (cfg.fine_bits + 1)], 1u);
+                if (code != CODE_INVALID && ord_bin_kept(code >> (cfg.fine_bits + 1), cfg)) atomicAdd(&s_hist[code >> (cfg.fine_bits + 1)], 1u);
             }
         }
     }
@@ -283,7 +286,8 @@ __global__ void __launch_bounds__(ORD_THREADS) k_ord_scatter(const uint4* __rest
             uint32_t carry = 0;
             for (int j = 0; j < cfg.windows; ++j) {
                 const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
-                if (code != CODE_INVALID) s_rank[j * cfg.spt + tid] = (uint16_t)atomicAdd(&s_cnt[code >> (cfg.fine_bits + 1)], 1u);
+                if (code != CODE_INVALID && ord_bin_kept(code >> (cfg.fine_bits + 1), cfg))
+                    s_rank[j * cfg.spt + tid] = (uint16_t)atomicAdd(&s_cnt[code >> (cfg.fine_bits + 1)], 1u);
             }
         }
         __syncthreads();
@@ -294,7 +298,7 @@ __global__ void __launch_bounds__(ORD_THREADS) k_ord_scatter(const uint4* __rest
             uint32_t carry = 0;
             for (int j = 0; j < cfg.windows; ++j) {
                 const uint32_t code = ord_digit(s_lim, tid, j, cfg, carry);
-                if (code != CODE_INVALID) {
+                if (code != CODE_INVALID && ord_bin_kept(code >> (cfg.fine_bits + 1), cfg)) {
                     const uint32_t slot = s_base[code >> (cfg.fine_bits + 1)] + s_rank[j * cfg.spt + tid];
                     if (PLK_CHK(slot < (uint32_t)ORD_TILE, CHK_TILE_STAGE)) s_ent[slot] = make_uint2(code, (uint32_t)((size_t)j * cfg.ent_stride + cfg.ent_first + i));
                 }
@@ -536,6 +540,8 @@ __global__ void __launch_bounds__(ORD2_THREADS) k_ord_tiles(const uint4* __restr
         for (int j = 0; j < ORD2_MAX_WINDOWS; ++j) {
             code0[j] = (j < cfg.windows && live0) ? ord_walk_next(w0, j, cfg) : CODE_INVALID;
             code1[j] = (j < cfg.windows && live1) ? ord_walk_next(w1, j, cfg) : CODE_INVALID;
+            if (code0[j] != CODE_INVALID && !ord_bin_kept((code0[j] >> 1) & bmask, cfg)) code0[j] = CODE_INVALID;  // another rank's buckets
+            if (code1[j] != CODE_INVALID && !ord_bin_kept((code1[j] >> 1) & bmask, cfg)) code1[j] = CODE_INVALID;
         }
     }
 #pragma unroll

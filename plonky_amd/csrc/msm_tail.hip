@@ -243,9 +243,9 @@ __global__ void __launch_bounds__(128) k_msm_gsum(TailBatch tb, int L, int H, in
     // (off[b + 1] == off[b]): k_msm_assemble writes the identity there, the lane-driven assembly (k_msm_heads) leaves the slot alone.
     const uint32_t* __restrict__ off = sl.off;
     auto load_bucket = [&](uint32_t b) {
-        XyzzZ<FP> v = xyzzz_load_raw<FP>(sl.p_start + (size_t)b * RU);
-        if (off[b + 1] == off[b]) v.inf = true;
-        return v;
+        // (an empty bucket is not read at all: a rank that holds a bucket range of a sharded vector sums mostly empty lines)
+        if (off[b + 1] == off[b]) return xyzzz_identity<FP>();
+        return xyzzz_load_raw<FP>(sl.p_start + (size_t)b * RU);
     };
     XyzzZ<FP> acc = xyzzz_identity<FP>();
     XyzzZ<FP> nxt = load_bucket(b0);
@@ -295,9 +295,8 @@ __global__ void __launch_bounds__(128) k_msm_gsum_tree(TailBatch tb, int L, int 
     }
     const uint32_t* __restrict__ off = sl.off;
     auto load_bucket = [&](uint32_t b) {
-        XyzzZ<FP> v = xyzzz_load_raw<FP>(sl.p_start + (size_t)b * RU);
-        if (off[b + 1] == off[b]) v.inf = true;  // an empty bucket is the identity whatever its slot holds (k_msm_gsum)
-        return v;
+        if (off[b + 1] == off[b]) return xyzzz_identity<FP>();  // an empty bucket is the identity whatever its slot holds (k_msm_gsum)
+        return xyzzz_load_raw<FP>(sl.p_start + (size_t)b * RU);
     };
     XyzzZ<FP> acc = xyzzz_identity<FP>();
     XyzzZ<FP> nxt = load_bucket(b0);
@@ -573,7 +572,8 @@ template <class C> int msm_launch_reduce_stage(int stage, const TailGeom& g, con
     const bool v2 = g.two_level && g.lpb_log == 0 && !tail_v1;
     if (stage == 0) {
         // hot buckets of a skewed scalar distribution (none for uniform scalars: the heavy launches then exit at once)
-        if (v2) k_msm_heads<C><<<dim3(512, cnt), 256, 0, stream>>>(tb, buckets, g.heavy_cap);  // 32768 quads per MSM, a loop over the list
+        // 32768 quads per MSM, a loop over the list (131072 when a bucket share is in the batch: ~130 k live head pieces, 180 us at 512 workgroups)
+        if (v2) k_msm_heads<C><<<dim3(g.many_heads ? 2048 : 512, cnt), 256, 0, stream>>>(tb, buckets, g.heavy_cap);
         else k_msm_heavy_list<<<dim3((buckets + 255) / 256, cnt), 256, 0, stream>>>(tb, buckets, g.heavy_cap, g.lpb_log);
         k_msm_heavy_chunks<C><<<dim3(256, cnt), 256, 0, stream>>>(tb, g.heavy_cap);
         k_msm_heavy_final<C><<<dim3(64, cnt), 256, 0, stream>>>(tb, g.heavy_cap);

@@ -130,9 +130,11 @@ def msm_execute_dev(pre, scalars, out_xy=None, out_zero=None):
     return out_xy, out_zero
 
 
-def msm_execute_parts_dev(pre, parts, out_xy=None, out_zero=None):
+def msm_execute_parts_dev(pre, parts, out_xy=None, out_zero=None, buckets=None):
     """plk_msm_execute_parts_dev: parts = [(first, scalars)] with scalars an (count, 4) int64 CUDA tensor for the generators
-    first .. first + count - 1 of `pre` (a tabled precomputation).  One batched call, one shared reduction -> ((batch, 2, L), (batch,))."""
+    first .. first + count - 1 of `pre` (a tabled precomputation).  One batched call, one shared reduction -> ((batch, 2, L), (batch,)).
+    buckets (optional): [(part, parts)] per vector - the vector keeps only the part-th of `parts` ranges of the coarse bucket bins
+    (plk_msm_execute_parts_buckets_dev: a rank's BUCKET share of a sharded vector; (0, 1): every bucket)."""
     batch = len(parts)
     L = _CURVE_LIMBS[pre.curve]
     dev0 = parts[0][1].device
@@ -145,6 +147,14 @@ def msm_execute_parts_dev(pre, parts, out_xy=None, out_zero=None):
     for _, t in parts:
         assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.shape[-1] == 4
     ptrs = (ctypes.c_void_p * batch)(*[p[1].data_ptr() for p in parts])
+    if buckets is not None:
+        assert len(buckets) == batch
+        bp = np.array([b[0] for b in buckets], dtype=np.uint32)
+        bn = np.array([b[1] for b in buckets], dtype=np.uint32)
+        _lib.check(_lib.load().plk_msm_execute_parts_buckets_dev(pre._ctx, batch, first.ctypes.data_as(ctypes.c_void_p), count.ctypes.data_as(ctypes.c_void_p),
+                                                                 ptrs, bp.ctypes.data_as(ctypes.c_void_p), bn.ctypes.data_as(ctypes.c_void_p),
+                                                                 ctypes.c_void_p(out_xy.data_ptr()), ctypes.c_void_p(out_zero.data_ptr()), _stream()))
+        return out_xy, out_zero
     _lib.check(_lib.load().plk_msm_execute_parts_dev(pre._ctx, batch, first.ctypes.data_as(ctypes.c_void_p), count.ctypes.data_as(ctypes.c_void_p), ptrs,
                                                      ctypes.c_void_p(out_xy.data_ptr()), ctypes.c_void_p(out_zero.data_ptr()), _stream()))
     return out_xy, out_zero

@@ -31,7 +31,11 @@ class BatchPlan:
     vectors SHARDED by contiguous base range (slot whole + j on every rank).  9 wire polynomials on 8 GPUs: one whole vector
     per rank and an eighth of the ninth.  A single MSM on N GPUs: the sharded case alone."""
 
-    def __init__(self, batch, world, rank, n):
+    def __init__(self, batch, world, rank, n, bucket_shard=False):
+        """bucket_shard (round 6): a sharded vector is shared by BUCKET range instead of by base range - every rank holds all the
+        generators and reads the whole vector, but keeps only the entries whose bucket falls into its world-th of the coarse bins
+        (plk_msm_execute_parts_buckets_dev): an N-th of the additions over an N-th of the buckets at the full-size window."""
+        self.bucket_shard = bool(bucket_shard)
         self.batch, self.world, self.rank, self.n = batch, world, rank, n
         self.whole = batch // world
         self.sharded = batch - self.whole * world
@@ -39,8 +43,8 @@ class BatchPlan:
         self.own = [rank + k * world for k in range(self.whole)]
         self.rem = list(range(self.whole * world, batch))
         self.lo, self.hi = shard_bounds(n, rank, world)
-        # whole vectors need every generator on every rank; a purely sharded job only its own base range
-        self.full_context = self.whole > 0
+        # whole vectors need every generator on every rank, and so does a bucket range; a job sharded by base range only its own range
+        self.full_context = self.whole > 0 or self.bucket_shard
         self.n_local = n if self.full_context else self.hi - self.lo
         self.first = 0 if self.full_context else self.lo
 
@@ -53,7 +57,9 @@ class BatchPlan:
         for k, v in enumerate(self.own):
             out[k] = vectors[v]
         for j, v in enumerate(self.rem):
-            if self.full_context:
+            if self.bucket_shard:
+                out[self.whole + j] = vectors[v]
+            elif self.full_context:
                 out[self.whole + j, self.lo:self.hi] = vectors[v, self.lo:self.hi]
             else:
                 out[self.whole + j] = vectors[v, self.lo:self.hi]
@@ -66,11 +72,22 @@ class BatchPlan:
         out = [(0, local[k]) for k in range(self.whole)]
         for j in range(self.sharded):
             row = local[self.whole + j]
-            out.append((self.lo, row[self.lo:self.hi]) if self.full_context else (0, row))
+            if self.bucket_shard:
+                out.append((0, row))
+            else:
+                out.append((self.lo, row[self.lo:self.hi]) if self.full_context else (0, row))
         return out
 
+    def buckets(self):
+        """the (part, parts) list that goes with parts() under bucket_shard (device.msm_execute_parts_dev(..., buckets=...)), else None"""
+        if not self.bucket_shard:
+            return None
+        return [(0, 1)] * self.whole + [(self.rank, self.world)] * self.sharded
+
     def pairs_local(self):
-        """scalar-point pairs this rank reduces per step"""
+        """scalar-point pairs this rank reduces per step (a bucket range: its share of a vector's additions)"""
+        if self.bucket_shard:
+            return self.whole * self.n + self.sharded * (self.n // self.world)
         return self.whole * self.n + self.sharded * (self.hi - self.lo)
 
 

@@ -106,3 +106,40 @@ def test_window20_sub_ranges_of_the_generators():
         v[f:f + cnt] = s[f:f + cnt]
         exp, ez = opre.execute(v, parallel=True, threads=THREADS)
         assert int(gz[k]) == ez and np.array_equal(got[k].reshape(exp.shape), exp), (k, f, cnt)
+
+
+@pytest.mark.parametrize("n,window", [((1 << 16) + 37, 20), (6000, 13), (3000, 9), (1 << 16, 16)], ids=["2p16+37_w20", "6000_w13", "3000_w9_one_level", "2p16_w16"])
+def test_bucket_ranges_add_up_to_the_msm(n, window):
+    """plk_msm_execute_parts_buckets_dev: the part-th of `parts` ranges of the coarse bucket bins per vector (a rank's BUCKET share of a sharded
+    vector).  The shares of all the ranks add up to the vector's MSM (the oracle's), for 2, 3 and 8 ranks, through both orderings (the
+    tile-major one at window 20 over >= 2^16 scalars, round 5's kernels elsewhere, the one-level form included), with a generator sub-range
+    and a whole vector in the same batched call."""
+    torch = pytest.importorskip("torch")
+    from plonky_amd import device as dev
+    c = br.TWEEDLEDEE
+    dev.init(0)
+    bases = _bases(c, n, 11)
+    s = synth.rand_field(c.scalar.field_id, 0x6F8000 + n, n)
+    s[10:200] = mont_arr(c.scalar, [1])[0]
+    s[200:300] = 0
+    opre = ol.MsmPrecomputation(c.curve_id, bases, 13, threads=THREADS)
+    exp, ez = opre.execute(s, parallel=True, threads=THREADS)
+    sub = np.zeros_like(s)
+    sub[n // 3: n // 2] = s[n // 3: n // 2]
+    exp_sub, ez_sub = opre.execute(sub, parallel=True, threads=THREADS)
+    db, ds = dev.to_device(bases.reshape(n, 2, -1)), dev.to_device(s)
+    pre = dev.msm_precompute_dev(c.curve_id, db, device_window=window)
+    for world in (2, 3, 8):
+        # every rank's call: a whole vector, its bucket share of the sharded one, its bucket share of a generator sub-range
+        pts, zs, pts_sub, zs_sub = [], [], [], []
+        for r in range(world):
+            oxy, oz = dev.msm_execute_parts_dev(pre, [(0, ds), (0, ds), (n // 3, ds[n // 3: n // 2].contiguous())], buckets=[(0, 1), (r, world), (r, world)])
+            got, gz = dev.to_host(oxy), oz.cpu().numpy()
+            assert int(gz[0]) == ez and np.array_equal(got[0].reshape(exp.shape), exp), (world, r, "whole vector beside the shares")
+            pts.append(got[1]); zs.append(int(gz[1])); pts_sub.append(got[2]); zs_sub.append(int(gz[2]))
+        tot, tz = pa.curve_sum_affine(c.curve_id, np.stack(pts), np.array(zs, dtype=np.uint8))
+        assert tz == ez and np.array_equal(tot.reshape(exp.shape), exp), (world, "bucket shares do not add up")
+        tot, tz = pa.curve_sum_affine(c.curve_id, np.stack(pts_sub), np.array(zs_sub, dtype=np.uint8))
+        assert tz == ez_sub and np.array_equal(tot.reshape(exp_sub.shape), exp_sub), (world, "bucket shares of a generator sub-range")
+    with pytest.raises(Exception):
+        dev.msm_execute_parts_dev(pre, [(0, ds)], buckets=[(3, 3)])
