@@ -4,7 +4,8 @@ Several mechanisms that were measured and NOT made the default stay in the libra
 the wave-shuffle form of a tile's first stages, the staggered start of a one-round pass, round 4's host pipeline of plk_ntt_batch,
 batches strictly one MSM after the other, reductions of a batch on a second stream, no fork for small batches, the fused table
 build, the table-free MSM and the generator fold without the endomorphism split, another table-free window, the pair kernel for
-every pairwise fold, the quotient numerator in slabs, and copies between the devices of a group staged through the host.  They
+every pairwise fold, the quotient numerator in slabs, copies between the devices of a group staged through the host, and round 5's
+bucket-ordering and reduction launches (with the other depths of the in-workgroup tree of the row / column sums).  They
 are read once per process, so each one runs a slice of the parity suite - the same oracle comparisons as the default path - in a
 process of its own.  A knob that changes nothing it should not: every selected test still passes bit-exact.
 """
@@ -27,6 +28,9 @@ MSM = ["tests/test_gpu_parity.py", "-k",
 FOLD = ["tests/test_gpu_parity.py", "tests/test_gpu_halo.py", "-k",
         "test_fold_generators or test_halo_round_matches_oracle or test_halo_whole_argument_closed_form or test_fold_multi_matches_big_integers"]
 VANISH = ["tests/test_gpu_plonk.py", "-k", "test_vanishing_points_match_oracle or test_honest_witness"]
+# round 6: the 20-bit-window ordering and reduction (skewed vectors, generator sub-ranges, bucket ranges) and the 2^16 seeded-generator
+# MSM through round 5's kernels, which stay in the library behind these knobs and for the geometries the new ones do not take
+MSM20 = ["tests/test_gpu_msm_order.py", "tests/test_gpu_msm_large.py", "-k", "Tweedledee_2p16 or sub_ranges or w20"]
 
 CASES = [
     ("PLK_NTT_SHUFFLE", "1", NTT),
@@ -41,10 +45,15 @@ CASES = [
     ("PLK_FOLD_NO_GLV", "1", FOLD),
     ("PLK_HALO_PAIR_FOLD", "1", FOLD),
     ("PLK_VANISH_SLAB_LOG", "10", VANISH),
+    ("PLK_MSM_ORDER_V1", "1", MSM20),
+    ("PLK_MSM_TAIL_V1", "1", MSM20),
+    ("PLK_MSM_FINAL_V1", "1", MSM20),
+    ("PLK_MSM_TREE", "3", MSM20),
+    ("PLK_MSM_TREE", "0", MSM20),
 ]
 
 
-@pytest.mark.parametrize("knob,value,selection", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("knob,value,selection", CASES, ids=[c[0] + ("=" + c[1] if c[0] == "PLK_MSM_TREE" else "") for c in CASES])
 def test_parity_slice_under_knob(knob, value, selection):
     env = dict(os.environ)
     env[knob] = value
