@@ -67,6 +67,24 @@ def msm_components(c):
     comp["msm_mpairs_per_s"] = (plan.pairs_local() if args.emulate_rank else pairs) / tm / 1e6
     if strong:
         return
+    # msm_execute_parallel with its OWN return type (curve_msm.rs:102-157 returns the ProjectivePoint, not normalised): the reduction ends
+    # with six products instead of the inversion.  Reported beside msm_ms, which stays the affine form of rounds 1-5 (and of `value`).
+    pxyz = torch.empty((1, 3, cv["limbs"]), dtype=torch.int64, device="cuda")
+    pz = torch.empty((1,), dtype=torch.uint8, device="cuda")
+    tp = loop(lambda: dev.msm_execute_dev(pre, s, pxyz, pz, projective=True), args.steps)
+    comp["msm_projective_ms"] = tp * 1e3
+    if not args.no_check:
+        # the same point: x / z, y / z against the affine result of the call above
+        sync()
+        dev.msm_execute_dev(pre, s, oxy, oz)
+        sync()
+        f = cv["base_field"]
+        P = c.MODULI[f]
+        hx = dev.to_host(pxyz)[0]
+        x, y, z = (c.synth.from_mont(f, hx[k]) for k in range(3))
+        zi = pow(z, -1, P) if z else 0
+        ha = dev.to_host(oxy).reshape(-1, 2, cv["limbs"])[0]
+        comp["_proj_check"] = bool(int(pz.item()) == 0 and (x * zi % P, y * zi % P) == (c.synth.from_mont(f, ha[0]), c.synth.from_mont(f, ha[1])))
     # commit_polynomials (plonk_util.rs:215-231): the 9 wire polynomials against the same generators, one call
     sb = s.unsqueeze(0).repeat(9, 1, 1).contiguous()
     oxy9 = torch.empty((9, 2, cv["limbs"]), dtype=torch.int64, device="cuda")

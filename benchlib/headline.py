@@ -242,6 +242,8 @@ def run(args):
             checks["msm_closed_form_bit_exact"] = bool(ok)
             if "_b9_check" in comp:
                 checks["msm_batch9_equals_single"] = comp.pop("_b9_check")
+            if "_proj_check" in comp:
+                checks["msm_projective_is_the_same_point"] = comp.pop("_proj_check")
             if "_os_check" in comp:
                 checks["msm_one_shot_equals_tabled"] = comp.pop("_os_check")
             if "_ipa_check" in comp:

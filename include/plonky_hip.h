@@ -232,6 +232,15 @@ int plk_msm_execute_batch(plk_msm_ctx* ctx, unsigned batch, const uint64_t* cons
  * d_out_zero = batch bytes.  Asynchronous on `stream`. */
 int plk_msm_execute_dev(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero,
                         void* stream);
+/* msm_execute_parallel with ITS OWN return type (src/curve/curve_msm.rs:102-157 returns the ProjectivePoint `y`, not normalised;
+ * src/curve/curve.rs:175-181: x / z, y / z and a zero flag): out_xyz = x | y | z (3L Montgomery limbs per vector), out_zero = the flag.
+ * The affine entry points above end their reduction with a field inversion on one lane (a third of the last kernel, ~40 us of a
+ * 1.3 ms MSM); this form ends with six products and leaves the inversion to the caller's to_affine / batch_to_affine
+ * (poly_commit.rs:58-66 normalises a whole batch with ONE inversion).  Any representative of the point may come back (z = 1 from comb and
+ * device-group contexts); compare on to_affine. */
+int plk_msm_execute_projective(plk_msm_ctx* ctx, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xyz, uint8_t* out_zero);
+int plk_msm_execute_projective_dev(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xyz, void* d_out_zero,
+                                   void* stream);
 /* The same batch when a vector only covers PART of the generators: result b = sum_{i < count[b]} scalars_b[i] * G[first[b] + i].
  * first / count: host arrays of `batch` entries (first[b] + count[b] <= n); d_scalars: host array of `batch` DEVICE pointers
  * (count[b] * 4 limbs each).  Tabled contexts only.  This is a rank's call in the multi-GPU split of a commitment batch

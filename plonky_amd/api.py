@@ -279,6 +279,18 @@ def msm_execute_parallel(precomputation, scalars):
 msm_execute = msm_execute_parallel
 
 
+def msm_execute_parallel_projective(precomputation, scalars):
+    """msm_execute_parallel with its OWN return type (curve_msm.rs:102-157 returns the ProjectivePoint `y`, not normalised):
+    ((3, L) x | y | z Montgomery limbs, zero flag).  ProjectivePoint::to_affine / batch_to_affine (curve.rs:206-232) gives the unique point."""
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    assert s.shape[0] == precomputation.n, "powers_per_generator.len() != scalars.len()"
+    L = _CURVE_LIMBS[precomputation.curve]
+    out = np.zeros((3, L), dtype=np.uint64)
+    oz = np.zeros(1, dtype=np.uint8)
+    _lib.check(_lib.load().plk_msm_execute_projective(precomputation._ctx, _ptr(s), s.shape[0], _ptr(out), _ptr(oz)))
+    return out, int(oz[0])
+
+
 def msm_execute_batch(precomputation, scalar_vectors):
     """commit_polynomials (plonk_util.rs:215-231): several scalar vectors, same generators."""
     sv = np.ascontiguousarray(scalar_vectors, dtype=np.uint64)

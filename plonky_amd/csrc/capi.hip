@@ -35,7 +35,7 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
                             plk_msm_ctx** out_ctx, const void* d_extra = nullptr, size_t n_extra = 0, const size_t* also_n = nullptr,
                             int also_count = 0);
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
-                         hipEvent_t* ready = nullptr, const MsmParts* parts = nullptr);
+                         hipEvent_t* ready = nullptr, const MsmParts* parts = nullptr, unsigned out_flags = 0);
 int msm_reserve_workspaces_impl(plk_msm_ctx* ctx, unsigned count, hipStream_t stream);
 int curve_sum_affine_dev_impl(int curve, size_t k, const void* d_pts, const void* d_zero, void* d_out_xy, void* d_out_zero, hipStream_t stream);
 int curve_gen_bases_dev_impl(int curve, size_t n, uint64_t first, const void* d_g0d, void* d_out, hipStream_t stream);
@@ -68,6 +68,8 @@ int ntt_padded_dev_impl(int field, unsigned log_n, unsigned batch, const void* d
 size_t msm_ctx_len(const plk_msm_ctx* ctx);
 unsigned msm_ctx_window(const plk_msm_ctx* ctx);
 int msm_ctx_curve(const plk_msm_ctx* ctx);
+int msm_ctx_is_comb(const plk_msm_ctx* ctx);
+int msm_affine_to_projective_impl(int curve, unsigned batch, const void* d_xy, const void* d_zero, void* d_xyz, hipStream_t stream);
 void msm_ctx_delete(plk_msm_ctx* ctx);
 // multi.hip
 void multi_plan_slot(int world, unsigned batch, size_t n, int d, unsigned slot, unsigned* vec, size_t* first, size_t* count);
@@ -829,6 +831,46 @@ int plk_msm_execute_dev(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars,
         return msm_execute_multi(ctx, batch, vecs.data(), false, n_scalars, d_out_xy, d_out_zero, as_stream(stream));
     }
     return msm_execute_dev_impl(ctx, batch, d_scalars, n_scalars, d_out_xy, d_out_zero, as_stream(stream));
+}
+
+// msm_execute_parallel's own return type (curve_msm.rs:102-157: a ProjectivePoint, not normalised): x | y | z per vector.  One-device
+// bucket contexts end their reduction with six products instead of an inversion; combs and device-group contexts, which normalise on the
+// way anyway, return their affine points with z = 1.
+int plk_msm_execute_projective_dev(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xyz, void* d_out_zero, void* stream) {
+    PLK_API;
+    if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
+    if (!msm_ctx_is_multi(ctx) && !msm_ctx_is_comb(ctx))
+        return msm_execute_dev_impl(ctx, batch, d_scalars, n_scalars, d_out_xyz, d_out_zero, as_stream(stream), nullptr, nullptr, 1u);
+    if (batch == 0) return PLK_OK;
+    if (!d_out_xyz || !d_out_zero) return set_error(PLK_ERR_INVALID_ARG, "null device pointer");
+    const size_t L = (size_t)curve_limbs(msm_ctx_curve(ctx));
+    hipStream_t st = as_stream(stream);
+    void* tmp = scratch_acquire((size_t)batch * 2 * L * 8, st);
+    if (!tmp) return PLK_ERR_OOM;
+    int rc = plk_msm_execute_dev(ctx, batch, d_scalars, n_scalars, tmp, d_out_zero, stream);
+    if (rc == PLK_OK) rc = msm_affine_to_projective_impl(msm_ctx_curve(ctx), batch, tmp, d_out_zero, d_out_xyz, st);
+    scratch_release(tmp, st);
+    return rc;
+}
+int plk_msm_execute_projective(plk_msm_ctx* ctx, const uint64_t* scalars, size_t n_scalars, uint64_t* out_xyz, uint8_t* out_zero) {
+    PLK_API;
+    if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
+    if (n_scalars != msm_ctx_len(ctx))
+        return set_error(PLK_ERR_SIZE_MISMATCH, "scalars.len() = %zu but the precomputation holds %zu generators (curve_msm.rs:67)", n_scalars, msm_ctx_len(ctx));
+    if ((n_scalars && !scalars) || !out_xyz || !out_zero) return set_error(PLK_ERR_INVALID_ARG, "null pointer");
+    const size_t L = (size_t)curve_limbs(msm_ctx_curve(ctx));
+    DeviceScope primary(msm_ctx_is_multi(ctx) ? 0 : thread_logical_device());
+    LaneCall c;
+    PLK_TRY(c.begin());
+    void *ds = nullptr, *dxyz = nullptr, *dz = nullptr;
+    c.pin(scalars, n_scalars * 32);
+    PLK_TRY(c.in(ds, scalars, n_scalars * 32));
+    PLK_TRY(c.tmp(dxyz, 3 * L * 8));
+    PLK_TRY(c.tmp(dz, 1));
+    PLK_TRY(plk_msm_execute_projective_dev(ctx, 1, ds, n_scalars, dxyz, dz, (void*)c.stream()));
+    PLK_TRY(c.out(out_xyz, dxyz, 3 * L * 8));
+    PLK_TRY(c.out(out_zero, dz, 1));
+    return c.finish();
 }
 
 int plk_msm_execute_parts_dev(plk_msm_ctx* ctx, unsigned batch, const uint64_t* first, const uint64_t* count, const void* const* d_scalars, void* d_out_xy,

@@ -278,6 +278,27 @@ template <class FP, bool ONE_LANE = false> PLK_DI void emit_affine(const XyzzZ<F
     *out_zero = ident ? 1 : 0;
 }
 
+// The reference's own return type: msm_execute[_parallel] hands back a ProjectivePoint (curve_msm.rs:102-157 ends in `y`, no
+// normalisation; curve.rs:175-181: x / z, y / z and a `zero` flag).  From XYZZ (x = X / ZZ, y = Y / ZZZ): (X ZZZ : Y ZZ : ZZ ZZZ) - six
+// products where emit_affine makes an inversion (a third of k_msm_final).  R-form, canonical limbs, x | y | z.
+template <class FP> PLK_DI void emit_projective(const XyzzZ<FP>& acc, uint4* out_xyz, uint8_t* out_zero) {
+    constexpr int W = FP::NL / 4;
+    const Fz<FP> back = fz_const_rprime_to_r<FP>();
+    Fe<FP> z = fe_zero<FP>();
+    if (!acc.inf) z = fz_to_fe_canonical<FP>(fz_mul<FP>(fz_mul<FP>(acc.zz, acc.zzz), back));
+    if (acc.inf || fe_is_zero<FP>(z)) {  // ProjectivePoint::ZERO
+        fe_store<FP>(out_xyz, fe_zero<FP>());
+        fe_store<FP>(out_xyz + W, fe_zero<FP>());
+        fe_store<FP>(out_xyz + 2 * W, fe_zero<FP>());
+        *out_zero = 1;
+        return;
+    }
+    fe_store<FP>(out_xyz, fz_to_fe_canonical<FP>(fz_mul<FP>(fz_mul<FP>(acc.x, acc.zzz), back)));
+    fe_store<FP>(out_xyz + W, fz_to_fe_canonical<FP>(fz_mul<FP>(fz_mul<FP>(acc.y, acc.zz), back)));
+    fe_store<FP>(out_xyz + 2 * W, z);
+    *out_zero = 0;
+}
+
 // the other lane's point (xor butterfly inside a wave)
 template <class FP> PLK_DI XyzzZ<FP> xyzzz_shfl_xor(const XyzzZ<FP>& a, int mask) {
     XyzzZ<FP> r;

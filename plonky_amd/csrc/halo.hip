@@ -49,7 +49,7 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
                             int also_count = 0);
 int msm_rebind_dev_impl(plk_msm_ctx* ctx, size_t n, const void* d_bases, const void* d_zero, const void* d_extra, size_t n_extra, hipStream_t stream);
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
-                         hipEvent_t* ready = nullptr, const MsmParts* parts = nullptr);
+                         hipEvent_t* ready = nullptr, const MsmParts* parts = nullptr, unsigned out_flags = 0);
 int msm_reserve_workspaces_impl(plk_msm_ctx* ctx, unsigned count, hipStream_t stream);
 void msm_ctx_delete(plk_msm_ctx* ctx);
 int curve_fold_pairs_dev_impl(int curve, size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero,

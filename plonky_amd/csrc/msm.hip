@@ -461,6 +461,7 @@ struct plk_msm_ctx {
     plk::CombPlan* comb = nullptr;
     bool auto_window = false;
     bool many_heads = false;  // the call in progress holds a bucket share (set and cleared under `mu` by msm_execute_dev_impl)
+    bool out_projective = false;  // the call in progress returns ProjectivePoints (likewise)
     ~plk_msm_ctx() {
         if (comb) plk::comb_free(comb);
         for (auto* v : {&peers, &shards})
@@ -985,6 +986,7 @@ static TailSlot tail_slot(const plk_msm_ctx* ctx, const MsmWork& w, void* d_out_
     t.dyn_chunk = (const uint32_t*)w.meta + (1024 + 1025 + 1025 + 2);
     t.out_xy = (uint4*)d_out_xy;
     t.out_zero = (uint8_t*)d_out_zero;
+    t.projective = ctx->out_projective ? 1 : 0;
     return t;
 }
 
@@ -1114,7 +1116,8 @@ static void work_done(MsmWork& w, hipStream_t stream) {
 // ready (optional): one event per scalar vector; vector b is not touched before ready[b] has completed (the host-pointer entry
 // point copies vector b + 1 through PCIe while vector b is being reduced)
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
-                         hipEvent_t* ready, const MsmParts* parts) {
+                         hipEvent_t* ready, const MsmParts* parts, unsigned out_flags) {
+    // out_flags bit 0: results as the reference's un-normalised ProjectivePoint, x | y | z (3 L limbs per vector), not the affine point
     if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");
     if (parts) {
         // vector b: parts->count[b] scalars at parts->scalars[b] for the generators parts->first[b] .. (plk_msm_execute_parts_dev)
@@ -1143,7 +1146,11 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
     const size_t L = (size_t)curve_limbs(ctx->curve);
     ctx->many_heads = false;
     for (unsigned b = 0; b < batch && parts && parts->bucket_parts; ++b) ctx->many_heads = ctx->many_heads || parts->bucket_parts[b] > 1;
+    const bool projective = (out_flags & 1u) != 0;
+    ctx->out_projective = projective;
+    const size_t out_stride = (projective ? 3 : 2) * L * 8;
     if (ctx->comb) {
+        if (projective) return set_error(PLK_ERR_INVALID_ARG, "a comb context returns affine points (the caller expands them)");
         // few generators: additions of table entries and a tree, two launches for the whole batch (comb.hip)
         std::vector<const void*> ptr(batch);
         std::vector<uint64_t> first(batch), count(batch);
@@ -1160,7 +1167,7 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
         const uint8_t* sc = parts ? (const uint8_t*)parts->scalars[b] : (const uint8_t*)d_scalars + (size_t)b * ctx->n * 32;
         const size_t first = parts ? (size_t)parts->first[b] : 0, count = parts ? (size_t)parts->count[b] : (size_t)-1;
         const uint32_t bp = (parts && parts->bucket_parts) ? parts->bucket_part[b] : 0u, bps = (parts && parts->bucket_parts) ? parts->bucket_parts[b] : 1u;
-        uint8_t* oxy = (uint8_t*)d_out_xy + (size_t)b * 2 * L * 8;
+        uint8_t* oxy = (uint8_t*)d_out_xy + (size_t)b * out_stride;
         uint8_t* oz = (uint8_t*)d_out_zero + b;
         switch (ctx->curve) {
             case PLK_CURVE_TWEEDLEDEE: return msm_execute_t<TweedledeeCurve>(ctx, w, sc, oxy, oz, st, phases, first, count, bp, bps);
@@ -1240,7 +1247,7 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
                 PLK_HIP_TRY(hipStreamWaitEvent(ctx->tail_stream, ctx->ev_acc[k], 0));
                 TailBatch tb;
                 tb.count = 1;
-                tb.s[0] = tail_slot(ctx, ctx->ws[k], (uint8_t*)d_out_xy + (size_t)b * 2 * L * 8, (uint8_t*)d_out_zero + b);
+                tb.s[0] = tail_slot(ctx, ctx->ws[k], (uint8_t*)d_out_xy + (size_t)b * out_stride, (uint8_t*)d_out_zero + b);
                 PLK_TRY(reduce(tb, ctx->tail_stream));
             }
         }
@@ -1284,7 +1291,7 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
                 PLK_HIP_TRY(hipEventRecord(ctx->ev_acc[k], st));
                 PLK_HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_acc[k], 0));
             }
-            tb.s[k] = tail_slot(ctx, ctx->ws[k], (uint8_t*)d_out_xy + (size_t)b * 2 * L * 8, (uint8_t*)d_out_zero + b);
+            tb.s[k] = tail_slot(ctx, ctx->ws[k], (uint8_t*)d_out_xy + (size_t)b * out_stride, (uint8_t*)d_out_zero + b);
         }
         int rc;
         auto nomark = [] {};
@@ -1300,6 +1307,32 @@ int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars
     }
     return PLK_OK;
 }
+
+// affine results as ProjectivePoints with z = 1 (contexts and paths that normalise anyway: combs, device groups)
+template <class FP> __global__ void k_affine_to_projective(const uint4* __restrict__ xy, const uint8_t* __restrict__ zero, uint4* __restrict__ xyz, unsigned batch) {
+    constexpr int W = FP::NL / 4;
+    const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const bool ident = zero[b] != 0;
+    fe_store<FP>(xyz + (size_t)b * 3 * W, ident ? fe_zero<FP>() : fe_load<FP>(xy + (size_t)b * 2 * W));
+    fe_store<FP>(xyz + (size_t)b * 3 * W + W, ident ? fe_zero<FP>() : fe_load<FP>(xy + (size_t)b * 2 * W + W));
+    fe_store<FP>(xyz + (size_t)b * 3 * W + 2 * W, ident ? fe_zero<FP>() : fe_one<FP>());
+}
+int msm_affine_to_projective_impl(int curve, unsigned batch, const void* d_xy, const void* d_zero, void* d_xyz, hipStream_t stream) {
+    if (batch == 0) return PLK_OK;
+    const unsigned blocks = (batch + 63) / 64;
+    switch (curve) {
+        case PLK_CURVE_TWEEDLEDEE: k_affine_to_projective<TweedledeeBaseParams><<<blocks, 64, 0, stream>>>((const uint4*)d_xy, (const uint8_t*)d_zero, (uint4*)d_xyz, batch); break;
+        case PLK_CURVE_TWEEDLEDUM: k_affine_to_projective<TweedledumBaseParams><<<blocks, 64, 0, stream>>>((const uint4*)d_xy, (const uint8_t*)d_zero, (uint4*)d_xyz, batch); break;
+        case PLK_CURVE_PALLAS: k_affine_to_projective<PallasBaseParams><<<blocks, 64, 0, stream>>>((const uint4*)d_xy, (const uint8_t*)d_zero, (uint4*)d_xyz, batch); break;
+        case PLK_CURVE_VESTA: k_affine_to_projective<VestaBaseParams><<<blocks, 64, 0, stream>>>((const uint4*)d_xy, (const uint8_t*)d_zero, (uint4*)d_xyz, batch); break;
+        case PLK_CURVE_BLS12_377: k_affine_to_projective<Bls12377BaseParams><<<blocks, 64, 0, stream>>>((const uint4*)d_xy, (const uint8_t*)d_zero, (uint4*)d_xyz, batch); break;
+        default: return set_error(PLK_ERR_INVALID_ARG, "bad curve id %d", curve);
+    }
+    PLK_HIP_TRY(hipGetLastError());
+    return PLK_OK;
+}
+int msm_ctx_is_comb(const plk_msm_ctx* ctx) { return ctx && ctx->comb ? 1 : 0; }
 
 int msm_set_profiling_impl(plk_msm_ctx* ctx, int enable) {
     if (!ctx) return set_error(PLK_ERR_INVALID_ARG, "null context");

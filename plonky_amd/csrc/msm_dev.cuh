@@ -127,8 +127,9 @@ struct TailSlot {
     uint4* win_pts;
     uint32_t* final_done;  // windows finished by k_msm_final (the last one adds them up); zero between executions
     const uint32_t* dyn_chunk;  // entries per accumulation lane of this execution (k_ord_scan1)
-    uint4* out_xy;
+    uint4* out_xy;        // the result: x | y affine, or (projective) x | y | z
     uint8_t* out_zero;
+    int projective;       // 1: the reference's ProjectivePoint, not normalised (emit_projective, ecz.cuh)
 };
 struct TailBatch {
     int count;

@@ -7,6 +7,13 @@
 
 namespace plk {
 
+// the result of an MSM as the slot asks for it: the unique affine point (one inversion on one lane), or the reference's un-normalised
+// ProjectivePoint (what msm_execute_parallel returns, curve_msm.rs:102-157)
+template <class FP> PLK_DI void emit_result(const XyzzZ<FP>& acc, const TailSlot& sl) {
+    if (sl.projective) emit_projective<FP>(acc, sl.out_xy, sl.out_zero);
+    else emit_affine<FP, true>(acc, sl.out_xy, sl.out_zero);
+}
+
 // ---------------------------------------------------------------------------------------------
 // reduction  sum_d d * bucket_d   (replaces the serial Yao tail of curve_msm.rs:149-154)
 // ---------------------------------------------------------------------------------------------
@@ -452,7 +459,7 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int w
         for (int k = 0; k < shift; ++k) acc = xyzzz_dbl_q<FP>(acc, ql);
         PLK_FT(6);
         if (windows == 1) {
-            if (tid == 0) emit_affine<FP, true>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
+            if (tid == 0) emit_result<FP>(acc, tb.s[slot]);
         } else {
             uint4* win_pts = tb.s[slot].win_pts;
             if (tid == 0) xyzzz_store_packed<FP>(win_pts + (size_t)win * 4 * W, acc);
@@ -472,7 +479,7 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final(TailBatch tb, int w
                     PLK_FT(8);
                     if (tid == 0) {
                         *tb.s[slot].final_done = 0;
-                        emit_affine<FP, true>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
+                        emit_result<FP>(acc, tb.s[slot]);
                     }
                     PLK_FT(9);
                 }
@@ -528,7 +535,7 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_msm_final_pair(TailBatch tb, 
     __syncthreads();
     if (tid < 4) {  // wave 0: the column window's quad
         acc = xyzzz_add_q<FP>(acc, xyzzz_load_raw<FP>(s_x), ql);
-        if (tid == 0) emit_affine<FP, true>(acc, tb.s[slot].out_xy, tb.s[slot].out_zero);
+        if (tid == 0) emit_result<FP>(acc, tb.s[slot]);
     }
 }
 
@@ -539,8 +546,6 @@ __global__ void __launch_bounds__(COMBINE_THREADS) k_msm_combine(TailBatch tb, i
     constexpr int W = FP::NL / 4;
     __shared__ uint4 s_pts[(COMBINE_THREADS / 64) * 4 * W];
     const uint4* __restrict__ win_pts = tb.s[blockIdx.x].win_pts;
-    uint4* __restrict__ out_xy = tb.s[blockIdx.x].out_xy;
-    uint8_t* __restrict__ out_zero = tb.s[blockIdx.x].out_zero;
     const int tid = threadIdx.x, ql = tid & 3, item = tid >> 2;
     XyzzZ<FP> acc = item < windows ? xyzzz_load_packed<FP>(win_pts + (size_t)item * 4 * W) : xyzzz_identity<FP>();
     acc = wave_sum_q<FP>(acc, 16, ql);
@@ -549,7 +554,7 @@ __global__ void __launch_bounds__(COMBINE_THREADS) k_msm_combine(TailBatch tb, i
     if (tid < 64) {
         acc = item < COMBINE_THREADS / 64 ? xyzzz_load_packed<FP>(s_pts + item * 4 * W) : xyzzz_identity<FP>();
         acc = wave_sum_q<FP>(acc, COMBINE_THREADS / 64, ql);
-        if (tid == 0) emit_affine<FP, true>(acc, out_xy, out_zero);
+        if (tid == 0) emit_result<FP>(acc, tb.s[blockIdx.x]);
     }
 }
 

@@ -36,7 +36,7 @@ int msm_precompute_dev_impl(int curve, size_t n, const void* d_bases, const void
                             plk_msm_ctx** out_ctx, const void* d_extra = nullptr, size_t n_extra = 0, const size_t* also_n = nullptr,
                             int also_count = 0);
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
-                         hipEvent_t* ready = nullptr, const MsmParts* parts = nullptr);
+                         hipEvent_t* ready = nullptr, const MsmParts* parts = nullptr, unsigned out_flags = 0);
 int msm_combine_partials_dev_impl(int curve, unsigned world, unsigned batch, unsigned whole_per_rank, const void* d_gathered, void* d_out_xy, void* d_out_zero,
                                   hipStream_t stream);
 size_t msm_partials_bytes(int curve, unsigned batch);

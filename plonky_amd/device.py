@@ -114,17 +114,23 @@ def msm_precompute_dev(curve, bases, w=11, zero=None, device_window=0, table_fre
     return MsmPrecomputation(curve, ctx, n, w)
 
 
-def msm_execute_dev(pre, scalars, out_xy=None, out_zero=None):
-    """scalars: (batch, n, 4) or (n, 4) int64 CUDA tensor.  Returns (out_xy (batch, 2, L), out_zero (batch,)) on device."""
+def msm_execute_dev(pre, scalars, out_xy=None, out_zero=None, projective=False):
+    """scalars: (batch, n, 4) or (n, 4) int64 CUDA tensor.  Returns (out_xy (batch, 2, L), out_zero (batch,)) on device.
+    projective: the reference's own return type - ProjectivePoints x | y | z, not normalised ((batch, 3, L); plk_msm_execute_projective_dev)."""
     assert scalars.is_cuda and scalars.dtype == torch.int64 and scalars.is_contiguous()
     n = scalars.shape[-2]
     assert n == pre.n, "powers_per_generator.len() != scalars.len()"
     batch = scalars.numel() // (n * 4) if n else 1
     L = _CURVE_LIMBS[pre.curve]
     if out_xy is None:
-        out_xy = torch.empty((batch, 2, L), dtype=torch.int64, device=scalars.device)
+        out_xy = torch.empty((batch, 3 if projective else 2, L), dtype=torch.int64, device=scalars.device)
     if out_zero is None:
         out_zero = torch.empty((batch,), dtype=torch.uint8, device=scalars.device)
+    if projective:
+        assert out_xy.numel() == batch * 3 * L
+        _lib.check(_lib.load().plk_msm_execute_projective_dev(pre._ctx, batch, ctypes.c_void_p(scalars.data_ptr()), n, ctypes.c_void_p(out_xy.data_ptr()),
+                                                              ctypes.c_void_p(out_zero.data_ptr()), _stream()))
+        return out_xy, out_zero
     _lib.check(_lib.load().plk_msm_execute_dev(pre._ctx, batch, ctypes.c_void_p(scalars.data_ptr()), n, ctypes.c_void_p(out_xy.data_ptr()),
                                                ctypes.c_void_p(out_zero.data_ptr()), _stream()))
     return out_xy, out_zero

@@ -65,6 +65,8 @@ SYMBOLS = [
     ("plk_msm_execute_dev", _i, [_vp, _u, _vp, _sz, _vp, _vp, _vp]),
     ("plk_msm_execute_parts_dev", _i, [_vp, _u, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("plk_msm_execute_parts_buckets_dev", _i, [_vp, _u, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("plk_msm_execute_projective", _i, [_vp, _vp, _sz, _vp, _vp]),
+    ("plk_msm_execute_projective_dev", _i, [_vp, _u, _vp, _sz, _vp, _vp, _vp]),
     ("plk_msm", _i, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
     ("plk_curve_sum_affine", _i, [_i, _sz, _vp, _vp, _vp, _vp]),
     ("plk_msm_partials_bytes", _sz, [_i, _u]),

@@ -143,3 +143,43 @@ def test_bucket_ranges_add_up_to_the_msm(n, window):
         assert tz == ez_sub and np.array_equal(tot.reshape(exp_sub.shape), exp_sub), (world, "bucket shares of a generator sub-range")
     with pytest.raises(Exception):
         dev.msm_execute_parts_dev(pre, [(0, ds)], buckets=[(3, 3)])
+
+
+@pytest.mark.parametrize("c,n,window", [(br.TWEEDLEDEE, 5000, 0), (br.TWEEDLEDEE, (1 << 16) + 37, 20), (br.BLS12_377, 3000, 13), (br.TWEEDLEDUM, 300, 0)],
+                         ids=["Tweedledee_5000", "Tweedledee_2p16+37_w20", "Bls12377_3000_w13", "Tweedledum_300_comb"])
+def test_projective_result_is_the_same_point(c, n, window):
+    """plk_msm_execute_projective[_dev]: msm_execute_parallel's own return type (curve_msm.rs:102-157 returns a ProjectivePoint, not
+    normalised).  Whatever representative comes back, ProjectivePoint::to_affine (curve.rs:206-214: x / z, y / z, on Python integers here)
+    is the affine point of the affine entry points = the oracle's; the all-zero vector gives ProjectivePoint::ZERO; a batch on the device."""
+    torch = pytest.importorskip("torch")
+    from plonky_amd import device as dev
+    dev.init(0)
+    f = c.base
+    bases = _bases(c, n, 21)
+    s = synth.rand_field(c.scalar.field_id, 0x6F9000 + n, n)
+    pre = pa.msm_precompute(c.curve_id, bases, 11, device_window=window)
+    axy, az = pa.msm_execute_parallel(pre, s)
+    exp, ez = ol.MsmPrecomputation(c.curve_id, bases, 8, threads=THREADS).execute(s, parallel=True, threads=THREADS)
+    assert az == ez and np.array_equal(axy, exp)
+
+    def to_affine(xyz):
+        x, y, z = (f.from_mont(synth.to_int(xyz[k])) for k in range(3))
+        zi = pow(z, -1, f.p)
+        return x * zi % f.p, y * zi % f.p
+
+    want = (f.from_mont(synth.to_int(axy[0])), f.from_mont(synth.to_int(axy[1])))
+    xyz, z = pa.msm_execute_parallel_projective(pre, s)
+    assert z == 0 and to_affine(xyz) == want
+    xyz0, z0 = pa.msm_execute_parallel_projective(pre, np.zeros_like(s))
+    assert z0 == 1 and not xyz0.any()
+    pre.free()
+    # device-resident, three vectors in one call (one of them all zero)
+    db = dev.to_device(bases.reshape(n, 2, -1))
+    dpre = dev.msm_precompute_dev(c.curve_id, db, device_window=window)
+    vecs = np.stack([s, np.zeros_like(s), np.roll(s, 3, axis=0)])
+    oxyz, oz = dev.msm_execute_dev(dpre, dev.to_device(vecs), projective=True)
+    oxy, oz2 = dev.msm_execute_dev(dpre, dev.to_device(vecs))
+    got, gz, aff, afz = dev.to_host(oxyz), oz.cpu().numpy(), dev.to_host(oxy), oz2.cpu().numpy()
+    assert list(gz) == [0, 1, 0] and list(afz) == [0, 1, 0]
+    for k in (0, 2):
+        assert to_affine(got[k]) == (f.from_mont(synth.to_int(aff[k][0])), f.from_mont(synth.to_int(aff[k][1]))), k
