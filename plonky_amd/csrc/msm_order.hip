@@ -821,6 +821,9 @@ PLK_DI void ord2_for_runs(const uint32_t* __restrict__ tmp, const uint32_t* s_ru
         }
     }
 }
+// CACHE (nt <= 1024, i.e. up to 2^20 scalars): the first 32 records of every run this lane reads in pass 1 stay in registers (4 steps x 8
+// runs) and pass 2 does not read the bin again; longer runs' tails are re-read.
+template <bool CACHE>
 __global__ void __launch_bounds__(ORD2_SORT_THREADS) k_ord_bin_sort(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ cnt1, uint32_t nt, uint32_t cap,
                                                                     const uint32_t* __restrict__ bin_base, int fine_bits, int nbins, uint32_t buckets,
                                                                     uint32_t* __restrict__ off, uint32_t* __restrict__ sorted, uint32_t entries_cap,
@@ -844,19 +847,57 @@ __global__ void __launch_bounds__(ORD2_SORT_THREADS) k_ord_bin_sort(const uint32
     for (int k = tid; k < nf; k += ORD2_SORT_THREADS) s_cur[k] = 0;
     for (uint32_t t = tid; t < nt; t += ORD2_SORT_THREADS) s_run[t] = cnt1[(size_t)bin * nt + t];
     __syncthreads();
+    auto count = [&](uint32_t r, uint32_t) { atomicAdd(&s_cur[(r >> 1) & fmask], 1u); };
+    auto place = [&](uint32_t r, uint32_t t) {
+        const uint32_t idx = atomicAdd(&s_cur[(r >> 1) & fmask], 1u);
+        // entry id = window * ent_stride + ent_first + scalar index (the table index; k_ord_scatter)
+        const uint32_t entry = ((r >> 12) & 15u) * ent_stride + ent_first + t * (uint32_t)ORD2_TS + (r >> 16);
+        if (PLK_CHK(idx < ORD2_BIN_CAP, CHK_SEG_STAGE)) s_out[idx] = (entry << 1) | (r & 1u);
+    };
+    constexpr int STEPS = 4;  // ORD2_SORT_UNROLL runs of each of the 32 half-waves per step: 1024 tiles in four steps
+    constexpr uint32_t HW = ORD2_SORT_THREADS / 32;
+    const uint32_t hw = (uint32_t)tid >> 5, hl = (uint32_t)tid & 31u;
+    uint32_t rc[STEPS * ORD2_SORT_UNROLL];
     // pass 1: the bin's entries per bucket
-    ord2_for_runs(tmp, s_run, nt, cap, [&](uint32_t r, uint32_t) { atomicAdd(&s_cur[(r >> 1) & fmask], 1u); });
+    if constexpr (CACHE) {
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+#pragma unroll
+            for (int u = 0; u < ORD2_SORT_UNROLL; ++u) {
+                const uint32_t t = hw + (uint32_t)(st * ORD2_SORT_UNROLL + u) * HW;
+                const uint32_t w = t < nt ? s_run[t] : 0u;
+                rc[st * ORD2_SORT_UNROLL + u] = 0;
+                if (hl < (w & 0xFFFFu)) rc[st * ORD2_SORT_UNROLL + u] = tmp[(size_t)t * cap + (w >> 16) + hl];
+            }
+#pragma unroll
+            for (int u = 0; u < ORD2_SORT_UNROLL; ++u) {
+                const uint32_t t = hw + (uint32_t)(st * ORD2_SORT_UNROLL + u) * HW;
+                const uint32_t w = t < nt ? s_run[t] : 0u, cnt = w & 0xFFFFu;
+                if (hl < cnt) count(rc[st * ORD2_SORT_UNROLL + u], t);
+                for (uint32_t i = hl + 32u; i < cnt; i += 32u) count(tmp[(size_t)t * cap + (w >> 16) + i], t);
+            }
+        }
+    } else {
+        ord2_for_runs(tmp, s_run, nt, cap, count);
+    }
     __syncthreads();
     block_excl_scan4(s_cur, nf, s_tmp);
     for (int k = tid; k < nf; k += ORD2_SORT_THREADS) off[((size_t)bin << fine_bits) + k] = bb + s_cur[k];
     __syncthreads();
     // pass 2: every entry to its bucket's cursor
-    ord2_for_runs(tmp, s_run, nt, cap, [&](uint32_t r, uint32_t t) {
-        const uint32_t idx = atomicAdd(&s_cur[(r >> 1) & fmask], 1u);
-        // entry id = window * ent_stride + ent_first + scalar index (the table index; k_ord_scatter)
-        const uint32_t entry = ((r >> 12) & 15u) * ent_stride + ent_first + t * (uint32_t)ORD2_TS + (r >> 16);
-        if (PLK_CHK(idx < ORD2_BIN_CAP, CHK_SEG_STAGE)) s_out[idx] = (entry << 1) | (r & 1u);
-    });
+    if constexpr (CACHE) {
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+            for (int u = 0; u < ORD2_SORT_UNROLL; ++u) {
+                const uint32_t t = hw + (uint32_t)(st * ORD2_SORT_UNROLL + u) * HW;
+                const uint32_t w = t < nt ? s_run[t] : 0u, cnt = w & 0xFFFFu;
+                if (hl < cnt) place(rc[st * ORD2_SORT_UNROLL + u], t);
+                for (uint32_t i = hl + 32u; i < cnt; i += 32u) place(tmp[(size_t)t * cap + (w >> 16) + i], t);
+            }
+    } else {
+        ord2_for_runs(tmp, s_run, nt, cap, place);
+    }
     __syncthreads();
     for (uint32_t i = tid; i < total; i += ORD2_SORT_THREADS)
         if (PLK_CHK(bb + i < entries_cap, CHK_SORTED_INDEX)) sorted[bb + i] = s_out[i];
@@ -888,9 +929,19 @@ template <class C> int msm_launch_order_stage(int stage, const OrdCfg& o, const 
             const unsigned segs = (unsigned)(entries / ORD_SEG + hot_bins + 1);  // <= the entries / ORD_SEG + nbins + 1 rows cnt2[] holds
             const size_t lds = (size_t)2 * (o.nt1 + 1) * 4, lds_s = lds + ((size_t)3 << o.fine_bits) * 4;
             const size_t lds_b = ((size_t)ORD2_BIN_CAP + ((size_t)1 << o.fine_bits) + o.nt1) * 4;
-            (void)hipFuncSetAttribute((const void*)k_ord_bin_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-            k_ord_bin_sort<<<o.nbins, ORD2_SORT_THREADS, lds_b, stream>>>((const uint32_t*)b.tmp, (const uint32_t*)b.cnt1, o.nt1, cap, b.bin_base, o.fine_bits, o.nbins,
-                                                                         b.buckets, (uint32_t*)b.off, (uint32_t*)b.sorted, o.entries_cap, o.ent_stride, o.ent_first);
+            // (the records of pass 1 stay in registers when the half-waves cover the tiles in four steps: up to 1024 tiles)
+            static const bool no_cache = getenv("PLK_MSM_BINSORT_NOCACHE") != nullptr;
+            if (o.nt1 <= 1024u && !no_cache) {
+                (void)hipFuncSetAttribute((const void*)k_ord_bin_sort<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+                k_ord_bin_sort<true><<<o.nbins, ORD2_SORT_THREADS, lds_b, stream>>>((const uint32_t*)b.tmp, (const uint32_t*)b.cnt1, o.nt1, cap, b.bin_base, o.fine_bits,
+                                                                                   o.nbins, b.buckets, (uint32_t*)b.off, (uint32_t*)b.sorted, o.entries_cap, o.ent_stride,
+                                                                                   o.ent_first);
+            } else {
+                (void)hipFuncSetAttribute((const void*)k_ord_bin_sort<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+                k_ord_bin_sort<false><<<o.nbins, ORD2_SORT_THREADS, lds_b, stream>>>((const uint32_t*)b.tmp, (const uint32_t*)b.cnt1, o.nt1, cap, b.bin_base, o.fine_bits,
+                                                                                    o.nbins, b.buckets, (uint32_t*)b.off, (uint32_t*)b.sorted, o.entries_cap, o.ent_stride,
+                                                                                    o.ent_first);
+            }
             const unsigned hot_grid = segs < 512u ? segs : 512u;
             k_ord_bin_count2<<<hot_grid, ORD_BIN_THREADS, lds, stream>>>((const uint32_t*)b.tmp, (const uint32_t*)b.cnt1, o.nt1, cap, b.bin_base, b.seg_base, o.fine_bits,
                                                                    o.nbins, (uint32_t*)b.cnt2);
