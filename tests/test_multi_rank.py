@@ -167,6 +167,33 @@ def test_batch_plan_parts_cover_every_pair_once():
         assert (seen == 1).all(), (batch, world, n)
 
 
+def test_batch_plan_bucket_shard_hands_every_rank_the_whole_vector():
+    """parallel.BatchPlan(bucket_shard=True) (round 6): a sharded vector goes to EVERY rank whole, with the rank's range of the coarse bucket
+    bins (plk_msm_execute_parts_buckets_dev); whole vectors are dealt as before with every bucket; the bin ranges of the ranks tile the
+    bins exactly as the library cuts them (msm_execute_t: the larger ranges first, like shard_bounds)."""
+    import numpy as np
+    import torch
+    from plonky_amd import parallel
+    for batch, world, n in ((9, 8, 64), (9, 4, 50), (1, 4, 40), (5, 3, 17)):
+        vectors = np.arange(batch * n * 4, dtype=np.uint64).reshape(batch, n, 4) + 1
+        for rank in range(world):
+            plan = parallel.BatchPlan(batch, world, rank, n, bucket_shard=True)
+            assert plan.full_context and plan.n_local == n and plan.first == 0
+            local = torch.from_numpy(plan.local_scalars(vectors).view(np.int64))
+            parts, buckets = plan.parts(local), plan.buckets()
+            assert len(parts) == len(buckets) == plan.slots
+            for k, ((first, sc), (bp, bn)) in enumerate(zip(parts, buckets)):
+                v = plan.own[k] if k < plan.whole else plan.rem[k - plan.whole]
+                assert first == 0 and np.array_equal(sc.numpy().view(np.uint64), vectors[v])
+                assert (bp, bn) == ((0, 1) if k < plan.whole else (rank, world))
+            assert plan.pairs_local() == plan.whole * n + plan.sharded * (n // world)
+        assert parallel.BatchPlan(batch, world, 0, n).buckets() is None
+    # the ranks' bin ranges: contiguous, disjoint, covering - the arithmetic of msm_execute_t
+    for nbins, world in ((512, 8), (512, 3), (64, 5)):
+        cuts = [parallel.shard_bounds(nbins, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == nbins and all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
+
+
 def test_bench_without_gpus_fails_loudly():
     """`python bench.py --gpus 2` as the driver types it: no assert on WORLD_SIZE - it spawns its ranks itself, and on a box
     without GPUs it exits non-zero naming the missing devices (there is no CPU path)."""
