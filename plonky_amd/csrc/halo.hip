@@ -51,6 +51,8 @@ int msm_rebind_dev_impl(plk_msm_ctx* ctx, size_t n, const void* d_bases, const v
 int msm_execute_dev_impl(plk_msm_ctx* ctx, unsigned batch, const void* d_scalars, size_t n_scalars, void* d_out_xy, void* d_out_zero, hipStream_t stream,
                          hipEvent_t* ready = nullptr, const MsmParts* parts = nullptr, unsigned out_flags = 0);
 int msm_reserve_workspaces_impl(plk_msm_ctx* ctx, unsigned count, hipStream_t stream);
+// hostnorm.cpp: ProjectivePoint::to_affine on the host for `count` points (x | y | z -> x | y)
+int host_projective_to_affine(int curve, unsigned count, const uint8_t* xyz, const uint8_t* zero, uint8_t* xy);
 void msm_ctx_delete(plk_msm_ctx* ctx);
 int curve_fold_pairs_dev_impl(int curve, size_t m, const void* d_lo, const void* d_lo_zero, const void* d_hi, const void* d_hi_zero,
                               const uint64_t* a_mont, const uint64_t* b_mont, void* d_out_xy, void* d_out_zero, hipStream_t stream,
@@ -60,6 +62,7 @@ int curve_fold_multi_dev_impl(int curve, size_t n_out, int r_bits, const void* d
 size_t msm_ctx_len(const plk_msm_ctx* ctx);
 int msm_ctx_curve(const plk_msm_ctx* ctx);
 int msm_ctx_table_free(const plk_msm_ctx* ctx);
+int msm_ctx_is_comb(const plk_msm_ctx* ctx);
 size_t msm_partials_bytes(int curve, unsigned slots);
 int msm_combine_partials_dev_impl(int curve, unsigned world, unsigned batch, unsigned whole_per_rank, const void* d_gathered, void* d_out_xy, void* d_out_zero,
                                   hipStream_t stream);
@@ -381,7 +384,7 @@ int halo_begin_dev_impl(int curve, size_t n, const void* d_a, const void* d_b, c
     c->scal_stride = cnt_max * 32;
     struct Part { uint8_t** p; size_t bytes; } parts[] = {
         {&c->a, n * 32}, {&c->b, n * 32}, {&c->g, n * pt}, {&c->gz, n}, {&c->extra, 2 * pt}, {&c->scal, 2 * c->scal_stride},
-        {&c->part, (size_t)2 * HALO_PART_BLOCKS * 32}, {&c->out, 2 * pt + 16}, {&c->coef, n * 32}, {&c->dsc, 5 * 32},
+        {&c->part, (size_t)2 * HALO_PART_BLOCKS * 32}, {&c->out, 3 * pt + 16}, {&c->coef, n * 32}, {&c->dsc, 5 * 32},
         {&c->ratios, (size_t)16 * 32}, {&c->rec, 2 * c->rec_bytes}, {&c->hu, 4 * 32},
     };
     size_t total = 0;
@@ -456,11 +459,19 @@ int halo_round_lr_impl(plk_halo_ctx* c, const uint64_t* l_blind, const uint64_t*
                                                                            (uint4*)(beside ? c->hu : sL), (uint4*)(beside ? c->hu + 64 : sR), c->lead_u,
                                                                            (const uint4*)(lead && c->lead_inside ? c->dsc + 4 * 32 : nullptr))));
     PLK_HIP_TRY(hipGetLastError());
+    // L_j and R_j leave the device as msm_execute's ProjectivePoints (halo.rs:93-101) and are normalised where the reference normalises
+    // them, on the host: the inversion is the last ~35 us of the round's dependency chain on ONE GPU lane and ~2 us on a core
+    // (PLK_HALO_DEVICE_AFFINE=1: the device normalises, as before round 6; the records of the beside-the-tables mode stay affine)
+    static const bool device_affine = getenv("PLK_HALO_DEVICE_AFFINE") != nullptr;
+    const plk_msm_ctx* used = lead ? c->lead_ctx : c->frozen ? c->mT : c->mL;  // (mR is mL's twin)
+    const bool proj = !device_affine && !(lead && !c->lead_inside) && !msm_ctx_is_comb(used);  // a comb context (few generators) returns affine points
+    const unsigned of = proj ? 1u : 0u;
+    const size_t ps = proj ? pt + pt / 2 : pt;  // bytes of one result
     uint8_t* out_xy = c->out;
-    uint8_t* out_z = c->out + 2 * pt;
+    uint8_t* out_z = c->out + 2 * ps;
     if (lead && c->lead_inside) {
         // H and U are generators of the caller's tables: their scalars went into the two vectors, the MSM gives L_j and R_j whole
-        PLK_TRY(msm_execute_dev_impl(c->lead_ctx, 2, sL, c->lead_n, out_xy, out_z, c->stream));
+        PLK_TRY(msm_execute_dev_impl(c->lead_ctx, 2, sL, c->lead_n, out_xy, out_z, c->stream, nullptr, nullptr, of));
     } else if (lead) {
         // record 0: <a s, G> from the caller's tables; record 1: [l] H + [<a, b>] U' (one lane each, ~130 doublings: two side
         // streams, mostly hidden behind the MSM); L_j, R_j = the sums of the two records
@@ -478,7 +489,7 @@ int halo_round_lr_impl(plk_halo_ctx* c, const uint64_t* l_blind, const uint64_t*
         PLK_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_side2, 0));
         PLK_TRY(msm_combine_partials_dev_impl(c->curve, 2, 2, 0, c->rec, out_xy, out_z, c->stream));
     } else if (c->frozen) {
-        PLK_TRY(msm_execute_dev_impl(c->mT, 2, sL, c->m0 + 2, out_xy, out_z, c->stream));
+        PLK_TRY(msm_execute_dev_impl(c->mT, 2, sL, c->m0 + 2, out_xy, out_z, c->stream, nullptr, nullptr, of));
     } else {
         // L on the caller's stream, R on the side stream: below ~2^16 points each is a dependency chain, not throughput.
         // Single round: L over the upper half of the generators, R over the lower.  Stage of virtual rounds: both over the whole set
@@ -487,17 +498,21 @@ int halo_round_lr_impl(plk_halo_ctx* c, const uint64_t* l_blind, const uint64_t*
         PLK_HIP_TRY(hipEventRecord(c->ev_main, c->stream));
         PLK_HIP_TRY(hipStreamWaitEvent(c->side, c->ev_main, 0));
         PLK_TRY(msm_rebind_dev_impl(c->mR, pts + 2, c->g, c->gz, c->extra, 2, c->side));
-        PLK_TRY(msm_execute_dev_impl(c->mR, 1, sR, pts + 2, out_xy + pt, out_z + 1, c->side));
+        PLK_TRY(msm_execute_dev_impl(c->mR, 1, sR, pts + 2, out_xy + ps, out_z + 1, c->side, nullptr, nullptr, of));
         PLK_HIP_TRY(hipEventRecord(c->ev_side, c->side));
         PLK_TRY(msm_rebind_dev_impl(c->mL, pts + 2, virt ? c->g : c->g + m * pt, virt ? c->gz : c->gz + m, c->extra, 2, c->stream));
-        PLK_TRY(msm_execute_dev_impl(c->mL, 1, sL, pts + 2, out_xy, out_z, c->stream));
+        PLK_TRY(msm_execute_dev_impl(c->mL, 1, sL, pts + 2, out_xy, out_z, c->stream, nullptr, nullptr, of));
         PLK_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_side, 0));
     }
-    PLK_HIP_TRY(hipMemcpyAsync(c->pin, c->out, 2 * pt + 2, hipMemcpyDeviceToHost, c->stream));
+    PLK_HIP_TRY(hipMemcpyAsync(c->pin, c->out, 2 * ps + 2, hipMemcpyDeviceToHost, c->stream));
     PLK_HIP_TRY(hipStreamSynchronize(c->stream));
-    memcpy(lr_xy, c->pin, 2 * pt);
-    lr_zero[0] = c->pin[2 * pt];
-    lr_zero[1] = c->pin[2 * pt + 1];
+    if (proj) {
+        if (host_projective_to_affine(c->curve, 2, c->pin, c->pin + 2 * ps, (uint8_t*)lr_xy) != 0) return set_error(PLK_ERR_INVALID_ARG, "unknown curve %d", c->curve);
+    } else {
+        memcpy(lr_xy, c->pin, 2 * pt);
+    }
+    lr_zero[0] = c->pin[2 * ps];
+    lr_zero[1] = c->pin[2 * ps + 1];
     c->lr_done = true;
     return PLK_OK;
 }

@@ -524,7 +524,9 @@ static int choose_window(size_t n, int curve) {
         // heavy-bucket path - ~120 us of workgroup-wide sums whatever the size; 24 windows of 11 leave the top one 3 bits, 18
         // of 15 one bit).  Measured in round 3 (profiles/r03_commit9_scaling.txt, r03_window_sweeps.txt): 2^14: 13 (0.41 ms
         // against 0.52 at 11), 2^16 / 2^17 / 2^18: 16 (0.53 against 0.68 at 14; 0.88 against 1.01 at 18), 2^19 (BLS12-377): 17,
-        // 2^20 and up: 20 (13 additions per scalar, 2^19 buckets: round 2).
+        // 2^20 and up: 20 (13 additions per scalar, 2^19 buckets: round 2).  Round 6 (the list-driven assembly, tools/gpu/r06_small_msm2.sh,
+        // profiles/r06_small_msm_windows.txt): at 2^14 the count is no longer the measure - every stage is a chain of a few point operations -
+        // and 16 wins (two vectors: 0.442 ms against 0.481 at 13; one bucket piece per lane, so no k_msm_assemble tree), with a smaller table.
         double best = 0;
         c = 0;
         for (int t = 10; t <= MSM_MAX_WINDOW - 1; ++t) {
@@ -534,6 +536,10 @@ static int choose_window(size_t n, int curve) {
                 best = cost;
                 c = t;
             }
+        }
+        if (lg == 14) {
+            c = 16;
+            if (const char* e = getenv("PLK_MSM_WINDOW_2P14")) c = atoi(e);  // A/B of this size alone (the IPA's frozen generators)
         }
     } else {
         c = lg - 4;

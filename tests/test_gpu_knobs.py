@@ -4,7 +4,8 @@ Several mechanisms that were measured and NOT made the default stay in the libra
 the wave-shuffle form of a tile's first stages, the staggered start of a one-round pass, round 4's host pipeline of plk_ntt_batch,
 batches strictly one MSM after the other, reductions of a batch on a second stream, no fork for small batches, the fused table
 build, the table-free MSM and the generator fold without the endomorphism split, another table-free window, the pair kernel for
-every pairwise fold, the quotient numerator in slabs, copies between the devices of a group staged through the host, and round 5's
+every pairwise fold, the L / R of an inner-product-argument round normalised on the device, another window for 2^14 generators, the
+quotient numerator in slabs, copies between the devices of a group staged through the host, and round 5's
 bucket-ordering and reduction launches (with the other depths of the in-workgroup tree of the row / column sums).  They
 are read once per process, so each one runs a slice of the parity suite - the same oracle comparisons as the default path - in a
 process of its own.  A knob that changes nothing it should not: every selected test still passes bit-exact.
@@ -44,6 +45,8 @@ CASES = [
     ("PLK_MSM_WINDOW_TF", "9", MSM),
     ("PLK_FOLD_NO_GLV", "1", FOLD),
     ("PLK_HALO_PAIR_FOLD", "1", FOLD),
+    ("PLK_HALO_DEVICE_AFFINE", "1", FOLD),
+    ("PLK_MSM_WINDOW_2P14", "13", FOLD),
     ("PLK_VANISH_SLAB_LOG", "10", VANISH),
     ("PLK_MSM_ORDER_V1", "1", MSM20),
     ("PLK_MSM_TAIL_V1", "1", MSM20),
