@@ -127,7 +127,8 @@ def crossover_sweep(args):
     dd = np.stack([synth.mont(0, D[0]), synth.mont(0, D[1])])
     lines = ["# tools/crossover_sweep.py: host-pointer C ABI (pageable numpy buffers, PCIe inside) against the oracle's CPU path, %d host threads available" % cores,
              "# times in microseconds, median of the repetitions; cpu_best = best of T in %s" % sweep,
-             "%-6s %12s %12s %12s %10s | %12s %12s %12s %10s" % ("log_n", "ntt_gpu", "ntt_cpu_T1", "ntt_cpu_best", "(threads)", "msm_gpu", "msm_cpu_T1", "msm_cpu_best", "(threads)")]
+             "%-6s %12s %12s %12s %10s | %12s %12s %10s | %12s %12s %12s %10s" % ("log_n", "ntt_gpu", "ntt_cpu_T1", "ntt_cpu_best", "(threads)", "intt_gpu", "intt_cpu_best", "(threads)",
+                                                                             "msm_gpu", "msm_cpu_T1", "msm_cpu_best", "(threads)")]
     for log_n in range(min_log_n, max_log_n + 1):
         n = 1 << log_n
         reps = 30 if log_n <= 14 else 10
@@ -140,6 +141,12 @@ def crossover_sweep(args):
         assert np.array_equal(exp, y), "NTT mismatch at 2^%d" % log_n
         cpu = {t: best_of(lambda t=t: pre.fft_with_precomputation_power_of_2(x, threads=t), 5 if log_n >= 18 else reps) for t in sweep}
         tb = min(cpu, key=cpu.get)
+        # the inverse transform (benches/fft.rs:32-53 times it beside the forward one): of the forward result, back to x
+        z = np.zeros_like(x)
+        t_igpu = best_of(lambda: lib.check(L.plk_ntt(0, log_n, 1, vp(y.ctypes.data), vp(z.ctypes.data))), reps)
+        assert np.array_equal(z, x) and np.array_equal(pre.ifft_with_precomputation_power_of_2(y, threads=1), x), "inverse NTT mismatch at 2^%d" % log_n
+        icpu = {t: best_of(lambda t=t: pre.ifft_with_precomputation_power_of_2(y, threads=t), 5 if log_n >= 18 else reps) for t in sweep}
+        itb = min(icpu, key=icpu.get)
         # MSM: tables prebuilt on both sides (src/bin/msms.rs:25 excludes msm_precompute from its timing)
         bases = ol.gen_bases(0, n, g0, dd)
         s = np.ascontiguousarray(synth.rand_field(1, 0x350000 + log_n, n))
@@ -153,18 +160,21 @@ def crossover_sweep(args):
         mcpu = {t: best_of(lambda t=t: opre.execute(s, parallel=True, threads=t), mrep) for t in sweep if not (t == 1 and log_n > 18)}
         mb = min(mcpu, key=mcpu.get)
         ctx.free()
-        lines.append("%-6d %12.1f %12.1f %12.1f %10d | %12.1f %12s %12.1f %10d" % (
-            log_n, t_gpu * 1e6, cpu[1] * 1e6, cpu[tb] * 1e6, tb, m_gpu * 1e6, ("%.1f" % (mcpu[1] * 1e6)) if 1 in mcpu else "-", mcpu[mb] * 1e6, mb))
+        lines.append("%-6d %12.1f %12.1f %12.1f %10d | %12.1f %12.1f %10d | %12.1f %12s %12.1f %10d" % (
+            log_n, t_gpu * 1e6, cpu[1] * 1e6, cpu[tb] * 1e6, tb, t_igpu * 1e6, icpu[itb] * 1e6, itb,
+            m_gpu * 1e6, ("%.1f" % (mcpu[1] * 1e6)) if 1 in mcpu else "-", mcpu[mb] * 1e6, mb))
         print(lines[-1], flush=True)
     ntt_cross = [l for l in lines[3:] if float(l.split()[1]) < float(l.split()[3])]
-    lines.append("# smallest size at which the GPU path beats the CPU's best: NTT 2^%s; plk_min_gpu_log_n() = %d" % (
-        ntt_cross[0].split()[0] if ntt_cross else "-", int(L.plk_min_gpu_log_n())))
+    intt_cross = [l for l in lines[3:] if float(l.split()[6]) < float(l.split()[7])]
+    lines.append("# smallest size at which the GPU path beats the CPU's best: NTT 2^%s, inverse NTT 2^%s; plk_min_gpu_log_n() = %d" % (
+        ntt_cross[0].split()[0] if ntt_cross else "-", intt_cross[0].split()[0] if intt_cross else "-", int(L.plk_min_gpu_log_n())))
     sys.stderr.write("\n".join(lines) + "\n")
     rows = [l.split() for l in lines[3:-1]]
     print(json.dumps({"metric": METRIC, "workload": "crossover: host-pointer plk_ntt / plk_msm_execute against the oracle's CPU path, 2^%d..2^%d" % (min_log_n, max_log_n),
                       "unit": "microseconds per call", "host_cores": cores, "min_gpu_log_n": int(L.plk_min_gpu_log_n()),
                       "rows": [{"log_n": int(r[0]), "ntt_gpu_us": float(r[1]), "ntt_cpu_1_thread_us": float(r[2]), "ntt_cpu_best_us": float(r[3]), "ntt_cpu_best_threads": int(r[4]),
-                                "msm_gpu_us": float(r[6]), "msm_cpu_1_thread_us": None if r[7] == "-" else float(r[7]), "msm_cpu_best_us": float(r[8]),
-                                "msm_cpu_best_threads": int(r[9])} for r in rows]}), flush=True)
+                                "intt_gpu_us": float(r[6]), "intt_cpu_best_us": float(r[7]), "intt_cpu_best_threads": int(r[8]),
+                                "msm_gpu_us": float(r[10]), "msm_cpu_1_thread_us": None if r[11] == "-" else float(r[11]), "msm_cpu_best_us": float(r[12]),
+                                "msm_cpu_best_threads": int(r[13])} for r in rows]}), flush=True)
 
 

@@ -384,7 +384,9 @@ int plk_halo_begin_tabled_dev(int curve, size_t n, const void* d_halo_a, const v
 int plk_halo_begin(int curve, size_t n, const uint64_t* halo_a, const uint64_t* halo_b, const uint64_t* halo_g_xy, const uint8_t* halo_g_zero,
                    const uint64_t* pedersen_h_xy, const uint64_t* u_prime_xy, unsigned freeze_log, plk_halo_ctx** out_ctx);
 /* L_j then R_j of the current round, unique affine form: lr_xy 2 x 2L limbs, lr_zero 2 bytes (host).  Blinding factors: 4 limbs
- * each, Montgomery, host.  Waits for the result (the transcript needs it). */
+ * each, Montgomery, host.  Waits for the result (the transcript needs it).  The two sums cross PCIe as msm_execute's ProjectivePoints
+ * and are normalised by the library on the calling thread, where halo.rs:93-101 calls to_affine() (PLK_HALO_DEVICE_AFFINE=1: on the
+ * device). */
 int plk_halo_round_lr(plk_halo_ctx* ctx, const uint64_t* l_blinding, const uint64_t* r_blinding, uint64_t* lr_xy, uint8_t* lr_zero);
 /* The folds of the round with the challenge u_j and its inverse (4 limbs each, Montgomery, host); halves the length.  Asynchronous. */
 int plk_halo_round_fold(plk_halo_ctx* ctx, const uint64_t* u_j, const uint64_t* u_j_inv);

@@ -121,7 +121,7 @@ def _source_hash():
     """sha256 over everything the two libraries are built from (sources, headers, Makefile)."""
     import hashlib
     h = hashlib.sha256()
-    names = sorted(f for f in os.listdir(_CSRC) if f.endswith((".hip", ".cuh", ".h")) or f == "Makefile")
+    names = sorted(f for f in os.listdir(_CSRC) if f.endswith((".hip", ".cuh", ".h", ".cpp")) or f == "Makefile")
     for f in names + [os.path.join("..", "..", "include", "plonky_hip.h")]:
         h.update(f.encode())
         with open(os.path.join(_CSRC, f), "rb") as fh:
