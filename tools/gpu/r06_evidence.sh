@@ -23,3 +23,4 @@ timeout 900 python bench.py --gpus 8 --single-process --virtual-devices --steps 
 (echo "# python tools/ipa_probe.py 20 14 tabled / 16 14 tabled (1 x MI355X, round 6): the plain argument, then the one over the prover's tables"; timeout 600 python tools/ipa_probe.py 20 14 tabled 2>/dev/null; timeout 300 python tools/ipa_probe.py 16 14 tabled 2>/dev/null | head -2) > $O/r06_ipa.txt; head -3 $O/r06_ipa.txt
 (echo "# python tools/prover_pipeline_probe.py 17 ipa / 20 ipa (1 x MI355X, round 6)"; timeout 600 python tools/prover_pipeline_probe.py 17 ipa 2>/dev/null; timeout 600 python tools/prover_pipeline_probe.py 20 ipa 2>/dev/null) > $O/r06_pipeline.txt; tail -3 $O/r06_pipeline.txt
 bash tools/gpu/r06_scaling.sh > $O/scaling.log 2>&1; cp gpurun_out/r06_commit9_scaling.txt $O/r06_commit9_scaling_rerun.txt; tail -16 $O/scaling.log
+timeout 1800 python bench.py --workload crossover --log-n 20 > $O/r06_crossover.json 2> $O/r06_crossover_host_pointer_vs_cpu.txt; tail -4 $O/r06_crossover_host_pointer_vs_cpu.txt | cut -c1-200
