@@ -175,6 +175,23 @@ def run(args):
     # ---- component timings (separate loops, benchlib/components.py) so both headline numbers are reported ----
     comp = {}
     two_streams_same = None
+    do_ntt_c, do_msm_c = (False, False) if args.timed_only else (do_ntt, do_msm)
+    c = SimpleNamespace(args=args, cv=cv, comp=comp, dev=dev, api=api, lib=lib, L=L, synth=synth, np=np, torch=torch, sync=sync, n=n, world=world, rank=rank,
+                        NTT_FIELD=NTT_FIELD, CURVE=CURVE, strong=strong, batch=batch, MODULI=MODULI, _mul=_mul)
+    if do_ntt:
+        c.x, c.y, c.x_host = x, y, x_host
+    if do_msm:
+        c.s, c.s_host, c.oxy, c.oz, c.pre, c.bases, c.plan, c.p, c.G = s, s_host, oxy, oz, pre, bases, plan, p, G
+    if do_ntt_c:
+        components.ntt_components(c)
+    if do_msm_c:
+        components.msm_components(c)
+    if do_msm_c and not strong and world == 1 and args.curve == "tweedledee" and args.log_n >= 12:
+        components.ipa_component(c)
+    if not args.timed_only and not strong and world == 1 and args.log_n >= 16:
+        components.host_pointer_components(c, do_ntt_c, do_msm_c)
+    # (last of the component loops: a second stream that has been used makes every later launch on torch's default - the NULL - stream
+    # look at it, ~4 us per kernel: the transform's own loop read 0.125 instead of 0.113 ms when this ran first)
     if do_ntt and do_msm and world == 1 and not strong and not args.timed_only:
         # The step's two calls are independent tasks (plonk.rs runs its transforms and commitments under Rayon): with the transform on a
         # second stream it runs under the MSM's reduction tail (a handful of workgroups for ~0.2 ms).  Reported beside the headline, which
@@ -196,21 +213,6 @@ def run(args):
         comp["step_two_streams_ms"] = (time.perf_counter() - t0) / args.steps * 1e3
         two_streams_same = bool(torch.equal(y, y_side))
         del y_side
-    do_ntt_c, do_msm_c = (False, False) if args.timed_only else (do_ntt, do_msm)
-    c = SimpleNamespace(args=args, cv=cv, comp=comp, dev=dev, api=api, lib=lib, L=L, synth=synth, np=np, torch=torch, sync=sync, n=n, world=world, rank=rank,
-                        NTT_FIELD=NTT_FIELD, CURVE=CURVE, strong=strong, batch=batch, MODULI=MODULI, _mul=_mul)
-    if do_ntt:
-        c.x, c.y, c.x_host = x, y, x_host
-    if do_msm:
-        c.s, c.s_host, c.oxy, c.oz, c.pre, c.bases, c.plan, c.p, c.G = s, s_host, oxy, oz, pre, bases, plan, p, G
-    if do_ntt_c:
-        components.ntt_components(c)
-    if do_msm_c:
-        components.msm_components(c)
-    if do_msm_c and not strong and world == 1 and args.curve == "tweedledee" and args.log_n >= 12:
-        components.ipa_component(c)
-    if not args.timed_only and not strong and world == 1 and args.log_n >= 16:
-        components.host_pointer_components(c, do_ntt_c, do_msm_c)
     if do_msm:
         comp["msm_window_bits"] = pre.window
         comp["msm_stage_ms"] = dict(zip(STAGES, [round(v, 4) for v in msm_stage_ms]))
