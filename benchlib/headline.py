@@ -190,8 +190,8 @@ def run(args):
         components.ipa_component(c)
     if not args.timed_only and not strong and world == 1 and args.log_n >= 16:
         components.host_pointer_components(c, do_ntt_c, do_msm_c)
-    # (last of the component loops: a second stream that has been used makes every later launch on torch's default - the NULL - stream
-    # look at it, ~4 us per kernel: the transform's own loop read 0.125 instead of 0.113 ms when this ran first)
+    # (last of the component loops: when it ran first, the transform's own 100-call loop read 0.125 instead of 0.113 ms on three leases;
+    # the cause was not isolated - tools/null_stream_probe.py does not reproduce it outside this harness - so nothing is measured after it)
     if do_ntt and do_msm and world == 1 and not strong and not args.timed_only:
         # The step's two calls are independent tasks (plonk.rs runs its transforms and commitments under Rayon): with the transform on a
         # second stream it runs under the MSM's reduction tail (a handful of workgroups for ~0.2 ms).  Reported beside the headline, which
