@@ -183,3 +183,27 @@ def test_projective_result_is_the_same_point(c, n, window):
     assert list(gz) == [0, 1, 0] and list(afz) == [0, 1, 0]
     for k in (0, 2):
         assert to_affine(got[k]) == (f.from_mont(synth.to_int(aff[k][0])), f.from_mont(synth.to_int(aff[k][1]))), k
+
+
+@pytest.mark.parametrize("c", [br.TWEEDLEDEE, br.TWEEDLEDUM, br.BLS12_377, br.PALLAS, br.VESTA], ids=lambda c: c.name)
+@pytest.mark.parametrize("n", [(1 << 14) + 2, 20011], ids=["2p14+2", "20011"])
+def test_default_window_at_2p14_generators_matches_oracle(c, n):
+    """2^14 <= n < 2^15 takes the 16-bit window since round 6 (msm.hip choose_window: the frozen generators of an inner-product argument are
+    2^14 + 2) - one bucket piece per lane, the list-driven assembly: uniform and skewed vectors, one by one and as one batched call, against
+    the oracle's msm_execute_parallel on every curve."""
+    bases = _bases(c, n, 0x2E)
+    pre = pa.msm_precompute(c.curve_id, bases, 11)
+    assert pre.window == 16
+    opre = ol.MsmPrecomputation(c.curve_id, bases, 11, threads=THREADS)
+    vecs = _vectors(c, n, 0x2E14 + n)
+    names = ["uniform", "all_equal", "sixteen_distinct", "below_2p20", "half_zero", "ones_minus_ones_random"]
+    expected = {name: opre.execute(vecs[name], parallel=True, threads=THREADS) for name in names}
+    for name in names:
+        exp, ez = expected[name]
+        got, gz = pa.msm_execute_parallel(pre, vecs[name])
+        assert gz == ez and np.array_equal(got, exp), name
+    bxy, bz = pa.msm_execute_batch(pre, np.stack([vecs[k] for k in names[:2]]))   # two vectors: the shape of an IPA round
+    for k, name in enumerate(names[:2]):
+        exp, ez = expected[name]
+        assert int(bz[k]) == ez and np.array_equal(bxy[k], exp), ("batch", name)
+    pre.free()
